@@ -1,0 +1,265 @@
+"""Oracle self-consistency + the reference's HPR property tests (libzen/hps.test.cu:160-372,
+libzen/hps_cpu_public.test.cu:63-101) run against the CPU restatement."""
+import numpy as np
+import pytest
+from scipy.ndimage import median_filter as sp_median
+from scipy.ndimage import uniform_filter1d
+
+from oracle import oracle as o
+
+ALL = o.OUTPUT_HARMONIC | o.OUTPUT_PERCUSSIVE | o.OUTPUT_RESIDUAL
+
+
+def noise(n, seed=0):
+    # hps.test.cu:24-36 : uniform(-1, 1) "realistic normalized floats"
+    return np.random.default_rng(seed).uniform(-1, 1, n).astype(np.float32)
+
+
+# ---------------------------------------------------------------- filters vs scipy / brute force
+@pytest.mark.parametrize("shape,flen", [((7, 33), 3), ((22, 1024), 13), ((22, 1024), 11), ((6, 4096), 47),
+                                        ((2, 1024), 187), ((40, 50), 21), ((5, 5), 5), ((1, 9), 1)])
+def test_median_matches_scipy_and_bruteforce(shape, flen):
+    rng = np.random.default_rng(flen)
+    d = rng.uniform(0, 10, shape).astype(np.float32)
+    d[rng.integers(0, shape[0], 5), rng.integers(0, shape[1], 5)] = 0   # ties
+    if flen <= shape[1]:
+        got = o.median_filter(d, flen, o.FREQUENCY)
+        assert np.array_equal(got, sp_median(d, size=(1, flen), mode="nearest"))
+        assert np.array_equal(got, o.median_filter_bruteforce(d, flen, o.FREQUENCY))
+    if flen <= shape[0]:
+        for direction in (o.TIME_CAUSAL, o.TIME_ANTICAUSAL):    # identical on CPU, mfilt.h:311-314
+            got = o.median_filter(d, flen, direction)
+            assert np.array_equal(got, sp_median(d, size=(flen, 1), mode="nearest"))
+            assert np.array_equal(got, o.median_filter_bruteforce(d, flen, direction))
+
+
+def test_box_matches_float64_mean():
+    rng = np.random.default_rng(1)
+    d = rng.uniform(0, 10, (12, 2048)).astype(np.float32)
+    got = o.box_filter(d, 23, o.FREQUENCY)
+    ref = uniform_filter1d(d.astype(np.float64), 23, axis=1, mode="nearest")
+    assert np.allclose(got, ref, rtol=2e-6)
+    got = o.box_filter(d, 7, o.TIME_ANTICAUSAL)
+    ref = uniform_filter1d(d.astype(np.float64), 7, axis=0, mode="nearest")
+    assert np.allclose(got, ref, rtol=2e-6)
+
+
+def test_cabs_is_libm_hypotf():
+    rng = np.random.default_rng(5)
+    z = (rng.normal(size=200000) * 10 ** rng.uniform(-6, 4, 200000)
+         + 1j * rng.normal(size=200000) * 10 ** rng.uniform(-6, 4, 200000)).astype(np.complex64)
+    assert np.array_equal(o.cabs(z), np.hypot(z.real, z.imag))   # numpy float32 hypot -> libm hypotf
+
+
+def test_twiddle_table_symmetry():
+    for n in (8, 64, 1024, 16384):
+        tw = o.twiddles(n)
+        assert tw.size == n // 2
+        q = n // 4
+        assert tw[0] == 1 and tw[q] == -1j
+        assert np.array_equal(tw[q:].real, tw[:q].imag) and np.array_equal(tw[q:].imag, -tw[:q].real)
+        assert np.abs(tw - np.exp(-2j * np.pi * np.arange(n // 2) / n)).max() < 6e-8
+
+
+# ---------------------------------------------------------------- parameter derivation
+@pytest.mark.parametrize("fs,hop,exp", [
+    (44100, 256, (512, 1024, 11, 22, 12)), (44100, 512, (1024, 2048, 6, 12, 23)),
+    (44100, 1024, (2048, 4096, 3, 6, 46)), (44100, 2048, (4096, 8192, 1, 2, 93)),
+    (44100, 4096, (8192, 16384, 1, 2, 186)), (48000, 256, (512, 1024, 12, 24, 11)),
+    (48000, 4096, (8192, 16384, 1, 2, 171))])
+def test_derived_sizes(fs, hop, exp):
+    h = o.HPR(float(fs), hop, 2.0, o.OUTPUT_PERCUSSIVE, o.TIME_ANTICAUSAL)
+    assert (h.nwin, h.nfft, h.l_harm, h.stft_width, h.l_perc) == exp
+    assert h.lag == h.l_harm
+    assert o.HPR(float(fs), hop, 2.0, o.OUTPUT_PERCUSSIVE, o.TIME_CAUSAL).lag == 1   # hps.h:265-268
+    assert abs(h.cola_factor - 4.0) < 1e-4                                        # nfft / sum(w^2)
+
+
+def test_window_is_periodic_sqrt_hann():
+    w = o.window_sqrt_hann(512)
+    ref = np.sqrt(0.5 * (1 - np.cos(2 * np.pi * np.arange(512) / 512)))
+    assert np.abs(w - ref).max() < 3e-4 and w[0] < 3e-4   # float PI / cosf; w[0] is sqrt of a tiny residue
+    assert abs((w[:256] ** 2 + w[256:] ** 2) - 1).max() < 1e-6   # COLA at hop = nwin/2
+
+
+# ---------------------------------------------------------------- hps.test.cu properties
+@pytest.fixture(scope="module")
+def variants():
+    hop, n_hops = 256, 100                     # hps.test.cu:136-157
+    data = noise(hop * n_hops)
+    out = {}
+    for caus in (o.TIME_CAUSAL, o.TIME_ANTICAUSAL):
+        for cb in (True, False):
+            h = o.HPR(48000.0, hop, 2.0, ALL, caus, cb)
+            out[(caus, cb)] = h.process_stream(data)
+    return data, out
+
+
+def test_processing_modifies_input(variants):
+    data, out = variants                        # hps.test.cu:160-226
+    for v in out.values():
+        for k in "PHR":
+            assert not np.any(v[k] == data)
+
+
+def test_copybord_is_ignored_on_cpu_and_causal_differs(variants):
+    _, out = variants                           # hps.test.cu:228-283
+    for caus in (o.TIME_CAUSAL, o.TIME_ANTICAUSAL):
+        for k in "PHR":
+            assert np.array_equal(out[(caus, True)][k], out[(caus, False)][k])
+    c, a = out[(o.TIME_CAUSAL, True)]["P"], out[(o.TIME_ANTICAUSAL, True)]["P"]
+    assert not np.any(c == a)
+
+
+def test_perc_only_leaves_h_and_r_zero():
+    hop = 256                                   # hps.test.cu:285-343
+    data = noise(hop * 40, 1)
+    for caus in (o.TIME_CAUSAL, o.TIME_ANTICAUSAL):
+        h = o.HPR(48000.0, hop, 2.0, o.OUTPUT_PERCUSSIVE, caus)
+        res = h.process_stream(data)
+        assert np.all(res["H"] == 0) and np.all(res["R"] == 0) and np.any(res["P"] != 0)
+
+
+def test_reset_gives_identical_rerun():
+    hop = 256                                   # hps.test.cu:345-372
+    data = noise(hop * 30, 2)
+    h = o.HPR(48000.0, hop, 2.0, o.OUTPUT_PERCUSSIVE, o.TIME_CAUSAL)
+    a = h.process_stream(data)["P"]
+    h.reset_buffers()
+    b = h.process_stream(data)["P"]
+    assert np.array_equal(a, b)
+    h.warmup()                                  # hps.cu:410-427 ends in reset_buffers
+    assert np.array_equal(h.process_stream(data)["P"], a)
+
+
+def test_q1_causal_time_median_is_identity_at_consumed_row():
+    hop = 256
+    h = o.HPR(48000.0, hop, 2.0, ALL, o.TIME_CAUSAL)
+    for i, x in enumerate(noise(hop * 30, 3).reshape(-1, hop)):
+        h.process_next_hop(x)
+        assert np.array_equal(h.matrix("harmonic_matrix")[-1], h.matrix("s_mag")[-1])
+
+
+def test_q4_sliding_rows_equal_whole_clip_filter():
+    hop, n = 256, 80
+    h = o.HPR(48000.0, hop, 2.0, ALL, o.TIME_ANTICAUSAL)
+    mags, hs, ps = [], [], []
+    r = h.stft_width - h.lag
+    for x in noise(hop * n, 4).reshape(-1, hop):
+        h.process_next_hop(x)
+        mags.append(h.matrix("s_mag")[-1])
+        hs.append(h.matrix("harmonic_matrix")[r])
+        ps.append(h.matrix("percussive_matrix")[r])
+    mags = np.array(mags)
+    W = h.stft_width
+    whole = np.vstack([np.zeros((W, h.nfft), np.float32), mags])       # zero history before the stream
+    Hw = o.median_filter(whole, h.l_harm, o.TIME_ANTICAUSAL)[W:]
+    Pw = o.median_filter(whole, h.l_perc, o.FREQUENCY)[W:]
+    lag = h.lag
+    # row r at hop i holds frame i - (lag - 1)
+    assert np.array_equal(np.array(hs)[lag - 1:], Hw[:n - lag + 1])
+    assert np.array_equal(np.array(ps)[lag - 1:], Pw[:n - lag + 1])
+
+
+def test_q7_percussive_matrix_not_mirror_symmetric_at_edges():
+    hop = 256
+    h = o.HPR(44100.0, hop, 2.0, ALL, o.TIME_CAUSAL)
+    for x in noise(hop * 30, 5).reshape(-1, hop):
+        h.process_next_hop(x)
+    P = h.matrix("percussive_matrix")          # all rows (the CPU filters the whole matrix)
+    N, mid = h.nfft, (h.l_perc + 1 - h.l_perc % 2) // 2
+    k = np.arange(1, N // 2)
+    asym = k[(P[:, k] != P[:, N - k]).any(axis=0)]
+    assert asym.size > 0 and asym.max() <= mid
+
+
+def test_hard_masks_are_binary_and_residual_is_complement():
+    hop = 512
+    h = o.HPR(44100.0, hop, 2.0, ALL, o.TIME_ANTICAUSAL)
+    for x in noise(hop * 20, 6).reshape(-1, hop):
+        h.process_next_hop(x)
+    r = h.stft_width - h.lag
+    pm, hm, rm = (h.matrix(n)[r] for n in ("percussive_mask", "harmonic_mask", "residual_mask"))
+    assert set(np.unique(pm)) <= {0.0, 1.0} and set(np.unique(hm)) <= {0.0, 1.0}
+    assert np.array_equal(rm, 1 - (hm + pm))
+
+
+def test_soft_mask_truncates_beta_and_skips_residual():
+    hop = 256
+    data = noise(hop * 30, 7)
+    a = o.HPR(44100.0, hop, 2.5, ALL, o.TIME_ANTICAUSAL)
+    b = o.HPR(44100.0, hop, 2.0, ALL, o.TIME_ANTICAUSAL)
+    a.use_soft_mask(), b.use_soft_mask()
+    ra, rb = a.process_stream(data), b.process_stream(data)
+    assert np.array_equal(ra["P"], rb["P"]) and np.array_equal(ra["H"], rb["H"])   # (int)2.5 == 2
+    assert np.all(ra["R"] == 0)                                                    # hps.cu:562
+
+
+def test_sse_path_runs_and_has_no_residual():
+    hop = 512
+    h = o.HPR(44100.0, hop, 2.0, ALL, o.TIME_CAUSAL, False)
+    h.use_sse_filter()
+    res = h.process_stream(noise(hop * 30, 8))
+    assert np.all(np.isfinite(res["P"])) and np.any(res["P"] != 0) and np.any(res["H"] != 0)
+    assert np.all(res["R"] == 0)
+
+
+def test_output_scale_q6():
+    hop = 256
+    x = noise(hop * 200, 9)
+    h = o.HPR(44100.0, hop, 2.0, ALL, o.TIME_CAUSAL)
+    res = h.process_stream(x)
+    total = (res["P"] + res["H"] + res["R"])[hop * 4:]
+    ratio = np.sqrt(np.mean(total.astype(np.float64) ** 2)) / np.sqrt(np.mean(x.astype(np.float64) ** 2))
+    assert 0.8 * 4 * h.nfft < ratio < 1.5 * 4 * h.nfft     # no 1/nfft, COLA ~ 4, |sin|+|cos| in [1, sqrt 2]
+
+
+# ---------------------------------------------------------------- HPRIOffline
+def test_chunk_padder():
+    assert o.chunk_padder(161571, 4096, 1) == (41, 41 * 4096)     # hps.cu:109-126
+    assert o.chunk_padder(161571, 256, 11) == (643, 643 * 256)
+    assert o.chunk_padder(20 * 4096, 4096, 1) == (21, 21 * 4096)
+
+
+def test_offline_hops_must_divide():
+    with pytest.raises(o.OracleError) as e:       # hps.cu:33-36
+        o.HPRIOffline(48000.0, 4096, 300)
+    assert e.value.code == o.E_HOPS_NOT_DIVISIBLE
+
+
+@pytest.mark.parametrize("extra", [0, 11])
+def test_offline_basic_and_with_padding(extra):
+    # hps_cpu_public.test.cu:63-101 : 20 x 4096 samples (+11), fs 48000, hops 4096/256, beta 2/2
+    data = np.concatenate([noise(20 * 4096, 10), np.zeros(extra, np.float32)])
+    off = o.HPRIOffline(48000.0, 4096, 256, 2.0, 2.0)
+    h, p, r = off.process(data)
+    assert p.size == data.size and h.size == data.size
+    assert not np.any(p[:20 * 4096] == data[:20 * 4096])
+    assert np.all(r == 0)                                            # Q8
+    pc = off.process_cpu(data)
+    assert np.array_equal(pc[0], p) and np.array_equal(pc[1], p) and np.array_equal(pc[2], p)
+    # running twice on the same object state-resets (a fresh object gives the same answer)
+    h2, p2, _ = o.HPRIOffline(48000.0, 4096, 256, 2.0, 2.0).process(data)
+    assert np.array_equal(p, p2) and np.array_equal(h, h2)
+
+
+def test_offline_is_two_streaming_passes():
+    """HPRIOffline == pass 1 (H+P+R, anticausal) -> P+R shifted by lag*hop -> pass 2 (P only)."""
+    fs, hh, hp, n = 44100.0, 1024, 256, 30000
+    x = noise(n, 11)
+    H, P, _ = o.HPRIOffline(fs, hh, hp, 2.0, 2.0).process(x)
+    h1 = o.HPR(fs, hh, 2.0, ALL, o.TIME_ANTICAUSAL)
+    n1, pad1 = o.chunk_padder(n, hh, h1.lag)
+    xp = np.zeros(pad1, np.float32)
+    xp[:n] = x
+    r1 = h1.process_stream(xp)
+    inter = r1["P"] + r1["R"]
+    sh = h1.lag * hh
+    inter[:pad1 - sh] = inter[sh:].copy()         # tail keeps stale values (Q9)
+    harm = r1["H"][sh:]
+    assert np.array_equal(H, harm[:n])
+    h2 = o.HPR(fs, hp, 2.0, o.OUTPUT_PERCUSSIVE, o.TIME_ANTICAUSAL)
+    n2, pad2 = o.chunk_padder(n, hp, h2.lag)
+    assert pad2 <= pad1
+    r2 = h2.process_stream(inter[:pad2])
+    assert np.array_equal(P, r2["P"][h2.lag * hp:][:n])
