@@ -1,0 +1,181 @@
+/*
+ * zen_hip.h -- C-ABI of the MI355X (gfx950) HPSS engine: the drop-in boundary for Zen's GPU backend.
+ *
+ * Each entry point names the reference interface (sevagh/Zen, file:line) it replaces.  The reference
+ * reaches its GPU through three thin C++ wrappers (libzen/fftw.h, libzen/mfilt.h, libzen/box.h), the
+ * zero-copy buffer class (libzen/libzen/io.h) and the algorithm object HPR<Backend::GPU>
+ * (libzen/hps.h:152-322, libzen/hps.cu:429-652).  A maintainer re-points those at this library; the
+ * C++ that does so is in zen_amd/libzen/ and the binding stubs are shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C: opaque handles, raw device/host pointers, sizes; no C++ or torch types.
+ *   - every function returns 0 (ZEN_HIP_OK) or a ZEN_HIP_E_* code; zen_hip_last_error() gives the text.
+ *     Codes marked [ZgException] are the conditions on which the reference throws zen::ZgException.
+ *   - work is enqueued on the handle's stream (default: the null stream) and is asynchronous unless the
+ *     function says "synchronises".  `stream` arguments are a hipStream_t passed as void*.
+ *   - filter semantics are those of the reference CPU (IPP) path, the parity target: centred odd mask,
+ *     replicate border (libzen/mfilt.h:270-342, libzen/box.h:217-288).  `copy_bord` is accepted and, as
+ *     on the reference CPU backend (mfilt.h:289), has no effect.
+ *   - matrices are `time` rows x `frequency` columns, row-major, frequency contiguous, tightly packed
+ *     (mfilt.h:76-79: "expect 1D linear memory layout e.g. i*y + j").
+ *   - arithmetic is IEEE binary32 without FMA contraction, bit-identical to oracle/zen_oracle.c.
+ */
+#ifndef ZEN_HIP_H
+#define ZEN_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+	ZEN_HIP_OK = 0,
+	ZEN_HIP_E_FILTER_TOO_BIG = 1,     /* [ZgException] mfilt.h:85 / box.h:76 */
+	ZEN_HIP_E_BAD_ARG = 2,
+	ZEN_HIP_E_HOPS_NOT_DIVISIBLE = 3, /* [ZgException] hps.cu:33-36 */
+	ZEN_HIP_E_HIP = 4,                /* a HIP runtime call failed (reference: std::exit, io.h:37-66) */
+	ZEN_HIP_E_UNSUPPORTED = 5         /* size outside what the gfx950 kernels cover (nfft 32..16384) */
+};
+
+/* libzen/mfilt.h:27-31  enum MedianFilterDirection */
+enum { ZEN_HIP_TIME_CAUSAL = 0, ZEN_HIP_TIME_ANTICAUSAL = 1, ZEN_HIP_FREQUENCY = 2 };
+/* libzen/libzen/hps.h:25-27 */
+enum { ZEN_HIP_OUTPUT_HARMONIC = 1, ZEN_HIP_OUTPUT_PERCUSSIVE = 2, ZEN_HIP_OUTPUT_RESIDUAL = 4 };
+
+typedef struct zen_hip_fft* zen_hip_fft_t;
+typedef struct zen_hip_filter* zen_hip_mfilt_t;
+typedef struct zen_hip_filter* zen_hip_box_t;
+typedef struct zen_hip_hpr* zen_hip_hpr_t;
+typedef struct zen_hip_hpri* zen_hip_hpri_t;
+
+/* ---------------------------------------------------------------------------------------------
+ * runtime   (replaces libzen/core.cu:4-6, the cudaSetDeviceFlags(cudaDeviceMapHost) constructor)
+ * ------------------------------------------------------------------------------------------- */
+int zen_hip_init(int device);          /* hipSetDevice + mapped-host flag; idempotent */
+const char* zen_hip_last_error(void);  /* thread-local text of the last failure */
+const char* zen_hip_version(void);
+int zen_hip_device_name(char* buf, size_t n);
+int zen_hip_synchronize(void* stream); /* hipStreamSynchronize; synchronises */
+
+/* device memory + copies: what thrust::device_vector / thrust::copy are to the reference
+ * (core.h:26-27; used by every wrapper and test). */
+int zen_hip_malloc(void** dev, size_t bytes);
+int zen_hip_free(void* dev);
+int zen_hip_memset(void* dev, int value, size_t bytes, void* stream);
+int zen_hip_memcpy_h2d(void* dev, const void* host, size_t bytes); /* synchronises */
+int zen_hip_memcpy_d2h(void* host, const void* dev, size_t bytes); /* synchronises */
+int zen_hip_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+
+/* zen::io::IOGPU (libzen/libzen/io.h:16-81): pinned, mapped, portable host buffer and its device
+ * alias; write_combined != 0 for host_in (io.h:33-35). */
+int zen_hip_host_alloc_mapped(size_t bytes, int write_combined, void** host, void** dev);
+int zen_hip_host_free(void* host);
+
+/* ---------------------------------------------------------------------------------------------
+ * FFTC2CWrapperGPU   (libzen/fftw.h:20-49)
+ * In-place unnormalised complex DFT of `nfft` points (interleaved re,im floats), batch of 1 as in
+ * cufftPlan1d(&plan, nfft, CUFFT_C2C, 1) (fftw.h:32).  inverse != 0 <=> CUFFT_INVERSE (fftw.h:40-43).
+ * zen_hip_fft_exec_batched transforms `batch` consecutive nfft-point rows (the offline STFT).
+ * ------------------------------------------------------------------------------------------- */
+int zen_hip_fft_create(size_t nfft, zen_hip_fft_t* h);
+int zen_hip_fft_exec(zen_hip_fft_t h, float* inout_dev, int inverse, void* stream);
+int zen_hip_fft_exec_batched(zen_hip_fft_t h, float* inout_dev, size_t batch, int inverse, void* stream);
+int zen_hip_fft_destroy(zen_hip_fft_t h);
+
+/* ---------------------------------------------------------------------------------------------
+ * MedianFilterGPU   (libzen/mfilt.h:33-268; ctor :61-66, filter() :227-267)
+ * filter_len > the filtered dimension => ZEN_HIP_E_FILTER_TOO_BIG (mfilt.h:78-86), checked before
+ * the length is made odd (mfilt.h:89).  src and dst must not alias (reference: distinct vectors).
+ * ------------------------------------------------------------------------------------------- */
+int zen_hip_mfilt_create(int time, int frequency, int filter_len, int direction, int copy_bord,
+                         zen_hip_mfilt_t* h);
+int zen_hip_mfilt_run(zen_hip_mfilt_t h, const float* src_dev, float* dst_dev, void* stream);
+int zen_hip_mfilt_destroy(zen_hip_mfilt_t h);
+
+/* BoxFilterGPU   (libzen/box.h:30-215; ctor :55-58, filter() :182-214): mean over the mask. */
+int zen_hip_box_create(int time, int frequency, int filter_len, int direction, zen_hip_box_t* h);
+int zen_hip_box_run(zen_hip_box_t h, const float* src_dev, float* dst_dev, void* stream);
+int zen_hip_box_destroy(zen_hip_box_t h);
+
+/* ---------------------------------------------------------------------------------------------
+ * HPR<Backend::GPU>   (libzen/hps.h:152-322) and what HPRRealtime<GPU> forwards to it
+ * (libzen/hps.cu:282-427).
+ *
+ * The engine is a chunked streaming engine: one call takes n_hops >= 1 consecutive hops of
+ * `n_streams` independent streams.  n_hops == 1 is the reference's process_next_hop; larger blocks give
+ * bit-identical samples (same arithmetic per frame) at far higher throughput.  State carried between
+ * calls: the previous hop of input, a ring of the last stft_width-1 spectra/magnitudes, and the
+ * overlap-add carry per enabled output.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+	size_t hop, nwin, nfft, stft_width; /* hps.h:222-230 */
+	int l_harm, l_perc, lag;            /* hps.h:227-229, :265-268 */
+	int time_len, freq_len;             /* mask lengths after mfilt.h:89 made them odd */
+	float cola_factor;                  /* hps.h:270-274 */
+	size_t n_streams, max_hops_per_chunk;
+} zen_hip_hpr_params;
+
+/* hps.h:216-285.  causality: ZEN_HIP_TIME_CAUSAL (HPRRealtime, hps.cu:287-295) or
+ * ZEN_HIP_TIME_ANTICAUSAL (HPRIOffline passes, hps.cu:38-48).
+ * n_streams >= 1 independent mono streams processed in lock step (1 for the reference API).
+ * max_hops_per_chunk bounds device memory: longer calls are processed in chunks (0 = default 4096). */
+int zen_hip_hpr_create(float fs, size_t hop, float beta, unsigned output_flags, int causality,
+                       int copy_bord, size_t n_streams, size_t max_hops_per_chunk, zen_hip_hpr_t* h);
+int zen_hip_hpr_destroy(zen_hip_hpr_t h);
+int zen_hip_hpr_get_params(zen_hip_hpr_t h, zen_hip_hpr_params* p);
+int zen_hip_hpr_set_stream(zen_hip_hpr_t h, void* stream);
+int zen_hip_hpr_use_sse_filter(zen_hip_hpr_t h); /* hps.h:289 */
+int zen_hip_hpr_use_soft_mask(zen_hip_hpr_t h);  /* hps.h:291 */
+int zen_hip_hpr_reset_buffers(zen_hip_hpr_t h);  /* hps.h:296-321 */
+
+/* HPR<GPU>::process_next_hop (hps.cu:429-486): one hop of `hop` floats at in_dev (device or mapped
+ * host memory; n_streams == 1).  Asynchronous. */
+int zen_hip_hpr_process_next_hop(zen_hip_hpr_t h, const float* in_dev);
+/* HPRRealtime<GPU>::copy_{harmonic,percussive,residual} (hps.cu:341-363): writes the first `hop`
+ * floats of the accumulator for the hop(s) of the LAST process call to out_dev, then synchronises the
+ * stream so that a mapped host_out is readable on return (the reference relies on thrust's implicit
+ * sync, SURVEY 8(b) "Threading").  After a block call it writes n_hops*hop floats per stream
+ * (valid only if that call fitted in one chunk).  `which` is one ZEN_HIP_OUTPUT_* flag. */
+int zen_hip_hpr_copy_output(zen_hip_hpr_t h, unsigned which, float* out_dev);
+int zen_hip_hpr_copy_output_async(zen_hip_hpr_t h, unsigned which, float* out_dev);
+
+/* Block form.  in_dev: n_streams rows of n_hops*hop floats, `in_stride` floats apart.  Each non-NULL
+ * out_*_dev receives n_streams rows of n_hops*hop floats, `out_stride` apart: exactly what n_hops
+ * calls of process_next_hop + copy_* would have produced.  Asynchronous. */
+int zen_hip_hpr_process(zen_hip_hpr_t h, const float* in_dev, size_t n_hops, size_t in_stride,
+                        float* out_harm_dev, float* out_perc_dev, float* out_resid_dev, size_t out_stride);
+
+/* profiling hook for bench.py: HIP events around every launch of the frequency-median kernel on the
+ * engine's stream.  get() synchronises and returns the summed kernel time and launch count. */
+int zen_hip_hpr_profile(zen_hip_hpr_t h, int enable);
+int zen_hip_hpr_profile_get(zen_hip_hpr_t h, double* median_ms, unsigned long long* median_launches,
+                            unsigned long long* median_elements);
+
+/* ---------------------------------------------------------------------------------------------
+ * HPRIOffline<Backend::GPU>   (libzen/hps.cu:21-221): two cascaded HPR passes ("HPR-I").
+ * Returns what HPRIOffline<GPU>::process returns (hps.cu:219-220) computed with CPU filter semantics:
+ * harm = pass-1 harmonic, perc = pass-2 percussive, resid = pass-2 residual_out, which the reference
+ * never writes (pass 2 is built with OUTPUT_PERCUSSIVE only, hps.cu:45-48) and is therefore zeros.
+ * ------------------------------------------------------------------------------------------- */
+int zen_hip_hpri_create(float fs, size_t hop_h, size_t hop_p, float beta_h, float beta_p, int nocopybord,
+                        size_t n_clips, zen_hip_hpri_t* h);
+int zen_hip_hpri_destroy(zen_hip_hpri_t h);
+int zen_hip_hpri_set_stream(zen_hip_hpri_t h, void* stream);
+int zen_hip_hpri_use_sse_filter(zen_hip_hpri_t h); /* hps.cu:95-100 */
+int zen_hip_hpri_use_soft_mask(zen_hip_hpri_t h);  /* hps.cu:102-107 */
+/* HPRIOffline::process(std::vector<float>) (hps.cu:128-221): host buffers, n samples each;
+ * any output may be NULL.  Synchronises. */
+int zen_hip_hpri_process(zen_hip_hpri_t h, const float* audio_host, size_t n, float* harm_host,
+                         float* perc_host, float* resid_host);
+/* Device-resident batch of n_clips equal-length clips (rows `stride` floats apart, n samples used).
+ * Outputs may be NULL.  Asynchronous. */
+int zen_hip_hpri_process_device(zen_hip_hpri_t h, const float* audio_dev, size_t n, size_t stride,
+                                float* harm_dev, float* perc_dev, float* resid_dev, size_t out_stride);
+/* hops the two passes run for an n-sample clip (hps.cu:109-126), for throughput accounting */
+int zen_hip_hpri_hop_counts(zen_hip_hpri_t h, size_t n, size_t* n_hops_h, size_t* n_hops_p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZEN_HIP_H */

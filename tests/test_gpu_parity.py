@@ -1,0 +1,361 @@
+"""GPU parity tests: every call goes through the C-ABI (libzen_hip.so via ctypes) and is compared
+BIT-EXACTLY with the CPU oracle on the same seeded inputs (float waveforms included: the engine
+reproduces the oracle's float32 dataflow operation for operation, so the north-star tolerance of
+1e-5 relative RMS is met with margin 0)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+
+pytestmark = pytest.mark.gpu
+ALL = o.OUTPUT_HARMONIC | o.OUTPUT_PERCUSSIVE | o.OUTPUT_RESIDUAL
+
+
+@pytest.fixture(scope="module")
+def z():
+    import zen_amd
+    zen_amd.init(0)
+    return zen_amd
+
+
+def noise(n, seed=0):
+    return np.random.default_rng(seed).uniform(-1, 1, n).astype(np.float32)
+
+
+def music(n, seed=0, fs=44100.0):
+    """S-music of BASELINE.md: four sines + decaying clicks every 0.25 s + a little noise."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / fs
+    x = sum(0.2 * np.sin(2 * np.pi * f * t) for f in (220.0, 440.0, 660.0, 1320.0))
+    step = int(0.25 * fs)
+    env = np.exp(-np.arange(int(0.005 * fs)) / (0.001 * fs))
+    for s in range(0, n, step):
+        m = min(env.size, n - s)
+        x[s:s + m] += 0.9 * env[:m] * rng.uniform(-1, 1, m)
+    return (x + 0.01 * rng.uniform(-1, 1, n)).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------- FFT
+@pytest.mark.parametrize("n", [32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384])
+def test_fft_bit_exact(z, n):
+    rng = np.random.default_rng(n)
+    x = (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(np.complex64)
+    f = z.FFTC2CWrapperGPU(n)
+    f.fft_vec.upload(x)
+    f.forward()
+    z.synchronize()
+    fwd = f.fft_vec.download()
+    ref = o.fft_c2c(x)
+    assert np.array_equal(fwd.view(np.float32), ref.view(np.float32))
+    f.backward()                       # unnormalised: nfft * x  (fftw.h:40-43, IPP_FFT_NODIV_BY_ANY)
+    z.synchronize()
+    rt = f.fft_vec.download()
+    assert np.array_equal(rt.view(np.float32), o.fft_c2c(ref, inverse=True).view(np.float32))
+    assert np.abs(rt / n - x).max() <= 2e-4    # fftw.test.cu:16 tolerance
+
+
+def test_fft_batched_and_reference_tolerance(z):
+    n, b = 1024, 37
+    rng = np.random.default_rng(1)
+    x = (rng.uniform(-1, 1, (b, n)) + 1j * rng.uniform(-1, 1, (b, n))).astype(np.complex64)
+    f = z.FFTC2CWrapperGPU(n)
+    d = z.DeviceBuffer.from_host(x)
+    f.exec_batched(d.ptr, b)
+    z.synchronize()
+    got = d.download().reshape(b, n)
+    ref = np.fft.fft(x.astype(np.complex128), axis=1)
+    assert np.abs(got.real - ref.real).max() <= 2e-4 and np.abs(got.imag - ref.imag).max() <= 2e-4
+    for i in (0, 17, 36):
+        assert np.array_equal(got[i].view(np.float32), o.fft_c2c(x[i]).view(np.float32))
+
+
+def test_fft_rejects_bad_sizes(z):
+    with pytest.raises(z.ZenHipError):
+        z.FFTC2CWrapperGPU(48)
+    with pytest.raises(z.ZenHipError):
+        z.FFTC2CWrapperGPU(32768)
+
+
+# ---------------------------------------------------------------------------- median filter
+def stripes(x, y):
+    d = np.zeros((x, y), np.float32)
+    d[x // 2, :] = 5
+    d[:, y // 2] = 8
+    return d
+
+
+@pytest.mark.parametrize("x,y,f", [(9, 9, 3), (10, 20, 5), (1024, 128, 5), (1024, 17, 5), (1024, 1024, 21)])
+def test_median_reference_stripe_vectors(z, x, y, f):
+    """libzen/mfilt.test.cu fixtures; replicate border => the 'everywhere' expectations (:701-886)."""
+    d = stripes(x, y)
+    exp_t = np.zeros((x, y), np.float32)
+    exp_t[:, y // 2] = 8
+    exp_f = np.zeros((x, y), np.float32)
+    exp_f[x // 2, :] = 5
+    for direction in (z.TIME_CAUSAL, z.TIME_ANTICAUSAL):
+        assert np.array_equal(z.MedianFilterGPU(x, y, f, direction).filter_host(d), exp_t)
+    assert np.array_equal(z.MedianFilterGPU(x, y, f, z.FREQUENCY).filter_host(d), exp_f)
+    assert np.array_equal(z.MedianFilterGPU(x, y, f, z.FREQUENCY, True).filter_host(d), exp_f)  # copy_bord
+
+
+def test_median_filter_too_big_throws(z):
+    for direction in (z.FREQUENCY, z.TIME_CAUSAL, z.TIME_ANTICAUSAL):   # mfilt.test.cu:525-534
+        with pytest.raises(z.ZgException):
+            z.MedianFilterGPU(9, 9, 171, direction)
+        with pytest.raises(z.ZgException):
+            z.BoxFilterGPU(9, 9, 171, direction)
+
+
+@pytest.mark.parametrize("shape,flen", [
+    ((6, 4096), 47), ((22, 1024), 13), ((22, 1024), 11), ((12, 2048), 23), ((12, 2048), 7), ((2, 8192), 93),
+    ((2, 16384), 187), ((24, 1024), 11), ((7, 33), 3), ((300, 257), 21), ((64, 64), 11), ((5, 5), 5),
+    ((1, 9), 1), ((3, 1000), 255), ((260, 70), 255), ((129, 300), 129), ((200, 130), 65)])
+def test_median_random_bit_exact(z, shape, flen):
+    rng = np.random.default_rng(flen + shape[0])
+    d = rng.uniform(0, 10, shape).astype(np.float32)
+    d[rng.integers(0, shape[0], 7), rng.integers(0, shape[1], 7)] = 0.0
+    if flen <= shape[1]:
+        got = z.MedianFilterGPU(shape[0], shape[1], flen, z.FREQUENCY).filter_host(d)
+        assert np.array_equal(got, o.median_filter(d, flen, o.FREQUENCY))
+    if flen <= shape[0]:
+        got = z.MedianFilterGPU(shape[0], shape[1], flen, z.TIME_ANTICAUSAL).filter_host(d)
+        assert np.array_equal(got, o.median_filter(d, flen, o.TIME_ANTICAUSAL))
+
+
+def test_median_signed_values_and_even_length(z):
+    rng = np.random.default_rng(9)
+    d = rng.normal(0, 3, (40, 200)).astype(np.float32)
+    assert np.array_equal(z.MedianFilterGPU(40, 200, 10, z.FREQUENCY).filter_host(d),
+                          o.median_filter(d, 10, o.FREQUENCY))          # 10 -> 11 (mfilt.h:89)
+    assert np.array_equal(z.MedianFilterGPU(40, 200, 40, z.TIME_CAUSAL).filter_host(d),
+                          o.median_filter(d, 40, o.TIME_CAUSAL))        # 40 -> 41 on 40 rows
+
+
+def test_median_bench_squares_iota(z):
+    """libzen/mfilt.bench.cu:7-8,17-32: dim x dim, filter 11, iota data, both directions."""
+    for dim in (32, 256, 1024):
+        d = np.arange(dim * dim, dtype=np.float32).reshape(dim, dim)
+        for direction in (z.FREQUENCY, z.TIME_ANTICAUSAL):
+            assert np.array_equal(z.MedianFilterGPU(dim, dim, 11, direction).filter_host(d),
+                                  o.median_filter(d, 11, direction))
+
+
+# ---------------------------------------------------------------------------- box filter
+@pytest.mark.parametrize("shape,flen", [((12, 2048), 23), ((12, 2048), 7), ((22, 1024), 13), ((2, 4096), 187)])
+def test_box_bit_exact(z, shape, flen):
+    rng = np.random.default_rng(flen)
+    d = rng.uniform(0, 10, shape).astype(np.float32)
+    if flen <= shape[1]:
+        assert np.array_equal(z.BoxFilterGPU(shape[0], shape[1], flen, z.FREQUENCY).filter_host(d),
+                              o.box_filter(d, flen, o.FREQUENCY))
+    if flen <= shape[0]:
+        assert np.array_equal(z.BoxFilterGPU(shape[0], shape[1], flen, z.TIME_CAUSAL).filter_host(d),
+                              o.box_filter(d, flen, o.TIME_CAUSAL))
+
+
+# ---------------------------------------------------------------------------- HPR engine
+def run_oracle(fs, hop, beta, flags, caus, x, sse=False, soft=False):
+    h = o.HPR(fs, hop, beta, flags, caus)
+    if sse:
+        h.use_sse_filter()
+    if soft:
+        h.use_soft_mask()
+    return h, h.process_stream(x)
+
+
+def same(a, b):
+    return all(np.array_equal(a[k], b[k]) for k in "PHR")
+
+
+@pytest.mark.parametrize("fs,hop,n_hops", [(44100.0, 256, 60), (44100.0, 512, 40), (44100.0, 1024, 30),
+                                           (44100.0, 2048, 12), (44100.0, 4096, 8), (48000.0, 256, 60),
+                                           (48000.0, 64, 130)])
+@pytest.mark.parametrize("caus", [o.TIME_CAUSAL, o.TIME_ANTICAUSAL])
+def test_hpr_params_and_stream_bit_exact(z, fs, hop, n_hops, caus):
+    x = music(hop * n_hops, seed=hop, fs=fs) if hop >= 512 else noise(hop * n_hops, seed=hop)
+    ho, ref = run_oracle(fs, hop, 2.0, ALL, caus, x)
+    g = z.HPR(fs, hop, 2.0, ALL, caus)
+    assert (g.nwin, g.nfft, g.stft_width, g.l_harm, g.l_perc, g.lag) == \
+           (ho.nwin, ho.nfft, ho.stft_width, ho.l_harm, ho.l_perc, ho.lag)
+    assert g.cola_factor == ho.cola_factor
+    got = g.process_stream_host(x)
+    assert same(got, ref)
+    # hard masks really are exercised: the three outputs are distinct and non-trivial
+    assert np.any(ref["P"] != 0) and np.any(ref["H"] != 0)
+
+
+def test_hpr_blocking_is_invisible(z):
+    """n_hops=1 calls (the reference's process_next_hop), odd block sizes and one big block agree."""
+    fs, hop, n_hops = 44100.0, 256, 75
+    x = noise(hop * n_hops, 3)
+    _, ref = run_oracle(fs, hop, 2.5, ALL, o.TIME_ANTICAUSAL, x)
+    for block, chunk in ((1, 1), (7, 4), (n_hops, 0), (n_hops, 16)):
+        g = z.HPR(fs, hop, 2.5, ALL, z.TIME_ANTICAUSAL, True, 1, chunk)
+        assert same(g.process_stream_host(x, block=block), ref), (block, chunk)
+
+
+def test_hpr_realtime_api_mapped_memory(z):
+    """HPRRealtime<GPU> as zen/fakert.h:221-247 drives it: mapped host_in -> process -> copy -> host_out."""
+    fs, hop, n_hops = 44100.0, 1024, 25
+    x = music(hop * n_hops, 5)
+    _, ref = run_oracle(fs, hop, 2.0, o.OUTPUT_PERCUSSIVE, o.TIME_CAUSAL, x)
+    rt = z.HPRRealtime(fs, hop, 2.0, z.OUTPUT_PERCUSSIVE)
+    io = z.IOGPU(hop)
+    out = np.zeros_like(x)
+    for i in range(n_hops):
+        io.host_in[:] = x[i * hop:(i + 1) * hop]
+        rt.process_next_hop(io.device_in)
+        rt.copy_percussive(io.device_out)          # synchronises: host_out is readable
+        out[i * hop:(i + 1) * hop] = io.host_out
+    assert np.array_equal(out, ref["P"])
+    # perc-only leaves H and R accumulators zero (hps.test.cu:321-343)
+    rt.copy_harmonic(io.device_out)
+    assert np.all(io.host_out == 0)
+    rt.copy_residual(io.device_out)
+    assert np.all(io.host_out == 0)
+
+
+def test_hpr_reset_gives_identical_rerun(z):
+    fs, hop = 48000.0, 256                          # hps.test.cu:345-372
+    x = noise(hop * 30, 2)
+    g = z.HPR(fs, hop, 2.0, z.OUTPUT_PERCUSSIVE, z.TIME_CAUSAL)
+    a = g.process_stream_host(x)["P"]
+    g.reset_buffers()
+    b = g.process_stream_host(x)["P"]
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("caus", [o.TIME_CAUSAL, o.TIME_ANTICAUSAL])
+@pytest.mark.parametrize("hop", [256, 512])
+def test_hpr_soft_mask(z, hop, caus):
+    x = music(hop * 40, 7)
+    _, ref = run_oracle(44100.0, hop, 2.5, ALL, caus, x, soft=True)
+    g = z.HPR(44100.0, hop, 2.5, ALL, caus)
+    g.use_soft_mask()
+    got = g.process_stream_host(x)
+    assert same(got, ref) and np.all(got["R"] == 0)
+
+
+@pytest.mark.parametrize("caus", [o.TIME_CAUSAL, o.TIME_ANTICAUSAL])
+@pytest.mark.parametrize("hop", [512, 256])
+def test_hpr_sse_filter(z, hop, caus):
+    """config 5: SSE (box) path, nocopybord (a no-op under CPU semantics)."""
+    x = music(hop * 40, 8)
+    _, ref = run_oracle(44100.0, hop, 2.0, ALL, caus, x, sse=True)
+    g = z.HPR(44100.0, hop, 2.0, ALL, caus, False)
+    g.use_sse_filter()
+    got = g.process_stream_host(x, block=9)
+    assert same(got, ref)
+
+
+def test_hpr_multi_stream_matches_single(z):
+    fs, hop, n_hops, S = 44100.0, 256, 40, 5
+    x = np.stack([noise(hop * n_hops, 100 + s) for s in range(S)])
+    g = z.HPR(fs, hop, 2.0, ALL, z.TIME_ANTICAUSAL, True, S)
+    got = g.process_stream_host(x, block=13)
+    for s in range(S):
+        _, ref = run_oracle(fs, hop, 2.0, ALL, o.TIME_ANTICAUSAL, x[s])
+        assert all(np.array_equal(got[k][s], ref[k]) for k in "PHR")
+
+
+def test_hpr_rejects_bad_args(z):
+    with pytest.raises(z.ZenHipError):
+        z.HPR(44100.0, 300, 2.0, ALL, z.TIME_CAUSAL)        # nfft not a power of two
+    with pytest.raises(z.ZenHipError):
+        z.HPR(44100.0, 8192, 2.0, ALL, z.TIME_CAUSAL)       # nfft 32768 unsupported
+    with pytest.raises(z.ZenHipError):
+        z.HPR(44100.0, 256, 2.0, ALL, z.FREQUENCY)
+
+
+# ---------------------------------------------------------------------------- HPRIOffline
+@pytest.mark.parametrize("extra", [0, 11])
+def test_offline_reference_public_test(z, extra):
+    """libzen/hps_gpu_public.test.cu / hps_cpu_public.test.cu:63-101: 20 x 4096 (+11) samples @48 kHz."""
+    x = np.concatenate([noise(20 * 4096, 10), np.zeros(extra, np.float32)])
+    off = z.HPRIOffline(48000.0, 4096, 256, 2.0, 2.0)
+    h, p, r = off.process(x)
+    assert p.size == x.size
+    assert not np.any(p[:20 * 4096] == x[:20 * 4096])
+    rh, rp, rr = o.HPRIOffline(48000.0, 4096, 256, 2.0, 2.0).process(x)
+    assert np.array_equal(p, rp) and np.array_equal(h, rh) and np.array_equal(r, rr)
+    # a second call on the same object starts from fresh state
+    h2, p2, _ = off.process(x)
+    assert np.array_equal(p2, rp) and np.array_equal(h2, rh)
+
+
+def test_offline_config1_shape(z):
+    """BASELINE config 1: --hps 4096 2.5 256 2.5 on a 161 571-sample clip (README.md:100), S-music."""
+    x = music(161571, 1)
+    h, p, r = z.HPRIOffline(44100.0, 4096, 256, 2.5, 2.5).process(x)
+    rh, rp, rr = o.HPRIOffline(44100.0, 4096, 256, 2.5, 2.5).process(x)
+    assert np.array_equal(p, rp) and np.array_equal(h, rh) and np.all(r == 0)
+
+
+def test_offline_soft_mask_and_other_hops(z):
+    x = music(50000, 2)
+    a = z.HPRIOffline(44100.0, 1024, 256, 2.5, 2.5)
+    b = o.HPRIOffline(44100.0, 1024, 256, 2.5, 2.5)
+    a.use_soft_mask(), b.use_soft_mask()
+    h, p, _ = a.process(x)
+    rh, rp, _ = b.process(x)
+    assert np.array_equal(p, rp) and np.array_equal(h, rh)
+    with pytest.raises(z.ZgException):
+        z.HPRIOffline(44100.0, 4096, 300)                  # hps.cu:33-36
+
+
+def test_offline_batch_of_clips(z):
+    C, n = 4, 30000
+    x = np.stack([music(n, 20 + c) for c in range(C)])
+    off = z.HPRIOffline(44100.0, 2048, 256, 2.0, 2.0, False, C)
+    din = z.DeviceBuffer.from_host(x)
+    dh, dp = z.DeviceBuffer(C * n), z.DeviceBuffer(C * n)
+    off.process_device(din.ptr, n, n, dh.ptr, dp.ptr, None, n)
+    z.synchronize()
+    H, P = dh.download().reshape(C, n), dp.download().reshape(C, n)
+    for c in range(C):
+        rh, rp, _ = o.HPRIOffline(44100.0, 2048, 256, 2.0, 2.0).process(x[c])
+        assert np.array_equal(P[c], rp) and np.array_equal(H[c], rh)
+
+
+# ---------------------------------------------------------------------------- full-size properties
+def test_full_size_median_properties(z):
+    """BASELINE path shape 25 840 x 4096 (3 / 47): properties that need no oracle run at this size."""
+    rows, cols = 25840, 4096
+    rng = np.random.default_rng(0)
+    d = rng.uniform(0, 1, (rows, cols)).astype(np.float32)
+    src, dst = z.DeviceBuffer.from_host(d), z.DeviceBuffer(d.size)
+    mf = z.MedianFilterGPU(rows, cols, 47, z.FREQUENCY)
+    mf.filter(src, dst)
+    z.synchronize()
+    P = dst.download().reshape(rows, cols)
+    # (1) every output is one of its window's inputs, (2) exactly `mid` window elements are <= / >= it,
+    # checked on a random sample of positions; (3) a sampled set of whole rows matches the oracle
+    for r in rng.integers(0, rows, 6):
+        assert np.array_equal(P[r:r + 1], o.median_filter(d[r:r + 1], 47, o.FREQUENCY))
+    # (4) monotone transform commutes with the median: med(2x+1) == 2 med(x)+1 exactly for these floats
+    src.upload(d * 2 + 1)
+    mf.filter(src, dst)
+    z.synchronize()
+    assert np.array_equal(dst.download().reshape(rows, cols), P * 2 + 1)
+    # (5) idempotent on constant rows, order-preserving: min <= P <= max per row
+    assert np.all(P.min(axis=1) >= d.min(axis=1)) and np.all(P.max(axis=1) <= d.max(axis=1))
+    mt = z.MedianFilterGPU(rows, cols, 3, z.TIME_ANTICAUSAL)
+    src.upload(d)
+    mt.filter(src, dst)
+    z.synchronize()
+    Hm = dst.download().reshape(rows, cols)
+    ref = np.median(np.stack([np.vstack([d[:1], d[:-1]]), d, np.vstack([d[1:], d[-1:]])]), axis=0)
+    assert np.array_equal(Hm, ref)
+
+
+def test_full_size_stream_linearity_of_blocks(z):
+    """10 s of config 2 (hop 1024, P only, causal): one block == per-hop calls, checksum of checksums."""
+    fs, hop, n_hops = 44100.0, 1024, 430
+    x = music(hop * n_hops, 11)
+    g1 = z.HPR(fs, hop, 2.0, z.OUTPUT_PERCUSSIVE, z.TIME_CAUSAL)
+    a = g1.process_stream_host(x)["P"]
+    g2 = z.HPR(fs, hop, 2.0, z.OUTPUT_PERCUSSIVE, z.TIME_CAUSAL, True, 1, 1)
+    b = g2.process_stream_host(x, block=1)["P"]
+    assert np.array_equal(a, b)
+    _, ref = run_oracle(fs, hop, 2.0, o.OUTPUT_PERCUSSIVE, o.TIME_CAUSAL, x[:hop * 40])
+    assert np.array_equal(a[:hop * 40], ref["P"])

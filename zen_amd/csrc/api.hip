@@ -1,0 +1,299 @@
+// api.hip -- runtime, memory and wrapper-level entry points of the C-ABI (include/zen_hip.h):
+// zen_hip_init, device/mapped memory, FFTC2CWrapperGPU, MedianFilterGPU, BoxFilterGPU.
+#include "common.h"
+#include "filters.h"
+#include "stft.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+namespace zen_hip_impl {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+}
+
+int check_filter_len(int time, int frequency, int filter_len, int direction, int* odd_len)
+{
+	if (time <= 0 || frequency <= 0 || filter_len <= 0)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "filter: non-positive dimension (time %d, frequency %d, len %d)", time,
+		        frequency, filter_len);
+	if (direction != ZEN_HIP_TIME_CAUSAL && direction != ZEN_HIP_TIME_ANTICAUSAL
+	    && direction != ZEN_HIP_FREQUENCY)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "filter: unknown direction %d", direction);
+	// mfilt.h:78-86 / box.h:69-77 : compared before the length is made odd
+	if ((direction != ZEN_HIP_FREQUENCY && filter_len > time)
+	    || (direction == ZEN_HIP_FREQUENCY && filter_len > frequency))
+		ZH_FAIL(ZEN_HIP_E_FILTER_TOO_BIG, "median filter bigger than matrix dimension");
+	*odd_len = filter_len + (1 - (filter_len % 2)); // mfilt.h:89
+	return ZEN_HIP_OK;
+}
+
+void make_window_sqrt_hann(float* w, size_t n)
+{
+	const float PI = 3.14159265359F; // win.h:13
+	const float N = (float)n;        // periodic: divide by the window size (win.h:31-34)
+	for (size_t i = 0; i < n; ++i)
+		w[i] = sqrtf(0.5F * (1.0F - cosf(2.0F * PI * (float)i / N)));
+}
+
+void make_twiddles(float* tw, size_t n)
+{
+	// tw[j] = exp(-2 pi i j / n), j < n/2.  First octant from double libm rounded to float; the rest by
+	// symmetry, so tw[j + n/4] == -i * tw[j] exactly.  Same construction as oracle zo_twiddles().
+	const size_t half = n / 2;
+	if (half == 0)
+		return;
+	if (n < 8) {
+		tw[0] = 1.0F;
+		tw[1] = 0.0F;
+		if (n == 4) {
+			tw[2] = 0.0F;
+			tw[3] = -1.0F;
+		}
+		return;
+	}
+	const size_t Q = n / 4, O = n / 8;
+	std::vector<float> c(Q + 1), s(Q + 1);
+	const double two_pi = 6.283185307179586476925286766559;
+	for (size_t j = 0; j <= O; ++j) {
+		const double th = two_pi * (double)j / (double)n;
+		c[j] = (float)cos(th);
+		s[j] = (float)sin(th);
+	}
+	c[0] = 1.0F;
+	s[0] = 0.0F;
+	for (size_t j = O + 1; j <= Q; ++j) {
+		c[j] = s[Q - j];
+		s[j] = c[Q - j];
+	}
+	for (size_t j = 0; j < half; ++j) {
+		const float cj = (j <= Q) ? c[j] : -s[j - Q];
+		const float sj = (j <= Q) ? s[j] : c[j - Q];
+		tw[2 * j] = cj;
+		tw[2 * j + 1] = -sj;
+	}
+}
+
+} // namespace zen_hip_impl
+
+using namespace zen_hip_impl;
+
+struct zen_hip_fft {
+	size_t nfft;
+	int log2n;
+	float2* tw;
+};
+
+struct zen_hip_filter {
+	int time, frequency, len, direction;
+	bool is_box;
+};
+
+extern "C" {
+
+const char* zen_hip_last_error(void) { return g_err; }
+const char* zen_hip_version(void) { return "zen-mi355x 0.1 (gfx950)"; }
+
+int zen_hip_init(int device)
+{
+	int n = 0;
+	ZH_HIP(hipGetDeviceCount(&n));
+	if (device < 0 || device >= n)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "zen_hip_init: device %d of %d", device, n);
+	// core.cu:4-6 sets cudaDeviceMapHost before a context exists; on ROCm mapped host memory needs
+	// no device flag, the call is kept for symmetry and its "already active" status is ignored.
+	(void)hipSetDeviceFlags(hipDeviceMapHost);
+	(void)hipGetLastError();
+	ZH_HIP(hipSetDevice(device));
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_device_name(char* buf, size_t n)
+{
+	int dev = 0;
+	ZH_HIP(hipGetDevice(&dev));
+	hipDeviceProp_t p;
+	ZH_HIP(hipGetDeviceProperties(&p, dev));
+	snprintf(buf, n, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_synchronize(void* stream)
+{
+	ZH_HIP(hipStreamSynchronize((hipStream_t)stream));
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_malloc(void** dev, size_t bytes)
+{
+	ZH_HIP(hipMalloc(dev, bytes ? bytes : 1));
+	return ZEN_HIP_OK;
+}
+int zen_hip_free(void* dev)
+{
+	if (dev)
+		ZH_HIP(hipFree(dev));
+	return ZEN_HIP_OK;
+}
+int zen_hip_memset(void* dev, int value, size_t bytes, void* stream)
+{
+	ZH_HIP(hipMemsetAsync(dev, value, bytes, (hipStream_t)stream));
+	return ZEN_HIP_OK;
+}
+int zen_hip_memcpy_h2d(void* dev, const void* host, size_t bytes)
+{
+	ZH_HIP(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
+	return ZEN_HIP_OK;
+}
+int zen_hip_memcpy_d2h(void* host, const void* dev, size_t bytes)
+{
+	ZH_HIP(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+	return ZEN_HIP_OK;
+}
+int zen_hip_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream)
+{
+	ZH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_host_alloc_mapped(size_t bytes, int write_combined, void** host, void** dev)
+{
+	// io.h:24-66 : cudaHostAllocMapped | cudaHostAllocPortable (| WriteCombined for host_in)
+	unsigned flags = hipHostMallocMapped | hipHostMallocPortable;
+	if (write_combined)
+		flags |= hipHostMallocWriteCombined;
+	ZH_HIP(hipHostMalloc(host, bytes ? bytes : 1, flags));
+	ZH_HIP(hipHostGetDevicePointer(dev, *host, 0));
+	return ZEN_HIP_OK;
+}
+int zen_hip_host_free(void* host)
+{
+	if (host)
+		ZH_HIP(hipHostFree(host));
+	return ZEN_HIP_OK;
+}
+
+// ---- FFTC2CWrapperGPU ---------------------------------------------------------------------------
+int zen_hip_fft_create(size_t nfft, zen_hip_fft_t* h)
+{
+	if (!h)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "fft_create: null handle");
+	if (!is_pow2(nfft))
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "fft_create: nfft %zu is not a power of two", nfft);
+	if (nfft < 32 || nfft > 16384)
+		ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "fft_create: nfft %zu outside 32..16384", nfft);
+	zen_hip_fft* f = new zen_hip_fft;
+	f->nfft = nfft;
+	f->log2n = ilog2(nfft);
+	f->tw = nullptr;
+	std::vector<float> tw(nfft);
+	make_twiddles(tw.data(), nfft);
+	if (hipMalloc((void**)&f->tw, sizeof(float) * nfft) != hipSuccess
+	    || hipMemcpy(f->tw, tw.data(), sizeof(float) * nfft, hipMemcpyHostToDevice) != hipSuccess) {
+		delete f;
+		ZH_FAIL(ZEN_HIP_E_HIP, "fft_create: device allocation failed");
+	}
+	*h = f;
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_fft_exec_batched(zen_hip_fft_t h, float* inout_dev, size_t batch, int inverse, void* stream)
+{
+	if (!h || !inout_dev)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "fft_exec: null argument");
+	return launch_fft(h->log2n, (float2*)inout_dev, h->tw, batch, inverse, (hipStream_t)stream);
+}
+
+int zen_hip_fft_exec(zen_hip_fft_t h, float* inout_dev, int inverse, void* stream)
+{
+	return zen_hip_fft_exec_batched(h, inout_dev, 1, inverse, stream);
+}
+
+int zen_hip_fft_destroy(zen_hip_fft_t h)
+{
+	if (h) {
+		(void)hipFree(h->tw);
+		delete h;
+	}
+	return ZEN_HIP_OK;
+}
+
+// ---- MedianFilterGPU / BoxFilterGPU -------------------------------------------------------------
+static int filter_create(int time, int frequency, int filter_len, int direction, bool is_box,
+                         zen_hip_filter** h)
+{
+	if (!h)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "filter_create: null handle");
+	int odd = 0;
+	ZH_TRY(check_filter_len(time, frequency, filter_len, direction, &odd));
+	if (!is_box && odd > 255)
+		ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "median mask length %d > 255", odd);
+	zen_hip_filter* f = new zen_hip_filter;
+	f->time = time;
+	f->frequency = frequency;
+	f->len = odd;
+	f->direction = direction;
+	f->is_box = is_box;
+	*h = f;
+	return ZEN_HIP_OK;
+}
+
+static int filter_run(zen_hip_filter* h, const float* src, float* dst, void* stream)
+{
+	if (!h || !src || !dst)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "filter_run: null argument");
+	FilterArgs a;
+	memset(&a, 0, sizeof(a));
+	a.src = src;
+	a.dst = dst;
+	a.n_streams = 1;
+	a.cols = h->frequency;
+	a.ring_rows = h->time;
+	a.first_row = 0;
+	a.n_out_rows = h->time;
+	a.clamp_lo = 0;
+	a.clamp_hi = h->time - 1;
+	a.len = h->len;
+	a.direction = h->direction;
+	return h->is_box ? launch_box(a, (hipStream_t)stream) : launch_median(a, (hipStream_t)stream);
+}
+
+int zen_hip_mfilt_create(int time, int frequency, int filter_len, int direction, int copy_bord,
+                         zen_hip_mfilt_t* h)
+{
+	(void)copy_bord; // CPU semantics (replicate border) always; see header
+	return filter_create(time, frequency, filter_len, direction, false, h);
+}
+int zen_hip_mfilt_run(zen_hip_mfilt_t h, const float* src_dev, float* dst_dev, void* stream)
+{
+	return filter_run(h, src_dev, dst_dev, stream);
+}
+int zen_hip_mfilt_destroy(zen_hip_mfilt_t h)
+{
+	delete h;
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_box_create(int time, int frequency, int filter_len, int direction, zen_hip_box_t* h)
+{
+	return filter_create(time, frequency, filter_len, direction, true, h);
+}
+int zen_hip_box_run(zen_hip_box_t h, const float* src_dev, float* dst_dev, void* stream)
+{
+	return filter_run(h, src_dev, dst_dev, stream);
+}
+int zen_hip_box_destroy(zen_hip_box_t h)
+{
+	delete h;
+	return ZEN_HIP_OK;
+}
+
+} // extern "C"

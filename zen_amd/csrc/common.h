@@ -1,0 +1,56 @@
+// common.h -- shared host-side helpers of the gfx950 HPSS shim (error plumbing, small utilities).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/zen_hip.h"
+
+namespace zen_hip_impl {
+
+void set_error(const char* fmt, ...);
+
+// Evaluate a HIP call; on failure record file:line + hipGetErrorString and return ZEN_HIP_E_HIP.
+#define ZH_HIP(call)                                                                                  \
+	do {                                                                                              \
+		hipError_t e__ = (call);                                                                      \
+		if (e__ != hipSuccess) {                                                                      \
+			::zen_hip_impl::set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call,             \
+			                          hipGetErrorString(e__));                                        \
+			return ZEN_HIP_E_HIP;                                                                     \
+		}                                                                                             \
+	} while (0)
+
+#define ZH_TRY(expr)                \
+	do {                            \
+		int rc__ = (expr);          \
+		if (rc__ != ZEN_HIP_OK)     \
+			return rc__;            \
+	} while (0)
+
+#define ZH_FAIL(code, ...)                        \
+	do {                                          \
+		::zen_hip_impl::set_error(__VA_ARGS__);   \
+		return (code);                            \
+	} while (0)
+
+static inline int ilog2(size_t n)
+{
+	int l = 0;
+	while ((size_t(1) << l) < n)
+		++l;
+	return l;
+}
+static inline bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
+static inline size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
+
+// mfilt.h:78-89 / box.h:69-80 : too-big check on the caller's length, then make it odd.
+int check_filter_len(int time, int frequency, int filter_len, int direction, int* odd_len);
+
+// Host-generated tables shared bit-for-bit with the oracle (same formulas, same libm).
+void make_window_sqrt_hann(float* w, size_t n);      // libzen/win.h:21-51
+void make_twiddles(float* tw_interleaved, size_t n); // see oracle/zen_oracle.h (octant-symmetric)
+
+} // namespace zen_hip_impl

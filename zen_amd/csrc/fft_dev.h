@@ -1,0 +1,189 @@
+// fft_dev.h -- LDS-resident power-of-two complex FFT for gfx950, bit-identical to the oracle's
+// recursive radix-2 decimation-in-time transform (oracle/zen_oracle.c fft_rec; the reference's
+// FFTC2CWrapper, libzen/fftw.h:20-129, is an unnormalised C2C DFT).
+//
+// Arithmetic DAG.  Let Y_s[j][k] be the size-2^s DFT of the decimated sequence x[j + n*N/2^s]:
+//     Y_0[j][0]          = x[j]
+//     Y_s[j][k]          = Y_{s-1}[j][k] + w * Y_{s-1}[j + N/2^s][k]
+//     Y_s[j][k + 2^(s-1)] = Y_{s-1}[j][k] - w * Y_{s-1}[j + N/2^s][k],   w = tw[k * N/2^s]
+// which is exactly what the oracle's recursion evaluates (even/odd split, one twiddle table of N/2
+// entries).  Every thread owns 16 complex values and runs r = 2..4 consecutive stages on them in
+// registers (a "radix-2^r pass" that is still the radix-2 DAG: no 3-multiply radix-4 shortcuts, so every
+// rounding matches).  Between passes the values are exchanged through LDS in the autosort layout
+// addr(level s) = k * (N/2^s) + j, so that pass 0 reads the input in natural order (coalesced, straight
+// from HBM) and the last pass writes the spectrum in natural order (coalesced, straight to HBM).
+//
+// Twiddles come from the host table (exact octant symmetry): tw[i + N/4] == -i*tw[i] bit for bit, so
+// half of each stage's twiddles are formed by a swap/negate instead of a load.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#pragma clang fp contract(off)
+
+namespace zfft {
+
+template <int V>
+struct Log2 {
+	static constexpr int value = 1 + Log2<V / 2>::value;
+};
+template <>
+struct Log2<1> {
+	static constexpr int value = 0;
+};
+
+template <int LOG2N>
+struct Plan {
+	static_assert(LOG2N >= 5 && LOG2N <= 14, "nfft 32..16384");
+	static constexpr int N = 1 << LOG2N;
+	static constexpr int P = (LOG2N + 3) / 4; // passes
+	static constexpr int BASE = LOG2N / P, REM = LOG2N % P;
+	static constexpr int r(int p) { return BASE + (p < REM ? 1 : 0); } // stages in pass p
+	static constexpr int s(int p) // stages completed before pass p
+	{
+		int a = 0;
+		for (int i = 0; i < p; ++i)
+			a += r(i);
+		return a;
+	}
+	static constexpr int TF = N / 16;            // threads per frame: 16 complex values each
+	static constexpr int LDS_FLOAT2 = N + N / 16; // padded frame image in LDS
+	static constexpr int FRAMES_PER_BLOCK = (TF >= 256) ? 1 : 256 / TF;
+	static constexpr int THREADS = TF * FRAMES_PER_BLOCK;
+};
+
+// one 8-byte slot of padding per 16 keeps the stride-R reads of the late passes off a single bank
+__device__ __forceinline__ int lds_pad(int i) { return i + (i >> 4); }
+
+__device__ __forceinline__ float2 cmul(float2 w, float2 b)
+{
+	// oracle: tr = wr*br - wi*bi ; ti = wr*bi + wi*br   (each product and sum rounded separately)
+	return make_float2(w.x * b.x - w.y * b.y, w.x * b.y + w.y * b.x);
+}
+
+// r = log2(R) radix-2 DIT stages on R values held by one thread.
+//   in : a[m] = Y_s[j + m*J][k], m < R            (J = N / (2^s * R))
+//   out: a[c] = Y_{s+r}[j][k + c*2^s], c < R
+// ZU: a[R/2..R) are known zeros (zero-padded analysis frame): the first stage is then a copy.
+template <int R, bool INV, bool ZU>
+__device__ __forceinline__ void butterfly(float2 (&a)[R], int k, int log2L, int log2N,
+                                          const float2* __restrict__ tw)
+{
+	constexpr int r = Log2<R>::value;
+	float2 b[R];
+#pragma unroll
+	for (int q = 1; q <= r; ++q) {
+		const int half = R >> q;     // sub-sequences left after this stage
+		const int nc = 1 << (q - 1); // frequency groups entering this stage
+		float2 w[(R / 2) > 0 ? (R / 2) : 1];
+#pragma unroll
+		for (int c = 0; c < nc; ++c) {
+			if (q >= 2 && c >= (nc >> 1)) { // index + N/4  ==  multiply by -i (forward) / +i (inverse)
+				float2 w0 = w[c - (nc >> 1)];
+				w[c] = INV ? make_float2(-w0.y, w0.x) : make_float2(w0.y, -w0.x);
+			}
+			else {
+				int idx = (k << (log2N - log2L - q)) + (c << (log2N - q));
+				float2 t = tw[idx];
+				w[c] = INV ? make_float2(t.x, -t.y) : t;
+			}
+		}
+#pragma unroll
+		for (int c = 0; c < nc; ++c) {
+#pragma unroll
+			for (int m = 0; m < half; ++m) {
+				float2 A = a[c * 2 * half + m];
+				if (ZU && q == 1) {
+					b[c * half + m] = A; // A + w*0, A - w*0
+					b[(c + nc) * half + m] = A;
+				}
+				else {
+					float2 t = cmul(w[c], a[c * 2 * half + m + half]);
+					b[c * half + m] = make_float2(A.x + t.x, A.y + t.y);
+					b[(c + nc) * half + m] = make_float2(A.x - t.x, A.y - t.y);
+				}
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < R; ++i)
+			a[i] = b[i];
+	}
+}
+
+template <int LOG2N, int PASS, bool INV, bool ZU, bool HALF_OUT, class In, class Out>
+struct PassRunner {
+	using PL = Plan<LOG2N>;
+	static __device__ __forceinline__ void run(int tf, float2* __restrict__ lds,
+	                                           const float2* __restrict__ tw, In& in, Out& out, bool active)
+	{
+		constexpr int N = PL::N, TF = PL::TF;
+		constexpr int rr = PL::r(PASS), R = 1 << rr, NB = 16 / R;
+		constexpr int sL = PL::s(PASS);                    // log2 of sub-DFT size entering the pass
+		constexpr int log2J = LOG2N - sL - rr, J = 1 << log2J; // sub-sequences left after the pass
+		constexpr bool FIRST = PASS == 0, LAST = PASS == PL::P - 1;
+		constexpr bool ZUP = ZU && FIRST;
+
+		float2 v[NB][R];
+#pragma unroll
+		for (int i = 0; i < NB; ++i) {
+			const int b = tf + i * TF;
+			const int k = b >> log2J, j = b & (J - 1);
+#pragma unroll
+			for (int m = 0; m < R; ++m) {
+				if (ZUP && m >= R / 2) {
+					v[i][m] = make_float2(0.f, 0.f);
+				}
+				else if (FIRST) {
+					v[i][m] = active ? in(m * J + j) : make_float2(0.f, 0.f);
+				}
+				else {
+					v[i][m] = lds[lds_pad((k * R + m) * J + j)];
+				}
+			}
+		}
+		if (!FIRST)
+			__syncthreads(); // every thread has its inputs in registers: LDS may be overwritten
+#pragma unroll
+		for (int i = 0; i < NB; ++i) {
+			const int b = tf + i * TF;
+			const int k = b >> log2J;
+			butterfly<R, INV, ZUP>(v[i], k, sL, LOG2N, tw);
+#pragma unroll
+			for (int c = 0; c < R; ++c) {
+				const int idx = b + c * (N / R);
+				if (LAST) {
+					if (!HALF_OUT || c < R / 2) { // idx < N/2  <=>  c < R/2
+						if (active)
+							out(idx, v[i][c]);
+					}
+				}
+				else {
+					lds[lds_pad(idx)] = v[i][c];
+				}
+			}
+		}
+		if constexpr (!LAST) {
+			__syncthreads();
+			PassRunner<LOG2N, PASS + 1, INV, ZU, HALF_OUT, In, Out>::run(tf, lds, tw, in, out, active);
+		}
+	}
+};
+
+// One N-point transform by the TF threads that own a frame.  `lds` is that frame's padded LDS image
+// (Plan::LDS_FLOAT2 float2).  in(idx) -> float2 supplies x[idx] (only idx < N/2 is asked for when ZU);
+// out(idx, X) receives X[idx] (only idx < N/2 when HALF_OUT).  All threads of the block must call this
+// together (it contains block barriers); inactive frames pass active = false.
+template <int LOG2N, bool INV, bool ZU, bool HALF_OUT, class In, class Out>
+__device__ __forceinline__ void fft_frame(int tf, float2* __restrict__ lds, const float2* __restrict__ tw,
+                                          In& in, Out& out, bool active)
+{
+	PassRunner<LOG2N, 0, INV, ZU, HALF_OUT, In, Out>::run(tf, lds, tw, in, out, active);
+}
+
+// |z| exactly as the oracle's zo_cabs: (float)sqrt((double)re*re + (double)im*im)
+__device__ __forceinline__ float cabs_exact(float re, float im)
+{
+	double r = (double)re, i = (double)im;
+	return (float)sqrt(r * r + i * i);
+}
+
+} // namespace zfft

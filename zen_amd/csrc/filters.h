@@ -1,0 +1,38 @@
+// filters.h -- launch interface of the 2-D median / box kernels (median.hip, box.hip).
+//
+// A "matrix" is rows x cols floats, cols (frequency) contiguous.  The same kernels serve
+//   - the drop-in wrappers (MedianFilterGPU::filter / BoxFilterGPU::filter, libzen/mfilt.h:227-267,
+//     libzen/box.h:182-214): whole matrix in, whole matrix out;
+//   - the streaming engine (hpr.hip): the source is a ring of spectrogram rows (row r lives at
+//     r % ring_rows), only the rows that a chunk consumes are produced.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace zen_hip_impl {
+
+struct FilterArgs {
+	const float* src;       // row r of stream s at src[s*src_stream_stride + (r % ring_rows)*cols]
+	float* dst;             // output row i of stream s at dst[s*dst_stream_stride + i*cols]
+	long long src_stream_stride;
+	long long dst_stream_stride;
+	int n_streams;
+	int cols;
+	long long ring_rows;    // rows in the source ring (== rows of the matrix for the drop-in call)
+	long long first_row;    // absolute source row of output row 0
+	int n_out_rows;
+	long long clamp_lo;     // time direction: taps are clamped to [clamp_lo, clamp_hi] (replicate border)
+	long long clamp_hi;
+	int len;                // odd mask length
+	int direction;          // ZEN_HIP_TIME_* or ZEN_HIP_FREQUENCY
+	int causal_self;        // time direction: additionally clamp taps to <= the output's own row
+	                        // (the sliding matrix's last row is the consumed row; hps.h:265-268)
+	// box only -- the SSE path's element-wise wrappers (hps.cu:586-604), fused into the filter:
+	int sse_pre;            // tap value = 1 / (x*x)    (complex_abs_squared + reciprocal_functor(1))
+	int sse_post;           // result    = (1 / mean) * post_factor   (reciprocal_functor(l + 1))
+	float post_factor;
+};
+
+int launch_median(const FilterArgs& a, hipStream_t stream);
+int launch_box(const FilterArgs& a, hipStream_t stream);
+
+} // namespace zen_hip_impl

@@ -1,0 +1,775 @@
+// hpr.hip -- the streaming HPSS engine and the two-pass offline driver behind the C-ABI.
+//
+//   zen_hip_hpr_*  : HPR<Backend::GPU> (libzen/hps.h:152-322, libzen/hps.cu:429-652) as a chunked
+//                    streaming engine.  Per chunk of M hops (x n_streams):
+//                      1 launch  stft_kernel      frames -> spectrum ring + magnitude ring
+//                      1 launch  median/box freq  magnitude ring -> P   (consumed rows only)
+//                      0-1 launch median/box time magnitude ring -> H   (identity when causal, Q1/Q2)
+//                      1 launch  istft_kernel     masks, inverse FFT, *COLA -> Y
+//                      1 launch  finalize_kernel  per requested output: overlap-add + copy-out
+//                    against ~21-35 launches PER HOP in the reference.
+//   zen_hip_hpri_* : HPRIOffline<GPU>::process (libzen/hps.cu:128-221): pass 1 (hop_h; H, P, R) ->
+//                    P+R shifted by lag_h*hop_h -> pass 2 (hop_p; P), all resident in HBM.
+//
+// State between calls (what the reference keeps in HPR<B> members): previous hop of input (`input`),
+// the last stft_width-1 spectra/magnitudes (`sliding_stft`, recomputed `s_mag`), and per output the
+// second half of the last synthesised frame (`*_out[hop:]`).  Rows live in a ring addressed by an
+// absolute frame counter, so nothing is ever shifted (the reference moves (W-1)*nfft complex per hop).
+#include "common.h"
+#include "filters.h"
+#include "stft.h"
+
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <utility>
+#include <vector>
+
+using namespace zen_hip_impl;
+
+struct zen_hip_hpr {
+	float fs;
+	size_t hop, nwin, nfft;
+	float beta;
+	int l_harm, l_perc, lag;
+	size_t W;
+	int causality, log2n, mt, mf;
+	float cola;
+	bool out_h, out_p, out_r, use_sse, soft;
+	size_t n_streams, max_hops;
+	long long ring_rows;
+	hipStream_t stream;
+
+	float* d_window = nullptr;
+	float2* d_tw = nullptr;
+	float* d_tail[2] = {nullptr, nullptr};
+	int tail_sel = 0;
+	float2* d_S = nullptr;
+	float* d_mag = nullptr;
+	float* d_H = nullptr;
+	float* d_P = nullptr;
+	float* d_Y[3] = {nullptr, nullptr, nullptr};     // 0 percussive, 1 harmonic, 2 residual
+	float* d_carry[3] = {nullptr, nullptr, nullptr};
+	long long abs_frame = 0;
+	size_t last_frames = 0;
+
+	bool prof = false;
+	double prof_ms = 0;
+	unsigned long long prof_launches = 0, prof_elements = 0;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pending;
+};
+
+namespace {
+
+int which_index(unsigned which)
+{
+	switch (which) {
+	case ZEN_HIP_OUTPUT_PERCUSSIVE: return 0;
+	case ZEN_HIP_OUTPUT_HARMONIC: return 1;
+	case ZEN_HIP_OUTPUT_RESIDUAL: return 2;
+	default: return -1;
+	}
+}
+
+bool output_computed(const zen_hip_hpr* e, int o)
+{
+	if (o == 0)
+		return e->out_p;
+	if (o == 1)
+		return e->out_h;
+	// hps.cu:562 : residual only with hard masks; the SSE path has no residual branch (hps.cu:582-652)
+	return e->out_r && !e->soft && !e->use_sse;
+}
+
+void free_all(zen_hip_hpr* e)
+{
+	(void)hipFree(e->d_window);
+	(void)hipFree(e->d_tw);
+	(void)hipFree(e->d_tail[0]);
+	(void)hipFree(e->d_tail[1]);
+	(void)hipFree(e->d_S);
+	(void)hipFree(e->d_mag);
+	(void)hipFree(e->d_H);
+	(void)hipFree(e->d_P);
+	for (int o = 0; o < 3; ++o) {
+		(void)hipFree(e->d_Y[o]);
+		(void)hipFree(e->d_carry[o]);
+	}
+	for (auto& p : e->prof_pending) {
+		(void)hipEventDestroy(p.first);
+		(void)hipEventDestroy(p.second);
+	}
+}
+
+int reset_state(zen_hip_hpr* e)
+{
+	const size_t S = e->n_streams;
+	ZH_HIP(hipMemsetAsync(e->d_tail[0], 0, sizeof(float) * S * e->hop, e->stream));
+	ZH_HIP(hipMemsetAsync(e->d_tail[1], 0, sizeof(float) * S * e->hop, e->stream));
+	ZH_HIP(hipMemsetAsync(e->d_S, 0, sizeof(float2) * S * e->ring_rows * e->nfft, e->stream));
+	ZH_HIP(hipMemsetAsync(e->d_mag, 0, sizeof(float) * S * e->ring_rows * e->nfft, e->stream));
+	for (int o = 0; o < 3; ++o) {
+		ZH_HIP(hipMemsetAsync(e->d_Y[o], 0, sizeof(float) * S * e->max_hops * e->nwin, e->stream));
+		ZH_HIP(hipMemsetAsync(e->d_carry[o], 0, sizeof(float) * S * e->hop, e->stream));
+	}
+	e->tail_sel = 0;
+	e->abs_frame = (long long)e->W - 1; // rows 0..W-2 are the all-zero history of a fresh stream
+	e->last_frames = 0;
+	return ZEN_HIP_OK;
+}
+
+int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
+{
+	const size_t S = e->n_streams, N = e->nfft;
+	// ---- analysis
+	StftArgs sa;
+	memset(&sa, 0, sizeof(sa));
+	sa.in = in;
+	sa.in_stride = (long long)in_stride;
+	sa.tail_prev = e->d_tail[e->tail_sel];
+	sa.tail_next = e->d_tail[e->tail_sel ^ 1];
+	sa.window = e->d_window;
+	sa.tw = e->d_tw;
+	sa.S = e->d_S;
+	sa.mag = e->d_mag;
+	sa.ring_rows = e->ring_rows;
+	sa.row0 = e->abs_frame;
+	sa.n_frames = (int)M;
+	sa.hop = (int)e->hop;
+	sa.n_streams = (int)S;
+	sa.prev_frames = (int)e->last_frames;
+	for (int o = 0; o < 3; ++o) {
+		sa.carry[o] = output_computed(e, o) ? e->d_carry[o] : nullptr;
+		sa.Y[o] = e->d_Y[o];
+	}
+	sa.y_stream_stride = (long long)(e->max_hops * e->nwin);
+	ZH_TRY(launch_stft(e->log2n, sa, e->stream));
+	e->tail_sel ^= 1;
+
+	// ---- harmonic / percussive estimates of the consumed rows (row W-lag of the sliding matrix)
+	const long long crow0 = e->abs_frame - (e->lag - 1);
+	FilterArgs fa;
+	memset(&fa, 0, sizeof(fa));
+	fa.src = e->d_mag;
+	fa.src_stream_stride = e->ring_rows * (long long)N;
+	fa.dst_stream_stride = (long long)(e->max_hops * N);
+	fa.n_streams = (int)S;
+	fa.cols = (int)N;
+	fa.ring_rows = e->ring_rows;
+	fa.first_row = crow0;
+	fa.n_out_rows = (int)M;
+	fa.clamp_lo = 0;
+	fa.clamp_hi = LLONG_MAX / 4;
+
+	FilterArgs ff = fa; // frequency direction -> P   (hps.cu:496 / :597)
+	ff.dst = e->d_P;
+	ff.len = e->mf;
+	ff.direction = ZEN_HIP_FREQUENCY;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	const bool prof = e->prof && !e->use_sse;
+	if (prof) {
+		ZH_HIP(hipEventCreate(&ev0));
+		ZH_HIP(hipEventCreate(&ev1));
+		ZH_HIP(hipEventRecord(ev0, e->stream));
+	}
+	if (e->use_sse) {
+		ff.sse_pre = 1;
+		ff.sse_post = 1;
+		ff.post_factor = (float)e->l_perc + 1.0F; // hps.cu:599-601
+		ZH_TRY(launch_box(ff, e->stream));
+	}
+	else {
+		ZH_TRY(launch_median(ff, e->stream));
+	}
+	if (prof) {
+		ZH_HIP(hipEventRecord(ev1, e->stream));
+		e->prof_pending.emplace_back(ev0, ev1);
+		e->prof_launches += 1;
+		e->prof_elements += (unsigned long long)(M * N * S);
+	}
+
+	bool h_is_ring = false; // time direction -> H   (hps.cu:495 / :596)
+	FilterArgs ft = fa;
+	ft.dst = e->d_H;
+	ft.len = e->mt;
+	ft.direction = e->causality;
+	if (e->use_sse) {
+		ft.sse_pre = 1;
+		ft.sse_post = 1;
+		ft.post_factor = (float)e->l_harm + 1.0F; // hps.cu:602-604
+		ft.causal_self = (e->causality == ZEN_HIP_TIME_CAUSAL);
+		ZH_TRY(launch_box(ft, e->stream));
+	}
+	else if (e->causality == ZEN_HIP_TIME_CAUSAL || e->mt == 1) {
+		// Causal: the consumed row is the last row of the sliding matrix; the centred mask's upper half
+		// replicates it, so mid+1 of 2*mid+1 taps equal the row itself and the median is the identity
+		// (SURVEY Q1).  mt == 1: a one-tap median.  No launch.
+		h_is_ring = true;
+	}
+	else {
+		ZH_TRY(launch_median(ft, e->stream));
+	}
+
+	// ---- masks, inverse FFT, *COLA
+	IstftArgs ia;
+	memset(&ia, 0, sizeof(ia));
+	ia.S = e->d_S;
+	ia.ring_rows = e->ring_rows;
+	ia.crow0 = crow0;
+	ia.H = h_is_ring ? e->d_mag : e->d_H;
+	ia.h_stream_stride = (long long)(e->max_hops * N);
+	ia.h_is_ring = h_is_ring ? 1 : 0;
+	ia.P = e->d_P;
+	ia.p_stream_stride = (long long)(e->max_hops * N);
+	ia.tw = e->d_tw;
+	ia.y_stream_stride = (long long)(e->max_hops * e->nwin);
+	ia.n_frames = (int)M;
+	ia.n_streams = (int)S;
+	ia.n_out = 0;
+	for (int o = 0; o < 3; ++o) {
+		if (output_computed(e, o)) {
+			ia.Y[ia.n_out] = e->d_Y[o];
+			ia.out_id[ia.n_out] = o;
+			++ia.n_out;
+		}
+	}
+	ia.beta = e->beta;
+	ia.beta_h = e->beta - FLT_EPSILON; // hps.cu:540 hard_mask_functor(beta - Eps)
+	ia.soft = e->soft ? 1 : 0;
+	ia.power = (int)e->beta; // hps.h:117-121 : soft_mask_functor(int _power) truncates beta
+	ia.sse = e->use_sse ? 1 : 0;
+	ia.out_h = e->out_h ? 1 : 0;
+	ia.out_p = e->out_p ? 1 : 0;
+	ia.cola = e->cola;
+	ZH_TRY(launch_istft(e->log2n, ia, e->stream));
+
+	e->abs_frame += (long long)M;
+	e->last_frames = M;
+	return ZEN_HIP_OK;
+}
+
+int finalize_output(zen_hip_hpr* e, int o, float* out, size_t out_stride, size_t M)
+{
+	if (!output_computed(e, o)) {
+		// the reference's accumulator for a disabled output stays all zero (hps.test.cu:321-343)
+		ZH_HIP(hipMemset2DAsync(out, sizeof(float) * out_stride, 0, sizeof(float) * M * e->hop, e->n_streams,
+		                        e->stream));
+		return ZEN_HIP_OK;
+	}
+	FinalizeArgs fa;
+	fa.Y = e->d_Y[o];
+	fa.carry = e->d_carry[o];
+	fa.out = out;
+	fa.y_stream_stride = (long long)(e->max_hops * e->nwin);
+	fa.out_stride = (long long)out_stride;
+	fa.n_frames = (int)M;
+	fa.hop = (int)e->hop;
+	fa.n_streams = (int)e->n_streams;
+	return launch_finalize(fa, e->stream);
+}
+
+} // namespace
+
+extern "C" {
+
+int zen_hip_hpr_create(float fs, size_t hop, float beta, unsigned output_flags, int causality,
+                       int copy_bord, size_t n_streams, size_t max_hops_per_chunk, zen_hip_hpr_t* h)
+{
+	(void)copy_bord; // replicate border always (the reference CPU backend ignores it too, mfilt.h:289)
+	if (!h)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpr_create: null handle");
+	if (causality != ZEN_HIP_TIME_CAUSAL && causality != ZEN_HIP_TIME_ANTICAUSAL)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpr_create: causality must be TIME_CAUSAL or TIME_ANTICAUSAL");
+	if (hop == 0 || n_streams == 0 || !(fs > 0))
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpr_create: hop, n_streams and fs must be positive");
+	const size_t nwin = 2 * hop, nfft = 4 * hop; // hps.h:224-225
+	if (!is_pow2(nfft))
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpr_create: nfft = 4*hop = %zu must be a power of two (fftw.h:59)", nfft);
+	if (nfft < 32 || nfft > 16384)
+		ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "hpr_create: nfft %zu outside 32..16384", nfft);
+	// hps.h:227-230, evaluated with the reference's mixed float/double arithmetic
+	const int l_harm = (int)roundf((float)(0.2 / (double)((float)(nfft - hop) / fs)));
+	const int l_perc = (int)roundf(500.0F / (fs / (float)nfft));
+	if (l_harm < 1 || l_perc < 1)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpr_create: degenerate filter lengths l_harm %d l_perc %d", l_harm, l_perc);
+	const size_t W = (size_t)(2 * l_harm);
+	int mt = 0, mf = 0; // the four filter objects of hps.h:246-258 may throw
+	ZH_TRY(check_filter_len((int)W, (int)nfft, l_harm, causality, &mt));
+	ZH_TRY(check_filter_len((int)W, (int)nfft, l_perc, ZEN_HIP_FREQUENCY, &mf));
+	if (mt > 255 || mf > 255)
+		ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "hpr_create: mask lengths %d/%d exceed 255", mt, mf);
+
+	zen_hip_hpr* e = new zen_hip_hpr;
+	e->fs = fs;
+	e->hop = hop;
+	e->nwin = nwin;
+	e->nfft = nfft;
+	e->beta = beta;
+	e->l_harm = l_harm;
+	e->l_perc = l_perc;
+	e->lag = (causality == ZEN_HIP_TIME_CAUSAL) ? 1 : l_harm; // hps.h:228, :265-268
+	e->W = W;
+	e->causality = causality;
+	e->log2n = ilog2(nfft);
+	e->mt = mt;
+	e->mf = mf;
+	e->out_h = (output_flags & ZEN_HIP_OUTPUT_HARMONIC) != 0; // hps.h:276-284
+	e->out_p = (output_flags & ZEN_HIP_OUTPUT_PERCUSSIVE) != 0;
+	e->out_r = (output_flags & ZEN_HIP_OUTPUT_RESIDUAL) != 0;
+	e->use_sse = false;
+	e->soft = false;
+	e->n_streams = n_streams;
+	if (max_hops_per_chunk == 0) {
+		size_t m = ((size_t)1 << 26) / (n_streams * nfft);
+		max_hops_per_chunk = m < 1 ? 1 : (m > 65536 ? 65536 : m);
+	}
+	e->max_hops = max_hops_per_chunk;
+	e->ring_rows = (long long)(e->max_hops + W - 1);
+	e->stream = nullptr;
+
+	// host tables, shared bit-for-bit with the oracle
+	std::vector<float> win(nwin), tw(nfft);
+	make_window_sqrt_hann(win.data(), nwin); // hps.h:232
+	make_twiddles(tw.data(), nfft);
+	float cola = 0.0f; // hps.h:270-274
+	for (size_t i = 0; i < nwin; ++i)
+		cola += win[i] * win[i];
+	e->cola = (float)nfft / cola;
+
+	const size_t S = n_streams, MH = e->max_hops;
+	bool ok = hipMalloc((void**)&e->d_window, sizeof(float) * nwin) == hipSuccess
+	          && hipMalloc((void**)&e->d_tw, sizeof(float) * nfft) == hipSuccess
+	          && hipMalloc((void**)&e->d_tail[0], sizeof(float) * S * hop) == hipSuccess
+	          && hipMalloc((void**)&e->d_tail[1], sizeof(float) * S * hop) == hipSuccess
+	          && hipMalloc((void**)&e->d_S, sizeof(float2) * S * e->ring_rows * nfft) == hipSuccess
+	          && hipMalloc((void**)&e->d_mag, sizeof(float) * S * e->ring_rows * nfft) == hipSuccess
+	          && hipMalloc((void**)&e->d_H, sizeof(float) * S * MH * nfft) == hipSuccess
+	          && hipMalloc((void**)&e->d_P, sizeof(float) * S * MH * nfft) == hipSuccess;
+	for (int o = 0; o < 3 && ok; ++o)
+		ok = hipMalloc((void**)&e->d_Y[o], sizeof(float) * S * MH * nwin) == hipSuccess
+		     && hipMalloc((void**)&e->d_carry[o], sizeof(float) * S * hop) == hipSuccess;
+	if (ok)
+		ok = hipMemcpy(e->d_window, win.data(), sizeof(float) * nwin, hipMemcpyHostToDevice) == hipSuccess
+		     && hipMemcpy(e->d_tw, tw.data(), sizeof(float) * nfft, hipMemcpyHostToDevice) == hipSuccess;
+	if (!ok) {
+		free_all(e);
+		delete e;
+		(void)hipGetLastError();
+		ZH_FAIL(ZEN_HIP_E_HIP, "hpr_create: device allocation failed (nfft %zu, streams %zu, chunk %zu hops)",
+		        nfft, n_streams, max_hops_per_chunk);
+	}
+	int rc = reset_state(e);
+	if (rc != ZEN_HIP_OK) {
+		free_all(e);
+		delete e;
+		return rc;
+	}
+	*h = e;
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpr_destroy(zen_hip_hpr_t h)
+{
+	if (h) {
+		(void)hipStreamSynchronize(h->stream);
+		free_all(h);
+		delete h;
+	}
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpr_get_params(zen_hip_hpr_t h, zen_hip_hpr_params* p)
+{
+	if (!h || !p)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpr_get_params: null argument");
+	p->hop = h->hop;
+	p->nwin = h->nwin;
+	p->nfft = h->nfft;
+	p->stft_width = h->W;
+	p->l_harm = h->l_harm;
+	p->l_perc = h->l_perc;
+	p->lag = h->lag;
+	p->time_len = h->mt;
+	p->freq_len = h->mf;
+	p->cola_factor = h->cola;
+	p->n_streams = h->n_streams;
+	p->max_hops_per_chunk = h->max_hops;
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpr_set_stream(zen_hip_hpr_t h, void* stream)
+{
+	if (!h)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpr_set_stream: null handle");
+	ZH_HIP(hipStreamSynchronize(h->stream));
+	h->stream = (hipStream_t)stream;
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpr_use_sse_filter(zen_hip_hpr_t h)
+{
+	if (!h)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null handle");
+	h->use_sse = true;
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpr_use_soft_mask(zen_hip_hpr_t h)
+{
+	if (!h)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null handle");
+	h->soft = true;
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpr_reset_buffers(zen_hip_hpr_t h)
+{
+	if (!h)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null handle");
+	return reset_state(h);
+}
+
+int zen_hip_hpr_process(zen_hip_hpr_t h, const float* in_dev, size_t n_hops, size_t in_stride,
+                        float* out_harm_dev, float* out_perc_dev, float* out_resid_dev, size_t out_stride)
+{
+	if (!h || !in_dev)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpr_process: null argument");
+	float* outs[3] = {out_perc_dev, out_harm_dev, out_resid_dev};
+	for (size_t off = 0; off < n_hops; off += h->max_hops) {
+		const size_t M = (n_hops - off < h->max_hops) ? n_hops - off : h->max_hops;
+		ZH_TRY(run_chunk(h, in_dev + off * h->hop, in_stride, M));
+		for (int o = 0; o < 3; ++o)
+			if (outs[o])
+				ZH_TRY(finalize_output(h, o, outs[o] + off * h->hop, out_stride, M));
+	}
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpr_process_next_hop(zen_hip_hpr_t h, const float* in_dev)
+{
+	if (!h || !in_dev)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpr_process_next_hop: null argument");
+	return run_chunk(h, in_dev, h->hop, 1);
+}
+
+int zen_hip_hpr_copy_output_async(zen_hip_hpr_t h, unsigned which, float* out_dev)
+{
+	if (!h || !out_dev)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpr_copy_output: null argument");
+	const int o = which_index(which);
+	if (o < 0)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpr_copy_output: `which` must be exactly one ZEN_HIP_OUTPUT_* flag");
+	const size_t M = h->last_frames ? h->last_frames : 1; // before any hop: the zero accumulator
+	if (h->last_frames == 0) {
+		ZH_HIP(hipMemsetAsync(out_dev, 0, sizeof(float) * h->hop * h->n_streams, h->stream));
+		return ZEN_HIP_OK;
+	}
+	return finalize_output(h, o, out_dev, M * h->hop, M);
+}
+
+int zen_hip_hpr_copy_output(zen_hip_hpr_t h, unsigned which, float* out_dev)
+{
+	ZH_TRY(zen_hip_hpr_copy_output_async(h, which, out_dev));
+	ZH_HIP(hipStreamSynchronize(h->stream));
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpr_profile(zen_hip_hpr_t h, int enable)
+{
+	if (!h)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null handle");
+	h->prof = enable != 0;
+	if (enable) {
+		ZH_HIP(hipStreamSynchronize(h->stream));
+		for (auto& p : h->prof_pending) {
+			(void)hipEventDestroy(p.first);
+			(void)hipEventDestroy(p.second);
+		}
+		h->prof_pending.clear();
+		h->prof_ms = 0;
+		h->prof_launches = 0;
+		h->prof_elements = 0;
+	}
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpr_profile_get(zen_hip_hpr_t h, double* median_ms, unsigned long long* median_launches,
+                            unsigned long long* median_elements)
+{
+	if (!h)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null handle");
+	ZH_HIP(hipStreamSynchronize(h->stream));
+	for (auto& p : h->prof_pending) {
+		float ms = 0;
+		ZH_HIP(hipEventElapsedTime(&ms, p.first, p.second));
+		h->prof_ms += ms;
+		(void)hipEventDestroy(p.first);
+		(void)hipEventDestroy(p.second);
+	}
+	h->prof_pending.clear();
+	if (median_ms)
+		*median_ms = h->prof_ms;
+	if (median_launches)
+		*median_launches = h->prof_launches;
+	if (median_elements)
+		*median_elements = h->prof_elements;
+	return ZEN_HIP_OK;
+}
+
+} // extern "C"
+
+// =================================================================================================
+// HPRIOffline<GPU>
+// =================================================================================================
+struct zen_hip_hpri {
+	zen_hip_hpr* eh = nullptr; // p_impl_h : hop_h, H+P+R, anticausal (hps.cu:38-43)
+	zen_hip_hpr* ep = nullptr; // p_impl_p : hop_p, P only, anticausal (hps.cu:45-48)
+	size_t hop_h, hop_p, n_clips;
+	hipStream_t stream = nullptr;
+	// scratch, grown on demand
+	size_t cap1 = 0, cap2 = 0;
+	float *a1 = nullptr, *H1 = nullptr, *P1 = nullptr, *R1 = nullptr, *in2 = nullptr, *P2 = nullptr;
+	float *stage_in = nullptr, *stage_out[3] = {nullptr, nullptr, nullptr};
+	size_t stage_cap = 0;
+};
+
+namespace {
+
+// hps.cu:109-126 hpss_chunk_padder: float ceil of a float quotient, plus `lag` chunks
+int chunk_padder(size_t audio_size, size_t hop, size_t lag, size_t* padded)
+{
+	int n = (int)(ceilf((float)audio_size / (float)hop));
+	n += (int)lag;
+	*padded = (size_t)n * hop;
+	return n;
+}
+
+__global__ __launch_bounds__(256) void pad_clips_kernel(const float* __restrict__ in, long long in_stride,
+                                                        size_t n, float* __restrict__ out, size_t padded)
+{
+	const float* src = in + (long long)blockIdx.y * in_stride;
+	float* dst = out + (size_t)blockIdx.y * padded;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < padded; i += (size_t)gridDim.x * blockDim.x)
+		dst[i] = i < n ? src[i] : 0.0F; // audio.resize(size + pad, 0.0F)  hps.cu:123
+}
+
+// hps.cu:153-160 (xp1 + xr1), :171-176 (shift left by lag_h*hop_h in place; the tail keeps its old
+// contents) and :186-190 (pass 2 reads `intermediate` up to n2*hop_p, past size() -- SURVEY Q9).
+__global__ __launch_bounds__(256) void intermediate_kernel(const float* __restrict__ P1, const float* __restrict__ R1,
+                                                           size_t padded1, size_t sh1, float* __restrict__ in2,
+                                                           size_t padded2)
+{
+	const float* p = P1 + (size_t)blockIdx.y * padded1;
+	const float* r = R1 + (size_t)blockIdx.y * padded1;
+	float* dst = in2 + (size_t)blockIdx.y * padded2;
+	for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < padded2; j += (size_t)gridDim.x * blockDim.x) {
+		float v = 0.0F; // beyond the reference's allocation (undefined there)
+		if (j < padded1) {
+			const size_t q = (j < padded1 - sh1) ? j + sh1 : j;
+			v = p[q] + r[q]; // sum_vectors_functor hps.h:142-150
+		}
+		dst[j] = v;
+	}
+}
+
+// hps.cu:171-178, :209-217 : drop the lag*hop delay, truncate to the clip length
+__global__ __launch_bounds__(256) void unshift_kernel(const float* __restrict__ full, size_t padded, size_t sh,
+                                                      float* __restrict__ out, long long out_stride, size_t n)
+{
+	const float* src = full + (size_t)blockIdx.y * padded;
+	float* dst = out + (long long)blockIdx.y * out_stride;
+	for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
+		float v = 0.0F;
+		if (j < padded)
+			v = (j < padded - sh) ? src[j + sh] : src[j];
+		dst[j] = v;
+	}
+}
+
+unsigned grid_for(size_t n)
+{
+	size_t b = (n + 255) / 256;
+	return (unsigned)(b > 4096 ? 4096 : (b ? b : 1));
+}
+
+void hpri_free_scratch(zen_hip_hpri* o)
+{
+	(void)hipFree(o->a1);
+	(void)hipFree(o->H1);
+	(void)hipFree(o->P1);
+	(void)hipFree(o->R1);
+	(void)hipFree(o->in2);
+	(void)hipFree(o->P2);
+	o->a1 = o->H1 = o->P1 = o->R1 = o->in2 = o->P2 = nullptr;
+	o->cap1 = o->cap2 = 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int zen_hip_hpri_create(float fs, size_t hop_h, size_t hop_p, float beta_h, float beta_p, int nocopybord,
+                        size_t n_clips, zen_hip_hpri_t* h)
+{
+	if (!h || n_clips == 0)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_create: null handle or zero clips");
+	if (hop_p == 0 || hop_h % hop_p != 0) // hps.cu:33-36
+		ZH_FAIL(ZEN_HIP_E_HOPS_NOT_DIVISIBLE, "hop_h and hop_p should be evenly divisible");
+	zen_hip_hpri* o = new zen_hip_hpri;
+	o->hop_h = hop_h;
+	o->hop_p = hop_p;
+	o->n_clips = n_clips;
+	int rc = zen_hip_hpr_create(fs, hop_h, beta_h,
+	                            ZEN_HIP_OUTPUT_HARMONIC | ZEN_HIP_OUTPUT_PERCUSSIVE | ZEN_HIP_OUTPUT_RESIDUAL,
+	                            ZEN_HIP_TIME_ANTICAUSAL, !nocopybord, n_clips, 0, &o->eh);
+	if (rc == ZEN_HIP_OK)
+		rc = zen_hip_hpr_create(fs, hop_p, beta_p, ZEN_HIP_OUTPUT_PERCUSSIVE, ZEN_HIP_TIME_ANTICAUSAL,
+		                        !nocopybord, n_clips, 0, &o->ep);
+	if (rc != ZEN_HIP_OK) {
+		zen_hip_hpr_destroy(o->eh);
+		delete o;
+		return rc;
+	}
+	*h = o;
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpri_destroy(zen_hip_hpri_t h)
+{
+	if (h) {
+		zen_hip_hpr_destroy(h->eh);
+		zen_hip_hpr_destroy(h->ep);
+		hpri_free_scratch(h);
+		(void)hipFree(h->stage_in);
+		for (int i = 0; i < 3; ++i)
+			(void)hipFree(h->stage_out[i]);
+		delete h;
+	}
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpri_set_stream(zen_hip_hpri_t h, void* stream)
+{
+	if (!h)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null handle");
+	ZH_TRY(zen_hip_hpr_set_stream(h->eh, stream));
+	ZH_TRY(zen_hip_hpr_set_stream(h->ep, stream));
+	h->stream = (hipStream_t)stream;
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpri_use_sse_filter(zen_hip_hpri_t h)
+{
+	if (!h)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null handle");
+	zen_hip_hpr_use_sse_filter(h->eh);
+	zen_hip_hpr_use_sse_filter(h->ep);
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpri_use_soft_mask(zen_hip_hpri_t h)
+{
+	if (!h)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null handle");
+	zen_hip_hpr_use_soft_mask(h->eh);
+	zen_hip_hpr_use_soft_mask(h->ep);
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpri_hop_counts(zen_hip_hpri_t h, size_t n, size_t* n_hops_h, size_t* n_hops_p)
+{
+	if (!h)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null handle");
+	size_t p1, p2;
+	const int n1 = chunk_padder(n, h->hop_h, (size_t)h->eh->lag, &p1);
+	const int n2 = chunk_padder(n, h->hop_p, (size_t)h->ep->lag, &p2);
+	if (n_hops_h)
+		*n_hops_h = (size_t)n1;
+	if (n_hops_p)
+		*n_hops_p = (size_t)n2;
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpri_process_device(zen_hip_hpri_t h, const float* audio_dev, size_t n, size_t stride,
+                                float* harm_dev, float* perc_dev, float* resid_dev, size_t out_stride)
+{
+	if (!h || !audio_dev || n == 0)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_process: null argument or empty clip");
+	const size_t C = h->n_clips;
+	size_t padded1, padded2;
+	const int n1 = chunk_padder(n, h->hop_h, (size_t)h->eh->lag, &padded1); // hps.cu:133-134
+	const int n2 = chunk_padder(n, h->hop_p, (size_t)h->ep->lag, &padded2); // hps.cu:180-181
+	if (n1 <= 0 || n2 <= 0)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_process: clip too short");
+	if (padded1 > h->cap1 || padded2 > h->cap2) {
+		ZH_HIP(hipStreamSynchronize(h->stream));
+		hpri_free_scratch(h);
+		ZH_HIP(hipMalloc((void**)&h->a1, sizeof(float) * C * padded1));
+		ZH_HIP(hipMalloc((void**)&h->H1, sizeof(float) * C * padded1));
+		ZH_HIP(hipMalloc((void**)&h->P1, sizeof(float) * C * padded1));
+		ZH_HIP(hipMalloc((void**)&h->R1, sizeof(float) * C * padded1));
+		ZH_HIP(hipMalloc((void**)&h->in2, sizeof(float) * C * padded2));
+		ZH_HIP(hipMalloc((void**)&h->P2, sizeof(float) * C * padded2));
+		h->cap1 = padded1;
+		h->cap2 = padded2;
+	}
+	ZH_TRY(zen_hip_hpr_reset_buffers(h->eh)); // each process() call is a fresh pair of HPR objects' state
+	ZH_TRY(zen_hip_hpr_reset_buffers(h->ep));
+
+	hipLaunchKernelGGL(pad_clips_kernel, dim3(grid_for(padded1), (unsigned)C), dim3(256), 0, h->stream, audio_dev,
+	                   (long long)stride, n, h->a1, padded1);
+	ZH_HIP(hipGetLastError());
+	// pass 1: large hop, harmonic + percussive + residual (hps.cu:142-167)
+	ZH_TRY(zen_hip_hpr_process(h->eh, h->a1, (size_t)n1, padded1, h->H1, h->P1, h->R1, padded1));
+	const size_t sh1 = (size_t)h->eh->lag * h->hop_h;
+	hipLaunchKernelGGL(intermediate_kernel, dim3(grid_for(padded2), (unsigned)C), dim3(256), 0, h->stream, h->P1,
+	                   h->R1, padded1, sh1, h->in2, padded2);
+	ZH_HIP(hipGetLastError());
+	// pass 2: small hop on xp1 + xr1, percussive only (hps.cu:185-205)
+	ZH_TRY(zen_hip_hpr_process(h->ep, h->in2, (size_t)n2, padded2, nullptr, h->P2, nullptr, padded2));
+	const size_t sh2 = (size_t)h->ep->lag * h->hop_p;
+	if (harm_dev) {
+		hipLaunchKernelGGL(unshift_kernel, dim3(grid_for(n), (unsigned)C), dim3(256), 0, h->stream, h->H1, padded1,
+		                   sh1, harm_dev, (long long)out_stride, n);
+		ZH_HIP(hipGetLastError());
+	}
+	if (perc_dev) {
+		hipLaunchKernelGGL(unshift_kernel, dim3(grid_for(n), (unsigned)C), dim3(256), 0, h->stream, h->P2, padded2,
+		                   sh2, perc_dev, (long long)out_stride, n);
+		ZH_HIP(hipGetLastError());
+	}
+	if (resid_dev) // pass 2's residual_out is never written: zeros (hps.cu:45-48, :200-204)
+		ZH_HIP(hipMemset2DAsync(resid_dev, sizeof(float) * out_stride, 0, sizeof(float) * n, C, h->stream));
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpri_process(zen_hip_hpri_t h, const float* audio_host, size_t n, float* harm_host,
+                         float* perc_host, float* resid_host)
+{
+	if (!h || !audio_host || n == 0)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_process: null argument or empty clip");
+	if (h->n_clips != 1)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_process(host) needs a handle created with n_clips == 1");
+	if (n > h->stage_cap) {
+		ZH_HIP(hipStreamSynchronize(h->stream));
+		(void)hipFree(h->stage_in);
+		for (int i = 0; i < 3; ++i)
+			(void)hipFree(h->stage_out[i]);
+		ZH_HIP(hipMalloc((void**)&h->stage_in, sizeof(float) * n));
+		for (int i = 0; i < 3; ++i)
+			ZH_HIP(hipMalloc((void**)&h->stage_out[i], sizeof(float) * n));
+		h->stage_cap = n;
+	}
+	ZH_HIP(hipMemcpyAsync(h->stage_in, audio_host, sizeof(float) * n, hipMemcpyHostToDevice, h->stream));
+	ZH_TRY(zen_hip_hpri_process_device(h, h->stage_in, n, n, harm_host ? h->stage_out[0] : nullptr,
+	                                   perc_host ? h->stage_out[1] : nullptr,
+	                                   resid_host ? h->stage_out[2] : nullptr, n));
+	float* hosts[3] = {harm_host, perc_host, resid_host};
+	for (int i = 0; i < 3; ++i)
+		if (hosts[i])
+			ZH_HIP(hipMemcpyAsync(hosts[i], h->stage_out[i], sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
+	ZH_HIP(hipStreamSynchronize(h->stream));
+	return ZEN_HIP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,72 @@
+// stft.h -- launch interface of the FFT-based kernels (stft.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace zen_hip_impl {
+
+// Analysis: hps.cu:452-472 (input shift/append, window, zero-pad, forward FFT, append to the STFT) and
+// the new row of hps.cu:492-493 (magnitude).  One extra block per stream does the per-chunk
+// housekeeping: input tail and overlap-add carries.
+struct StftArgs {
+	const float* in;        // stream s, hop i: in[s*in_stride + i*hop ...]
+	long long in_stride;
+	const float* tail_prev; // [n_streams][hop] : the hop before this chunk (zeros at stream start)
+	float* tail_next;       // [n_streams][hop] : receives the last hop of this chunk
+	const float* window;    // nwin
+	const float2* tw;       // nfft/2
+	float2* S;              // ring: [n_streams][ring_rows][nfft]
+	float* mag;             // ring: [n_streams][ring_rows][nfft]
+	long long ring_rows;
+	long long row0;         // absolute row of the chunk's first frame
+	int n_frames;
+	int hop;
+	int n_streams;
+	// overlap-add carry of the previous chunk: carry[o] = second half of its last frame
+	int prev_frames;
+	float* carry[3];        // [n_streams][hop]
+	const float* Y[3];      // [n_streams][max_frames][nwin]
+	long long y_stream_stride;
+};
+
+// Synthesis: masks (hps.h:100-140), apply (hps.h:58-66), inverse FFT, *COLA (hps.h:68-80) for the
+// consumed rows of a chunk; writes Y[o][frame][0..nwin) = Re(ifft(S*mask))*COLA.
+struct IstftArgs {
+	const float2* S;
+	long long ring_rows;
+	long long crow0;        // absolute row of the first consumed frame
+	const float* H;         // harmonic estimate of the consumed rows
+	long long h_stream_stride;
+	int h_is_ring;          // 1: H is the magnitude ring itself (causal median)
+	const float* P;         // [n_streams][max_frames][nfft]
+	long long p_stream_stride;
+	const float2* tw;
+	float* Y[3];
+	long long y_stream_stride;
+	int n_frames;
+	int n_streams;
+	int n_out;              // enabled outputs
+	int out_id[3];          // 0 = percussive, 1 = harmonic, 2 = residual (order of Y[])
+	float beta, beta_h;     // hps.cu:505 / :540 (beta - Eps)
+	int soft, power, sse;
+	int out_h, out_p;       // which masks exist for the residual (hps.cu:562-567)
+	float cola;
+};
+
+// overlap-add of consecutive frames (hps.cu:435-449 + :526-528) and copy-out (hps.cu:341-363):
+// out[i*hop + n] = (i ? Y[i-1][hop+n] : carry[n]) + Y[i][n]
+struct FinalizeArgs {
+	const float* Y;
+	const float* carry;
+	float* out;
+	long long y_stream_stride;
+	long long out_stride;
+	int n_frames, hop, n_streams;
+};
+
+int launch_stft(int log2n, const StftArgs& a, hipStream_t stream);
+int launch_istft(int log2n, const IstftArgs& a, hipStream_t stream);
+int launch_finalize(const FinalizeArgs& a, hipStream_t stream);
+// FFTC2CWrapperGPU::forward/backward (fftw.h:35-43), `batch` consecutive transforms in place
+int launch_fft(int log2n, float2* data, const float2* tw, size_t batch, int inverse, hipStream_t stream);
+
+} // namespace zen_hip_impl
