@@ -57,6 +57,9 @@ const char* zen_hip_last_error(void);  /* thread-local text of the last failure 
 const char* zen_hip_version(void);
 int zen_hip_device_name(char* buf, size_t n);
 int zen_hip_synchronize(void* stream); /* hipStreamSynchronize; synchronises */
+/* process-wide tuning/debug switches (no reference counterpart).  "median_general" = 1 forces the general
+ * wave-cooperative median kernel even where the sorting-network fast path (masks <= 63 taps) applies. */
+int zen_hip_set_option(const char* name, int value);
 
 /* device memory + copies: what thrust::device_vector / thrust::copy are to the reference
  * (core.h:26-27; used by every wrapper and test). */

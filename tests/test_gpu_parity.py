@@ -18,6 +18,14 @@ def z():
     return zen_amd
 
 
+@pytest.fixture(params=["net", "general"])
+def zk(z, request):
+    """Both median kernels: the sorting-network fast path (default) and the general wave kernel."""
+    z.set_option("median_general", 1 if request.param == "general" else 0)
+    yield z
+    z.set_option("median_general", 0)
+
+
 def noise(n, seed=0):
     return np.random.default_rng(seed).uniform(-1, 1, n).astype(np.float32)
 
@@ -85,17 +93,17 @@ def stripes(x, y):
 
 
 @pytest.mark.parametrize("x,y,f", [(9, 9, 3), (10, 20, 5), (1024, 128, 5), (1024, 17, 5), (1024, 1024, 21)])
-def test_median_reference_stripe_vectors(z, x, y, f):
+def test_median_reference_stripe_vectors(zk, x, y, f):
     """libzen/mfilt.test.cu fixtures; replicate border => the 'everywhere' expectations (:701-886)."""
     d = stripes(x, y)
     exp_t = np.zeros((x, y), np.float32)
     exp_t[:, y // 2] = 8
     exp_f = np.zeros((x, y), np.float32)
     exp_f[x // 2, :] = 5
-    for direction in (z.TIME_CAUSAL, z.TIME_ANTICAUSAL):
-        assert np.array_equal(z.MedianFilterGPU(x, y, f, direction).filter_host(d), exp_t)
-    assert np.array_equal(z.MedianFilterGPU(x, y, f, z.FREQUENCY).filter_host(d), exp_f)
-    assert np.array_equal(z.MedianFilterGPU(x, y, f, z.FREQUENCY, True).filter_host(d), exp_f)  # copy_bord
+    for direction in (zk.TIME_CAUSAL, zk.TIME_ANTICAUSAL):
+        assert np.array_equal(zk.MedianFilterGPU(x, y, f, direction).filter_host(d), exp_t)
+    assert np.array_equal(zk.MedianFilterGPU(x, y, f, zk.FREQUENCY).filter_host(d), exp_f)
+    assert np.array_equal(zk.MedianFilterGPU(x, y, f, zk.FREQUENCY, True).filter_host(d), exp_f)  # copy_bord
 
 
 def test_median_filter_too_big_throws(z):
@@ -109,34 +117,36 @@ def test_median_filter_too_big_throws(z):
 @pytest.mark.parametrize("shape,flen", [
     ((6, 4096), 47), ((22, 1024), 13), ((22, 1024), 11), ((12, 2048), 23), ((12, 2048), 7), ((2, 8192), 93),
     ((2, 16384), 187), ((24, 1024), 11), ((7, 33), 3), ((300, 257), 21), ((64, 64), 11), ((5, 5), 5),
-    ((1, 9), 1), ((3, 1000), 255), ((260, 70), 255), ((129, 300), 129), ((200, 130), 65)])
-def test_median_random_bit_exact(z, shape, flen):
+    ((1, 9), 1), ((3, 1000), 255), ((260, 70), 255), ((129, 300), 129), ((200, 130), 65),
+    ((70, 4097), 47), ((33, 5000), 63), ((100, 37), 9), ((77, 1030), 31), ((64, 8192), 15), ((300, 12), 3),
+    ((41, 2050), 25), ((1000, 260), 33), ((90, 1026), 61), ((513, 1028), 5)])
+def test_median_random_bit_exact(zk, shape, flen):
     rng = np.random.default_rng(flen + shape[0])
     d = rng.uniform(0, 10, shape).astype(np.float32)
     d[rng.integers(0, shape[0], 7), rng.integers(0, shape[1], 7)] = 0.0
     if flen <= shape[1]:
-        got = z.MedianFilterGPU(shape[0], shape[1], flen, z.FREQUENCY).filter_host(d)
+        got = zk.MedianFilterGPU(shape[0], shape[1], flen, zk.FREQUENCY).filter_host(d)
         assert np.array_equal(got, o.median_filter(d, flen, o.FREQUENCY))
     if flen <= shape[0]:
-        got = z.MedianFilterGPU(shape[0], shape[1], flen, z.TIME_ANTICAUSAL).filter_host(d)
+        got = zk.MedianFilterGPU(shape[0], shape[1], flen, zk.TIME_ANTICAUSAL).filter_host(d)
         assert np.array_equal(got, o.median_filter(d, flen, o.TIME_ANTICAUSAL))
 
 
-def test_median_signed_values_and_even_length(z):
+def test_median_signed_values_and_even_length(zk):
     rng = np.random.default_rng(9)
     d = rng.normal(0, 3, (40, 200)).astype(np.float32)
-    assert np.array_equal(z.MedianFilterGPU(40, 200, 10, z.FREQUENCY).filter_host(d),
+    assert np.array_equal(zk.MedianFilterGPU(40, 200, 10, zk.FREQUENCY).filter_host(d),
                           o.median_filter(d, 10, o.FREQUENCY))          # 10 -> 11 (mfilt.h:89)
-    assert np.array_equal(z.MedianFilterGPU(40, 200, 40, z.TIME_CAUSAL).filter_host(d),
+    assert np.array_equal(zk.MedianFilterGPU(40, 200, 40, zk.TIME_CAUSAL).filter_host(d),
                           o.median_filter(d, 40, o.TIME_CAUSAL))        # 40 -> 41 on 40 rows
 
 
-def test_median_bench_squares_iota(z):
+def test_median_bench_squares_iota(zk):
     """libzen/mfilt.bench.cu:7-8,17-32: dim x dim, filter 11, iota data, both directions."""
     for dim in (32, 256, 1024):
         d = np.arange(dim * dim, dtype=np.float32).reshape(dim, dim)
-        for direction in (z.FREQUENCY, z.TIME_ANTICAUSAL):
-            assert np.array_equal(z.MedianFilterGPU(dim, dim, 11, direction).filter_host(d),
+        for direction in (zk.FREQUENCY, zk.TIME_ANTICAUSAL):
+            assert np.array_equal(zk.MedianFilterGPU(dim, dim, 11, direction).filter_host(d),
                                   o.median_filter(d, 11, direction))
 
 

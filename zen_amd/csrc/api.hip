@@ -11,6 +11,7 @@
 namespace zen_hip_impl {
 
 static thread_local char g_err[512] = "";
+int g_opt_median_general = 0;
 
 void set_error(const char* fmt, ...)
 {
@@ -114,6 +115,15 @@ int zen_hip_init(int device)
 	(void)hipGetLastError();
 	ZH_HIP(hipSetDevice(device));
 	return ZEN_HIP_OK;
+}
+
+int zen_hip_set_option(const char* name, int value)
+{
+	if (name && !strcmp(name, "median_general")) {
+		g_opt_median_general = value;
+		return ZEN_HIP_OK;
+	}
+	ZH_FAIL(ZEN_HIP_E_BAD_ARG, "zen_hip_set_option: unknown option '%s'", name ? name : "(null)");
 }
 
 int zen_hip_device_name(char* buf, size_t n)

@@ -11,6 +11,7 @@
 namespace zen_hip_impl {
 
 void set_error(const char* fmt, ...);
+extern int g_opt_median_general; // zen_hip_set_option("median_general")
 
 // Evaluate a HIP call; on failure record file:line + hipGetErrorString and return ZEN_HIP_E_HIP.
 #define ZH_HIP(call)                                                                                  \

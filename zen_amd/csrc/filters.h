@@ -30,9 +30,11 @@ struct FilterArgs {
 	int sse_pre;            // tap value = 1 / (x*x)    (complex_abs_squared + reciprocal_functor(1))
 	int sse_post;           // result    = (1 / mean) * post_factor   (reciprocal_functor(l + 1))
 	float post_factor;
+	int force_general;      // tests: skip the sorting-network fast path, use the general wave kernel
 };
 
 int launch_median(const FilterArgs& a, hipStream_t stream);
+int launch_median_net(const FilterArgs& a, hipStream_t stream, bool* handled); // masks <= 63 taps
 int launch_box(const FilterArgs& a, hipStream_t stream);
 
 } // namespace zen_hip_impl

@@ -278,6 +278,12 @@ int launch_median(const FilterArgs& a, hipStream_t stream)
 		ZH_HIP(hipGetLastError());
 		return ZEN_HIP_OK;
 	}
+	if (!a.force_general && !g_opt_median_general) { // sorting-network fast path (median_net.hip) for masks <= 63 taps
+		bool handled = false;
+		ZH_TRY(launch_median_net(a, stream, &handled));
+		if (handled)
+			return ZEN_HIP_OK;
+	}
 	if (a.direction == ZEN_HIP_FREQUENCY)
 		return launch_dir<0>(a, stream);
 	return launch_dir<1>(a, stream);

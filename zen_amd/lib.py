@@ -44,6 +44,7 @@ SYMBOLS = [
     ("zen_hip_version", C.c_char_p, []),
     ("zen_hip_device_name", _i, [C.c_char_p, _sz]),
     ("zen_hip_synchronize", _i, [_vp]),
+    ("zen_hip_set_option", _i, [C.c_char_p, _i]),
     ("zen_hip_malloc", _i, [_pvp, _sz]),
     ("zen_hip_free", _i, [_vp]),
     ("zen_hip_memset", _i, [_vp, _i, _sz, _vp]),
@@ -118,6 +119,10 @@ def init(device=0):
 
 def synchronize(stream=None):
     _ck(load().zen_hip_synchronize(stream))
+
+
+def set_option(name, value):
+    _ck(load().zen_hip_set_option(name.encode(), int(value)))
 
 
 def device_name():
