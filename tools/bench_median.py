@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the standalone median kernel (zen_hip_mfilt_run) on the reference's bench shapes
+(libzen/mfilt.bench.cu: dim x dim, filter 11) and on the BASELINE path shapes.  Prints one JSON line per
+case: achieved algorithmic GB/s (8 B per element) and fraction of the 8 TB/s HBM roof."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import zen_amd  # noqa: E402
+
+
+def run(rows, cols, flen, direction, iters, general=False, nonneg=True):
+    zen_amd.set_option("median_general", int(general))
+    rng = np.random.default_rng(0)
+    d = rng.uniform(0, 1, (rows, cols)).astype(np.float32)
+    src, dst = zen_amd.DeviceBuffer.from_host(d), zen_amd.DeviceBuffer(d.size)
+    f = zen_amd.MedianFilterGPU(rows, cols, flen, direction)
+    for _ in range(3):
+        f.filter(src, dst)
+    zen_amd.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        f.filter(src, dst)
+    zen_amd.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    gbs = 8.0 * rows * cols / dt / 1e9
+    return {"rows": rows, "cols": cols, "filter_len": flen,
+            "direction": "frequency" if direction == zen_amd.FREQUENCY else "time",
+            "kernel": "general" if general else "auto", "ms": 1e3 * dt, "GBps": gbs, "frac_of_8TBps": gbs / 8000.0}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--suite", default="path", choices=["path", "squares", "one"])
+    ap.add_argument("--rows", type=int, default=25840)
+    ap.add_argument("--cols", type=int, default=4096)
+    ap.add_argument("--len", type=int, default=47)
+    ap.add_argument("--dir", default="frequency")
+    args = ap.parse_args()
+    zen_amd.init(0)
+    F, Tm = zen_amd.FREQUENCY, zen_amd.TIME_ANTICAUSAL
+    if args.suite == "one":
+        cases = [(args.rows, args.cols, args.len, F if args.dir == "frequency" else Tm)]
+    elif args.suite == "path":   # SURVEY 8(d) path shapes
+        cases = [(25840, 4096, 47, F), (25840, 4096, 3, Tm), (103360, 1024, 13, F), (103360, 1024, 11, Tm),
+                 (51680, 2048, 23, F), (51680, 2048, 7, Tm), (6460, 16384, 187, F), (12920, 8192, 93, F)]
+    else:                        # libzen/mfilt.bench.cu:222-262
+        cases = [(1 << k, 1 << k, 11, d) for k in range(5, 15) for d in (F, Tm)]
+    for rows, cols, flen, direction in cases:
+        print(json.dumps(run(rows, cols, flen, direction, args.iters)), flush=True)

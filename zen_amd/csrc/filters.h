@@ -30,6 +30,7 @@ struct FilterArgs {
 	int sse_pre;            // tap value = 1 / (x*x)    (complex_abs_squared + reciprocal_functor(1))
 	int sse_post;           // result    = (1 / mean) * post_factor   (reciprocal_functor(l + 1))
 	float post_factor;
+	int nonneg;             // every source sample is >= +0 (magnitudes): ordering keys are the raw bits
 	int force_general;      // tests: skip the sorting-network fast path, use the general wave kernel
 };
 

@@ -160,6 +160,7 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 	fa.n_out_rows = (int)M;
 	fa.clamp_lo = 0;
 	fa.clamp_hi = LLONG_MAX / 4;
+	fa.nonneg = 1; // |S| >= +0
 
 	FilterArgs ff = fa; // frequency direction -> P   (hps.cu:496 / :597)
 	ff.dst = e->d_P;

@@ -27,9 +27,6 @@ namespace {
 using znet::f2key;
 using znet::key2f;
 
-__device__ __forceinline__ int lds_off(int g) { return g + 4 * (g >> 6); }
-constexpr int lds_words(int n) { return n + 4 * ((n + 63) / 64) + 4; }
-
 // 32-bit row addressing prepared by the host (see prepare())
 struct RowMap {
 	int base;    // first_row % ring_rows
@@ -47,15 +44,45 @@ __device__ __forceinline__ int map_row(const RowMap& m, int row_rel)
 }
 
 // -------------------------------------------------------------------------------------------------
-template <int W>
+// LDS row image of the frequency kernel: T-word chunks (one per thread) spaced STRIDE = T + PAD words
+// apart.  PAD makes the 16 lanes that a ds_read_b128 services together land on 16 different 4-bank
+// groups (chunk starts 20t, 12t, 4t words for T = 16, 8, 4: 5t, 3t, t mod 16 are all distinct), and
+// because a thread's window is a run of whole chunks its vector v sits at the compile-time offset
+// (4v/T)*STRIDE + (4v)%T from its own chunk: one base register, immediate offsets, no address math.
+template <int T>
+struct RowImage {
+	static constexpr int PAD = T >= 8 ? 4 : 0;
+	static constexpr int STRIDE = T + PAD;
+	static constexpr int LOG2T = T == 16 ? 4 : (T == 8 ? 3 : 2);
+	static __device__ __forceinline__ int addr(int g) { return (g >> LOG2T) * STRIDE + (g & (T - 1)); }
+	static constexpr int caddr(int g) { return (g / T) * STRIDE + (g % T); }
+	static constexpr int words(int n) { return ((n + T - 1) / T) * STRIDE; }
+};
+
+template <bool NONNEG>
+__device__ __forceinline__ int to_key(float f)
+{
+	// non-negative floats (spectrogram magnitudes) already order like their bit patterns
+	return NONNEG ? __float_as_int(f) : f2key(f);
+}
+template <bool NONNEG>
+__device__ __forceinline__ float from_key(int k)
+{
+	return NONNEG ? __int_as_float(k) : key2f(k);
+}
+
+template <int W, bool NONNEG>
 __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowMap rm, int segs_per_row, int vec_ok)
 {
 	constexpr int T = znet::outputs_per_thread(W), mid = W / 2;
-	constexpr int NV = (W + T - 1 + 3) / 4, NE = NV * 4;
+	static_assert(T >= 4, "16-byte LDS path needs T >= 4");
+	using IM = RowImage<T>;
+	constexpr int MID_AL = (mid + 3) & ~3;     // image word 0 is column col0 - MID_AL (16-byte aligned)
+	constexpr int DELTA = MID_AL - mid;        // a thread's window starts DELTA words into its chunk
+	constexpr int NV = (DELTA + W + T - 1 + 3) / 4, NE = NV * 4;
 	constexpr int OUTS = 256 * T;
-	constexpr int SPAN = 255 * T + NE; // last word any thread reads, + 1
-	__shared__ __attribute__((aligned(16))) int tile[lds_words(SPAN)];
-	__shared__ __attribute__((aligned(16))) int otile[lds_words(OUTS)];
+	constexpr int SPANV = (255 * T) / 4 + NV;  // vectors in the image
+	__shared__ __attribute__((aligned(16))) int tile[IM::words(SPANV * 4)];
 
 	const int tid = threadIdx.x;
 	const int row = blockIdx.x / segs_per_row, seg = blockIdx.x - row * segs_per_row;
@@ -63,66 +90,71 @@ __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowM
 	const float* __restrict__ srow =
 	    a.src + (long long)blockIdx.y * a.src_stream_stride + (long long)map_row(rm, row) * cols;
 	float* __restrict__ drow = a.dst + (long long)blockIdx.y * a.dst_stream_stride + (long long)row * cols;
+	const int c_lo = col0 - MID_AL; // column of image word 0
 
-	const int g_lo = col0 - mid; // column of tile word 0
-	if (vec_ok) {
-		// interior: aligned float4 loads, each word dropped at its tile position
-		int v0 = g_lo < 0 ? 0 : (g_lo & ~3);
-		int v1 = col0 + OUTS + mid;
-		v1 = v1 > cols ? cols : v1;
-		for (int vc = v0 + 4 * tid; vc < v1; vc += 4 * 256) {
-			const float4 x = *reinterpret_cast<const float4*>(srow + vc);
-			const float xs[4] = {x.x, x.y, x.z, x.w};
+	if (vec_ok) { // cols % 4 == 0 and 16-byte aligned rows: a vector is wholly inside or wholly outside
+		constexpr int NLD = (SPANV + 255) / 256;
+		float4 x[NLD];
 #pragma unroll
-			for (int j = 0; j < 4; ++j) {
-				const int g = vc + j - g_lo;
-				if (g >= 0 && g < SPAN)
-					tile[lds_off(g)] = f2key(xs[j]);
+		for (int i = 0; i < NLD; ++i) { // all loads in flight before the first use
+			int vc = c_lo + 4 * (tid + 256 * i);
+			vc = vc < 0 ? 0 : (vc > cols - 4 ? cols - 4 : vc);
+			x[i] = *reinterpret_cast<const float4*>(srow + vc);
+		}
+#pragma unroll
+		for (int i = 0; i < NLD; ++i) {
+			const int vi = tid + 256 * i;
+			const int vc = c_lo + 4 * vi;
+			if (vi < SPANV) {
+				int4 k = make_int4(to_key<NONNEG>(x[i].x), to_key<NONNEG>(x[i].y), to_key<NONNEG>(x[i].z),
+				                   to_key<NONNEG>(x[i].w));
+				if (vc < 0) // replicate border (ippBorderRepl): the clamped vector starts at column 0
+					k = make_int4(k.x, k.x, k.x, k.x);
+				else if (vc >= cols) // ... or ends at column cols-1
+					k = make_int4(k.w, k.w, k.w, k.w);
+				*reinterpret_cast<int4*>(&tile[IM::addr(4 * vi)]) = k;
 			}
-		}
-		// replicate border (only the first / last segment of a row has any)
-		if (g_lo < 0) {
-			const int k0 = f2key(srow[0]);
-			for (int g = tid; g < -g_lo; g += 256)
-				tile[lds_off(g)] = k0;
-		}
-		if (col0 + OUTS + mid > cols) {
-			const int k1 = f2key(srow[cols - 1]);
-			for (int g = cols - g_lo + tid; g < OUTS + 2 * mid; g += 256)
-				tile[lds_off(g)] = k1;
 		}
 	}
 	else {
-		for (int g = tid; g < OUTS + 2 * mid; g += 256) {
-			int c = g_lo + g;
+		for (int g = tid; g < SPANV * 4; g += 256) {
+			int c = c_lo + g;
 			c = c < 0 ? 0 : (c > cols - 1 ? cols - 1 : c);
-			tile[lds_off(g)] = f2key(srow[c]);
+			tile[IM::addr(g)] = to_key<NONNEG>(srow[c]);
 		}
 	}
 	__syncthreads();
 
-	int e[NE], out[T];
+	int ld[NE], e[W + T - 1], out[T];
+	const int* mine = &tile[tid * IM::STRIDE];
 #pragma unroll
 	for (int v = 0; v < NV; ++v) {
-		const int4 x = *reinterpret_cast<const int4*>(&tile[lds_off(tid * T + 4 * v)]);
-		e[4 * v] = x.x;
-		e[4 * v + 1] = x.y;
-		e[4 * v + 2] = x.z;
-		e[4 * v + 3] = x.w;
+		const int4 q = *reinterpret_cast<const int4*>(mine + IM::caddr(4 * v));
+		ld[4 * v] = q.x;
+		ld[4 * v + 1] = q.y;
+		ld[4 * v + 2] = q.z;
+		ld[4 * v + 3] = q.w;
 	}
-	znet::medians<W, T, NE>(e, out);
+#pragma unroll
+	for (int q = 0; q < W + T - 1; ++q)
+		e[q] = ld[q + DELTA];
+	__syncthreads(); // every window is in registers: the image can take the results
+	znet::medians<W, T, W + T - 1>(e, out);
 #pragma unroll
 	for (int v = 0; v < T / 4; ++v)
-		*reinterpret_cast<int4*>(&otile[lds_off(tid * T + 4 * v)]) =
+		*reinterpret_cast<int4*>(&tile[tid * IM::STRIDE + 4 * v]) =
 		    make_int4(out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]);
 	__syncthreads();
 
 	if (vec_ok) {
-		for (int g = 4 * tid; g < OUTS; g += 4 * 256) {
+#pragma unroll
+		for (int i = 0; i < T / 4; ++i) {
+			const int g = 4 * tid + 1024 * i;
 			const int c = col0 + g;
-			if (c < cols) { // cols % 4 == 0: whole vector inside
-				const int4 k = *reinterpret_cast<const int4*>(&otile[lds_off(g)]);
-				*reinterpret_cast<float4*>(drow + c) = make_float4(key2f(k.x), key2f(k.y), key2f(k.z), key2f(k.w));
+			if (c < cols) {
+				const int4 k = *reinterpret_cast<const int4*>(&tile[IM::addr(g)]);
+				*reinterpret_cast<float4*>(drow + c) = make_float4(from_key<NONNEG>(k.x), from_key<NONNEG>(k.y),
+				                                                   from_key<NONNEG>(k.z), from_key<NONNEG>(k.w));
 			}
 		}
 	}
@@ -130,7 +162,7 @@ __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowM
 		for (int g = tid; g < OUTS; g += 256) {
 			const int c = col0 + g;
 			if (c < cols)
-				drow[c] = key2f(otile[lds_off(g)]);
+				drow[c] = from_key<NONNEG>(tile[IM::addr(g)]);
 		}
 	}
 }
@@ -264,9 +296,21 @@ int launch_freq(const FilterArgs& a, const RowMap& rm, hipStream_t stream)
 	                   && ((reinterpret_cast<uintptr_t>(a.dst) & 15) == 0) && (a.src_stream_stride % 4 == 0)
 	                   && (a.dst_stream_stride % 4 == 0);
 	dim3 grid((unsigned)((long long)a.n_out_rows * segs), (unsigned)a.n_streams);
-	hipLaunchKernelGGL(median_net_freq_kernel<W>, grid, dim3(256), 0, stream, a, rm, segs, vec_ok);
+	if (a.nonneg)
+		hipLaunchKernelGGL((median_net_freq_kernel<W, true>), grid, dim3(256), 0, stream, a, rm, segs, vec_ok);
+	else
+		hipLaunchKernelGGL((median_net_freq_kernel<W, false>), grid, dim3(256), 0, stream, a, rm, segs, vec_ok);
 	ZH_HIP(hipGetLastError());
 	return ZEN_HIP_OK;
+}
+
+template <int W>
+int launch_freq_guard(const FilterArgs& a, const RowMap& rm, hipStream_t stream)
+{
+	if constexpr (W >= 7)
+		return launch_freq<W>(a, rm, stream);
+	else
+		return ZEN_HIP_E_BAD_ARG; // never reached: masks < 7 taps are routed to the general kernel
 }
 
 template <int W, int VC>
@@ -315,7 +359,7 @@ int launch_median_net(const FilterArgs& a, hipStream_t stream, bool* handled)
 	*handled = true;
 	switch (a.len) {
 #define X(W) \
-	case W: return freq ? launch_freq<W>(a, rm, stream) : launch_time<W>(a, rm, stream);
+	case W: return freq ? launch_freq_guard<W>(a, rm, stream) : launch_time<W>(a, rm, stream);
 		ZH_NET_WIDTHS(X)
 #undef X
 	default: *handled = false; return ZEN_HIP_OK;
