@@ -1,0 +1,113 @@
+"""C++ host mirror (zen_amd/libzen) and the `zen` command line tool.
+
+CPU part: the binaries build, `zen version` / `zen help` work and `--cpu` is refused.
+GPU part: tests/cpp/test_libzen (the reference's gtest cases against the C++ classes, oracle as checker)
+and an end-to-end run of `zen offline` / `zen fakert` on a synthetic WAV whose PCM16 outputs are compared
+sample for sample with what the reference CLI's conversions (zen/offline.h:180-223, zen/fakert.h:15-34,
+:117-287) yield when fed the oracle's waveforms."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ZEN = os.path.join(ROOT, "zen_amd", "bin", "zen")
+TEST_EXE = os.path.join(ROOT, "tests", "cpp", "test_libzen")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    if not (os.path.exists(ZEN) and os.path.exists(TEST_EXE)):
+        from oracle import oracle as o
+        from zen_amd import build
+        o.build()
+        build.build()
+        build.build_host()
+
+
+def write_wav_pcm16(path, x, fs, channels=1):
+    pcm = np.asarray(x, dtype="<i2")
+    data = pcm.tobytes()
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt " +
+                struct.pack("<IHHIIHH", 16, 1, channels, fs, fs * 2 * channels, 2 * channels, 16) +
+                b"data" + struct.pack("<I", len(data)) + data)
+
+
+def read_wav_pcm16(path):
+    b = open(path, "rb").read()
+    assert b[:4] == b"RIFF" and b[8:12] == b"WAVE" and b[12:16] == b"fmt " and b[36:40] == b"data"
+    fmt, ch, fs, _, _, bits = struct.unpack("<HHIIHH", b[20:36])
+    assert (fmt, ch, bits) == (1, 1, 16)
+    n = struct.unpack("<I", b[40:44])[0]
+    return fs, np.frombuffer(b[44:44 + n], dtype="<i2")
+
+
+def test_cli_version_help_and_cpu_refusal(tmp_path):
+    assert subprocess.run([ZEN, "version"], capture_output=True, text=True).stdout == "version 1.0\n"
+    out = subprocess.run([ZEN, "help"], capture_output=True, text=True).stdout
+    assert "zen offline" in out and "zen fakert" in out and "--only-percussive" in out
+    r = subprocess.run([ZEN, "offline", "-i", "x.wav", "--cpu"], capture_output=True, text=True)
+    assert r.returncode == 2 and "--cpu" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_reference_suites():
+    r = subprocess.run([TEST_EXE], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-2000:])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " 0 failures" in r.stdout
+
+
+def pcm16(x):
+    v = (x.astype(np.float32) * np.float32(32767.0)).astype(np.float64)   # float32 product, exact in f64
+    return (np.sign(v) * np.floor(np.abs(v) + 0.5)).astype(np.int64)      # lroundf: half away from zero
+
+
+@pytest.mark.gpu
+def test_cli_offline_and_fakert_end_to_end(tmp_path):
+    from oracle import oracle as o
+    fs, n = 44100, 161571                      # README.md:100 clip length
+    rng = np.random.default_rng(0)
+    t = np.arange(n) / fs
+    left = 0.3 * np.sin(2 * np.pi * 440 * t) + 0.1 * rng.uniform(-1, 1, n)
+    right = 0.3 * np.sin(2 * np.pi * 660 * t) + 0.1 * rng.uniform(-1, 1, n)
+    left[::11025] += 0.5
+    st = np.empty(2 * n, np.int16)
+    st[0::2] = np.round(left * 20000)
+    st[1::2] = np.round(right * 20000)
+    wav = str(tmp_path / "in.wav")
+    write_wav_pcm16(wav, st, fs, channels=2)
+    # what the CLI does to the file: /32767.f then (L+R)/2.0f
+    f32 = st.astype(np.float32) / np.float32(32767.0)
+    mono = ((f32[0::2] + f32[1::2]) / np.float32(2.0)).astype(np.float32)
+
+    r = subprocess.run([ZEN, "offline", "-i", wav, "--hps", "4096", "2.5", "256", "2.5", "-o", str(tmp_path / "off")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "Processing input signal of size 161571 with HPR-I separation using harmonic params: 4096,2.5, " \
+           "percussive params: 256,2.5" in r.stdout
+    assert "2-pass HPR-I-Offline took" in r.stdout and "compute: gpu" in r.stdout
+    h, p, _ = o.HPRIOffline(float(fs), 4096, 256, 2.5, 2.5).process(mono)
+    for name, ref in (("off_harm.wav", h), ("off_perc.wav", p)):
+        rfs, got = read_wav_pcm16(str(tmp_path / name))
+        peak = max(-ref.min(), ref.max())
+        exp = pcm16(ref / np.float32(peak))
+        assert rfs == fs and np.array_equal(got.astype(np.int64), exp), name
+    assert os.path.exists(str(tmp_path / "off_residual.wav"))     # all-zero / max 0 -> NaN -> written as is
+
+    hop = 1024
+    r = subprocess.run([ZEN, "fakert", "-i", wav, "--hps", str(hop), "2.0", "-o", str(tmp_path / "rt.wav")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    n_chunks = len(range(0, n - hop, hop))                        # fakert.h:23-27
+    assert "Slicing buffer size %d into %d chunks of size %d" % (n, n_chunks, hop) in r.stdout
+    assert "average processing duration(us)" in r.stdout
+    eng = o.HPR(float(fs), hop, 2.0, o.OUTPUT_PERCUSSIVE, o.TIME_CAUSAL)
+    ref = mono.copy()                                             # fakert.h:132: output starts as the input
+    ref[:n_chunks * hop] = eng.process_stream(mono[:n_chunks * hop])["P"]
+    peak = max(-ref.min(), ref.max())
+    _, got = read_wav_pcm16(str(tmp_path / "rt.wav"))
+    assert np.array_equal(got.astype(np.int64), pcm16(ref / np.float32(peak)))

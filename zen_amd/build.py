@@ -50,5 +50,45 @@ def build(force=False, verbose=False):
     return OUT
 
 
+def build_host(verbose=False):
+    """C++ host mirror of the reference's libzen (zen_amd/libzen -> zen_amd/libzen.so), the `zen` command
+    line tool (zen_amd/bin/zen) and the C++ test program (tests/cpp/test_libzen).  Plain g++: the host
+    layer reaches the GPU only through the C-ABI of libzen_hip.so."""
+    root = os.path.dirname(HERE)
+    inc = ["-I", os.path.join(root, "include"), "-I", os.path.join(HERE, "libzen")]
+    cxx = [os.environ.get("CXX", "g++"), "-std=c++17", "-O2", "-fPIC", "-Wall", "-ffp-contract=off"]
+    libzen = os.path.join(HERE, "libzen.so")
+    src = os.path.join(HERE, "libzen", "hps.cpp")
+    link_hip = ["-L", HERE, "-lzen_hip", "-Wl,-rpath,$ORIGIN"]
+
+    def stale(out, deps):
+        return not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps)
+
+    hdrs = []
+    for d, _, fs in os.walk(os.path.join(HERE, "libzen")):
+        hdrs += [os.path.join(d, f) for f in fs]
+    hdrs.append(os.path.join(root, "include", "zen_hip.h"))
+    if stale(libzen, hdrs + [OUT]):
+        subprocess.check_call(cxx + inc + ["-shared", src, "-o", libzen] + link_hip)
+    os.makedirs(os.path.join(HERE, "bin"), exist_ok=True)
+    cli = os.path.join(HERE, "bin", "zen")
+    cli_src = [os.path.join(HERE, "cli", "main.cpp"), os.path.join(HERE, "cli", "wav.h")]
+    if stale(cli, cli_src + [libzen]):
+        subprocess.check_call(cxx + inc + [cli_src[0], "-o", cli, "-L", HERE, "-lzen", "-lzen_hip",
+                                           "-Wl,-rpath,$ORIGIN/.."])
+    tdir = os.path.join(root, "tests", "cpp")
+    texe = os.path.join(tdir, "test_libzen")
+    oracle_dir = os.path.join(root, "oracle")
+    oracle_so = os.path.join(oracle_dir, "libzen_oracle.so")
+    if os.path.exists(oracle_so) and stale(texe, [os.path.join(tdir, "test_libzen.cpp"), libzen, oracle_so]):
+        subprocess.check_call(cxx + inc + [os.path.join(tdir, "test_libzen.cpp"), "-o", texe, "-L", HERE, "-lzen",
+                                           "-lzen_hip", "-L", oracle_dir, "-lzen_oracle",
+                                           "-Wl,-rpath,$ORIGIN/../../zen_amd", "-Wl,-rpath,$ORIGIN/../../oracle"])
+    if verbose:
+        print("built", libzen, cli, texe)
+    return libzen, cli, texe
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
+    build_host(verbose=True)

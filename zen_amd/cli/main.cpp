@@ -1,0 +1,282 @@
+// zen -- command line tool of the MI355X HPSS engine: `zen offline`, `zen fakert`, help, version.
+// Same sub-commands, flags, defaults and console lines as the reference's zen/main.cu:12-92,
+// zen/offline.h and zen/fakert.h (clipp grammar re-done by hand; libnyquist replaced by cli/wav.h).
+// Differences: the `compute:` / timing lines name this backend, and `--cpu` is refused -- this tool is
+// the GPU drop-in; the CPU restatement lives under oracle/ as test infrastructure only.
+#include <algorithm>
+#include <array>
+#include <chrono>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include <libzen/hps.h>
+#include <libzen/io.h>
+#include <libzen/zen.h>
+
+#include "wav.h"
+
+namespace {
+
+struct OfflineParams { // zen/offline.h:19-32
+	std::string infile = "", outfile_prefix = "";
+	bool do_hps = false, cpu = false, nocopybord = false, use_sse = false, soft_mask = false, only_percussive = false;
+	std::size_t hop_h = 4096, hop_p = 256;
+	float beta_h = 2.0, beta_p = 2.0;
+};
+
+struct FakeRtParams { // zen/fakert.h:39-49
+	std::string infile = "", outfile = "";
+	bool do_hps = false, cpu = false, nocopybord = false, use_sse = false, soft_mask = false;
+	std::size_t hop = 256;
+	float beta = 2.0;
+};
+
+void usage(std::ostream& os)
+{
+	os << "usage:\n\n"
+	      "  zen offline -i <infile> [--hps [<hop-h> [<beta-h> [<hop-p> [<beta-p>]]]]] [-o <outfile_prefix>]\n"
+	      "      [--sse] [--only-percussive] [--soft-mask] [--nocopybord]\n"
+	      "  zen fakert -i <infile> [--hps [<hop> [<beta>]]] [-o <outfile>] [--sse] [--soft-mask] [--nocopybord]\n"
+	      "  zen help|-h|--help\n"
+	      "  zen version|-v|--version\n";
+}
+
+bool is_number(const char* s)
+{
+	char* end = nullptr;
+	std::strtod(s, &end);
+	return end != s && *end == '\0';
+}
+
+std::vector<float> load_mono(const std::string& path, zen::wav::AudioData& fd)
+{
+	zen::wav::load(fd, path);
+	std::cout << "Audio file info:" << std::endl;
+	std::cout << "\tsample rate: " << fd.sampleRate << std::endl;
+	std::cout << "\tlen samples: " << fd.samples.size() << std::endl;
+	std::cout << "\tframe size: " << fd.frameSize << std::endl;
+	std::cout << "\tseconds: " << fd.lengthSeconds << std::endl;
+	std::cout << "\tchannels: " << fd.channelCount << std::endl;
+	if (fd.channelCount == 2) { // offline.h:106-113
+		std::vector<float> mono(fd.samples.size() / 2);
+		zen::wav::stereo_to_mono(fd.samples.data(), mono.data(), fd.samples.size());
+		return mono;
+	}
+	return fd.samples;
+}
+
+void peak_normalise(std::vector<float>& x, std::size_t n) // offline.h:182-191, fakert.h:260-269
+{
+	auto limits = std::minmax_element(x.begin(), x.end());
+	const float real_max = std::max(-1 * (*limits.first), *limits.second);
+	for (std::size_t j = 0; j < n; ++j)
+		x[j] /= real_max;
+}
+
+int run_offline(const OfflineParams& p)
+{
+	std::cout << "Running zen-offline with the following params:"
+	          << "\n\tinfile: " << p.infile << "\n\toutfile_prefix: " << p.outfile_prefix
+	          << "\n\tonly_percussive: " << p.only_percussive;
+	if (p.do_hps) {
+		std::cout << "\n\tdo hps: yes"
+		          << "\n\t\tharmonic hop: " << p.hop_h << "\n\t\tharmonic beta: " << p.beta_h
+		          << "\n\t\tpercussive hop: " << p.hop_p << "\n\t\tpercussive beta: " << p.beta_p;
+		std::cout << (p.soft_mask ? "\n\t\tmask: soft/Wiener" : "\n\t\tmask: hard/binary");
+		std::cout << (p.use_sse ? "\n\t\tfilter: sse" : "\n\t\tfilter: median");
+	}
+	else {
+		std::cout << "\n\tdo hps: no";
+	}
+	std::cout << "\n\tcompute: gpu (hip/gfx950)" << std::endl;
+
+	zen::wav::AudioData fd;
+	std::vector<float> audio = load_mono(p.infile, fd);
+	std::array<std::vector<float>, 3> all_out;
+	if (p.do_hps) {
+		std::cout << "Processing input signal of size " << audio.size()
+		          << " with HPR-I separation using harmonic params: " << p.hop_h << "," << p.beta_h
+		          << ", percussive params: " << p.hop_p << "," << p.beta_p << std::endl;
+		zen::hps::HPRIOffline<zen::Backend::GPU> hpss((float)fd.sampleRate, p.hop_h, p.hop_p, p.beta_h, p.beta_p,
+		                                              p.nocopybord);
+		if (p.use_sse)
+			hpss.use_sse_filter();
+		if (p.soft_mask)
+			hpss.use_soft_mask();
+		auto t1 = std::chrono::high_resolution_clock::now();
+		all_out = hpss.process(audio);
+		auto t2 = std::chrono::high_resolution_clock::now();
+		auto dur = std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count();
+		std::cout << "GPU/HIP/gfx950: 2-pass HPR-I-Offline took " << dur << " ms" << std::endl;
+	}
+	else {
+		all_out = {audio, audio, audio};
+	}
+	static const char* suffix[3] = {"_harm.wav", "_perc.wav", "_residual.wav"};
+	if (p.outfile_prefix != "") {
+		for (int i = 0; i < 3; ++i) {
+			if (p.only_percussive && i != 1)
+				continue;
+			peak_normalise(all_out[i], audio.size());
+			zen::wav::encode_pcm16_mono(all_out[i], fd.sampleRate, p.outfile_prefix + suffix[i]);
+		}
+	}
+	return 0;
+}
+
+// zen/fakert.h:15-34 -- emits only whole chunks and stops before the last one
+std::vector<std::pair<std::size_t, std::size_t>> get_chunk_limits(const std::vector<float>& container, std::size_t k)
+{
+	std::vector<std::pair<std::size_t, std::size_t>> ret;
+	const std::size_t size = container.size();
+	std::size_t i = 0;
+	if (size > k)
+		for (; i < size - k; i += k)
+			ret.push_back({i, i + k});
+	if (i % k)
+		ret.push_back({i, i + (i % k)});
+	return ret;
+}
+
+int run_fakert(const FakeRtParams& p)
+{
+	std::cout << "Running zen-fakert with the following params:"
+	          << "\n\tinfile: " << p.infile << "\n\toutfile: " << p.outfile;
+	if (p.do_hps) {
+		std::cout << "\n\tdo hps: yes"
+		          << "\n\t\thop: " << p.hop << "\n\t\tbeta: " << p.beta;
+		std::cout << (p.soft_mask ? "\n\t\tmask: soft/Wiener" : "\n\t\tmask: hard/binary");
+		std::cout << (p.use_sse ? "\n\t\tfilter: sse" : "\n\t\tfilter: median");
+	}
+	else {
+		std::cout << "\n\tdo hps: no";
+	}
+	std::cout << "\n\tcompute: gpu (hip/gfx950)" << std::endl;
+
+	zen::wav::AudioData fd;
+	std::vector<float> audio = load_mono(p.infile, fd);
+	std::vector<float> percussive_out = audio; // fakert.h:132: the unprocessed tail stays raw input
+	const auto chunk_limits = get_chunk_limits(audio, p.hop);
+	std::cout << "Slicing buffer size " << audio.size() << " into " << chunk_limits.size() << " chunks of size "
+	          << p.hop << std::endl;
+
+	std::size_t n = 0;
+	const float delta_t = 1000 * (float)p.hop / fd.sampleRate;
+	zen::hps::HPRRealtime<zen::Backend::GPU> hpss((float)fd.sampleRate, p.hop, p.beta, zen::hps::OUTPUT_PERCUSSIVE,
+	                                              p.nocopybord);
+	zen::io::IOGPU io(p.hop);
+	if (p.use_sse)
+		hpss.use_sse_filter();
+	if (p.soft_mask)
+		hpss.use_soft_mask();
+	hpss.warmup(io);
+
+	float iters = 0.0F;
+	long time_tot = 0;
+	for (const auto& chunk : chunk_limits) {
+		auto t1 = std::chrono::high_resolution_clock::now();
+		if (p.do_hps) {
+			std::copy(audio.begin() + chunk.first, audio.begin() + chunk.second, io.host_in);
+			hpss.process_next_hop(io.device_in);
+			hpss.copy_percussive(io.device_out);
+			std::copy(io.host_out, io.host_out + p.hop, percussive_out.begin() + n);
+		}
+		else {
+			std::copy(audio.begin() + chunk.first, audio.begin() + chunk.second, percussive_out.begin() + n);
+		}
+		auto t2 = std::chrono::high_resolution_clock::now();
+		time_tot += std::chrono::duration_cast<std::chrono::microseconds>(t2 - t1).count();
+		n += p.hop;
+		iters += 1.0F;
+	}
+	std::cout << "PRealtime GPU:  Δn = " << p.hop << ", Δt(ms) = " << delta_t
+	          << ", average processing duration(us) = " << (float)time_tot / iters << std::endl;
+
+	if (p.outfile != "") {
+		peak_normalise(percussive_out, audio.size());
+		zen::wav::encode_pcm16_mono(percussive_out, fd.sampleRate, p.outfile);
+	}
+	return 0;
+}
+
+} // namespace
+
+int main(int argc, char* argv[])
+{
+	std::vector<std::string> a(argv + 1, argv + argc);
+	if (a.empty()) {
+		usage(std::cerr);
+		return 0;
+	}
+	const std::string cmd = a[0];
+	if (cmd == "help" || cmd == "-h" || cmd == "--help") {
+		usage(std::cout);
+		return 0;
+	}
+	if (cmd == "version" || cmd == "-v" || cmd == "--version") {
+		std::cout << "version 1.0\n";
+		return 0;
+	}
+	if (cmd != "offline" && cmd != "fakert") {
+		usage(std::cerr);
+		return 0;
+	}
+	OfflineParams op;
+	FakeRtParams fp;
+	bool cpu = false, have_input = false;
+	for (std::size_t i = 1; i < a.size(); ++i) {
+		const std::string& s = a[i];
+		auto next_is_number = [&]() { return i + 1 < a.size() && is_number(a[i + 1].c_str()); };
+		if ((s == "-i" || s == "--input") && i + 1 < a.size()) {
+			op.infile = fp.infile = a[++i];
+			have_input = true;
+		}
+		else if (s == "--hps") {
+			op.do_hps = fp.do_hps = true;
+			if (cmd == "offline") {
+				if (next_is_number()) op.hop_h = std::strtoul(a[++i].c_str(), nullptr, 10);
+				if (next_is_number()) op.beta_h = std::strtof(a[++i].c_str(), nullptr);
+				if (next_is_number()) op.hop_p = std::strtoul(a[++i].c_str(), nullptr, 10);
+				if (next_is_number()) op.beta_p = std::strtof(a[++i].c_str(), nullptr);
+			}
+			else {
+				if (next_is_number()) fp.hop = std::strtoul(a[++i].c_str(), nullptr, 10);
+				if (next_is_number()) fp.beta = std::strtof(a[++i].c_str(), nullptr);
+			}
+		}
+		else if ((s == "-o" || (cmd == "offline" && s == "--out-prefix") || (cmd == "fakert" && s == "--output"))
+		         && i + 1 < a.size()) {
+			op.outfile_prefix = fp.outfile = a[++i];
+		}
+		else if (s == "--cpu") cpu = true;
+		else if (s == "--sse") op.use_sse = fp.use_sse = true;
+		else if (s == "--soft-mask") op.soft_mask = fp.soft_mask = true;
+		else if (s == "--nocopybord") op.nocopybord = fp.nocopybord = true;
+		else if (s == "--only-percussive" && cmd == "offline") op.only_percussive = true;
+		else {
+			usage(std::cerr);
+			return 0;
+		}
+	}
+	if (!have_input) {
+		usage(std::cerr);
+		return 0;
+	}
+	if (cpu) {
+		std::cerr << "zen: --cpu is not available in the MI355X drop-in (GPU backend only)" << std::endl;
+		return 2;
+	}
+	try {
+		if (zen_hip_init(0) != ZEN_HIP_OK) {
+			std::cerr << "zen: " << zen_hip_last_error() << std::endl;
+			return 1;
+		}
+		return cmd == "offline" ? run_offline(op) : run_fakert(fp);
+	}
+	catch (const std::exception& e) {
+		std::cerr << "zen: " << e.what() << std::endl;
+		return 1;
+	}
+}

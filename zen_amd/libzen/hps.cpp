@@ -1,0 +1,306 @@
+// hps.cpp -- HPR<GPU>, HPRRealtime<GPU>, HPRIOffline<GPU> over the C-ABI engine.
+// Mirrors the control flow of the reference's libzen/hps.cu:21-427; the per-hop arithmetic
+// (hps.cu:429-652) runs inside libzen_hip.so.
+#include <cstdlib>
+#include <iostream>
+#include <numeric>
+
+#include <hps.h>
+#include <libzen/hps.h>
+#include <libzen/io.h>
+#include <libzen/zen.h>
+
+namespace zen {
+
+void throw_or_die(int rc, const char* where)
+{
+	if (rc == ZEN_HIP_OK)
+		return;
+	if (rc == ZEN_HIP_E_FILTER_TOO_BIG)
+		throw ZgException("median filter bigger than matrix dimension"); // mfilt.h:85
+	if (rc == ZEN_HIP_E_HOPS_NOT_DIVISIBLE)
+		throw ZgException("hop_h and hop_p should be evenly divisible"); // hps.cu:34
+	if (rc == ZEN_HIP_E_BAD_ARG || rc == ZEN_HIP_E_UNSUPPORTED)
+		throw ZgException(std::string(where) + ": " + zen_hip_last_error());
+	std::cerr << where << ": " << zen_hip_last_error() << std::endl; // mfilt.h:166-215, io.h:37-66
+	std::exit(1);
+}
+
+namespace internal {
+	namespace hps {
+
+		HPR<Backend::GPU>::HPR(float fs, std::size_t hop, float beta, unsigned int output_flags,
+		                       mfilt::MedianFilterDirection causality, bool copy_bord, std::size_t max_hops)
+		    : fs(fs)
+		    , hop(hop)
+		    , nwin(2 * hop)
+		    , nfft(4 * hop)
+		    , beta(beta)
+		    , output_percussive((output_flags & zen::hps::OUTPUT_PERCUSSIVE) != 0)
+		    , output_harmonic((output_flags & zen::hps::OUTPUT_HARMONIC) != 0)
+		    , output_residual((output_flags & zen::hps::OUTPUT_RESIDUAL) != 0)
+		    , use_sse(false)
+		    , soft_mask(false)
+		    , engine(nullptr)
+		{
+			throw_or_die(zen_hip_hpr_create(fs, hop, beta, output_flags, (int)causality, copy_bord ? 1 : 0, 1,
+			                                max_hops, &engine),
+			             "HPR");
+			zen_hip_hpr_params p;
+			throw_or_die(zen_hip_hpr_get_params(engine, &p), "HPR");
+			l_harm = p.l_harm;
+			l_perc = p.l_perc;
+			lag = p.lag;
+			stft_width = p.stft_width;
+			COLA_factor = p.cola_factor;
+		}
+
+		HPR<Backend::GPU>::~HPR() { zen_hip_hpr_destroy(engine); }
+
+		void HPR<Backend::GPU>::use_sse_filter()
+		{
+			use_sse = true;
+			throw_or_die(zen_hip_hpr_use_sse_filter(engine), "use_sse_filter");
+		}
+
+		void HPR<Backend::GPU>::use_soft_mask()
+		{
+			soft_mask = true;
+			throw_or_die(zen_hip_hpr_use_soft_mask(engine), "use_soft_mask");
+		}
+
+		void HPR<Backend::GPU>::reset_buffers() { throw_or_die(zen_hip_hpr_reset_buffers(engine), "reset_buffers"); }
+
+		void HPR<Backend::GPU>::process_next_hop(InputPointer in_hop)
+		{
+			throw_or_die(zen_hip_hpr_process_next_hop(engine, in_hop.get()), "process_next_hop");
+		}
+
+		void HPR<Backend::GPU>::process_hops(InputPointer in, std::size_t n_hops, float* harm, float* perc,
+		                                     float* resid)
+		{
+			throw_or_die(zen_hip_hpr_process(engine, in.get(), n_hops, n_hops * hop, harm, perc, resid, n_hops * hop),
+			             "process_hops");
+		}
+
+		void HPR<Backend::GPU>::copy_out(unsigned int which, float* out_dev)
+		{
+			throw_or_die(zen_hip_hpr_copy_output(engine, which, out_dev), "copy_out");
+		}
+
+		std::vector<float> HPR<Backend::GPU>::snapshot(unsigned int which)
+		{
+			zen::internal::device_vector<float> tmp(hop);
+			copy_out(which, tmp.raw());
+			return tmp.to_host();
+		}
+		std::vector<float> HPR<Backend::GPU>::percussive_out() { return snapshot(zen::hps::OUTPUT_PERCUSSIVE); }
+		std::vector<float> HPR<Backend::GPU>::harmonic_out() { return snapshot(zen::hps::OUTPUT_HARMONIC); }
+		std::vector<float> HPR<Backend::GPU>::residual_out() { return snapshot(zen::hps::OUTPUT_RESIDUAL); }
+
+	} // namespace hps
+} // namespace internal
+
+namespace hps {
+	using zen::internal::hps::mfilt::MedianFilterDirection;
+	typedef zen::internal::hps::HPR<Backend::GPU> HPRG;
+
+	// ---- HPRRealtime<GPU> (reference libzen/hps.cu:282-427) --------------------------------------
+	template <>
+	HPRRealtime<Backend::GPU>::~HPRRealtime()
+	{
+		delete p_impl;
+	}
+
+	template <>
+	HPRRealtime<Backend::GPU>::HPRRealtime(float fs, std::size_t hop, float beta, unsigned int output_flags)
+	    : p_impl(new HPRG(fs, hop, beta, output_flags, MedianFilterDirection::TimeCausal, true))
+	{
+	}
+
+	template <>
+	HPRRealtime<Backend::GPU>::HPRRealtime(float fs, std::size_t hop, float beta, unsigned int output_flags,
+	                                       bool nocopybord)
+	    : p_impl(new HPRG(fs, hop, beta, output_flags, MedianFilterDirection::TimeCausal, !nocopybord))
+	{
+	}
+
+	template <>
+	HPRRealtime<Backend::GPU>::HPRRealtime(float fs, std::size_t hop, unsigned int output_flags)
+	    : HPRRealtime(fs, hop, 2.0, output_flags)
+	{
+	}
+
+	template <>
+	HPRRealtime<Backend::GPU>::HPRRealtime(float fs, unsigned int output_flags)
+	    : HPRRealtime(fs, 256, 2.0, output_flags)
+	{
+	}
+
+	template <>
+	void HPRRealtime<Backend::GPU>::use_sse_filter()
+	{
+		p_impl->use_sse_filter();
+	}
+
+	template <>
+	void HPRRealtime<Backend::GPU>::use_soft_mask()
+	{
+		p_impl->use_soft_mask();
+	}
+
+	template <>
+	void HPRRealtime<Backend::GPU>::process_next_hop(thrust::device_ptr<float> in_hop)
+	{
+		p_impl->process_next_hop(in_hop);
+	}
+
+	template <>
+	void HPRRealtime<Backend::GPU>::copy_harmonic(thrust::device_ptr<float> out_hop)
+	{
+		p_impl->copy_out(OUTPUT_HARMONIC, out_hop.get());
+	}
+
+	template <>
+	void HPRRealtime<Backend::GPU>::copy_percussive(thrust::device_ptr<float> out_hop)
+	{
+		p_impl->copy_out(OUTPUT_PERCUSSIVE, out_hop.get());
+	}
+
+	template <>
+	void HPRRealtime<Backend::GPU>::copy_residual(thrust::device_ptr<float> out_hop)
+	{
+		p_impl->copy_out(OUTPUT_RESIDUAL, out_hop.get());
+	}
+
+	// The float* overloads are the CPU backend's in the reference (hps.cu:365-390).  On this backend a
+	// raw pointer is taken to be device-accessible memory (device or mapped host), like device_ptr.
+	template <>
+	void HPRRealtime<Backend::GPU>::process_next_hop(float* in_hop)
+	{
+		p_impl->process_next_hop(thrust::device_pointer_cast(in_hop));
+	}
+	template <>
+	void HPRRealtime<Backend::GPU>::copy_harmonic(float* out)
+	{
+		p_impl->copy_out(OUTPUT_HARMONIC, out);
+	}
+	template <>
+	void HPRRealtime<Backend::GPU>::copy_percussive(float* out)
+	{
+		p_impl->copy_out(OUTPUT_PERCUSSIVE, out);
+	}
+	template <>
+	void HPRRealtime<Backend::GPU>::copy_residual(float* out)
+	{
+		p_impl->copy_out(OUTPUT_RESIDUAL, out);
+	}
+
+	template <>
+	void HPRRealtime<Backend::GPU>::process_hops(thrust::device_ptr<float> in, std::size_t n_hops,
+	                                             thrust::device_ptr<float> harm, thrust::device_ptr<float> perc,
+	                                             thrust::device_ptr<float> resid)
+	{
+		p_impl->process_hops(in, n_hops, harm.get(), perc.get(), resid.get());
+	}
+
+	template <>
+	void HPRRealtime<Backend::GPU>::warmup(zen::io::IOGPU& io)
+	{
+		// reference hps.cu:392-408: 1000 hops of iota through the mapped buffers, then a reset
+		const int test_iters = 1000;
+		const std::size_t hop = p_impl->hop;
+		std::vector<float> testdata(test_iters * hop);
+		std::vector<float> outdata(test_iters * hop);
+		std::iota(testdata.begin(), testdata.end(), 0.0F);
+		for (int i = 0; i < test_iters; ++i) {
+			std::copy(testdata.begin() + i * hop, testdata.begin() + (i + 1) * hop, io.host_in);
+			p_impl->process_next_hop(io.device_in);
+			p_impl->copy_out(OUTPUT_PERCUSSIVE, io.device_out.get()); // synchronises: host_in may be reused
+			std::copy(io.host_out, io.host_out + hop, outdata.begin() + i * hop);
+		}
+		p_impl->reset_buffers();
+		zen_hip_synchronize(nullptr);
+	}
+
+	template <>
+	void HPRRealtime<Backend::GPU>::warmup()
+	{
+		zen::io::IOGPU io(p_impl->hop);
+		warmup(io);
+	}
+
+	// ---- HPRIOffline<GPU> (reference libzen/hps.cu:21-221) ----------------------------------------
+	static void* make_offline(float fs, std::size_t hop_h, std::size_t hop_p, float beta_h, float beta_p,
+	                          bool nocopybord)
+	{
+		zen_hip_hpri_t e = nullptr;
+		throw_or_die(zen_hip_hpri_create(fs, hop_h, hop_p, beta_h, beta_p, nocopybord ? 1 : 0, 1, &e), "HPRIOffline");
+		return e;
+	}
+
+	template <>
+	HPRIOffline<Backend::GPU>::~HPRIOffline()
+	{
+		zen_hip_hpri_destroy(static_cast<zen_hip_hpri_t>(engine));
+	}
+
+	template <>
+	HPRIOffline<Backend::GPU>::HPRIOffline(float fs, std::size_t hop_h, std::size_t hop_p, float beta_h,
+	                                       float beta_p, bool nocopybord)
+	    : p_impl_h(nullptr)
+	    , p_impl_p(nullptr)
+	    , hop_h(hop_h)
+	    , hop_p(hop_p)
+	    , engine(make_offline(fs, hop_h, hop_p, beta_h, beta_p, nocopybord))
+	{
+	}
+
+	template <>
+	HPRIOffline<Backend::GPU>::HPRIOffline(float fs, std::size_t hop_h, std::size_t hop_p, float beta_h,
+	                                       float beta_p)
+	    : HPRIOffline(fs, hop_h, hop_p, beta_h, beta_p, false)
+	{
+	}
+
+	template <>
+	HPRIOffline<Backend::GPU>::HPRIOffline(float fs, std::size_t hop_h, std::size_t hop_p)
+	    : HPRIOffline(fs, hop_h, hop_p, 2.0, 2.0)
+	{
+	}
+
+	template <>
+	HPRIOffline<Backend::GPU>::HPRIOffline(float fs)
+	    : HPRIOffline(fs, 4096, 256, 2.0, 2.0)
+	{
+	}
+
+	template <>
+	void HPRIOffline<Backend::GPU>::use_sse_filter()
+	{
+		throw_or_die(zen_hip_hpri_use_sse_filter(static_cast<zen_hip_hpri_t>(engine)), "use_sse_filter");
+	}
+
+	template <>
+	void HPRIOffline<Backend::GPU>::use_soft_mask()
+	{
+		throw_or_die(zen_hip_hpri_use_soft_mask(static_cast<zen_hip_hpri_t>(engine)), "use_soft_mask");
+	}
+
+	template <>
+	std::array<std::vector<float>, 3> HPRIOffline<Backend::GPU>::process(std::vector<float> audio)
+	{
+		// return same-sized vectors as a result (hps.cu:131, :219-220)
+		const std::size_t n = audio.size();
+		std::vector<float> harmonic_out(n), percussive_out(n), residual_out(n);
+		if (n > 0)
+			throw_or_die(zen_hip_hpri_process(static_cast<zen_hip_hpri_t>(engine), audio.data(), n,
+			                                  harmonic_out.data(), percussive_out.data(), residual_out.data()),
+			             "HPRIOffline::process");
+		return std::array<std::vector<float>, 3>{harmonic_out, percussive_out, residual_out};
+	}
+
+	template class HPRIOffline<Backend::GPU>;
+	template class HPRRealtime<Backend::GPU>;
+} // namespace hps
+} // namespace zen
