@@ -3,27 +3,31 @@
 
 Metric (BASELINE.json): "hops/sec (1024-hop HPR, 44.1 kHz mono) + median-filter HBM GB/s vs roofline".
 
-Workload at N = 1 (BASELINE configs[1]): HPRRealtime<GPU> semantics -- hop 1024 (nwin 2048, transform
-size 4096), beta 2.0, OUTPUT_PERCUSSIVE, hard mask, causal -- on a synthetic 44.1 kHz mono stream
-(S-music of BASELINE.md) that is already resident in HBM.  One "step" pushes the next `--hops` hops
-(default 25 840 = 10 minutes of audio) of the stream through zen_hip_hpr_process, percussive output
-included (STFT -> frequency median -> mask -> iSTFT -> overlap-add); state carries over between steps,
-exactly as consecutive process_next_hop calls would leave it, and the samples are bit-identical to
-per-hop calls (tests/test_gpu_parity.py::test_hpr_blocking_is_invisible).
+Default workload (BASELINE configs[1], the one `value` is quoted on): HPRRealtime<GPU> semantics -- hop
+1024 (nwin 2048, transform size 4096), beta 2.0, OUTPUT_PERCUSSIVE, hard mask, causal -- on a synthetic
+44.1 kHz mono stream (S-music of BASELINE.md) already resident in HBM.  One "step" pushes the next
+`--hops` hops (default 25 840 = 10 minutes of audio) of the stream through zen_hip_hpr_process with the
+percussive output written (STFT -> 47-tap frequency median -> hard mask -> iSTFT -> overlap-add).  State
+carries over between steps exactly as consecutive process_next_hop calls leave it, and the samples are
+bit-identical to per-hop calls (tests/test_gpu_parity.py::test_hpr_blocking_is_invisible).
 
-N > 1: the realtime stream is a sequential recurrence and does not shard ("replicas only"):
+N > 1: a realtime stream is a sequential recurrence and does not shard ("replicas only"):
 every rank runs its own independent stream of the same size (weak scaling), no data-path collective;
-torch.distributed (RCCL) is used for the barrier and the max-over-ranks time only.
+torch.distributed (RCCL) carries the barrier and the max-over-ranks time only.
 
 Also in the JSON line:
   roofline     -- the frequency-direction median kernel (47 taps over the 25 840 x 4096 magnitude
-                  matrix), algorithmic bytes = 8 B/element (4 read + 4 written) divided by
+                  matrix): algorithmic bytes = 8 B/element (4 read + 4 written) divided by
                   its mean launch duration, measured with HIP events on the engine's stream inside the
                   timed region (zen_hip_hpr_profile).
-  cpu_baseline -- the CPU oracle (restatement of the reference's CPU/IPP path, "port") timed on this
+  cpu_baseline -- the CPU oracle (restatement of the reference's CPU/IPP path, kind "port") timed on this
                   box's host, one thread, on a bounded prefix of the same stream; rank 0, N = 1 only.
   realtime     -- the single-stream per-hop call path (process_next_hop + copy_percussive through mapped
-                  host memory, as zen/fakert.h:221-247 times it), outside the timed region.
+                  host memory, timed like zen/fakert.h:221-247), outside the timed region.
+
+Other workloads (not the headline; `--workload`):
+  offline_batch -- BASELINE configs[3]: independent 30 s mono clips, HPRIOffline<GPU> 4096/256 hard mask,
+                   clips sharded over the ranks (64 per GPU by default), two passes resident in HBM.
 """
 import argparse
 import json
@@ -55,8 +59,18 @@ def s_music(n, seed=0, fs=FS):
     return (x + 0.01 * rng.uniform(-1, 1, n)).astype(np.float32)
 
 
-def cpu_baseline(x, budget_s=12.0):
-    """Oracle HPR<CPU> (hop 1024, P only, causal) on a prefix of x; returns dict for the JSON line."""
+def host_cpu_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_realtime(x, budget_s=12.0):
+    """Oracle HPR<CPU> (hop 1024, P only, causal) on a prefix of x."""
     from oracle import oracle as o
     h = o.HPR(FS, HOP, BETA, o.OUTPUT_PERCUSSIVE, o.TIME_CAUSAL)
     probe = 40
@@ -71,18 +85,25 @@ def cpu_baseline(x, budget_s=12.0):
         h.process_next_hop(x[i * HOP:(i + 1) * HOP])
         _ = h.percussive_out            # copy_percussive
     dt = time.perf_counter() - t0
-    cpu = "unknown"
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                cpu = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
     return {"value": n / dt, "unit": "hops/s", "cores": 1, "kind": "port",
             "sample": "first %d hops (%.1f s of audio) of the same S-music stream, oracle/zen_oracle.c "
                       "HPR<CPU> hop 1024 P-only causal, 1 thread" % (n, n * HOP / FS),
-            "ms_per_hop": 1e3 * dt / n, "host_cpu": cpu, "host_cores_available": os.cpu_count()}
+            "ms_per_hop": 1e3 * dt / n, "host_cpu": host_cpu_name(), "host_cores_available": os.cpu_count()}
+
+
+def cpu_baseline_offline(x, hop_h, hop_p, total_hops_per_clip, seconds=6.0):
+    """Oracle HPRIOffline on a prefix of one clip (what zen/offline.h:141-147 times), one thread."""
+    from oracle import oracle as o
+    n = int(min(x.size, seconds * FS))
+    eng = o.HPRIOffline(FS, hop_h, hop_p, BETA, BETA)
+    t0 = time.perf_counter()
+    eng.process(x[:n])
+    dt = time.perf_counter() - t0
+    n1, _ = o.chunk_padder(n, hop_h, 1)
+    n2, _ = o.chunk_padder(n, hop_p, 11)
+    return {"value": (n1 + n2) / dt, "unit": "hops/s", "cores": 1, "kind": "port",
+            "sample": "first %.1f s of clip 0, oracle HPRIOffline %d/%d hard mask, 1 thread" % (n / FS, hop_h, hop_p),
+            "x_realtime": (n / FS) / dt, "host_cpu": host_cpu_name(), "host_cores_available": os.cpu_count()}
 
 
 def realtime_leg(zen_amd, x, n_hops=400):
@@ -101,6 +122,7 @@ def realtime_leg(zen_amd, x, n_hops=400):
         _ = io.host_out[0]
     dt = time.perf_counter() - t0
     return {"us_per_hop": 1e6 * dt / n_hops, "hops_per_s": n_hops / dt, "launches_per_hop": 4,
+            "x_realtime": (n_hops / dt) * HOP / FS,
             "note": "process_next_hop + copy_percussive via mapped host memory, host-timed incl. copies "
                     "(zen/fakert.h:221-247); latency-bound, no roofline quoted"}
 
@@ -110,108 +132,126 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="realtime_block", choices=["realtime_block", "offline_batch"])
     ap.add_argument("--hops", type=int, default=25840, help="hops per step per stream (25840 = 10 min)")
     ap.add_argument("--streams", type=int, default=1, help="independent streams per GPU")
+    ap.add_argument("--clips", type=int, default=64, help="offline_batch: clips per GPU")
+    ap.add_argument("--clip-seconds", type=float, default=30.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-realtime", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
+    from zen_amd import dist as zdist
+    rank, local_rank, world = zdist.env_world()
+    torch.cuda.set_device(local_rank)
+    grp = zdist.Group("nccl", torch.device("cuda", local_rank))
 
     import zen_amd
     zen_amd.init(local_rank)
 
-    M, S = args.hops, args.streams
-    n = M * HOP
-    x = np.stack([s_music(n, seed=1000 * rank + s) for s in range(S)])
-    d_in = zen_amd.DeviceBuffer.from_host(x)
-    d_out = zen_amd.DeviceBuffer(S * n)
-    eng = zen_amd.HPR(FS, HOP, BETA, zen_amd.OUTPUT_PERCUSSIVE, zen_amd.TIME_CAUSAL, True, S, M)
-
     def barrier():
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        grp.barrier()
         torch.cuda.synchronize()
 
-    def step():
-        eng.process(d_in.ptr, M, n, None, d_out.ptr, None, n)
+    out = {"metric": "hops/sec (1024-hop HPR, 44.1 kHz mono)", "unit": "hops/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    eng.profile(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    med_ms, med_launches, med_elems = eng.profile_get()
-    eng.profile(False)
+    if args.workload == "realtime_block":
+        M, S = args.hops, args.streams
+        n = M * HOP
+        x = np.stack([s_music(n, seed=1000 * rank + s) for s in range(S)])
+        d_in = zen_amd.DeviceBuffer.from_host(x)
+        d_out = zen_amd.DeviceBuffer(S * n)
+        eng = zen_amd.HPR(FS, HOP, BETA, zen_amd.OUTPUT_PERCUSSIVE, zen_amd.TIME_CAUSAL, True, S, M)
 
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        chk = torch.tensor([float(np.abs(d_out.download(4096)).sum())], dtype=torch.float64, device="cuda")
-        dist.all_reduce(chk, op=dist.ReduceOp.SUM)   # bytes-sized: a liveness checksum, not data path
+        def step():
+            eng.process(d_in.ptr, M, n, None, d_out.ptr, None, n)
 
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        eng.profile(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt = grp.max(time.perf_counter() - t0)
+        med_ms, med_launches, med_elems = eng.profile_get()
+        eng.profile(False)
+        chk = grp.sum([float(np.abs(d_out.download(4096)).sum())])[0]   # liveness only; bytes, not data path
+        if rank == 0:
+            total_hops = world * S * M * args.steps
+            value = total_hops / dt
+            t_launch = 1e-3 * med_ms / max(med_launches, 1)
+            achieved = 8.0 * med_elems / max(med_launches, 1) / t_launch / 1e9 if t_launch > 0 else 0.0
+            out.update({
+                "value": value, "ms_per_step": 1e3 * dt / args.steps,
+                "config": {
+                    "workload": "HPRRealtime<GPU> semantics: hop 1024, nwin 2048, transform 4096, beta 2.0, "
+                                "OUTPUT_PERCUSSIVE, hard mask, causal; S-music 44.1 kHz mono stream resident "
+                                "in HBM; block mode (zen_hip_hpr_process), %d hops/step/stream" % M,
+                    "hops_per_step": M, "streams_per_gpu": S, "fs": FS, "hop": HOP,
+                    "time_mask": 3, "freq_mask": 47, "parallelism": "replicas x%d" % world},
+                "x_realtime": value * HOP / FS,
+                "checksum": chk,
+                "roofline": {
+                    "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                    "frac": achieved / 8000.0, "traffic": None,
+                    "kernel": "median_net_freq_kernel<47, nonneg> (frequency direction, 47 taps)",
+                    "elements_per_launch": med_elems / max(med_launches, 1),
+                    "algorithmic_bytes_per_element": 8, "avg_launch_ms": 1e3 * t_launch,
+                    "launches": med_launches, "share_of_step": (med_ms / 1e3) / dt if dt > 0 else None,
+                    "note": "VALU-bound, not HBM-bound: v_min/v_max/v_med3 issue at half rate on gfx950 "
+                            "(profiles/r01_ubench_valu_rates.txt, profiles/r01_c_median47_pmc.json)"}})
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline_realtime(x[0])
+                out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            if world == 1 and not args.no_realtime:
+                out["realtime"] = realtime_leg(zen_amd, x[0])
+    else:
+        C = args.clips
+        n = int(args.clip_seconds * FS)
+        hop_h, hop_p = 4096, 256
+        ids = zdist.shard_units(C * world, world, rank)          # clip ids of this rank (C each)
+        x = np.stack([s_music(n, seed=7000 + i) for i in ids])
+        d_in = zen_amd.DeviceBuffer.from_host(x)
+        d_h, d_p = zen_amd.DeviceBuffer(C * n), zen_amd.DeviceBuffer(C * n)
+        eng = zen_amd.HPRIOffline(FS, hop_h, hop_p, BETA, BETA, False, C)
+        n1, n2 = eng.hop_counts(n)
+
+        def step():
+            eng.process_device(d_in.ptr, n, n, d_h.ptr, d_p.ptr, None, n)
+
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt = grp.max(time.perf_counter() - t0)
+        chk = grp.sum([float(np.abs(d_p.download(4096)).sum())])[0]
+        if rank == 0:
+            total_hops = world * C * (n1 + n2) * args.steps
+            value = total_hops / dt
+            out.update({
+                "metric": "hops/sec (HPR-I offline, hops of both passes)", "value": value,
+                "ms_per_step": 1e3 * dt / args.steps,
+                "config": {
+                    "workload": "HPRIOffline<GPU> 4096/256 beta 2.0 hard mask, %d x %.0f s mono S-music clips per "
+                                "GPU resident in HBM, both passes + harmonic/percussive outputs" % (C, args.clip_seconds),
+                    "clips_per_gpu": C, "clip_samples": n, "hops_pass1": n1, "hops_pass2": n2,
+                    "parallelism": "clips sharded x%d, no data-path collective" % world},
+                "x_realtime": world * C * args.clip_seconds * args.steps / dt,
+                "checksum": chk})
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline_offline(x[0], hop_h, hop_p, n1 + n2)
     if rank == 0:
-        total_hops = world * S * M * args.steps
-        value = total_hops / dt
-        bytes_per_launch = 8.0 * med_elems / max(med_launches, 1)
-        t_launch = 1e-3 * med_ms / max(med_launches, 1)
-        achieved = bytes_per_launch / t_launch / 1e9 if t_launch > 0 else 0.0
-        out = {
-            "metric": "hops/sec (1024-hop HPR, 44.1 kHz mono)",
-            "value": value,
-            "unit": "hops/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": "HPRRealtime<GPU> semantics: hop 1024, nwin 2048, transform 4096, beta 2.0, "
-                            "OUTPUT_PERCUSSIVE, hard mask, causal; S-music 44.1 kHz mono stream resident "
-                            "in HBM; block mode (zen_hip_hpr_process), %d hops/step/stream" % M,
-                "hops_per_step": M, "streams_per_gpu": S, "fs": FS, "hop": HOP,
-                "time_mask": 3, "freq_mask": 47, "parallelism": "replicas x%d" % world,
-            },
-            "x_realtime": value * HOP / FS,
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                "frac": achieved / 8000.0, "traffic": None,
-                "kernel": "median_wave_kernel<1,0> (frequency direction, 47 taps)",
-                "elements_per_launch": med_elems / max(med_launches, 1),
-                "algorithmic_bytes_per_element": 8, "avg_launch_ms": 1e3 * t_launch,
-                "launches": med_launches,
-                "share_of_step": (med_ms / 1e3) / dt if dt > 0 else None,
-            },
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(x[0])
-            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-        if world == 1 and not args.no_realtime:
-            out["realtime"] = realtime_leg(zen_amd, x[0])
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    grp.close()
 
 
 if __name__ == "__main__":

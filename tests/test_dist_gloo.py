@@ -1,0 +1,89 @@
+"""The N > 1 path on CPU: two processes, gloo backend.  Clips are sharded with zen_amd.dist.shard_units,
+each rank separates its own clips (the CPU oracle stands in for the GPU engine here -- this is a test of
+the sharding / aggregation plumbing, not of the kernels), and the reduced counters and checksums must
+equal a single-process run over all clips."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from zen_amd import dist as zdist  # noqa: E402
+
+
+def clip(i, n):
+    return np.random.default_rng(100 + i).uniform(-1, 1, n).astype(np.float32)
+
+
+def separate(ids, n):
+    from oracle import oracle as o
+    eng = o.HPRIOffline(44100.0, 1024, 256, 2.0, 2.0)
+    hops = len(ids) * (o.chunk_padder(n, 1024, 3)[0] + o.chunk_padder(n, 256, 11)[0])
+    chk = 0.0
+    for i in ids:
+        h, p, _ = eng.process(clip(i, n))
+        chk += float(np.abs(p).astype(np.float64).sum() + np.abs(h).astype(np.float64).sum())
+    return hops, chk
+
+
+def worker(rank, world, port, n_clips, n, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    g = zdist.Group("gloo")
+    ids = zdist.shard_units(n_clips, g.world, g.rank)
+    g.barrier()
+    hops, chk = separate(ids, n)
+    t = g.max(1.0 + rank)                      # max over ranks
+    tot = g.sum([hops, chk, len(ids)])
+    if g.rank == 0:
+        out.put((t, tot))
+    g.close()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_sharded_offline_matches_single_process():
+    n_clips, n, world = 5, 6000, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, world, free_port_holder[0], n_clips, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    t, tot = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    hops, chk = separate(list(range(n_clips)), n)
+    assert t == 2.0                              # max(1.0, 2.0)
+    assert tot[0] == hops and tot[2] == n_clips
+    assert abs(tot[1] - chk) <= 1e-9 * abs(chk)
+
+
+free_port_holder = [free_port()]
+
+
+def test_shard_units_partitions():
+    for world in (1, 2, 3, 8):
+        got = sorted(i for r in range(world) for i in zdist.shard_units(512, world, r))
+        assert got == list(range(512))
+        sizes = [len(zdist.shard_units(512, world, r)) for r in range(world)]
+        assert max(sizes) - min(sizes) <= 1
+    assert zdist.shard_units(512, 8, 3)[:3] == [3, 11, 19] and len(zdist.shard_units(512, 8, 3)) == 64
+    lengths = [100, 1, 1, 1, 50, 50, 3, 3]
+    parts = [zdist.shard_units(8, 2, r, lengths) for r in range(2)]
+    assert sorted(parts[0] + parts[1]) == list(range(8))
+    loads = [sum(lengths[i] for i in p) for p in parts]
+    assert abs(loads[0] - loads[1]) <= 10
+    with pytest.raises(ValueError):
+        zdist.shard_units(4, 2, 2)

@@ -1,0 +1,84 @@
+"""Multi-GPU plumbing for the paths that shard.
+
+Only independent work units shard: whole clips of the batched offline HPR-I, or independent realtime
+streams (replicas).  There is no data-path collective -- each rank owns its units end to end; the
+process group (RCCL on GPUs, gloo in the CPU tests) carries a barrier and a few scalars: the max-over-ranks
+wall time, unit counts and an output checksum so that rank 0 can print the whole-job figure.
+"""
+import os
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torchrun environment; (0, 0, 1) when launched plainly."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def shard_units(n_units, world, rank, lengths=None):
+    """Unit ids owned by `rank`.
+
+    Equal-length units: round robin (rank r gets ids r, r+world, ...), so every rank gets
+    floor/ceil(n/world) units.  With `lengths`, longest-first greedy assignment to the least-loaded rank
+    (deterministic: ties go to the lower rank), which keeps the per-rank sample counts balanced."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad world/rank %d/%d" % (world, rank))
+    if lengths is None:
+        return list(range(rank, n_units, world))
+    if len(lengths) != n_units:
+        raise ValueError("lengths must have n_units entries")
+    order = sorted(range(n_units), key=lambda i: (-lengths[i], i))
+    load = [0] * world
+    owner = [0] * n_units
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        owner[i] = r
+        load[r] += lengths[i]
+    return [i for i in range(n_units) if owner[i] == rank]
+
+
+class Group:
+    """Thin wrapper over torch.distributed (or nothing, for world == 1)."""
+
+    def __init__(self, backend=None, device=None):
+        self.rank, self.local_rank, self.world = env_world()
+        self.dist = None
+        self.device = device
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            self.torch = torch
+            if not dist.is_initialized():
+                kw = {}
+                if backend == "nccl" and device is not None:
+                    kw["device_id"] = device
+                dist.init_process_group(backend or "gloo", **kw)
+            self.dist = dist
+
+    def _tensor(self, values):
+        t = self.torch.tensor(values, dtype=self.torch.float64)
+        return t.to(self.device) if self.device is not None else t
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max(self, value):
+        if self.dist is None:
+            return float(value)
+        t = self._tensor([float(value)])
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum(self, values):
+        values = [float(v) for v in values]
+        if self.dist is None:
+            return values
+        t = self._tensor(values)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()]
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+            self.dist = None
