@@ -180,6 +180,7 @@ def main():
         barrier()
         dt = grp.max(time.perf_counter() - t0)
         med_ms, med_launches, med_elems = eng.profile_get()
+        breakdown = eng.profile_get_all()
         eng.profile(False)
         chk = grp.sum([float(np.abs(d_out.download(4096)).sum())])[0]   # liveness only; bytes, not data path
         if rank == 0:
@@ -197,6 +198,7 @@ def main():
                     "time_mask": 3, "freq_mask": 47, "parallelism": "replicas x%d" % world},
                 "x_realtime": value * HOP / FS,
                 "checksum": chk,
+                "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in breakdown.items() if v["launches"]},
                 "roofline": {
                     "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                     "frac": achieved / 8000.0, "traffic": None,

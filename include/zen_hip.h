@@ -149,11 +149,13 @@ int zen_hip_hpr_copy_output_async(zen_hip_hpr_t h, unsigned which, float* out_de
 int zen_hip_hpr_process(zen_hip_hpr_t h, const float* in_dev, size_t n_hops, size_t in_stride,
                         float* out_harm_dev, float* out_perc_dev, float* out_resid_dev, size_t out_stride);
 
-/* profiling hook for bench.py: HIP events around every launch of the frequency-median kernel on the
- * engine's stream.  get() synchronises and returns the summed kernel time and launch count. */
+/* profiling hook for bench.py: HIP events around every kernel launch on the engine's stream.  get() synchronises and returns the summed kernel time and launch count. */
 int zen_hip_hpr_profile(zen_hip_hpr_t h, int enable);
 int zen_hip_hpr_profile_get(zen_hip_hpr_t h, double* median_ms, unsigned long long* median_launches,
                             unsigned long long* median_elements);
+/* summed milliseconds / launch counts per kernel class:
+ * [0] STFT, [1] frequency filter, [2] time filter, [3] iSTFT, [4] overlap-add/copy-out */
+int zen_hip_hpr_profile_get_all(zen_hip_hpr_t h, double ms[5], unsigned long long launches[5]);
 
 /* ---------------------------------------------------------------------------------------------
  * HPRIOffline<Backend::GPU>   (libzen/hps.cu:21-221): two cascaded HPR passes ("HPR-I").

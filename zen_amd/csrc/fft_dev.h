@@ -153,7 +153,7 @@ struct PassRunner {
 				if (LAST) {
 					if (!HALF_OUT || c < R / 2) { // idx < N/2  <=>  c < R/2
 						if (active)
-							out(idx, v[i][c]);
+							out(idx, v[i][c], /*lower_half=*/c < R / 2);
 					}
 				}
 				else {
@@ -170,7 +170,8 @@ struct PassRunner {
 
 // One N-point transform by the TF threads that own a frame.  `lds` is that frame's padded LDS image
 // (Plan::LDS_FLOAT2 float2).  in(idx) -> float2 supplies x[idx] (only idx < N/2 is asked for when ZU);
-// out(idx, X) receives X[idx] (only idx < N/2 when HALF_OUT).  All threads of the block must call this
+// out(idx, X, lower) receives X[idx] (only idx < N/2 when HALF_OUT); `lower` is the compile-time
+// fact idx < N/2.  All threads of the block must call this
 // together (it contains block barriers); inactive frames pass active = false.
 template <int LOG2N, bool INV, bool ZU, bool HALF_OUT, class In, class Out>
 __device__ __forceinline__ void fft_frame(int tf, float2* __restrict__ lds, const float2* __restrict__ tw,

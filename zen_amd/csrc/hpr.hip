@@ -38,6 +38,7 @@ struct zen_hip_hpr {
 	bool out_h, out_p, out_r, use_sse, soft;
 	size_t n_streams, max_hops;
 	long long ring_rows;
+	size_t s_stride; // float2 per spectrum-ring row: nfft/2 + 1 bins, padded to a 64-byte multiple
 	hipStream_t stream;
 
 	float* d_window = nullptr;
@@ -53,11 +54,52 @@ struct zen_hip_hpr {
 	long long abs_frame = 0;
 	size_t last_frames = 0;
 
+	// profiling hook (bench.py): HIP events around every launch, per kernel class
+	enum { K_STFT = 0, K_FREQ = 1, K_TIME = 2, K_ISTFT = 3, K_FINALIZE = 4, K_COUNT = 5 };
 	bool prof = false;
-	double prof_ms = 0;
-	unsigned long long prof_launches = 0, prof_elements = 0;
-	std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pending;
+	double prof_ms[K_COUNT] = {0, 0, 0, 0, 0};
+	unsigned long long prof_launches[K_COUNT] = {0, 0, 0, 0, 0};
+	unsigned long long prof_elements = 0; // elements filtered by the frequency-direction kernel
+	struct Pending {
+		int k;
+		hipEvent_t e0, e1;
+	};
+	std::vector<Pending> prof_pending;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
 };
+
+namespace {
+struct ProfScope {
+	zen_hip_hpr* e;
+	int k;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	ProfScope(zen_hip_hpr* e_, int k_)
+	    : e(e_)
+	    , k(k_)
+	{
+		if (!e->prof)
+			return;
+		if (!e->prof_pool.empty()) {
+			e0 = e->prof_pool.back().first;
+			e1 = e->prof_pool.back().second;
+			e->prof_pool.pop_back();
+		}
+		else if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+			e0 = e1 = nullptr;
+			return;
+		}
+		(void)hipEventRecord(e0, e->stream);
+	}
+	~ProfScope()
+	{
+		if (!e0)
+			return;
+		(void)hipEventRecord(e1, e->stream);
+		e->prof_pending.push_back({k, e0, e1});
+		e->prof_launches[k] += 1;
+	}
+};
+} // namespace
 
 namespace {
 
@@ -96,6 +138,10 @@ void free_all(zen_hip_hpr* e)
 		(void)hipFree(e->d_carry[o]);
 	}
 	for (auto& p : e->prof_pending) {
+		(void)hipEventDestroy(p.e0);
+		(void)hipEventDestroy(p.e1);
+	}
+	for (auto& p : e->prof_pool) {
 		(void)hipEventDestroy(p.first);
 		(void)hipEventDestroy(p.second);
 	}
@@ -106,7 +152,7 @@ int reset_state(zen_hip_hpr* e)
 	const size_t S = e->n_streams;
 	ZH_HIP(hipMemsetAsync(e->d_tail[0], 0, sizeof(float) * S * e->hop, e->stream));
 	ZH_HIP(hipMemsetAsync(e->d_tail[1], 0, sizeof(float) * S * e->hop, e->stream));
-	ZH_HIP(hipMemsetAsync(e->d_S, 0, sizeof(float2) * S * e->ring_rows * e->nfft, e->stream));
+	ZH_HIP(hipMemsetAsync(e->d_S, 0, sizeof(float2) * S * e->ring_rows * e->s_stride, e->stream));
 	ZH_HIP(hipMemsetAsync(e->d_mag, 0, sizeof(float) * S * e->ring_rows * e->nfft, e->stream));
 	for (int o = 0; o < 3; ++o) {
 		ZH_HIP(hipMemsetAsync(e->d_Y[o], 0, sizeof(float) * S * e->max_hops * e->nwin, e->stream));
@@ -131,6 +177,7 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 	sa.window = e->d_window;
 	sa.tw = e->d_tw;
 	sa.S = e->d_S;
+	sa.s_stride = (long long)e->s_stride;
 	sa.mag = e->d_mag;
 	sa.ring_rows = e->ring_rows;
 	sa.row0 = e->abs_frame;
@@ -143,7 +190,10 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 		sa.Y[o] = e->d_Y[o];
 	}
 	sa.y_stream_stride = (long long)(e->max_hops * e->nwin);
-	ZH_TRY(launch_stft(e->log2n, sa, e->stream));
+	{
+		ProfScope ps(e, zen_hip_hpr::K_STFT);
+		ZH_TRY(launch_stft(e->log2n, sa, e->stream));
+	}
 	e->tail_sel ^= 1;
 
 	// ---- harmonic / percussive estimates of the consumed rows (row W-lag of the sliding matrix)
@@ -166,27 +216,19 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 	ff.dst = e->d_P;
 	ff.len = e->mf;
 	ff.direction = ZEN_HIP_FREQUENCY;
-	hipEvent_t ev0 = nullptr, ev1 = nullptr;
-	const bool prof = e->prof && !e->use_sse;
-	if (prof) {
-		ZH_HIP(hipEventCreate(&ev0));
-		ZH_HIP(hipEventCreate(&ev1));
-		ZH_HIP(hipEventRecord(ev0, e->stream));
-	}
-	if (e->use_sse) {
-		ff.sse_pre = 1;
-		ff.sse_post = 1;
-		ff.post_factor = (float)e->l_perc + 1.0F; // hps.cu:599-601
-		ZH_TRY(launch_box(ff, e->stream));
-	}
-	else {
-		ZH_TRY(launch_median(ff, e->stream));
-	}
-	if (prof) {
-		ZH_HIP(hipEventRecord(ev1, e->stream));
-		e->prof_pending.emplace_back(ev0, ev1);
-		e->prof_launches += 1;
-		e->prof_elements += (unsigned long long)(M * N * S);
+	{
+		ProfScope ps(e, zen_hip_hpr::K_FREQ);
+		if (e->use_sse) {
+			ff.sse_pre = 1;
+			ff.sse_post = 1;
+			ff.post_factor = (float)e->l_perc + 1.0F; // hps.cu:599-601
+			ZH_TRY(launch_box(ff, e->stream));
+		}
+		else {
+			ZH_TRY(launch_median(ff, e->stream));
+		}
+		if (e->prof)
+			e->prof_elements += (unsigned long long)(M * N * S);
 	}
 
 	bool h_is_ring = false; // time direction -> H   (hps.cu:495 / :596)
@@ -199,6 +241,7 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 		ft.sse_post = 1;
 		ft.post_factor = (float)e->l_harm + 1.0F; // hps.cu:602-604
 		ft.causal_self = (e->causality == ZEN_HIP_TIME_CAUSAL);
+		ProfScope ps(e, zen_hip_hpr::K_TIME);
 		ZH_TRY(launch_box(ft, e->stream));
 	}
 	else if (e->causality == ZEN_HIP_TIME_CAUSAL || e->mt == 1) {
@@ -208,6 +251,7 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 		h_is_ring = true;
 	}
 	else {
+		ProfScope ps(e, zen_hip_hpr::K_TIME);
 		ZH_TRY(launch_median(ft, e->stream));
 	}
 
@@ -215,6 +259,7 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 	IstftArgs ia;
 	memset(&ia, 0, sizeof(ia));
 	ia.S = e->d_S;
+	ia.s_stride = (long long)e->s_stride;
 	ia.ring_rows = e->ring_rows;
 	ia.crow0 = crow0;
 	ia.H = h_is_ring ? e->d_mag : e->d_H;
@@ -242,7 +287,10 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 	ia.out_h = e->out_h ? 1 : 0;
 	ia.out_p = e->out_p ? 1 : 0;
 	ia.cola = e->cola;
-	ZH_TRY(launch_istft(e->log2n, ia, e->stream));
+	{
+		ProfScope ps(e, zen_hip_hpr::K_ISTFT);
+		ZH_TRY(launch_istft(e->log2n, ia, e->stream));
+	}
 
 	e->abs_frame += (long long)M;
 	e->last_frames = M;
@@ -266,6 +314,7 @@ int finalize_output(zen_hip_hpr* e, int o, float* out, size_t out_stride, size_t
 	fa.n_frames = (int)M;
 	fa.hop = (int)e->hop;
 	fa.n_streams = (int)e->n_streams;
+	ProfScope ps(e, zen_hip_hpr::K_FINALIZE);
 	return launch_finalize(fa, e->stream);
 }
 
@@ -326,6 +375,7 @@ int zen_hip_hpr_create(float fs, size_t hop, float beta, unsigned output_flags, 
 	}
 	e->max_hops = max_hops_per_chunk;
 	e->ring_rows = (long long)(e->max_hops + W - 1);
+	e->s_stride = (nfft / 2 + 1 + 7) & ~(size_t)7;
 	e->stream = nullptr;
 
 	// host tables, shared bit-for-bit with the oracle
@@ -342,7 +392,7 @@ int zen_hip_hpr_create(float fs, size_t hop, float beta, unsigned output_flags, 
 	          && hipMalloc((void**)&e->d_tw, sizeof(float) * nfft) == hipSuccess
 	          && hipMalloc((void**)&e->d_tail[0], sizeof(float) * S * hop) == hipSuccess
 	          && hipMalloc((void**)&e->d_tail[1], sizeof(float) * S * hop) == hipSuccess
-	          && hipMalloc((void**)&e->d_S, sizeof(float2) * S * e->ring_rows * nfft) == hipSuccess
+	          && hipMalloc((void**)&e->d_S, sizeof(float2) * S * e->ring_rows * e->s_stride) == hipSuccess
 	          && hipMalloc((void**)&e->d_mag, sizeof(float) * S * e->ring_rows * nfft) == hipSuccess
 	          && hipMalloc((void**)&e->d_H, sizeof(float) * S * MH * nfft) == hipSuccess
 	          && hipMalloc((void**)&e->d_P, sizeof(float) * S * MH * nfft) == hipSuccess;
@@ -475,20 +525,30 @@ int zen_hip_hpr_copy_output(zen_hip_hpr_t h, unsigned which, float* out_dev)
 	return ZEN_HIP_OK;
 }
 
+static int prof_drain(zen_hip_hpr_t h)
+{
+	ZH_HIP(hipStreamSynchronize(h->stream));
+	for (auto& p : h->prof_pending) {
+		float ms = 0;
+		ZH_HIP(hipEventElapsedTime(&ms, p.e0, p.e1));
+		h->prof_ms[p.k] += ms;
+		h->prof_pool.emplace_back(p.e0, p.e1);
+	}
+	h->prof_pending.clear();
+	return ZEN_HIP_OK;
+}
+
 int zen_hip_hpr_profile(zen_hip_hpr_t h, int enable)
 {
 	if (!h)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null handle");
+	ZH_TRY(prof_drain(h));
 	h->prof = enable != 0;
 	if (enable) {
-		ZH_HIP(hipStreamSynchronize(h->stream));
-		for (auto& p : h->prof_pending) {
-			(void)hipEventDestroy(p.first);
-			(void)hipEventDestroy(p.second);
+		for (int k = 0; k < zen_hip_hpr::K_COUNT; ++k) {
+			h->prof_ms[k] = 0;
+			h->prof_launches[k] = 0;
 		}
-		h->prof_pending.clear();
-		h->prof_ms = 0;
-		h->prof_launches = 0;
 		h->prof_elements = 0;
 	}
 	return ZEN_HIP_OK;
@@ -499,21 +559,25 @@ int zen_hip_hpr_profile_get(zen_hip_hpr_t h, double* median_ms, unsigned long lo
 {
 	if (!h)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null handle");
-	ZH_HIP(hipStreamSynchronize(h->stream));
-	for (auto& p : h->prof_pending) {
-		float ms = 0;
-		ZH_HIP(hipEventElapsedTime(&ms, p.first, p.second));
-		h->prof_ms += ms;
-		(void)hipEventDestroy(p.first);
-		(void)hipEventDestroy(p.second);
-	}
-	h->prof_pending.clear();
+	ZH_TRY(prof_drain(h));
 	if (median_ms)
-		*median_ms = h->prof_ms;
+		*median_ms = h->prof_ms[zen_hip_hpr::K_FREQ];
 	if (median_launches)
-		*median_launches = h->prof_launches;
+		*median_launches = h->prof_launches[zen_hip_hpr::K_FREQ];
 	if (median_elements)
 		*median_elements = h->prof_elements;
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpr_profile_get_all(zen_hip_hpr_t h, double ms[5], unsigned long long launches[5])
+{
+	if (!h || !ms || !launches)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null argument");
+	ZH_TRY(prof_drain(h));
+	for (int k = 0; k < zen_hip_hpr::K_COUNT; ++k) {
+		ms[k] = h->prof_ms[k];
+		launches[k] = h->prof_launches[k];
+	}
 	return ZEN_HIP_OK;
 }
 

@@ -14,7 +14,8 @@ struct StftArgs {
 	float* tail_next;       // [n_streams][hop] : receives the last hop of this chunk
 	const float* window;    // nwin
 	const float2* tw;       // nfft/2
-	float2* S;              // ring: [n_streams][ring_rows][nfft]
+	float2* S;              // ring: [n_streams][ring_rows][s_stride], bins 0..nfft/2 of each frame
+	long long s_stride;     // float2 per ring row (>= nfft/2 + 1)
 	float* mag;             // ring: [n_streams][ring_rows][nfft]
 	long long ring_rows;
 	long long row0;         // absolute row of the chunk's first frame
@@ -32,6 +33,7 @@ struct StftArgs {
 // consumed rows of a chunk; writes Y[o][frame][0..nwin) = Re(ifft(S*mask))*COLA.
 struct IstftArgs {
 	const float2* S;
+	long long s_stride;
 	long long ring_rows;
 	long long crow0;        // absolute row of the first consumed frame
 	const float* H;         // harmonic estimate of the consumed rows

@@ -36,11 +36,15 @@ struct StftIn {
 };
 
 struct StftOut {
-	float2* S;
-	float* mag;
-	__device__ __forceinline__ void operator()(int idx, float2 X) const
+	float2* S;  // n/2 + 1 bins are kept: the frame is real, so the spectrum is exactly Hermitian
+	            // (radix-2 DAG + a twiddle table with tw[n/2-j] == -conj(tw[j]) bit for bit) and the
+	            // synthesis kernel rebuilds S[n-k] = conj(S[k]).  Halves the spectrum traffic.
+	float* mag; // all n bins: the frequency median runs over the full spectrum
+	int n;
+	__device__ __forceinline__ void operator()(int idx, float2 X, bool lower) const
 	{
-		S[idx] = X;
+		if (lower || idx == (n >> 1))
+			S[idx] = X;
 		mag[idx] = zfft::cabs_exact(X.x, X.y); // complex_abs_functor hps.h:82-89
 	}
 };
@@ -78,8 +82,9 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void stft_kernel(StftArgs a)
 	in.hop = hop;
 	const long long row = ((a.row0 + f) % a.ring_rows) + (long long)s * a.ring_rows;
 	StftOut out;
-	out.S = a.S + row * PL::N;
+	out.S = a.S + row * a.s_stride;
 	out.mag = a.mag + row * PL::N;
+	out.n = PL::N;
 	zfft::fft_frame<LOG2N, false, true, false>(tf, lds + slot * PL::LDS_FLOAT2, a.tw, in, out, active);
 }
 
@@ -99,29 +104,41 @@ __device__ __forceinline__ float powi(float x, int p) // oracle powi(): repeated
 	return r;
 }
 
-// which: 0 percussive, 1 harmonic, 2 residual
-__device__ __forceinline__ float mask_value(int which, float h, float p, const MaskCfg& c)
+__device__ __forceinline__ float pmask_value(float h, float p, const MaskCfg& c)
 {
 	const float EPS = FLT_EPSILON;
-	float pm, hm;
-	if (c.sse) { // sse_mask_functor hps.h:132-140
-		pm = p * p / (p * p + h * h + EPS);
-		hm = h * h / (h * h + p * p + EPS);
-	}
-	else if (c.soft) { // soft_mask_functor hps.h:116-129
+	if (c.sse) // sse_mask_functor hps.h:132-140
+		return p * p / (p * p + h * h + EPS);
+	if (c.soft) { // soft_mask_functor hps.h:116-129
 		const float xp = powi(p, c.power), yp = powi(h, c.power);
-		pm = xp / (xp + yp + EPS);
-		hm = yp / (yp + xp + EPS);
+		return xp / (xp + yp + EPS);
 	}
-	else { // hard_mask_functor hps.h:100-113
-		pm = (float)((p / (h + EPS)) >= c.beta);
-		hm = (float)((h / (p + EPS)) >= c.beta_h);
+	return (float)((p / (h + EPS)) >= c.beta); // hard_mask_functor hps.h:100-113
+}
+
+__device__ __forceinline__ float hmask_value(float h, float p, const MaskCfg& c)
+{
+	const float EPS = FLT_EPSILON;
+	if (c.sse)
+		return h * h / (h * h + p * p + EPS);
+	if (c.soft) {
+		const float xp = powi(h, c.power), yp = powi(p, c.power);
+		return xp / (xp + yp + EPS);
 	}
+	return (float)((h / (p + EPS)) >= c.beta_h);
+}
+
+// which: 0 percussive, 1 harmonic, 2 residual.  `which` and the cfg flags are wave-uniform, so only the
+// division(s) the requested output needs are executed.
+__device__ __forceinline__ float mask_value(int which, float h, float p, const MaskCfg& c)
+{
 	if (which == 0)
-		return pm;
+		return pmask_value(h, p, c);
 	if (which == 1)
-		return hm;
-	return 1 - ((c.out_h ? hm : 0.0f) + (c.out_p ? pm : 0.0f)); // residual_mask_functor hps.h:35-43
+		return hmask_value(h, p, c);
+	const float hm = c.out_h ? hmask_value(h, p, c) : 0.0f;
+	const float pm = c.out_p ? pmask_value(h, p, c) : 0.0f;
+	return 1 - (hm + pm); // residual_mask_functor hps.h:35-43
 }
 
 struct IstftIn {
@@ -130,9 +147,13 @@ struct IstftIn {
 	const float* P;
 	MaskCfg cfg;
 	int which;
+	int n;
 	__device__ __forceinline__ float2 operator()(int idx) const
 	{
-		const float2 z = S[idx];
+		const bool mirror = idx > (n >> 1); // upper half: S[n-k] = conj(S[k])
+		float2 z = S[mirror ? n - idx : idx];
+		if (mirror)
+			z.y = -z.y;
 		const float m = mask_value(which, H[idx], P[idx], cfg);
 		return make_float2(z.x * m, z.y * m); // apply_mask_functor hps.h:58-66
 	}
@@ -141,7 +162,7 @@ struct IstftIn {
 struct IstftOut {
 	float* Y;
 	float cola;
-	__device__ __forceinline__ void operator()(int idx, float2 x) const
+	__device__ __forceinline__ void operator()(int idx, float2 x, bool) const
 	{
 		Y[idx] = x.x * cola; // the product of overlap_add_functor hps.h:68-80; the sum is in finalize
 	}
@@ -158,7 +179,8 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void istft_kernel(IstftArgs a
 	const bool active = f < a.n_frames;
 	const long long ring_row = ((a.crow0 + f) % a.ring_rows) + (long long)s * a.ring_rows;
 	IstftIn in;
-	in.S = a.S + ring_row * PL::N;
+	in.S = a.S + ring_row * a.s_stride;
+	in.n = PL::N;
 	in.H = a.h_is_ring ? a.H + ring_row * PL::N : a.H + (long long)s * a.h_stream_stride + (long long)f * PL::N;
 	in.P = a.P + (long long)s * a.p_stream_stride + (long long)f * PL::N;
 	in.cfg = MaskCfg{a.beta, a.beta_h, a.soft, a.power, a.sse, a.out_h, a.out_p};
@@ -193,7 +215,7 @@ struct PlainIn {
 };
 struct PlainOut {
 	float2* d;
-	__device__ __forceinline__ void operator()(int idx, float2 X) const { d[idx] = X; }
+	__device__ __forceinline__ void operator()(int idx, float2 X, bool) const { d[idx] = X; }
 };
 
 template <int LOG2N, bool INV>

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libzen_hip.so")
+_SO = os.environ.get("ZEN_HIP_SO") or os.path.join(_HERE, "libzen_hip.so")  # override: A/B builds
 
 TIME_CAUSAL, TIME_ANTICAUSAL, FREQUENCY = 0, 1, 2
 OUTPUT_HARMONIC, OUTPUT_PERCUSSIVE, OUTPUT_RESIDUAL = 1, 2, 4
@@ -77,6 +77,7 @@ SYMBOLS = [
     ("zen_hip_hpr_profile", _i, [_vp, _i]),
     ("zen_hip_hpr_profile_get", _i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong),
                                      C.POINTER(C.c_ulonglong)]),
+    ("zen_hip_hpr_profile_get_all", _i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong)]),
     ("zen_hip_hpri_create", _i, [_f, _sz, _sz, _f, _f, _i, _sz, _pvp]),
     ("zen_hip_hpri_destroy", _i, [_vp]),
     ("zen_hip_hpri_set_stream", _i, [_vp, _vp]),
@@ -320,6 +321,12 @@ class HPR:
         ms, n, el = C.c_double(), C.c_ulonglong(), C.c_ulonglong()
         _ck(load().zen_hip_hpr_profile_get(self._h, C.byref(ms), C.byref(n), C.byref(el)))
         return ms.value, n.value, el.value
+
+    def profile_get_all(self):
+        ms, n = (C.c_double * 5)(), (C.c_ulonglong * 5)()
+        _ck(load().zen_hip_hpr_profile_get_all(self._h, ms, n))
+        names = ("stft", "freq_filter", "time_filter", "istft", "finalize")
+        return {k: {"ms": ms[i], "launches": n[i]} for i, k in enumerate(names)}
 
     # ---- host-side convenience for tests ---------------------------------------------------------
     def process_stream_host(self, x, block=None):
