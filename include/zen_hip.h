@@ -58,7 +58,9 @@ const char* zen_hip_version(void);
 int zen_hip_device_name(char* buf, size_t n);
 int zen_hip_synchronize(void* stream); /* hipStreamSynchronize; synchronises */
 /* process-wide tuning/debug switches (no reference counterpart).  "median_general" = 1 forces the general
- * wave-cooperative median kernel even where the sorting-network fast path (masks <= 63 taps) applies. */
+ * wave-cooperative median kernel even where the sorting-network fast path (masks <= 63 taps) applies;
+ * "median47_shared" = 1 routes 47-tap frequency masks to the experimental neighbour-sharing kernel
+ * (median47.hip; same results, currently not faster), "median47_blocks" = n makes it persistent on n workgroups. */
 int zen_hip_set_option(const char* name, int value);
 
 /* device memory + copies: what thrust::device_vector / thrust::copy are to the reference

@@ -18,12 +18,17 @@ def z():
     return zen_amd
 
 
-@pytest.fixture(params=["net", "general"])
+@pytest.fixture(params=["net", "general", "shared47", "shared47_persistent"])
 def zk(z, request):
-    """Both median kernels: the sorting-network fast path (default) and the general wave kernel."""
+    """All median kernels: sorting networks (default), the general wave kernel, and the experimental
+    neighbour-sharing 47-tap kernel (one workgroup per row / persistent)."""
     z.set_option("median_general", 1 if request.param == "general" else 0)
+    z.set_option("median47_shared", 1 if request.param.startswith("shared47") else 0)
+    z.set_option("median47_blocks", 7 if request.param == "shared47_persistent" else 0)
     yield z
     z.set_option("median_general", 0)
+    z.set_option("median47_shared", 0)
+    z.set_option("median47_blocks", 0)
 
 
 def noise(n, seed=0):
@@ -119,7 +124,8 @@ def test_median_filter_too_big_throws(z):
     ((2, 16384), 187), ((24, 1024), 11), ((7, 33), 3), ((300, 257), 21), ((64, 64), 11), ((5, 5), 5),
     ((1, 9), 1), ((3, 1000), 255), ((260, 70), 255), ((129, 300), 129), ((200, 130), 65),
     ((70, 4097), 47), ((33, 5000), 63), ((100, 37), 9), ((77, 1030), 31), ((64, 8192), 15), ((300, 12), 3),
-    ((41, 2050), 25), ((1000, 260), 33), ((90, 1026), 61), ((513, 1028), 5)])
+    ((41, 2050), 25), ((1000, 260), 33), ((90, 1026), 61), ((513, 1028), 5),
+    ((37, 4096), 47), ((19, 8192), 47), ((50, 12), 47), ((23, 100), 47), ((9, 12288), 47)])
 def test_median_random_bit_exact(zk, shape, flen):
     rng = np.random.default_rng(flen + shape[0])
     d = rng.uniform(0, 10, shape).astype(np.float32)

@@ -44,6 +44,9 @@ if __name__ == "__main__":
     ap.add_argument("--dir", default="frequency")
     args = ap.parse_args()
     zen_amd.init(0)
+    for opt in ("median47_blocks", "median47_shared"):
+        if os.environ.get("ZEN_" + opt.upper()):
+            zen_amd.set_option(opt, int(os.environ["ZEN_" + opt.upper()]))
     F, Tm = zen_amd.FREQUENCY, zen_amd.TIME_ANTICAUSAL
     if args.suite == "one":
         cases = [(args.rows, args.cols, args.len, F if args.dir == "frequency" else Tm)]

@@ -12,6 +12,8 @@ namespace zen_hip_impl {
 
 static thread_local char g_err[512] = "";
 int g_opt_median_general = 0;
+int g_opt_median47_shared = 0;
+int g_opt_median47_blocks = 0;
 
 void set_error(const char* fmt, ...)
 {
@@ -121,6 +123,14 @@ int zen_hip_set_option(const char* name, int value)
 {
 	if (name && !strcmp(name, "median_general")) {
 		g_opt_median_general = value;
+		return ZEN_HIP_OK;
+	}
+	if (name && !strcmp(name, "median47_blocks")) {
+		g_opt_median47_blocks = value;
+		return ZEN_HIP_OK;
+	}
+	if (name && !strcmp(name, "median47_shared")) {
+		g_opt_median47_shared = value;
 		return ZEN_HIP_OK;
 	}
 	ZH_FAIL(ZEN_HIP_E_BAD_ARG, "zen_hip_set_option: unknown option '%s'", name ? name : "(null)");

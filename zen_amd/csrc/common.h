@@ -12,6 +12,8 @@ namespace zen_hip_impl {
 
 void set_error(const char* fmt, ...);
 extern int g_opt_median_general; // zen_hip_set_option("median_general")
+extern int g_opt_median47_blocks;  // zen_hip_set_option("median47_blocks"): persistent grid size (0 = one block per row)
+extern int g_opt_median47_shared; // zen_hip_set_option("median47_shared"): use the experimental block-sharing 47-tap kernel
 
 // Evaluate a HIP call; on failure record file:line + hipGetErrorString and return ZEN_HIP_E_HIP.
 #define ZH_HIP(call)                                                                                  \

@@ -167,3 +167,195 @@ __device__ __forceinline__ void medians(const int (&e)[NE], int (&out)[T])
 }
 
 } // namespace znet
+
+// ---------------------------------------------------------------------------------------------------
+// Pieces of the block-sharing 47-tap kernel (median_net.hip: median47_shared_kernel).
+namespace znet {
+
+// Batcher odd-even merge of the two sorted halves of a[0..N) (N a power of two), as a comparator list.
+template <int N>
+struct OddEvenMerge {
+	static constexpr int MAXCE = N * 4;
+	struct List {
+		int i[MAXCE];
+		int j[MAXCE];
+		int n;
+	};
+	static constexpr void rec(List& L, int lo, int n, int r)
+	{
+		const int step = r * 2;
+		if (step < n) {
+			rec(L, lo, n, step);
+			rec(L, lo + r, n, step);
+			for (int i = lo + r; i + r < lo + n; i += step) {
+				L.i[L.n] = i;
+				L.j[L.n] = i + r;
+				++L.n;
+			}
+		}
+		else {
+			L.i[L.n] = lo;
+			L.j[L.n] = lo + r;
+			++L.n;
+		}
+	}
+	static constexpr List make()
+	{
+		List L{};
+		L.n = 0;
+		rec(L, 0, N, 1);
+		return L;
+	}
+};
+
+// a[OFF..OFF+N): both halves sorted -> whole range sorted
+template <int N, int OFF, int NA>
+__device__ __forceinline__ void oe_merge(int (&a)[NA])
+{
+	constexpr auto L = OddEvenMerge<N>::make();
+#pragma unroll
+	for (int c = 0; c < L.n; ++c) {
+		const int x = a[OFF + L.i[c]], y = a[OFF + L.j[c]];
+		a[OFF + L.i[c]] = min(x, y);
+		a[OFF + L.j[c]] = max(x, y);
+	}
+}
+
+// sort a bitonic sequence of 8 ascending (3 half-cleaner stages)
+__device__ __forceinline__ void bitonic_sort8(int (&v)[8])
+{
+#pragma unroll
+	for (int d = 4; d >= 1; d >>= 1) {
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			if ((i & d) == 0) {
+				const int x = v[i], y = v[i + d];
+				v[i] = min(x, y);
+				v[i + d] = max(x, y);
+			}
+		}
+	}
+}
+
+// cand[0..16) = ranks 8..23 of merge(A, B) for sorted A[16], B[16]
+__device__ __forceinline__ void mid16_of_two_sorted16(const int (&A)[16], const int (&B)[16], int (&cand)[16])
+{
+	int lo[16], hi[16];
+#pragma unroll
+	for (int i = 0; i < 16; ++i) { // lo: the 16 smallest (bitonic), hi: the 16 largest (bitonic)
+		lo[i] = min(A[i], B[15 - i]);
+		hi[i] = max(A[i], B[15 - i]);
+	}
+	int u[8], l[8];
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		u[i] = max(lo[i], lo[i + 8]); // the 8 largest of lo  = ranks 8..15
+		l[i] = min(hi[i], hi[i + 8]); // the 8 smallest of hi = ranks 16..23
+	}
+	bitonic_sort8(u);
+	bitonic_sort8(l);
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		cand[i] = u[i];
+		cand[8 + i] = l[i];
+	}
+}
+
+} // namespace znet
+
+namespace znet {
+
+// Sorted-block pyramid of one 16-sample block: s16 = the block sorted, oct = its two halves sorted,
+// quad = its four quarters sorted (the intermediate stages of Batcher's odd-even merge sort).
+__device__ __forceinline__ void pyramid16(const int (&raw)[16], int (&s16)[16], int (&oct)[16], int (&quad)[16])
+{
+#pragma unroll
+	for (int i = 0; i < 16; ++i)
+		s16[i] = raw[i];
+	oe_merge<2, 0>(s16);
+	oe_merge<2, 2>(s16);
+	oe_merge<2, 4>(s16);
+	oe_merge<2, 6>(s16);
+	oe_merge<2, 8>(s16);
+	oe_merge<2, 10>(s16);
+	oe_merge<2, 12>(s16);
+	oe_merge<2, 14>(s16);
+	oe_merge<4, 0>(s16);
+	oe_merge<4, 4>(s16);
+	oe_merge<4, 8>(s16);
+	oe_merge<4, 12>(s16);
+#pragma unroll
+	for (int i = 0; i < 16; ++i)
+		quad[i] = s16[i];
+	oe_merge<8, 0>(s16);
+	oe_merge<8, 8>(s16);
+#pragma unroll
+	for (int i = 0; i < 16; ++i)
+		oct[i] = s16[i];
+	oe_merge<16, 0>(s16);
+}
+
+// 47-tap medians of 16 consecutive outputs 16t..16t+15 from blocks shared with the neighbours.
+// With x the row and B(u) = x[16u-8 .. 16u+7]:
+//   A, B   : B(t), B(t+1) sorted                 (the 32 samples common to all 16 windows)
+//   lo*    : from B(t-1): octU = its upper half sorted, quad1 / quad3 = its 2nd / 4th quarter sorted,
+//            raw = the block as is (pairs and singles are taken from it)
+//   hi*    : from B(t+2): octL = lower half sorted, quad0 / quad2 = 1st / 3rd quarter sorted, raw
+// Same tree as medians<47,16>: only the sorting of the root and of the 8/4-sample chunks is replaced
+// by reads of the neighbours' pyramids.
+struct Shared47 {
+	int cand[16];
+	int lo_oct[8], hi_oct[8];
+	int lo_q[2][4], hi_q[2][4];
+	int lo_raw[16], hi_raw[16];
+};
+
+template <int TN, int G0>
+struct Node47 {
+	static __device__ __forceinline__ void run(const Shared47& s, const int (&cand)[TN], int (&out)[16])
+	{
+		constexpr int h = TN / 2;
+		int L[h], R[h], cl[h], cr[h];
+		if constexpr (TN == 16) {
+#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				L[i] = s.lo_oct[i];
+				R[i] = s.hi_oct[i];
+			}
+		}
+		else if constexpr (TN == 8) {
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				L[i] = s.lo_q[G0 / 8][i];
+				R[i] = s.hi_q[G0 / 8][i];
+			}
+		}
+		else if constexpr (TN == 4) {
+			L[0] = min(s.lo_raw[G0 + 2], s.lo_raw[G0 + 3]);
+			L[1] = max(s.lo_raw[G0 + 2], s.lo_raw[G0 + 3]);
+			R[0] = min(s.hi_raw[G0], s.hi_raw[G0 + 1]);
+			R[1] = max(s.hi_raw[G0], s.hi_raw[G0 + 1]);
+		}
+		else {
+			L[0] = s.lo_raw[G0 + 1];
+			R[0] = s.hi_raw[G0];
+		}
+		merge_mid<TN>(cand, L, cl);
+		if constexpr (h == 1)
+			out[G0] = cl[0];
+		else
+			Node47<h, G0>::run(s, cl, out);
+		merge_mid<TN>(cand, R, cr);
+		if constexpr (h == 1)
+			out[G0 + 1] = cr[0];
+		else
+			Node47<h, G0 + h>::run(s, cr, out);
+	}
+};
+
+__device__ __forceinline__ void medians47_shared(const Shared47& s, int (&out)[16])
+{
+	Node47<16, 0>::run(s, s.cand, out);
+}
+
+} // namespace znet
