@@ -187,6 +187,13 @@ def main():
             total_hops = world * S * M * args.steps
             value = total_hops / dt
             t_launch = 1e-3 * med_ms / max(med_launches, 1)
+            traffic = None          # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot
+            try:                    # run inside this process); only quoted for the shape it was measured on
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_e_hbm_traffic.json")))
+                if tj["shape"]["elements"] == med_elems // max(med_launches, 1):
+                    traffic = tj["kernels"]["median_net_freq_kernel<47,nonneg>"]["hbm_bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                pass
             achieved = 8.0 * med_elems / max(med_launches, 1) / t_launch / 1e9 if t_launch > 0 else 0.0
             out.update({
                 "value": value, "ms_per_step": 1e3 * dt / args.steps,
@@ -201,7 +208,9 @@ def main():
                 "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in breakdown.items() if v["launches"]},
                 "roofline": {
                     "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                    "frac": achieved / 8000.0, "traffic": None,
+                    "frac": achieved / 8000.0, "traffic": traffic,
+                    "traffic_source": "profiles/r01_e_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                      "FETCH doubled per the gfx950 correction)" if traffic else None,
                     "kernel": "median_net_freq_kernel<47, nonneg> (frequency direction, 47 taps)",
                     "elements_per_launch": med_elems / max(med_launches, 1),
                     "algorithmic_bytes_per_element": 8, "avg_launch_ms": 1e3 * t_launch,
