@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <iostream>
 #include <numeric>
+#include <utility>
 
 #include <hps.h>
 #include <libzen/hps.h>
@@ -297,7 +298,8 @@ namespace hps {
 			throw_or_die(zen_hip_hpri_process(static_cast<zen_hip_hpri_t>(engine), audio.data(), n,
 			                                  harmonic_out.data(), percussive_out.data(), residual_out.data()),
 			             "HPRIOffline::process");
-		return std::array<std::vector<float>, 3>{harmonic_out, percussive_out, residual_out};
+		return std::array<std::vector<float>, 3>{std::move(harmonic_out), std::move(percussive_out),
+		                                         std::move(residual_out)};
 	}
 
 	template class HPRIOffline<Backend::GPU>;
