@@ -375,3 +375,81 @@ def test_full_size_stream_linearity_of_blocks(z):
     assert np.array_equal(a, b)
     _, ref = run_oracle(fs, hop, 2.0, o.OUTPUT_PERCUSSIVE, o.TIME_CAUSAL, x[:hop * 40])
     assert np.array_equal(a[:hop * 40], ref["P"])
+
+
+# ---------------------------------------------------------------------------- edge cases
+@pytest.mark.parametrize("n", [1, 7, 255, 256, 257, 4095, 4096, 4097, 10000])
+def test_offline_ragged_and_tiny_clips(z, n):
+    """Clip lengths around the hop sizes, down to a single sample (hps.cu:109-126 padding arithmetic)."""
+    x = noise(n, 40 + n)
+    h, p, r = z.HPRIOffline(44100.0, 1024, 256, 2.0, 2.0).process(x)
+    rh, rp, rr = o.HPRIOffline(44100.0, 1024, 256, 2.0, 2.0).process(x)
+    assert h.size == n and np.array_equal(p, rp) and np.array_equal(h, rh) and np.all(r == 0)
+
+
+def test_offline_silence_and_constant(z):
+    for x in (np.zeros(9000, np.float32), np.full(9000, 0.25, np.float32)):
+        h, p, _ = z.HPRIOffline(44100.0, 2048, 256, 2.0, 2.0).process(x)
+        rh, rp, _ = o.HPRIOffline(44100.0, 2048, 256, 2.0, 2.0).process(x)
+        assert np.array_equal(p, rp) and np.array_equal(h, rh)
+        assert np.all(np.isfinite(p)) and np.all(np.isfinite(h))
+
+
+def test_hpr_largest_supported_hop_48k(z):
+    """hop 4096 @ 48 kHz: nfft 16384, l_perc 171 -> mask 171, the largest transform."""
+    fs, hop = 48000.0, 4096
+    x = music(hop * 10, 12, fs)
+    for caus in (o.TIME_CAUSAL, o.TIME_ANTICAUSAL):
+        ho, ref = run_oracle(fs, hop, 2.0, ALL, caus, x)
+        g = z.HPR(fs, hop, 2.0, ALL, caus)
+        assert g.freq_len == 171 and g.nfft == 16384
+        assert same(g.process_stream_host(x, block=3), ref)
+
+
+def test_hpr_smallest_hops(z):
+    """hop 32 (libzen/hps.bench.cu:62 lower end): nfft 128, time mask 93+ taps, frequency mask 1."""
+    for fs, hop in ((48000.0, 32), (44100.0, 16), (44100.0, 8)):
+        try:
+            ho = o.HPR(fs, hop, 2.0, ALL, o.TIME_ANTICAUSAL)
+        except o.OracleError:
+            with pytest.raises(z.ZenHipError):
+                z.HPR(fs, hop, 2.0, ALL, z.TIME_ANTICAUSAL)
+            continue
+        n_hops = 3 * ho.stft_width
+        x = noise(hop * n_hops, hop)
+        for caus in (o.TIME_CAUSAL, o.TIME_ANTICAUSAL):
+            _, ref = run_oracle(fs, hop, 2.0, ALL, caus, x)
+            try:
+                g = z.HPR(fs, hop, 2.0, ALL, caus)
+            except z.ZenHipError as e:        # mask > 255 taps is outside what the kernels cover
+                assert e.code == 5
+                continue
+            assert same(g.process_stream_host(x, block=50), ref)
+
+
+def test_hpr_multi_stream_chunked_soft_sse(z):
+    fs, hop, n_hops, S = 44100.0, 512, 30, 3
+    x = np.stack([music(hop * n_hops, 200 + s) for s in range(S)])
+    for mode in ("soft", "sse"):
+        g = z.HPR(fs, hop, 2.0, ALL, z.TIME_ANTICAUSAL, True, S, 4)      # 4-hop chunks
+        getattr(g, "use_soft_mask" if mode == "soft" else "use_sse_filter")()
+        got = g.process_stream_host(x, block=11)
+        for s in range(S):
+            _, ref = run_oracle(fs, hop, 2.0, ALL, o.TIME_ANTICAUSAL, x[s], sse=(mode == "sse"), soft=(mode == "soft"))
+            assert all(np.array_equal(got[k][s], ref[k]) for k in "PHR"), (mode, s)
+
+
+def test_copy_output_before_any_hop_is_zero(z):
+    g = z.HPR(44100.0, 256, 2.0, ALL, z.TIME_CAUSAL)
+    d = z.DeviceBuffer(256)
+    d.upload(np.ones(256, np.float32))
+    g.copy_output(z.OUTPUT_PERCUSSIVE, d.ptr)
+    assert np.all(d.download() == 0)
+
+
+def test_median_negative_zero_and_infinities(zk):
+    d = np.array([[0.0, -0.0, np.inf, 1.0, -np.inf, 2.0, -1.0, 3.0, 0.5, -0.5, 7.0, 8.0]], np.float32)
+    d = np.repeat(d, 5, axis=0)
+    for flen in (3, 5, 7, 9):
+        got = zk.MedianFilterGPU(5, 12, flen, zk.FREQUENCY).filter_host(d)
+        assert np.array_equal(got, o.median_filter(d, flen, o.FREQUENCY))
