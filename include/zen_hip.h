@@ -59,6 +59,7 @@ int zen_hip_device_name(char* buf, size_t n);
 int zen_hip_synchronize(void* stream); /* hipStreamSynchronize; synchronises */
 /* process-wide tuning/debug switches (no reference counterpart).  "median_general" = 1 forces the general
  * wave-cooperative median kernel even where the sorting-network fast path (masks <= 63 taps) applies;
+ * "no_rt_fused" = 1 sends single-hop calls through the three-kernel block path instead of rt_fused.hip;
  * "median47_shared" = 1 routes 47-tap frequency masks to the experimental neighbour-sharing kernel
  * (median47.hip; same results, currently not faster), "median47_blocks" = n makes it persistent on n workgroups. */
 int zen_hip_set_option(const char* name, int value);

@@ -453,3 +453,38 @@ def test_median_negative_zero_and_infinities(zk):
     for flen in (3, 5, 7, 9):
         got = zk.MedianFilterGPU(5, 12, flen, zk.FREQUENCY).filter_host(d)
         assert np.array_equal(got, o.median_filter(d, flen, o.FREQUENCY))
+
+
+@pytest.mark.parametrize("fs,hop", [(44100.0, 128), (48000.0, 256), (44100.0, 256), (48000.0, 512), (44100.0, 512),
+                                    (48000.0, 1024), (44100.0, 1024)])
+@pytest.mark.parametrize("soft", [False, True])
+def test_realtime_fused_single_launch_hop(z, fs, hop, soft):
+    """Per-hop calls (one fused launch, rt_fused.hip) == the three-kernel path == the oracle, all outputs."""
+    n_hops = 40
+    x = music(hop * n_hops, 300 + hop, fs)
+    _, ref = run_oracle(fs, hop, 2.0, ALL, o.TIME_CAUSAL, x, soft=soft)
+    outs = []
+    for no_fused in (0, 1):
+        z.set_option("no_rt_fused", no_fused)
+        try:
+            g = z.HPR(fs, hop, 2.0, ALL, z.TIME_CAUSAL, True, 1, 8)
+            if soft:
+                g.use_soft_mask()
+            outs.append(g.process_stream_host(x, block=1))
+        finally:
+            z.set_option("no_rt_fused", 0)
+    assert same(outs[0], ref) and same(outs[1], ref)
+    # mixing single hops and blocks on one engine
+    g = z.HPR(fs, hop, 2.0, ALL, z.TIME_CAUSAL, True, 1, 8)
+    if soft:
+        g.use_soft_mask()
+    din = z.DeviceBuffer.from_host(x)
+    dout = {k: z.DeviceBuffer(x.size) for k in "PHR"}
+    off = 0
+    for m in (1, 1, 5, 1, 8, 3, 1):
+        g.process(din.offset(off * hop), m, m * hop, dout["H"].offset(off * hop), dout["P"].offset(off * hop),
+                  dout["R"].offset(off * hop), m * hop)
+        off += m
+    z.synchronize()
+    for k in "PHR":
+        assert np.array_equal(dout[k].download()[:off * hop], ref[k][:off * hop])

@@ -12,6 +12,7 @@ namespace zen_hip_impl {
 
 static thread_local char g_err[512] = "";
 int g_opt_median_general = 0;
+int g_opt_no_rt_fused = 0;
 int g_opt_median47_shared = 0;
 int g_opt_median47_blocks = 0;
 
@@ -123,6 +124,10 @@ int zen_hip_set_option(const char* name, int value)
 {
 	if (name && !strcmp(name, "median_general")) {
 		g_opt_median_general = value;
+		return ZEN_HIP_OK;
+	}
+	if (name && !strcmp(name, "no_rt_fused")) {
+		g_opt_no_rt_fused = value;
 		return ZEN_HIP_OK;
 	}
 	if (name && !strcmp(name, "median47_blocks")) {

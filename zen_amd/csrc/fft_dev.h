@@ -133,7 +133,7 @@ struct PassRunner {
 					v[i][m] = make_float2(0.f, 0.f);
 				}
 				else if (FIRST) {
-					v[i][m] = active ? in(m * J + j) : make_float2(0.f, 0.f);
+					v[i][m] = active ? in(m * J + j, /*slot=*/m * NB + i) : make_float2(0.f, 0.f);
 				}
 				else {
 					v[i][m] = lds[lds_pad((k * R + m) * J + j)];
@@ -153,7 +153,7 @@ struct PassRunner {
 				if (LAST) {
 					if (!HALF_OUT || c < R / 2) { // idx < N/2  <=>  c < R/2
 						if (active)
-							out(idx, v[i][c], /*lower_half=*/c < R / 2);
+							out(idx, v[i][c], /*lower_half=*/c < R / 2, /*slot=*/c * NB + i);
 					}
 				}
 				else {
@@ -169,9 +169,11 @@ struct PassRunner {
 };
 
 // One N-point transform by the TF threads that own a frame.  `lds` is that frame's padded LDS image
-// (Plan::LDS_FLOAT2 float2).  in(idx) -> float2 supplies x[idx] (only idx < N/2 is asked for when ZU);
-// out(idx, X, lower) receives X[idx] (only idx < N/2 when HALF_OUT); `lower` is the compile-time
-// fact idx < N/2.  All threads of the block must call this
+// (Plan::LDS_FLOAT2 float2).  in(idx, slot) -> float2 supplies x[idx] (only idx < N/2 is asked for when ZU);
+// out(idx, X, lower, slot) receives X[idx] (only idx < N/2 when HALF_OUT); `lower` is the compile-time
+// fact idx < N/2.  `slot` (compile-time, 0..15) numbers a thread's 16 values: idx = tf + slot*TF both for
+// the first pass's inputs and the last pass's outputs, so a spectrum can stay in registers between a
+// forward and an inverse transform (rt_fused.hip).  All threads of the block must call this
 // together (it contains block barriers); inactive frames pass active = false.
 template <int LOG2N, bool INV, bool ZU, bool HALF_OUT, class In, class Out>
 __device__ __forceinline__ void fft_frame(int tf, float2* __restrict__ lds, const float2* __restrict__ tw,

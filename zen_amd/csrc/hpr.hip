@@ -17,6 +17,7 @@
 // absolute frame counter, so nothing is ever shifted (the reference moves (W-1)*nfft complex per hop).
 #include "common.h"
 #include "filters.h"
+#include "rt_fused.h"
 #include "stft.h"
 
 #include <cfloat>
@@ -164,9 +165,56 @@ int reset_state(zen_hip_hpr* e)
 	return ZEN_HIP_OK;
 }
 
+// M == 1, causal, median path: the whole hop in one launch (rt_fused.hip)
+int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride)
+{
+	RtFusedArgs a;
+	memset(&a, 0, sizeof(a));
+	a.in = in;
+	a.in_stride = (long long)in_stride;
+	a.tail_prev = e->d_tail[e->tail_sel];
+	a.tail_next = e->d_tail[e->tail_sel ^ 1];
+	a.window = e->d_window;
+	a.tw = e->d_tw;
+	a.S = e->d_S;
+	a.s_stride = (long long)e->s_stride;
+	a.mag = e->d_mag;
+	a.ring_rows = e->ring_rows;
+	a.row0 = e->abs_frame;
+	a.hop = (int)e->hop;
+	a.n_streams = (int)e->n_streams;
+	a.prev_frames = (int)e->last_frames;
+	a.y_stream_stride = (long long)(e->max_hops * e->nwin);
+	for (int o = 0; o < 3; ++o) {
+		a.Y[o] = e->d_Y[o];
+		if (output_computed(e, o)) {
+			a.carry[o] = e->d_carry[o];
+			a.out_id[a.n_out++] = o;
+		}
+	}
+	a.beta = e->beta;
+	a.beta_h = e->beta - FLT_EPSILON;
+	a.cola = e->cola;
+	a.soft = e->soft ? 1 : 0;
+	a.power = (int)e->beta;
+	a.out_h = e->out_h ? 1 : 0;
+	a.out_p = e->out_p ? 1 : 0;
+	{
+		ProfScope ps(e, zen_hip_hpr::K_STFT);
+		ZH_TRY(launch_rt_fused(e->log2n, e->mf, a, e->stream));
+	}
+	e->tail_sel ^= 1;
+	e->abs_frame += 1;
+	e->last_frames = 1;
+	return ZEN_HIP_OK;
+}
+
 int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 {
 	const size_t S = e->n_streams, N = e->nfft;
+	if (M == 1 && e->causality == ZEN_HIP_TIME_CAUSAL && !e->use_sse && !g_opt_no_rt_fused
+	    && rt_fused_available(e->log2n, e->mf))
+		return run_hop_fused(e, in, in_stride);
 	// ---- analysis
 	StftArgs sa;
 	memset(&sa, 0, sizeof(sa));

@@ -1,0 +1,64 @@
+// masks.h -- the element-wise mask functors of the reference (libzen/hps.h:35-43, :100-140), shared by
+// the synthesis kernel (stft.hip) and the fused realtime kernel (rt_fused.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+
+#pragma clang fp contract(off)
+
+namespace zen_hip_impl {
+
+struct MaskCfg {
+	float beta, beta_h;
+	int soft, power, sse, out_h, out_p;
+};
+
+__device__ __forceinline__ float powi(float x, int p) // oracle powi(): repeated multiplication
+{
+	if (p <= 0)
+		return 1.0F;
+	float r = x;
+	for (int i = 1; i < p; ++i)
+		r = r * x;
+	return r;
+}
+
+__device__ __forceinline__ float pmask_value(float h, float p, const MaskCfg& c)
+{
+	const float EPS = FLT_EPSILON;
+	if (c.sse) // sse_mask_functor hps.h:132-140
+		return p * p / (p * p + h * h + EPS);
+	if (c.soft) { // soft_mask_functor hps.h:116-129
+		const float xp = powi(p, c.power), yp = powi(h, c.power);
+		return xp / (xp + yp + EPS);
+	}
+	return (float)((p / (h + EPS)) >= c.beta); // hard_mask_functor hps.h:100-113
+}
+
+__device__ __forceinline__ float hmask_value(float h, float p, const MaskCfg& c)
+{
+	const float EPS = FLT_EPSILON;
+	if (c.sse)
+		return h * h / (h * h + p * p + EPS);
+	if (c.soft) {
+		const float xp = powi(h, c.power), yp = powi(p, c.power);
+		return xp / (xp + yp + EPS);
+	}
+	return (float)((h / (p + EPS)) >= c.beta_h);
+}
+
+// which: 0 percussive, 1 harmonic, 2 residual.  `which` and the cfg flags are wave-uniform, so only the
+// division(s) the requested output needs are executed.
+__device__ __forceinline__ float mask_value(int which, float h, float p, const MaskCfg& c)
+{
+	if (which == 0)
+		return pmask_value(h, p, c);
+	if (which == 1)
+		return hmask_value(h, p, c);
+	const float hm = c.out_h ? hmask_value(h, p, c) : 0.0f;
+	const float pm = c.out_p ? pmask_value(h, p, c) : 0.0f;
+	return 1 - (hm + pm); // residual_mask_functor hps.h:35-43
+}
+
+} // namespace zen_hip_impl

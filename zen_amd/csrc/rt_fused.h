@@ -1,0 +1,34 @@
+// rt_fused.h -- launch interface of the one-launch-per-hop realtime kernel (rt_fused.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace zen_hip_impl {
+
+struct RtFusedArgs {
+	const float* in;        // stream s: in[s*in_stride .. +hop)
+	long long in_stride;
+	const float* tail_prev; // [n_streams][hop]
+	float* tail_next;
+	const float* window;
+	const float2* tw;
+	float2* S;              // spectrum ring (bins 0..nfft/2 per row)
+	long long s_stride;
+	float* mag;             // magnitude ring
+	long long ring_rows;
+	long long row0;         // absolute row of this hop's frame
+	int hop;
+	int n_streams;
+	int prev_frames;        // frames of the previous call (overlap-add carry source)
+	float* carry[3];        // indexed by output id: 0 percussive, 1 harmonic, 2 residual (null = not computed)
+	float* Y[3];            // indexed by output id
+	long long y_stream_stride;
+	int n_out;              // enabled outputs
+	int out_id[3];
+	float beta, beta_h, cola;
+	int soft, power, out_h, out_p;
+};
+
+bool rt_fused_available(int log2n, int freq_len);
+int launch_rt_fused(int log2n, int freq_len, const RtFusedArgs& a, hipStream_t stream);
+
+} // namespace zen_hip_impl

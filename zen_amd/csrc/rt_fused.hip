@@ -1,0 +1,239 @@
+// rt_fused.hip -- one launch per hop for the single-stream realtime call path
+// (HPRRealtime<GPU>::process_next_hop, libzen/hps.cu:334-339 -> HPR::process_next_hop :429-486 ->
+// apply_median_filter :488-580).  The reference issues ~21 launches here; the block engine of hpr.hip
+// needs 3 (STFT, median, iSTFT); at one frame per call those are pure launch latency, so this kernel runs
+// the whole hop in one workgroup per stream:
+//
+//   window + zero-padded forward FFT         -> spectrum stays in REGISTERS (16 bins per thread, the very
+//                                               bins pass 0 of the inverse transform reads: fft_dev.h slot)
+//   |S| (double-precision hypot)             -> registers + an LDS row image (+ the rings, for block calls)
+//   frequency median of the row (W taps)     -> sorting-network medians from the LDS image (median_net.h)
+//   causal time median                       -> identity: H = |S|
+//   per output: mask, S*mask, inverse FFT    -> Y row (the two-term overlap-add is done by copy_output)
+//
+// Same arithmetic, same buffers and same carry protocol as the three-kernel path: the two are
+// interchangeable hop by hop (tests/test_gpu_parity.py::test_hpr_blocking_is_invisible).
+#include "common.h"
+#include "fft_dev.h"
+#include "masks.h"
+#include "median_net.h"
+#include "rt_fused.h"
+
+#pragma clang fp contract(off)
+
+namespace zen_hip_impl {
+namespace {
+
+using zfft::Plan;
+
+// LDS row image of the median stage: T-word chunks spaced T+PAD apart (see median_net.hip RowImage)
+template <int T>
+struct RtImage {
+	static constexpr int PAD = T >= 8 ? 4 : 0;
+	static constexpr int STRIDE = T + PAD;
+	static constexpr int LOG2T = T == 16 ? 4 : (T == 8 ? 3 : 2);
+	static __device__ __forceinline__ int addr(int g) { return (g >> LOG2T) * STRIDE + (g & (T - 1)); }
+	static constexpr int caddr(int g) { return (g / T) * STRIDE + (g % T); }
+	static constexpr int words(int n) { return ((n + T - 1) / T) * STRIDE; }
+};
+
+struct Regs {
+	float2 S[16];
+	float mag[16];
+};
+
+template <int LOG2N>
+struct FwdIn {
+	const float* prev;
+	const float* cur;
+	const float* window;
+	int hop;
+	__device__ __forceinline__ float2 operator()(int idx, int) const
+	{
+		const float x = idx < hop ? prev[idx] : cur[idx - hop];
+		return make_float2(x * window[idx], 0.0f); // window_functor hps.h:24-33
+	}
+};
+
+template <int T>
+struct FwdOut {
+	Regs* r;
+	float2* S;   // ring row (bins 0..n/2)
+	float* mag;  // ring row
+	int* img;    // LDS image of the magnitudes, word 0 = column -MID_AL
+	int n, mid_al;
+	__device__ __forceinline__ void operator()(int idx, float2 X, bool lower, int slot) const
+	{
+		const float m = zfft::cabs_exact(X.x, X.y); // complex_abs_functor hps.h:82-89
+		r->S[slot] = X;
+		r->mag[slot] = m;
+		if (lower || idx == (n >> 1))
+			S[idx] = X;
+		mag[idx] = m;
+		img[RtImage<T>::addr(idx + mid_al)] = __float_as_int(m); // |S| >= +0: the bits are the ordering key
+	}
+};
+
+struct InvIn {
+	const Regs* r;
+	const float* P; // LDS, natural bin order
+	MaskCfg cfg;
+	int which;
+	__device__ __forceinline__ float2 operator()(int idx, int slot) const
+	{
+		const float2 z = r->S[slot];
+		const float m = mask_value(which, r->mag[slot], P[idx], cfg);
+		return make_float2(z.x * m, z.y * m); // apply_mask_functor hps.h:58-66
+	}
+};
+
+struct InvOut {
+	float* Y;
+	float cola;
+	__device__ __forceinline__ void operator()(int idx, float2 x, bool, int) const { Y[idx] = x.x * cola; }
+};
+
+template <int LOG2N, int W>
+__global__ __launch_bounds__(Plan<LOG2N>::TF) void rt_fused_kernel(RtFusedArgs a)
+{
+	using PL = Plan<LOG2N>;
+	constexpr int N = PL::N, TF = PL::TF;
+	constexpr int T = znet::outputs_per_thread(W), mid = W / 2;
+	static_assert(T >= 4, "needs the 16-byte LDS path");
+	using IM = RtImage<T>;
+	constexpr int MID_AL = (mid + 3) & ~3, DELTA = MID_AL - mid;
+	constexpr int NV = (DELTA + W + T - 1 + 3) / 4, NE = NV * 4;
+	constexpr int NCHUNK = N / T, CPT = 16 / T; // median chunks in the row / per thread
+	constexpr int IMG_WORDS = IM::words((NCHUNK - 1) * T + NE);
+	static_assert(IMG_WORDS * 4 <= PL::LDS_FLOAT2 * 8, "magnitude image must fit in the FFT image");
+
+	extern __shared__ float2 lds[];       // [FFT image | P row]; the magnitude image aliases the FFT image
+	int* img = reinterpret_cast<int*>(lds);
+	float* Prow = reinterpret_cast<float*>(lds + PL::LDS_FLOAT2);
+
+	const int tf = threadIdx.x, s = blockIdx.x, hop = a.hop;
+	const float* in_s = a.in + (long long)s * a.in_stride;
+
+	// ---- per-hop housekeeping (as the extra block of stft_kernel): overlap-add carries, input tail
+	if (a.prev_frames > 0) {
+		for (int o = 0; o < 3; ++o) {
+			if (!a.carry[o])
+				continue;
+			const float* y = a.Y[o] + (long long)s * a.y_stream_stride + (long long)(a.prev_frames - 1) * (2 * hop) + hop;
+			for (int i = tf; i < hop; i += TF)
+				a.carry[o][(long long)s * hop + i] = y[i];
+		}
+	}
+	for (int i = tf; i < hop; i += TF)
+		a.tail_next[(long long)s * hop + i] = in_s[i];
+
+	// ---- analysis: hps.cu:452-472, :492
+	Regs r;
+	{
+		FwdIn<LOG2N> in;
+		in.prev = a.tail_prev + (long long)s * hop;
+		in.cur = in_s;
+		in.window = a.window;
+		in.hop = hop;
+		const long long row = (a.row0 % a.ring_rows) + (long long)s * a.ring_rows;
+		FwdOut<T> out;
+		out.r = &r;
+		out.S = a.S + row * a.s_stride;
+		out.mag = a.mag + row * N;
+		out.img = img;
+		out.n = N;
+		out.mid_al = MID_AL;
+		// the last pass overwrites the FFT image with the magnitude image: every thread has read its
+		// inputs of that pass before the barrier inside PassRunner, so the aliasing is safe
+		zfft::fft_frame<LOG2N, false, true, false>(tf, lds, a.tw, in, out, true);
+	}
+	__syncthreads();
+	// replicate border of the magnitude row (ippBorderRepl)
+	{
+		const int v0 = img[IM::addr(MID_AL)], v1 = img[IM::addr(N - 1 + MID_AL)];
+		for (int g = tf; g < MID_AL; g += TF)
+			img[IM::addr(g)] = v0;
+		for (int g = N + MID_AL + tf; g < (NCHUNK - 1) * T + NE; g += TF)
+			img[IM::addr(g)] = v1;
+	}
+	__syncthreads();
+
+	// ---- percussive estimate: frequency-direction median of the new row (hps.cu:496)
+#pragma unroll
+	for (int ci = 0; ci < CPT; ++ci) {
+		const int ch = tf * CPT + ci;
+		int ld[NE], e[W + T - 1], out[T];
+		const int* mine = &img[ch * IM::STRIDE];
+#pragma unroll
+		for (int v = 0; v < NV; ++v) {
+			const int4 q = *reinterpret_cast<const int4*>(mine + IM::caddr(4 * v));
+			ld[4 * v] = q.x;
+			ld[4 * v + 1] = q.y;
+			ld[4 * v + 2] = q.z;
+			ld[4 * v + 3] = q.w;
+		}
+#pragma unroll
+		for (int q = 0; q < W + T - 1; ++q)
+			e[q] = ld[q + DELTA];
+		znet::medians<W, T, W + T - 1>(e, out);
+#pragma unroll
+		for (int v = 0; v < T / 4; ++v)
+			*reinterpret_cast<int4*>(&Prow[ch * T + 4 * v]) =
+			    make_int4(out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]);
+	}
+	__syncthreads(); // P row complete; the magnitude image is dead, the FFT image is free again
+
+	// ---- synthesis per enabled output: hps.cu:498-579 (H = |S| of the same row: causal)
+	for (int oi = 0; oi < a.n_out; ++oi) {
+		InvIn in;
+		in.r = &r;
+		in.P = Prow;
+		in.cfg = MaskCfg{a.beta, a.beta_h, a.soft, a.power, 0, a.out_h, a.out_p};
+		in.which = a.out_id[oi];
+		InvOut out;
+		out.Y = a.Y[a.out_id[oi]] + (long long)s * a.y_stream_stride;
+		out.cola = a.cola;
+		zfft::fft_frame<LOG2N, true, false, true>(tf, lds, a.tw, in, out, true);
+		__syncthreads();
+	}
+}
+
+template <int LOG2N, int W>
+int launch_t(const RtFusedArgs& a, hipStream_t stream)
+{
+	using PL = Plan<LOG2N>;
+	const size_t lds = sizeof(float2) * PL::LDS_FLOAT2 + sizeof(float) * PL::N;
+	auto kern = rt_fused_kernel<LOG2N, W>;
+	if (lds > 64 * 1024)
+		ZH_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	hipLaunchKernelGGL(kern, dim3((unsigned)a.n_streams), dim3(PL::TF), lds, stream, a);
+	ZH_HIP(hipGetLastError());
+	return ZEN_HIP_OK;
+}
+
+} // namespace
+
+// (transform size, frequency mask) pairs with a fused kernel: hops 128..1024 at 44.1 and 48 kHz
+bool rt_fused_available(int log2n, int freq_len)
+{
+	switch (log2n * 100 + freq_len) {
+	case 907: case 1011: case 1013: case 1121: case 1123: case 1243: case 1247: return true;
+	default: return false;
+	}
+}
+
+int launch_rt_fused(int log2n, int freq_len, const RtFusedArgs& a, hipStream_t stream)
+{
+	switch (log2n * 100 + freq_len) {
+	case 907: return launch_t<9, 7>(a, stream);
+	case 1011: return launch_t<10, 11>(a, stream);
+	case 1013: return launch_t<10, 13>(a, stream);
+	case 1121: return launch_t<11, 21>(a, stream);
+	case 1123: return launch_t<11, 23>(a, stream);
+	case 1243: return launch_t<12, 43>(a, stream);
+	case 1247: return launch_t<12, 47>(a, stream);
+	default: ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "no fused realtime kernel for nfft 2^%d, mask %d", log2n, freq_len);
+	}
+}
+
+} // namespace zen_hip_impl

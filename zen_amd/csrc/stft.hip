@@ -10,6 +10,7 @@
 //   fft_kernel    : the plain FFTC2CWrapperGPU transform (fftw.h:35-43).
 #include "common.h"
 #include "fft_dev.h"
+#include "masks.h"
 #include "stft.h"
 
 #include <cfloat>
@@ -28,7 +29,7 @@ struct StftIn {
 	const float* cur;  // hop samples
 	const float* window;
 	int hop;
-	__device__ __forceinline__ float2 operator()(int idx) const
+	__device__ __forceinline__ float2 operator()(int idx, int) const
 	{
 		const float x = idx < hop ? prev[idx] : cur[idx - hop];
 		return make_float2(x * window[idx], 0.0f); // window_functor hps.h:24-33
@@ -41,7 +42,7 @@ struct StftOut {
 	            // synthesis kernel rebuilds S[n-k] = conj(S[k]).  Halves the spectrum traffic.
 	float* mag; // all n bins: the frequency median runs over the full spectrum
 	int n;
-	__device__ __forceinline__ void operator()(int idx, float2 X, bool lower) const
+	__device__ __forceinline__ void operator()(int idx, float2 X, bool lower, int) const
 	{
 		if (lower || idx == (n >> 1))
 			S[idx] = X;
@@ -89,58 +90,6 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void stft_kernel(StftArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
-struct MaskCfg {
-	float beta, beta_h;
-	int soft, power, sse, out_h, out_p;
-};
-
-__device__ __forceinline__ float powi(float x, int p) // oracle powi(): repeated multiplication
-{
-	if (p <= 0)
-		return 1.0F;
-	float r = x;
-	for (int i = 1; i < p; ++i)
-		r = r * x;
-	return r;
-}
-
-__device__ __forceinline__ float pmask_value(float h, float p, const MaskCfg& c)
-{
-	const float EPS = FLT_EPSILON;
-	if (c.sse) // sse_mask_functor hps.h:132-140
-		return p * p / (p * p + h * h + EPS);
-	if (c.soft) { // soft_mask_functor hps.h:116-129
-		const float xp = powi(p, c.power), yp = powi(h, c.power);
-		return xp / (xp + yp + EPS);
-	}
-	return (float)((p / (h + EPS)) >= c.beta); // hard_mask_functor hps.h:100-113
-}
-
-__device__ __forceinline__ float hmask_value(float h, float p, const MaskCfg& c)
-{
-	const float EPS = FLT_EPSILON;
-	if (c.sse)
-		return h * h / (h * h + p * p + EPS);
-	if (c.soft) {
-		const float xp = powi(h, c.power), yp = powi(p, c.power);
-		return xp / (xp + yp + EPS);
-	}
-	return (float)((h / (p + EPS)) >= c.beta_h);
-}
-
-// which: 0 percussive, 1 harmonic, 2 residual.  `which` and the cfg flags are wave-uniform, so only the
-// division(s) the requested output needs are executed.
-__device__ __forceinline__ float mask_value(int which, float h, float p, const MaskCfg& c)
-{
-	if (which == 0)
-		return pmask_value(h, p, c);
-	if (which == 1)
-		return hmask_value(h, p, c);
-	const float hm = c.out_h ? hmask_value(h, p, c) : 0.0f;
-	const float pm = c.out_p ? pmask_value(h, p, c) : 0.0f;
-	return 1 - (hm + pm); // residual_mask_functor hps.h:35-43
-}
-
 struct IstftIn {
 	const float2* S;
 	const float* H;
@@ -148,7 +97,7 @@ struct IstftIn {
 	MaskCfg cfg;
 	int which;
 	int n;
-	__device__ __forceinline__ float2 operator()(int idx) const
+	__device__ __forceinline__ float2 operator()(int idx, int) const
 	{
 		const bool mirror = idx > (n >> 1); // upper half: S[n-k] = conj(S[k])
 		float2 z = S[mirror ? n - idx : idx];
@@ -162,7 +111,7 @@ struct IstftIn {
 struct IstftOut {
 	float* Y;
 	float cola;
-	__device__ __forceinline__ void operator()(int idx, float2 x, bool) const
+	__device__ __forceinline__ void operator()(int idx, float2 x, bool, int) const
 	{
 		Y[idx] = x.x * cola; // the product of overlap_add_functor hps.h:68-80; the sum is in finalize
 	}
@@ -211,11 +160,11 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a)
 // ------------------------------------------------------------------------------------------------
 struct PlainIn {
 	const float2* d;
-	__device__ __forceinline__ float2 operator()(int idx) const { return d[idx]; }
+	__device__ __forceinline__ float2 operator()(int idx, int) const { return d[idx]; }
 };
 struct PlainOut {
 	float2* d;
-	__device__ __forceinline__ void operator()(int idx, float2 X, bool) const { d[idx] = X; }
+	__device__ __forceinline__ void operator()(int idx, float2 X, bool, int) const { d[idx] = X; }
 };
 
 template <int LOG2N, bool INV>
