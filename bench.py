@@ -130,8 +130,8 @@ def realtime_leg(zen_amd, x, n_hops=400):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="realtime_block", choices=["realtime_block", "offline_batch"])
     ap.add_argument("--hops", type=int, default=25840, help="hops per step per stream (25840 = 10 min)")
     ap.add_argument("--streams", type=int, default=1, help="independent streams per GPU")
