@@ -6,7 +6,8 @@
 // directions).  One 64-lane wavefront keeps the current window as a SORTED array spread over its lanes
 // (position p lives in register p/64, lane p%64) and slides it one sample at a time: the leaving and the
 // entering sample are located with two wave-wide compares + ballots (popcount = rank, the array is
-// sorted so each ballot is a prefix mask), the elements between the two ranks move one lane up or down,
+// sorted so each ballot is a prefix mask), the elements between the two ranks move one lane up or down
+// (wave-wide DPP shift + a select under a scalar lane mask),
 // and the middle position is the output.  No data-dependent memory traffic: the line being filtered is
 // staged once into LDS with coalesced loads, results go back through LDS so that stores are coalesced
 // in both directions.  Values are ordered through the usual monotone float->int key, so the result is
@@ -33,7 +34,10 @@ __device__ __forceinline__ long long clampll(long long v, long long lo, long lon
 	return v < lo ? lo : (v > hi ? hi : v);
 }
 
-// Sorted window of up to 64*R keys held by one wavefront.
+// Sorted window of up to 64*R keys held by one wavefront: position p lives in register p/64, lane p%64.
+// One slide step = two rank computations (v_cmp + s_bcnt1 per register), then per register one
+// wave-wide DPP shift (wave_shl:1 / wave_shr:1, lane i <- lane i+1 / i-1, verified on gfx950 by
+// tools/probe_dpp.hip), one range test and two selects.
 template <int R>
 struct SortedWindow {
 	int s[R];
@@ -62,37 +66,33 @@ struct SortedWindow {
 			const int lo = p_out, hi = c_in - 1;
 #pragma unroll
 			for (int r = 0; r < R; ++r) {
-				int nb = __shfl_down(s[r], 1);
-				if (r + 1 < R) {
-					int carry = __shfl(s[r + 1], 0);
-					nb = (lane == 63) ? carry : nb;
-				}
+				const int carry = (r + 1 < R) ? __builtin_amdgcn_readlane(s[r + 1], 0) : 0;
+				const int nb = __builtin_amdgcn_update_dpp(carry, s[r], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
 				const int p = r * 64 + lane;
-				s[r] = (p >= lo && p < hi) ? nb : ((p == hi) ? vi : s[r]);
+				const int t = ((unsigned)(p - lo) < (unsigned)(hi - lo)) ? nb : s[r];
+				s[r] = (p == hi) ? vi : t;
 			}
 		}
 		else { // vi lands at c_in, positions (c_in, p_out] take their lower neighbour
 			const int lo = c_in, hi = p_out;
 #pragma unroll
 			for (int r = R - 1; r >= 0; --r) {
-				int nb = __shfl_up(s[r], 1);
-				if (r > 0) {
-					int carry = __shfl(s[r - 1], 63);
-					nb = (lane == 0) ? carry : nb;
-				}
+				const int carry = (r > 0) ? __builtin_amdgcn_readlane(s[r - 1], 63) : 0;
+				const int nb = __builtin_amdgcn_update_dpp(carry, s[r], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 				const int p = r * 64 + lane;
-				s[r] = (p > lo && p <= hi) ? nb : ((p == lo) ? vi : s[r]);
+				const int t = ((unsigned)(p - lo - 1) < (unsigned)(hi - lo)) ? nb : s[r];
+				s[r] = (p == lo) ? vi : t;
 			}
 		}
 	}
 
-	__device__ __forceinline__ int at(int pos) const // pos wave-uniform
+	__device__ __forceinline__ int at(int pos) const // pos wave-uniform; result wave-uniform
 	{
 		int v = 0;
 #pragma unroll
 		for (int r = 0; r < R; ++r)
 			if ((pos >> 6) == r)
-				v = __shfl(s[r], pos & 63);
+				v = __builtin_amdgcn_readlane(s[r], pos & 63);
 		return v;
 	}
 };
@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void median_wave_kernel(FilterArgs a)
 	constexpr int pout = SEG + 1;
 	int* tin = smem;
 	int* tout = smem + NL * pin;
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: the per-line control flow is wave-uniform
 	const float* __restrict__ src = a.src + (long long)blockIdx.z * a.src_stream_stride;
 	float* __restrict__ dst = a.dst + (long long)blockIdx.z * a.dst_stream_stride;
 	const int cols = a.cols;
