@@ -1,7 +1,6 @@
-// core.h -- the policy layer.  Same role and typedef names as the reference's libzen/core.h:17-41:
-// TypeTraits<Backend> bundles the vector / FFT / median / box / window types one algorithm template is
-// written against.  Only the GPU bundle ships in the product; the CPU bundle (the oracle-backed
-// restatement used as the parity reference) lives under oracle/ and is test infrastructure.
+// core.h -- the policy layer: TypeTraits<Backend> names the container / FFT / filter / window types that
+// one algorithm template is written against (same role and member names as the reference's
+// libzen/core.h:17-41).  Only the GPU bundle ships; the CPU bundle is the oracle (test infrastructure).
 #ifndef ZG_CORE_H
 #define ZG_CORE_H
 
@@ -17,19 +16,18 @@
 namespace zen {
 namespace internal {
 	namespace core {
-		template <zen::Backend T>
-		struct TypeTraits {
-		};
+		template <zen::Backend>
+		struct TypeTraits;
 
 		template <>
 		struct TypeTraits<zen::Backend::GPU> {
-			typedef thrust::device_ptr<float> InputPointer;
-			typedef zen::internal::device_vector<float> RealVector;
-			typedef zen::internal::device_vector<std::complex<float>> ComplexVector;
-			typedef zen::internal::fftw::FFTC2CWrapperGPU FFTC2CWrapper;
-			typedef zen::internal::hps::mfilt::MedianFilterGPU MedianFilter;
-			typedef zen::internal::hps::box::BoxFilterGPU BoxFilter;
-			typedef zen::internal::win::WindowGPU Window;
+			using InputPointer = thrust::device_ptr<float>;
+			using RealVector = zen::internal::device_vector<float>;
+			using ComplexVector = zen::internal::device_vector<std::complex<float>>;
+			using Window = zen::internal::win::WindowGPU;
+			using FFTC2CWrapper = zen::internal::fftw::FFTC2CWrapperGPU;
+			using MedianFilter = zen::internal::hps::mfilt::MedianFilterGPU;
+			using BoxFilter = zen::internal::hps::box::BoxFilterGPU;
 		};
 	} // namespace core
 } // namespace internal
