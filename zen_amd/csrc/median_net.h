@@ -86,6 +86,22 @@ __device__ __forceinline__ void sort_net(int (&a)[N])
 	}
 }
 
+// sort a bitonic sequence of 8 ascending (3 half-cleaner stages, 12 comparators)
+__device__ __forceinline__ void bitonic_sort8(int (&v)[8])
+{
+#pragma unroll
+	for (int d = 4; d >= 1; d >>= 1) {
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			if ((i & d) == 0) {
+				const int x = v[i], y = v[i + d];
+				v[i] = min(x, y);
+				v[i + d] = max(x, y);
+			}
+		}
+	}
+}
+
 // out[p'] = merge(A, B)[h + p'], p' < h, for sorted A (n = 2h) and sorted B (h)
 template <int NA>
 __device__ __forceinline__ void merge_mid(const int (&A)[NA], const int (&B)[NA / 2], int (&out)[NA / 2])
@@ -93,6 +109,19 @@ __device__ __forceinline__ void merge_mid(const int (&A)[NA], const int (&B)[NA 
 	constexpr int h = NA / 2;
 	if constexpr (h == 1) {
 		out[0] = med3i(A[0], A[1], B[0]);
+	}
+	else if constexpr (h == 8) {
+		// ranks 8..15 of A[16] u B[8] by two bitonic half-merges (64 min/max instead of 96):
+		// the 16 smallest are A[0..8) plus the 8 smallest of A[8..16) u B, of which we want the top 8.
+		int d[8];
+#pragma unroll
+		for (int i = 0; i < 8; ++i)
+			d[i] = min(A[8 + i], B[7 - i]); // the 8 smallest of A[8..16) u B (bitonic)
+		bitonic_sort8(d);
+#pragma unroll
+		for (int i = 0; i < 8; ++i)
+			out[i] = max(A[i], d[7 - i]); // the 8 largest of A[0..8) u d (bitonic)
+		bitonic_sort8(out);
 	}
 	else {
 #pragma unroll
@@ -218,22 +247,6 @@ __device__ __forceinline__ void oe_merge(int (&a)[NA])
 		const int x = a[OFF + L.i[c]], y = a[OFF + L.j[c]];
 		a[OFF + L.i[c]] = min(x, y);
 		a[OFF + L.j[c]] = max(x, y);
-	}
-}
-
-// sort a bitonic sequence of 8 ascending (3 half-cleaner stages)
-__device__ __forceinline__ void bitonic_sort8(int (&v)[8])
-{
-#pragma unroll
-	for (int d = 4; d >= 1; d >>= 1) {
-#pragma unroll
-		for (int i = 0; i < 8; ++i) {
-			if ((i & d) == 0) {
-				const int x = v[i], y = v[i + d];
-				v[i] = min(x, y);
-				v[i + d] = max(x, y);
-			}
-		}
 	}
 }
 
