@@ -28,6 +28,8 @@ Also in the JSON line:
 Other workloads (not the headline; `--workload`):
   offline_batch -- BASELINE configs[3]: independent 30 s mono clips, HPRIOffline<GPU> 4096/256 hard mask,
                    clips sharded over the ranks (64 per GPU by default), two passes resident in HBM.
+  offline_long  -- BASELINE configs[2]: one 10-minute stereo clip, soft mask; with N ranks each channel is
+                   cut into N time ranges computed independently (strong scaling).
 """
 import argparse
 import json
@@ -132,7 +134,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="realtime_block", choices=["realtime_block", "offline_batch"])
+    ap.add_argument("--workload", default="realtime_block", choices=["realtime_block", "offline_batch", "offline_long"])
     ap.add_argument("--hops", type=int, default=25840, help="hops per step per stream (25840 = 10 min)")
     ap.add_argument("--streams", type=int, default=1, help="independent streams per GPU")
     ap.add_argument("--clips", type=int, default=64, help="offline_batch: clips per GPU")
@@ -222,7 +224,7 @@ def main():
                 out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
             if world == 1 and not args.no_realtime:
                 out["realtime"] = realtime_leg(zen_amd, x[0])
-    else:
+    elif args.workload == "offline_batch":
         C = args.clips
         n = int(args.clip_seconds * FS)
         hop_h, hop_p = 4096, 256
@@ -260,6 +262,43 @@ def main():
                 "checksum": chk})
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_offline(x[0], hop_h, hop_p, n1 + n2)
+    if args.workload == "offline_long":
+        # BASELINE configs[2]: one 10-minute stereo clip = 2 mono channels, HPR-I 4096/256, soft mask p = 2.
+        # N > 1: every channel is cut into N time ranges, rank r computes range r of both
+        # channels from its own halo of input; strong scaling, no exchange.
+        n = int(600 * FS)
+        hop_h, hop_p = 4096, 256
+        b, e = zdist.time_shards(n, world, hop_h)[rank]
+        chans = [s_music(n, seed=9000 + c) for c in range(2)]
+        d_in = [zen_amd.DeviceBuffer.from_host(c) for c in chans]
+        d_h, d_p = zen_amd.DeviceBuffer(max(e - b, 1)), zen_amd.DeviceBuffer(max(e - b, 1))
+        eng = zen_amd.HPRIOffline(FS, hop_h, hop_p, 2.5, 2.5, False, 1)
+        eng.use_soft_mask()
+        n1, n2 = eng.hop_counts(n)
+
+        def step():
+            for c in range(2):
+                if e > b:
+                    eng.process_range(d_in[c].ptr, n, b, e, d_h.ptr, d_p.ptr)
+
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt = grp.max(time.perf_counter() - t0)
+        chk = grp.sum([float(np.abs(d_p.download(min(4096, max(e - b, 1)))).sum())])[0]
+        if rank == 0:
+            out.update({
+                "metric": "hops/sec (HPR-I offline, hops of both passes)", "scaling": "strong",
+                "value": 2 * (n1 + n2) * args.steps / dt, "ms_per_step": 1e3 * dt / args.steps,
+                "config": {"workload": "HPRIOffline<GPU> 4096/256 beta 2.5 soft mask (p = 2), one 10-minute stereo "
+                                       "clip (2 mono channels of 26 460 000 samples) resident in HBM",
+                           "hops_pass1": n1, "hops_pass2": n2,
+                           "parallelism": "each channel time-sharded x%d with warm-up halos, no exchange" % world},
+                "x_realtime": 600.0 * args.steps / dt, "checksum": chk})
     if rank == 0:
         print(json.dumps(out))
     grp.close()

@@ -180,6 +180,15 @@ int zen_hip_hpri_process(zen_hip_hpri_t h, const float* audio_host, size_t n, fl
  * Outputs may be NULL.  Asynchronous. */
 int zen_hip_hpri_process_device(zen_hip_hpri_t h, const float* audio_dev, size_t n, size_t stride,
                                 float* harm_dev, float* perc_dev, float* resid_dev, size_t out_stride);
+/* Time-sharding one long clip across GPUs (no reference counterpart).  Writes output
+ * samples [begin, end) of the n-sample clip at audio_dev (indexed from sample 0 of the clip; only
+ * [in_begin, in_end) as reported by zen_hip_hpri_range_halo is read) to harm_dev / perc_dev (end - begin
+ * floats each, either may be NULL).  Bit-identical to the same range of zen_hip_hpri_process_device: each
+ * shard re-runs a short warm-up (2*stft_width + 2 hops per pass) instead of exchanging state.
+ * Handle created with n_clips == 1.  Asynchronous. */
+int zen_hip_hpri_range_halo(zen_hip_hpri_t h, size_t n, size_t begin, size_t end, size_t* in_begin, size_t* in_end);
+int zen_hip_hpri_process_range(zen_hip_hpri_t h, const float* audio_dev, size_t n, size_t begin, size_t end,
+                               float* harm_dev, float* perc_dev);
 /* hops the two passes run for an n-sample clip (hps.cu:109-126), for throughput accounting */
 int zen_hip_hpri_hop_counts(zen_hip_hpri_t h, size_t n, size_t* n_hops_h, size_t* n_hops_p);
 

@@ -87,3 +87,12 @@ def test_shard_units_partitions():
     assert abs(loads[0] - loads[1]) <= 10
     with pytest.raises(ValueError):
         zdist.shard_units(4, 2, 2)
+
+
+def test_time_shards_cover_the_clip():
+    for n, world, align in ((26460000, 8, 4096), (161571, 3, 1024), (1000, 4, 256), (5, 2, 1)):
+        sh = zdist.time_shards(n, world, align)
+        assert len(sh) == world and sh[0][0] == 0 and sh[-1][1] == n
+        for (b0, e0), (b1, e1) in zip(sh, sh[1:]):
+            assert e0 == b1 and b0 <= e0
+        assert all(b % align == 0 for b, _ in sh)

@@ -488,3 +488,29 @@ def test_realtime_fused_single_launch_hop(z, fs, hop, soft):
     z.synchronize()
     for k in "PHR":
         assert np.array_equal(dout[k].download()[:off * hop], ref[k][:off * hop])
+
+
+@pytest.mark.parametrize("hop_h,hop_p,n", [(4096, 256, 400000), (1024, 256, 161571), (2048, 512, 90000)])
+def test_offline_time_sharded_equals_whole_clip(z, hop_h, hop_p, n):
+    """one clip cut into time ranges, every range computed independently (as different GPUs
+    would) with a warm-up halo, must reproduce the single-pass result bit for bit."""
+    from zen_amd import dist as zdist
+    x = music(n, 77)
+    whole = z.HPRIOffline(44100.0, hop_h, hop_p, 2.0, 2.0)
+    h_ref, p_ref, _ = whole.process(x)
+    d_in = z.DeviceBuffer.from_host(x)
+    for world in (2, 3, 7):
+        eng = z.HPRIOffline(44100.0, hop_h, hop_p, 2.0, 2.0)
+        for rank, (b, e) in enumerate(zdist.time_shards(n, world, hop_h)):
+            if b == e:
+                continue
+            ib, ie = eng.range_halo(n, b, e)
+            assert 0 <= ib <= b and e <= max(ie, e) and ie <= n
+            dh, dp = z.DeviceBuffer(e - b), z.DeviceBuffer(e - b)
+            eng.process_range(d_in.ptr, n, b, e, dh.ptr, dp.ptr)
+            z.synchronize()
+            assert np.array_equal(dh.download(), h_ref[b:e]), (world, rank, "harm")
+            assert np.array_equal(dp.download(), p_ref[b:e]), (world, rank, "perc")
+    # the halo is local: a middle shard of a long clip reads far less than the clip
+    ib, ie = whole.range_halo(n, n // 2, n // 2 + hop_h)
+    assert ie - ib < n // 2

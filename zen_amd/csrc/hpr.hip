@@ -856,6 +856,167 @@ int zen_hip_hpri_process_device(zen_hip_hpri_t h, const float* audio_dev, size_t
 	return ZEN_HIP_OK;
 }
 
+// ---- time-sharding one long clip ---------------------------------------------------
+// Output samples [begin, end) of an n-sample clip, bit-identical to the same range of
+// zen_hip_hpri_process.  Both passes are streaming recurrences whose state (input tail, the last W-1
+// spectra, the overlap-add carry) is a function of the last <= W+1 hops only, so a shard that starts
+// 2W+2 hops early from zero state reaches exactly the serial state before its first kept sample.  The
+// shard therefore needs only a halo of input: (2W_p+2)*hop_p + lag_p*hop_p for pass 2 on top of
+// (2W_h+2)*hop_h + lag_h*hop_h for pass 1; ranks exchange nothing.
+namespace {
+
+struct RangePlan {
+	size_t padded1, padded2, sh1, sh2;
+	size_t q1, k1;   // pass-1 hops [q1, k1) are run
+	size_t q2, m1;   // pass-2 hops [q2, m1) are run
+	size_t in_begin, in_end; // input samples read (clipped to n; beyond n is zero padding)
+};
+
+int plan_range(zen_hip_hpri* h, size_t n, size_t begin, size_t end, RangePlan* p)
+{
+	if (!(begin < end) || end > n)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri range [%zu, %zu) outside the clip of %zu samples", begin, end, n);
+	const size_t hop_h = h->hop_h, hop_p = h->hop_p;
+	const int n1 = chunk_padder(n, hop_h, (size_t)h->eh->lag, &p->padded1);
+	const int n2 = chunk_padder(n, hop_p, (size_t)h->ep->lag, &p->padded2);
+	if (n1 <= 0 || n2 <= 0)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri range: clip too short");
+	p->sh1 = (size_t)h->eh->lag * hop_h;
+	p->sh2 = (size_t)h->ep->lag * hop_p;
+	const size_t warm_p = 2 * h->ep->W + 2, warm_h = 2 * h->eh->W + 2;
+	// pass-2 output positions [begin + sh2, end + sh2) (or unshifted near the very end: Q9-style tail)
+	size_t m0 = begin / hop_p;                       // conservative: positions j or j + sh2
+	p->m1 = ceil_div(end + p->sh2, hop_p);
+	if (p->m1 > (size_t)n2)
+		p->m1 = (size_t)n2;
+	if (m0 > p->m1)
+		m0 = p->m1;
+	p->q2 = m0 > warm_p ? m0 - warm_p : 0;
+	// pass-1 output positions: pass-2 input j in [q2*hop_p, m1*hop_p) reads position j or j + sh1;
+	// the harmonic output reads [begin, end + sh1)
+	size_t a1 = p->q2 * hop_p < begin ? p->q2 * hop_p : begin;
+	size_t b1 = p->m1 * hop_p + p->sh1;
+	if (end + p->sh1 > b1)
+		b1 = end + p->sh1;
+	if (b1 > p->padded1)
+		b1 = p->padded1;
+	const size_t k0 = a1 / hop_h;
+	p->k1 = ceil_div(b1, hop_h);
+	if (p->k1 > (size_t)n1)
+		p->k1 = (size_t)n1;
+	p->q1 = k0 > warm_h ? k0 - warm_h : 0;
+	p->in_begin = p->q1 * hop_h;
+	p->in_end = p->k1 * hop_h < n ? p->k1 * hop_h : n;
+	if (p->in_begin > p->in_end)
+		p->in_begin = p->in_end;
+	return ZEN_HIP_OK;
+}
+
+// a1[i] = audio[off + i] (zero beyond n), i < count
+__global__ __launch_bounds__(256) void range_input_kernel(const float* __restrict__ audio, size_t n, size_t off,
+                                                          float* __restrict__ dst, size_t count)
+{
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+		dst[i] = (off + i < n) ? audio[off + i] : 0.0F;
+}
+
+// pass-2 input positions j in [j0, j0+count): intermediate'[j] as intermediate_kernel defines it;
+// P1/R1 hold pass-1 output positions [base1, ...)
+__global__ __launch_bounds__(256) void range_intermediate_kernel(const float* __restrict__ P1, const float* __restrict__ R1,
+                                                                 size_t base1, size_t padded1, size_t sh1, size_t j0,
+                                                                 float* __restrict__ dst, size_t count)
+{
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+		const size_t j = j0 + i;
+		float v = 0.0F;
+		if (j < padded1) {
+			const size_t q = (j < padded1 - sh1) ? j + sh1 : j;
+			v = P1[q - base1] + R1[q - base1];
+		}
+		dst[i] = v;
+	}
+}
+
+// out[i] = full'[begin + i] where full' is `full` with the lag*hop delay removed (unshift_kernel);
+// `full` holds positions [base, ...)
+__global__ __launch_bounds__(256) void range_unshift_kernel(const float* __restrict__ full, size_t base, size_t padded,
+                                                            size_t sh, size_t begin, float* __restrict__ out, size_t count)
+{
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+		const size_t j = begin + i;
+		float v = 0.0F;
+		if (j < padded) {
+			const size_t q = (j < padded - sh) ? j + sh : j;
+			v = full[q - base];
+		}
+		out[i] = v;
+	}
+}
+
+} // namespace
+
+int zen_hip_hpri_range_halo(zen_hip_hpri_t h, size_t n, size_t begin, size_t end, size_t* in_begin, size_t* in_end)
+{
+	if (!h)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null handle");
+	RangePlan p;
+	ZH_TRY(plan_range(h, n, begin, end, &p));
+	if (in_begin)
+		*in_begin = p.in_begin;
+	if (in_end)
+		*in_end = p.in_end;
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpri_process_range(zen_hip_hpri_t h, const float* audio_dev, size_t n, size_t begin, size_t end,
+                               float* harm_dev, float* perc_dev)
+{
+	if (!h || !audio_dev)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_process_range: null argument");
+	if (h->n_clips != 1)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_process_range needs a handle created with n_clips == 1");
+	RangePlan p;
+	ZH_TRY(plan_range(h, n, begin, end, &p));
+	const size_t hop_h = h->hop_h, hop_p = h->hop_p;
+	const size_t c1 = (p.k1 - p.q1) * hop_h, c2 = (p.m1 - p.q2) * hop_p;
+	if (c1 > h->cap1 || c2 > h->cap2) {
+		ZH_HIP(hipStreamSynchronize(h->stream));
+		hpri_free_scratch(h);
+		ZH_HIP(hipMalloc((void**)&h->a1, sizeof(float) * c1));
+		ZH_HIP(hipMalloc((void**)&h->H1, sizeof(float) * c1));
+		ZH_HIP(hipMalloc((void**)&h->P1, sizeof(float) * c1));
+		ZH_HIP(hipMalloc((void**)&h->R1, sizeof(float) * c1));
+		ZH_HIP(hipMalloc((void**)&h->in2, sizeof(float) * (c2 ? c2 : 1)));
+		ZH_HIP(hipMalloc((void**)&h->P2, sizeof(float) * (c2 ? c2 : 1)));
+		h->cap1 = c1;
+		h->cap2 = c2;
+	}
+	ZH_TRY(zen_hip_hpr_reset_buffers(h->eh));
+	ZH_TRY(zen_hip_hpr_reset_buffers(h->ep));
+	const size_t base1 = p.q1 * hop_h, base2 = p.q2 * hop_p;
+	hipLaunchKernelGGL(range_input_kernel, dim3(grid_for(c1)), dim3(256), 0, h->stream, audio_dev, n, base1, h->a1, c1);
+	ZH_HIP(hipGetLastError());
+	ZH_TRY(zen_hip_hpr_process(h->eh, h->a1, p.k1 - p.q1, c1, h->H1, h->P1, h->R1, c1));
+	if (c2) {
+		hipLaunchKernelGGL(range_intermediate_kernel, dim3(grid_for(c2)), dim3(256), 0, h->stream, h->P1, h->R1, base1,
+		                   p.padded1, p.sh1, base2, h->in2, c2);
+		ZH_HIP(hipGetLastError());
+		ZH_TRY(zen_hip_hpr_process(h->ep, h->in2, p.m1 - p.q2, c2, nullptr, h->P2, nullptr, c2));
+	}
+	const size_t cnt = end - begin;
+	if (harm_dev) {
+		hipLaunchKernelGGL(range_unshift_kernel, dim3(grid_for(cnt)), dim3(256), 0, h->stream, h->H1, base1, p.padded1,
+		                   p.sh1, begin, harm_dev, cnt);
+		ZH_HIP(hipGetLastError());
+	}
+	if (perc_dev) {
+		hipLaunchKernelGGL(range_unshift_kernel, dim3(grid_for(cnt)), dim3(256), 0, h->stream, h->P2, base2, p.padded2,
+		                   p.sh2, begin, perc_dev, cnt);
+		ZH_HIP(hipGetLastError());
+	}
+	return ZEN_HIP_OK;
+}
+
 int zen_hip_hpri_process(zen_hip_hpri_t h, const float* audio_host, size_t n, float* harm_host,
                          float* perc_host, float* resid_host)
 {

@@ -36,6 +36,23 @@ def shard_units(n_units, world, rank, lengths=None):
     return [i for i in range(n_units) if owner[i] == rank]
 
 
+def time_shards(n_samples, world, align=1):
+    """Split [0, n_samples) into `world` contiguous output ranges (one long clip over several
+    GPUs).  Boundaries are multiples of `align` (e.g. the larger hop); empty tails are possible for tiny
+    clips.  Each rank then calls zen_hip_hpri_process_range on its range: no exchange between ranks, the
+    halo of input each shard needs is reported by zen_hip_hpri_range_halo."""
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    per = -(-n_samples // world)
+    per = -(-per // align) * align
+    out = []
+    for r in range(world):
+        b = min(n_samples, r * per)
+        e = min(n_samples, (r + 1) * per)
+        out.append((b, e))
+    return out
+
+
 class Group:
     """Thin wrapper over torch.distributed (or nothing, for world == 1)."""
 

@@ -85,6 +85,8 @@ SYMBOLS = [
     ("zen_hip_hpri_use_soft_mask", _i, [_vp]),
     ("zen_hip_hpri_process", _i, [_vp, _vp, _sz, _vp, _vp, _vp]),
     ("zen_hip_hpri_process_device", _i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _sz]),
+    ("zen_hip_hpri_range_halo", _i, [_vp, _sz, _sz, _sz, C.POINTER(_sz), C.POINTER(_sz)]),
+    ("zen_hip_hpri_process_range", _i, [_vp, _vp, _sz, _sz, _sz, _vp, _vp]),
     ("zen_hip_hpri_hop_counts", _i, [_vp, _sz, C.POINTER(_sz), C.POINTER(_sz)]),
 ]
 
@@ -426,6 +428,15 @@ class HPRIOffline:
         _ck(load().zen_hip_hpri_process(self._h, audio.ctypes.data, n, h.ctypes.data, p.ctypes.data,
                                         r.ctypes.data))
         return h, p, r
+
+    def range_halo(self, n, begin, end):
+        a, b = C.c_size_t(), C.c_size_t()
+        _ck(load().zen_hip_hpri_range_halo(self._h, n, begin, end, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def process_range(self, audio_dev, n, begin, end, harm=None, perc=None):
+        """Output samples [begin, end) of the clip (time-sharding)."""
+        _ck(load().zen_hip_hpri_process_range(self._h, audio_dev, n, begin, end, harm, perc))
 
     def process_device(self, audio_dev, n, stride, harm=None, perc=None, resid=None, out_stride=None):
         out_stride = n if out_stride is None else out_stride
