@@ -514,3 +514,29 @@ def test_offline_time_sharded_equals_whole_clip(z, hop_h, hop_p, n):
     # the halo is local: a middle shard of a long clip reads far less than the clip
     ib, ie = whole.range_halo(n, n // 2, n // 2 + hop_h)
     assert ie - ib < n // 2
+
+
+def test_full_size_offline_batch_config4_properties(z):
+    """BASELINE configs[3] per-GPU shape: 64 x 30 s clips, HPR-I 4096/256.  Too big for the oracle, so:
+    (1) batching is invisible -- clips 0, 31, 63 of the batch equal single-clip runs; (2) the first second
+    of clip 0 equals the oracle on the prefix (outputs at sample n depend on input up to n + halo only);
+    (3) identical clips give identical outputs."""
+    C, n = 64, 1323000
+    rng = np.random.default_rng(5)
+    base = rng.uniform(-1, 1, (4, n)).astype(np.float32)
+    x = base[np.arange(C) % 4]                       # 64 clips, 4 distinct
+    off = z.HPRIOffline(44100.0, 4096, 256, 2.0, 2.0, False, C)
+    din = z.DeviceBuffer.from_host(x)
+    dh, dp = z.DeviceBuffer(C * n), z.DeviceBuffer(C * n)
+    off.process_device(din.ptr, n, n, dh.ptr, dp.ptr, None, n)
+    z.synchronize()
+    H, P = dh.download().reshape(C, n), dp.download().reshape(C, n)
+    single = z.HPRIOffline(44100.0, 4096, 256, 2.0, 2.0)
+    for c in (0, 31, 63):
+        h1, p1, _ = single.process(x[c])
+        assert np.array_equal(H[c], h1) and np.array_equal(P[c], p1)
+    assert np.array_equal(P[1], P[5]) and np.array_equal(H[2], H[62])
+    m = 44100
+    halo = 4 * 4096 + 30 * 256
+    rh, rp, _ = o.HPRIOffline(44100.0, 4096, 256, 2.0, 2.0).process(x[0][:m + halo])
+    assert np.array_equal(P[0][:m], rp[:m]) and np.array_equal(H[0][:m], rh[:m])
