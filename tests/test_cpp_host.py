@@ -111,3 +111,30 @@ def test_cli_offline_and_fakert_end_to_end(tmp_path):
     peak = max(-ref.min(), ref.max())
     _, got = read_wav_pcm16(str(tmp_path / "rt.wav"))
     assert np.array_equal(got.astype(np.int64), pcm16(ref / np.float32(peak)))
+
+
+@pytest.mark.gpu
+def test_cli_batch_directory(tmp_path):
+    """`zen batch`: a directory of clips (two lengths) separated in batches == per-clip `zen offline`."""
+    fs = 44100
+    rng = np.random.default_rng(3)
+    indir, outdir = tmp_path / "in", tmp_path / "out"
+    indir.mkdir()
+    outdir.mkdir()
+    names = []
+    for i, n in enumerate((30000, 30000, 30000, 41000)):
+        x = np.round(rng.uniform(-1, 1, n) * 12000).astype(np.int16)
+        write_wav_pcm16(str(indir / ("clip%d.wav" % i)), x, fs)
+        names.append("clip%d" % i)
+    r = subprocess.run([ZEN, "batch", "-i", str(indir), "-o", str(outdir), "--hps", "1024", "2.0", "256", "2.0"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "4 wav files in 2 (rate, length) groups" in r.stdout
+    for nm in names:
+        r1 = subprocess.run([ZEN, "offline", "-i", str(indir / (nm + ".wav")), "--hps", "1024", "2.0", "256", "2.0",
+                             "-o", str(tmp_path / nm)], capture_output=True, text=True, timeout=600)
+        assert r1.returncode == 0, r1.stderr
+        for suffix in ("_harm.wav", "_perc.wav"):
+            a = open(str(outdir / (nm + suffix)), "rb").read()
+            b = open(str(tmp_path / (nm + suffix)), "rb").read()
+            assert a == b, nm + suffix

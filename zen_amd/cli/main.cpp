@@ -7,7 +7,9 @@
 #include <array>
 #include <chrono>
 #include <cstdlib>
+#include <dirent.h>
 #include <iostream>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -39,6 +41,8 @@ void usage(std::ostream& os)
 	      "  zen offline -i <infile> [--hps [<hop-h> [<beta-h> [<hop-p> [<beta-p>]]]]] [-o <outfile_prefix>]\n"
 	      "      [--sse] [--only-percussive] [--soft-mask] [--nocopybord]\n"
 	      "  zen fakert -i <infile> [--hps [<hop> [<beta>]]] [-o <outfile>] [--sse] [--soft-mask] [--nocopybord]\n"
+	      "  zen batch -i <indir> -o <outdir> [--hps [<hop-h> [<beta-h> [<hop-p> [<beta-p>]]]]] [--sse] [--soft-mask]\n"
+	      "      (MI355X extension: every .wav of <indir>, equal-length clips separated together in one batch)\n"
 	      "  zen help|-h|--help\n"
 	      "  zen version|-v|--version\n";
 }
@@ -123,6 +127,105 @@ int run_offline(const OfflineParams& p)
 			zen::wav::encode_pcm16_mono(all_out[i], fd.sampleRate, p.outfile_prefix + suffix[i]);
 		}
 	}
+	return 0;
+}
+
+// `zen batch`: the many-clip offline case (BASELINE configs[3]) from the command line.  Clips of equal
+// sample rate and length go through zen_hip_hpri_process_device together (n_clips streams in lock step);
+// outputs are written as <outdir>/<stem>_harm.wav and <stem>_perc.wav with the same peak normalisation
+// and PCM16 encoding as `zen offline`.
+#define ZEN_CK(call)                                                        \
+	do {                                                                    \
+		if ((call) != ZEN_HIP_OK)                                           \
+			throw std::runtime_error(std::string(#call ": ") + zen_hip_last_error()); \
+	} while (0)
+
+int run_batch(const OfflineParams& p, const std::string& outdir)
+{
+	std::vector<std::string> files;
+	if (DIR* d = opendir(p.infile.c_str())) {
+		while (dirent* e = readdir(d)) {
+			const std::string name = e->d_name;
+			if (name.size() > 4 && name.substr(name.size() - 4) == ".wav")
+				files.push_back(name);
+		}
+		closedir(d);
+	}
+	else {
+		throw std::runtime_error("cannot open directory " + p.infile);
+	}
+	std::sort(files.begin(), files.end());
+	struct Clip {
+		std::string stem;
+		std::vector<float> mono;
+	};
+	std::map<std::pair<int, std::size_t>, std::vector<Clip>> groups; // (sample rate, length) -> clips
+	for (const auto& f : files) {
+		zen::wav::AudioData fd;
+		zen::wav::load(fd, p.infile + "/" + f);
+		Clip c;
+		c.stem = f.substr(0, f.size() - 4);
+		if (fd.channelCount == 2) {
+			c.mono.resize(fd.samples.size() / 2);
+			zen::wav::stereo_to_mono(fd.samples.data(), c.mono.data(), fd.samples.size());
+		}
+		else {
+			c.mono = fd.samples;
+		}
+		if (!c.mono.empty())
+			groups[{fd.sampleRate, c.mono.size()}].push_back(std::move(c));
+	}
+	std::cout << "zen batch: " << files.size() << " wav files in " << groups.size() << " (rate, length) groups"
+	          << std::endl;
+	const std::size_t max_batch = 64;
+	double total_audio_s = 0;
+	long total_ms = 0;
+	for (auto& g : groups) {
+		const int fs = g.first.first;
+		const std::size_t n = g.first.second;
+		auto& clips = g.second;
+		for (std::size_t c0 = 0; c0 < clips.size(); c0 += max_batch) {
+			const std::size_t C = std::min(max_batch, clips.size() - c0);
+			zen_hip_hpri_t eng = nullptr;
+			int rc = zen_hip_hpri_create((float)fs, p.hop_h, p.hop_p, p.beta_h, p.beta_p, p.nocopybord ? 1 : 0, C, &eng);
+			if (rc == ZEN_HIP_E_HOPS_NOT_DIVISIBLE)
+				throw zen::ZgException("hop_h and hop_p should be evenly divisible");
+			ZEN_CK(rc);
+			if (p.use_sse)
+				ZEN_CK(zen_hip_hpri_use_sse_filter(eng));
+			if (p.soft_mask)
+				ZEN_CK(zen_hip_hpri_use_soft_mask(eng));
+			void *d_in = nullptr, *d_h = nullptr, *d_p = nullptr;
+			ZEN_CK(zen_hip_malloc(&d_in, C * n * sizeof(float)));
+			ZEN_CK(zen_hip_malloc(&d_h, C * n * sizeof(float)));
+			ZEN_CK(zen_hip_malloc(&d_p, C * n * sizeof(float)));
+			for (std::size_t c = 0; c < C; ++c)
+				ZEN_CK(zen_hip_memcpy_h2d((float*)d_in + c * n, clips[c0 + c].mono.data(), n * sizeof(float)));
+			auto t1 = std::chrono::high_resolution_clock::now();
+			ZEN_CK(zen_hip_hpri_process_device(eng, (const float*)d_in, n, n, (float*)d_h, (float*)d_p, nullptr, n));
+			ZEN_CK(zen_hip_synchronize(nullptr));
+			auto t2 = std::chrono::high_resolution_clock::now();
+			const long ms = (long)std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count();
+			total_ms += ms;
+			total_audio_s += (double)C * n / fs;
+			std::cout << "GPU/HIP/gfx950: 2-pass HPR-I-Offline of " << C << " clips x " << n << " samples took " << ms
+			          << " ms" << std::endl;
+			std::vector<float> out(n);
+			for (std::size_t c = 0; c < C; ++c) {
+				for (int which = 0; which < 2; ++which) {
+					ZEN_CK(zen_hip_memcpy_d2h(out.data(), (float*)(which ? d_p : d_h) + c * n, n * sizeof(float)));
+					peak_normalise(out, n);
+					zen::wav::encode_pcm16_mono(out, fs, outdir + "/" + clips[c0 + c].stem + (which ? "_perc.wav" : "_harm.wav"));
+				}
+			}
+			zen_hip_free(d_in);
+			zen_hip_free(d_h);
+			zen_hip_free(d_p);
+			zen_hip_hpri_destroy(eng);
+		}
+	}
+	std::cout << "zen batch: " << total_audio_s << " s of audio separated in " << total_ms << " ms of GPU time"
+	          << std::endl;
 	return 0;
 }
 
@@ -219,7 +322,7 @@ int main(int argc, char* argv[])
 		std::cout << "version 1.0\n";
 		return 0;
 	}
-	if (cmd != "offline" && cmd != "fakert") {
+	if (cmd != "offline" && cmd != "fakert" && cmd != "batch") {
 		usage(std::cerr);
 		return 0;
 	}
@@ -235,7 +338,7 @@ int main(int argc, char* argv[])
 		}
 		else if (s == "--hps") {
 			op.do_hps = fp.do_hps = true;
-			if (cmd == "offline") {
+			if (cmd != "fakert") {
 				if (next_is_number()) op.hop_h = std::strtoul(a[++i].c_str(), nullptr, 10);
 				if (next_is_number()) op.beta_h = std::strtof(a[++i].c_str(), nullptr);
 				if (next_is_number()) op.hop_p = std::strtoul(a[++i].c_str(), nullptr, 10);
@@ -246,7 +349,7 @@ int main(int argc, char* argv[])
 				if (next_is_number()) fp.beta = std::strtof(a[++i].c_str(), nullptr);
 			}
 		}
-		else if ((s == "-o" || (cmd == "offline" && s == "--out-prefix") || (cmd == "fakert" && s == "--output"))
+		else if ((s == "-o" || (cmd != "fakert" && s == "--out-prefix") || (cmd == "fakert" && s == "--output"))
 		         && i + 1 < a.size()) {
 			op.outfile_prefix = fp.outfile = a[++i];
 		}
@@ -272,6 +375,13 @@ int main(int argc, char* argv[])
 		if (zen_hip_init(0) != ZEN_HIP_OK) {
 			std::cerr << "zen: " << zen_hip_last_error() << std::endl;
 			return 1;
+		}
+		if (cmd == "batch") {
+			if (op.outfile_prefix == "") {
+				usage(std::cerr);
+				return 0;
+			}
+			return run_batch(op, op.outfile_prefix);
 		}
 		return cmd == "offline" ? run_offline(op) : run_fakert(fp);
 	}
