@@ -138,6 +138,27 @@ def test_median_random_bit_exact(zk, shape, flen):
         assert np.array_equal(got, o.median_filter(d, flen, o.TIME_ANTICAUSAL))
 
 
+@pytest.mark.parametrize("shape,flen", [
+    ((3, 16384), 187), ((3, 16384), 171), ((5, 8192), 93), ((5, 8192), 85), ((2, 4100), 187), ((4, 5000), 93),
+    ((3, 188), 187), ((3, 88), 85), ((2, 180), 171), ((2, 172), 171), ((7, 12288), 187), ((2, 16386), 187), ((2, 4097), 93)])
+def test_median_long_frequency_masks(z, shape, flen):
+    """The block-merge kernel (median_big.hip: 85/93/171/187 taps) against the oracle and the general wave
+    kernel: segment seams (cols > 4096), rows shorter than the mask, signed values, ragged widths that take
+    the general kernel instead."""
+    rng = np.random.default_rng(flen * 7 + shape[1])
+    for signed in (False, True):
+        d = rng.standard_normal(shape).astype(np.float32) if signed else rng.random(shape, dtype=np.float32)
+        d[0, : min(40, shape[1])] = 0.25     # ties
+        exp = o.median_filter(d, flen, o.FREQUENCY)
+        z.set_option("median_general", 0)
+        assert np.array_equal(z.MedianFilterGPU(shape[0], shape[1], flen, z.FREQUENCY).filter_host(d), exp)
+        z.set_option("median_general", 1)
+        try:
+            assert np.array_equal(z.MedianFilterGPU(shape[0], shape[1], flen, z.FREQUENCY).filter_host(d), exp)
+        finally:
+            z.set_option("median_general", 0)
+
+
 def test_median_signed_values_and_even_length(zk):
     rng = np.random.default_rng(9)
     d = rng.normal(0, 3, (40, 200)).astype(np.float32)

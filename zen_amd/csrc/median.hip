@@ -287,6 +287,9 @@ int launch_median(const FilterArgs& a, hipStream_t stream)
 		ZH_TRY(launch_median_net(a, stream, &handled));
 		if (handled)
 			return ZEN_HIP_OK;
+		ZH_TRY(launch_median_big(a, stream, &handled)); // block-merge kernel for the long frequency masks
+		if (handled)
+			return ZEN_HIP_OK;
 	}
 	if (a.direction == ZEN_HIP_FREQUENCY)
 		return launch_dir<0>(a, stream);

@@ -1,0 +1,169 @@
+// median_big.h -- register-resident exact sliding median for odd windows 65..255 whose common part is
+// 2^k or 2^k + 1 aligned 16-sample blocks (all frequency masks of hop 2048/4096 at 44.1 and 48 kHz: 85,
+// 93, 171, 187 taps).  Extends the scheme of median_net.h:
+//
+//   * the row is cut into aligned 16-sample blocks; every block is sorted ONCE (by the thread that owns
+//     it) and published in LDS;
+//   * a thread produces 16 consecutive outputs.  The samples common to its 16 windows are NB whole blocks
+//     plus rl + rr <= 30 loose samples.  It merges the 2^k sorted blocks pairwise (Batcher odd-even
+//     merges, 16 -> 32 -> 64 -> 128) into one sorted list A, sorts the loose samples together with the
+//     optional (2^k + 1)-th block into a second sorted list R, and reads the 16 candidate order statistics
+//     off the two lists with the selection identity merge(A,R)[p] = min_q max(A[p-q], R[q-1]);
+//   * the 15 + 15 flank samples then go through the same selection tree as for small windows.
+//
+// ~250 min/max per output at 187 taps, all with compile-time indices (no data-dependent addressing),
+// instead of ~60 wave-wide instructions per output in the sliding wave-window kernel.
+#pragma once
+#include "median_net.h"
+
+namespace zbig {
+
+constexpr int KEY_INF = 0x7fffffff;
+
+template <int W>
+struct Geo {
+	static constexpr int m = W / 2;
+	static constexpr int a = (m - 15) / 16;      // whole blocks left of the thread's own block
+	static constexpr int rl = (m - 15) % 16;     // loose common samples on the left
+	static constexpr int b = (m + 1) / 16;       // whole blocks from the own block on
+	static constexpr int rr = (m + 1) % 16;      // loose common samples on the right
+	static constexpr int NB = a + b;             // whole common blocks: t-a .. t+b-1
+	static constexpr int BIG = NB >= 8 ? 8 : (NB >= 4 ? 4 : (NB >= 2 ? 2 : 1));
+	static constexpr int REST = NB - BIG;        // 0 or 1 supported
+	static constexpr int NA = BIG * 16;
+	static constexpr int NX = rl + rr;           // loose samples
+	static constexpr int NR = REST * 16 + NX;    // second sorted list
+	static constexpr bool supported = (W & 1) && W >= 65 && W <= 255 && (REST == 0 || REST == 1) && NX <= 32;
+};
+
+template <int N, int TOTAL, int OFF = 0>
+struct MergeLevel {
+	template <int NA>
+	static __device__ __forceinline__ void run(int (&x)[NA])
+	{
+		znet::oe_merge<N, OFF>(x);
+		if constexpr (OFF + N < TOTAL)
+			MergeLevel<N, TOTAL, OFF + N>::run(x);
+	}
+};
+
+// The thread reads through a loader: sorted(i, v) = sorted block t-a+i (i < NB), rawl(j, v) = raw block
+// t-a-2+j, rawr(j, v) = raw block t+b+j (j = 0, 1).  out[g] = median of the W samples centred on sample
+// 16t+g.  The three phases (loose samples, block merge + candidates, flanks + tree) are fenced so that the
+// loads of one phase are not hoisted into the previous one: peak register use stays near 128.
+__device__ __forceinline__ void phase_fence() { asm volatile("" ::: "memory"); }
+
+template <int W, class LD>
+__device__ __forceinline__ void medians_big(const LD& ld, int (&out)[16])
+{
+	using G = Geo<W>;
+	static_assert(G::supported, "window not covered by the block-merge kernel");
+	// ---- A: the 2^k whole blocks merged into one sorted list; only ranks ALO..AHI can become candidates
+	constexpr int ALO = (G::m - 15 - G::NR) < 0 ? 0 : (G::m - 15 - G::NR);
+	constexpr int AHI = G::m > G::NA - 1 ? G::NA - 1 : G::m;
+	int An[AHI - ALO + 1];
+	{
+		int A[G::NA];
+#pragma unroll
+		for (int i = 0; i < G::BIG; ++i) {
+			int B[16];
+			ld.sorted(i, B);
+#pragma unroll
+			for (int j = 0; j < 16; ++j)
+				A[16 * i + j] = B[j];
+		}
+		if constexpr (G::NA >= 32)
+			MergeLevel<32, G::NA>::run(A);
+		if constexpr (G::NA >= 64)
+			MergeLevel<64, G::NA>::run(A);
+		if constexpr (G::NA >= 128)
+			MergeLevel<128, G::NA>::run(A);
+#pragma unroll
+		for (int i = ALO; i <= AHI; ++i)
+			An[i - ALO] = A[i];
+	}
+	phase_fence();
+	// ---- R: loose samples (+ the extra block), sorted, padded with +inf
+	constexpr int NRP = G::REST ? 64 : 32;
+	int R[NRP];
+	{
+		int X[32];
+		{
+			int L[16], Rr[16];
+			ld.rawl(1, L);
+			ld.rawr(0, Rr);
+#pragma unroll
+			for (int i = 0; i < 32; ++i)
+				X[i] = KEY_INF;
+#pragma unroll
+			for (int i = 0; i < G::rl; ++i)
+				X[i] = L[16 - G::rl + i];
+#pragma unroll
+			for (int i = 0; i < G::rr; ++i)
+				X[G::rl + i] = Rr[i];
+		}
+		znet::sort_net<32>(X);
+		if constexpr (G::REST) {
+			int B[16];
+			ld.sorted(G::BIG, B);
+#pragma unroll
+			for (int i = 0; i < 16; ++i) {
+				R[i] = B[i];
+				R[16 + i] = KEY_INF;
+			}
+#pragma unroll
+			for (int i = 0; i < 32; ++i)
+				R[32 + i] = X[i];
+			znet::oe_merge<64, 0>(R);
+		}
+		else {
+#pragma unroll
+			for (int i = 0; i < 32; ++i)
+				R[i] = X[i];
+		}
+	}
+	// ---- candidates = ranks m-15 .. m of A u R:  merge(A,R)[p] = min_q max(A[p-q], R[q-1])
+	int cand[16];
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		const int p = G::m - 15 + i;
+		int best = KEY_INF;
+#pragma unroll
+		for (int q = 0; q <= G::NR; ++q) { // q samples from R, p + 1 - q from A
+			const int ia = p - q;          // last sample taken from A
+			if (ia > G::NA - 1 || ia < -1)
+				continue;                  // A or R cannot supply that many
+			int term;
+			if (ia < 0)
+				term = R[q - 1];
+			else if (q == 0)
+				term = An[ia - ALO];
+			else
+				term = max(An[ia - ALO], R[q - 1]);
+			best = min(best, term);
+		}
+		cand[i] = best;
+	}
+	phase_fence();
+	// ---- flanks and the selection tree
+	constexpr int NE = W + 15;
+	int e[NE];
+	{
+		int L32[32], R32[32];
+		ld.rawl(0, L32);
+		ld.rawl(1, L32 + 16);
+		ld.rawr(0, R32);
+		ld.rawr(1, R32 + 16);
+#pragma unroll
+		for (int q = 0; q < NE; ++q)
+			e[q] = 0;
+#pragma unroll
+		for (int q = 0; q < 15; ++q) {
+			e[q] = L32[32 - (G::rl + 15) + q];
+			e[W + q] = R32[G::rr + q];
+		}
+	}
+	znet::Node<W, 16, 0, NE, 16>::run(e, cand, out);
+}
+
+} // namespace zbig
