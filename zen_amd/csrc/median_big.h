@@ -1,13 +1,13 @@
-// median_big.h -- register-resident exact sliding median for odd windows 65..255 whose common part is
-// 2^k or 2^k + 1 aligned 16-sample blocks (all frequency masks of hop 2048/4096 at 44.1 and 48 kHz: 85,
-// 93, 171, 187 taps).  Extends the scheme of median_net.h:
+// median_big.h -- register-resident exact sliding median for odd windows 65..255 (the frequency masks of
+// hop 2048/4096 at 44.1 and 48 kHz: 85, 93, 171, 187 taps; 65 and 129 taps at 16/32 kHz).  Extends the
+// scheme of median_net.h:
 //
 //   * the row is cut into aligned 16-sample blocks; every block is sorted ONCE (by the thread that owns
 //     it) and published in LDS;
 //   * a thread produces 16 consecutive outputs.  The samples common to its 16 windows are NB whole blocks
-//     plus rl + rr <= 30 loose samples.  It merges the 2^k sorted blocks pairwise (Batcher odd-even
-//     merges, 16 -> 32 -> 64 -> 128) into one sorted list A, sorts the loose samples together with the
-//     optional (2^k + 1)-th block into a second sorted list R, and reads the 16 candidate order statistics
+//     plus rl + rr <= 30 loose samples.  It merges the first 2^k sorted blocks pairwise (Batcher odd-even
+//     merges, 16 -> 32 -> 64 -> 128) into one sorted list A, sorts the loose samples and merges them with
+//     the remaining blocks into a second sorted list R, and reads the 16 candidate order statistics
 //     off the two lists with the selection identity merge(A,R)[p] = min_q max(A[p-q], R[q-1]);
 //   * the 15 + 15 flank samples then go through the same selection tree as for small windows.
 //
@@ -29,11 +29,13 @@ struct Geo {
 	static constexpr int rr = (m + 1) % 16;      // loose common samples on the right
 	static constexpr int NB = a + b;             // whole common blocks: t-a .. t+b-1
 	static constexpr int BIG = NB >= 8 ? 8 : (NB >= 4 ? 4 : (NB >= 2 ? 2 : 1));
-	static constexpr int REST = NB - BIG;        // 0 or 1 supported
+	static constexpr int REST = NB - BIG;        // remaining whole blocks (0 .. BIG-1)
 	static constexpr int NA = BIG * 16;
 	static constexpr int NX = rl + rr;           // loose samples
 	static constexpr int NR = REST * 16 + NX;    // second sorted list
-	static constexpr bool supported = (W & 1) && W >= 65 && W <= 255 && (REST == 0 || REST == 1) && NX <= 32;
+	static constexpr int RREAL = 32 + 16 * REST; // R slots in use: 32 for the loose samples + the blocks
+	static constexpr int NRP = RREAL <= 32 ? 32 : (RREAL <= 64 ? 64 : (RREAL <= 128 ? 128 : 256));
+	static constexpr bool supported = (W & 1) && W >= 65 && W <= 255;
 };
 
 template <int N, int TOTAL, int OFF = 0>
@@ -44,6 +46,19 @@ struct MergeLevel {
 		znet::oe_merge<N, OFF>(x);
 		if constexpr (OFF + N < TOTAL)
 			MergeLevel<N, TOTAL, OFF + N>::run(x);
+	}
+};
+
+// merges of R: slots past REAL hold +inf only, a merge whose second half is all +inf is the identity
+template <int N, int TOTAL, int REAL, int OFF>
+struct MergeLevelR {
+	template <int NA>
+	static __device__ __forceinline__ void run(int (&x)[NA])
+	{
+		if constexpr (OFF + N / 2 < REAL)
+			znet::oe_merge<N, OFF>(x);
+		if constexpr (OFF + N < TOTAL)
+			MergeLevelR<N, TOTAL, REAL, OFF + N>::run(x);
 	}
 };
 
@@ -83,44 +98,50 @@ __device__ __forceinline__ void medians_big(const LD& ld, int (&out)[16])
 			An[i - ALO] = A[i];
 	}
 	phase_fence();
-	// ---- R: loose samples (+ the extra block), sorted, padded with +inf
-	constexpr int NRP = G::REST ? 64 : 32;
+	// ---- R: loose samples and the remaining blocks, sorted, padded with +inf
+	constexpr int NRP = G::NRP;
 	int R[NRP];
 	{
-		int X[32];
+#pragma unroll
+		for (int i = 0; i < NRP; ++i)
+			R[i] = KEY_INF;
 		{
-			int L[16], Rr[16];
-			ld.rawl(1, L);
-			ld.rawr(0, Rr);
+			int X[32];
+			{
+				int L[16], Rr[16];
+				ld.rawl(1, L);
+				ld.rawr(0, Rr);
 #pragma unroll
-			for (int i = 0; i < 32; ++i)
-				X[i] = KEY_INF;
+				for (int i = 0; i < 32; ++i)
+					X[i] = KEY_INF;
 #pragma unroll
-			for (int i = 0; i < G::rl; ++i)
-				X[i] = L[16 - G::rl + i];
+				for (int i = 0; i < G::rl; ++i)
+					X[i] = L[16 - G::rl + i];
 #pragma unroll
-			for (int i = 0; i < G::rr; ++i)
-				X[G::rl + i] = Rr[i];
-		}
-		znet::sort_net<32>(X);
-		if constexpr (G::REST) {
-			int B[16];
-			ld.sorted(G::BIG, B);
-#pragma unroll
-			for (int i = 0; i < 16; ++i) {
-				R[i] = B[i];
-				R[16 + i] = KEY_INF;
+				for (int i = 0; i < G::rr; ++i)
+					X[G::rl + i] = Rr[i];
 			}
-#pragma unroll
-			for (int i = 0; i < 32; ++i)
-				R[32 + i] = X[i];
-			znet::oe_merge<64, 0>(R);
-		}
-		else {
+			znet::sort_net<32>(X);
 #pragma unroll
 			for (int i = 0; i < 32; ++i)
 				R[i] = X[i];
 		}
+#pragma unroll
+		for (int k = 0; k < G::REST; ++k) {
+			int B[16];
+			ld.sorted(G::BIG + k, B);
+#pragma unroll
+			for (int i = 0; i < 16; ++i)
+				R[32 + 16 * k + i] = B[i];
+		}
+		if constexpr (NRP >= 64) {
+			MergeLevelR<32, NRP, G::RREAL, 32>::run(R); // pairs of blocks (slot 0 is the sorted loose samples)
+			MergeLevelR<64, NRP, G::RREAL, 0>::run(R);
+		}
+		if constexpr (NRP >= 128)
+			MergeLevelR<128, NRP, G::RREAL, 0>::run(R);
+		if constexpr (NRP >= 256)
+			MergeLevelR<256, NRP, G::RREAL, 0>::run(R);
 	}
 	// ---- candidates = ranks m-15 .. m of A u R:  merge(A,R)[p] = min_q max(A[p-q], R[q-1])
 	int cand[16];

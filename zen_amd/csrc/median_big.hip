@@ -1,5 +1,5 @@
 // median_big.hip -- frequency-direction median for the long percussive masks of hop 2048 / 4096
-// (l_perc = 500 / (fs / nfft), libzen/hps.h:229: 85, 93, 171, 187 taps), results identical to
+// (l_perc = 500 / (fs / nfft), libzen/hps.h:229: 85, 93, 171, 187 taps; 65, 129 at 16/32 kHz; 255), results identical to
 // MedianFilterCPU (libzen/mfilt.h:270-342) and to the general wave kernel of median.hip.
 // Algorithm: median_big.h.  One workgroup = 4096 consecutive outputs of one row; LDS holds the raw
 // samples of the segment (with halo) and one sorted copy of every aligned 16-sample block.
@@ -46,8 +46,11 @@ __device__ __forceinline__ void st16(int* p, const int (&v)[16])
 }
 
 // Preconditions (checked by the launcher): cols % 4 == 0, rows and pointers 16-byte aligned.
+#ifndef ZEN_BIG_MINB
+#define ZEN_BIG_MINB 2
+#endif
 template <int W, bool NONNEG>
-__global__ __launch_bounds__(256, 2) void median_big_kernel(FilterArgs a, int row_base, int ring, int segs_per_row)
+__global__ __launch_bounds__(256, ZEN_BIG_MINB) void median_big_kernel(FilterArgs a, int row_base, int ring, int segs_per_row)
 {
 	using G = zbig::Geo<W>;
 	// raw image: chunk c = block c - (a+2) of the segment; sorted image: entry s = block s - a
@@ -136,13 +139,19 @@ int launch_w(const FilterArgs& a, hipStream_t stream)
 	return ZEN_HIP_OK;
 }
 
+// l_perc of hops 512..4096 at the usual sample rates (8..96 kHz), and the longest mask the API accepts
+bool median_big_available(int len)
+{
+	return len == 65 || len == 85 || len == 93 || len == 129 || len == 171 || len == 187 || len == 255;
+}
+
 } // namespace
 
 // long frequency masks with vector-aligned geometry.  *handled = false: use the general kernel.
 int launch_median_big(const FilterArgs& a, hipStream_t stream, bool* handled)
 {
 	*handled = false;
-	if (a.direction != ZEN_HIP_FREQUENCY || (a.len != 85 && a.len != 93 && a.len != 171 && a.len != 187))
+	if (a.direction != ZEN_HIP_FREQUENCY || !median_big_available(a.len))
 		return ZEN_HIP_OK;
 	const bool vec_ok = (a.cols % 4 == 0) && a.cols >= 4 && ((reinterpret_cast<uintptr_t>(a.src) & 15) == 0)
 	                    && ((reinterpret_cast<uintptr_t>(a.dst) & 15) == 0) && (a.src_stream_stride % 4 == 0)
@@ -152,10 +161,13 @@ int launch_median_big(const FilterArgs& a, hipStream_t stream, bool* handled)
 		return ZEN_HIP_OK;
 	*handled = true;
 	switch (a.len) {
+	case 65: return launch_w<65>(a, stream);
 	case 85: return launch_w<85>(a, stream);
 	case 93: return launch_w<93>(a, stream);
+	case 129: return launch_w<129>(a, stream);
 	case 171: return launch_w<171>(a, stream);
-	default: return launch_w<187>(a, stream);
+	case 187: return launch_w<187>(a, stream);
+	default: return launch_w<255>(a, stream);
 	}
 }
 
