@@ -141,6 +141,9 @@ def main():
     ap.add_argument("--clip-seconds", type=float, default=30.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-realtime", action="store_true")
+    ap.add_argument("--no-block-fused", action="store_true",
+                    help="realtime_block: STFT / median / iSTFT kernels instead of the fused per-hop kernel")
+    ap.add_argument("--fused-minb", type=int, default=0, help="tuning: occupancy the fused kernel is built for")
     args = ap.parse_args()
 
     import torch
@@ -151,6 +154,10 @@ def main():
 
     import zen_amd
     zen_amd.init(local_rank)
+    if args.no_block_fused:
+        zen_amd.set_option("no_block_fused", 1)
+    if args.fused_minb:
+        zen_amd.set_option("block_fused_minb", args.fused_minb)
 
     def barrier():
         torch.cuda.synchronize()
@@ -185,18 +192,78 @@ def main():
         breakdown = eng.profile_get_all()
         eng.profile(False)
         chk = grp.sum([float(np.abs(d_out.download(4096)).sum())])[0]   # liveness only; bytes, not data path
+        fused = breakdown["rt_fused"]["launches"] > 0
+        three = None
+        if fused and rank == 0:
+            # second leg, outside the timed region: the same stream through the general engine (STFT / median /
+            # iSTFT kernels) for the stand-alone median kernel's roofline, BASELINE's second metric
+            zen_amd.set_option("no_block_fused", 1)
+            for _ in range(3):
+                step()
+            zen_amd.synchronize()
+            eng.profile(True)
+            t1 = time.perf_counter()
+            for _ in range(10):
+                step()
+            zen_amd.synchronize()
+            dt3 = (time.perf_counter() - t1) / 10
+            med_ms, med_launches, med_elems = eng.profile_get()
+            three = {"ms_per_step": 1e3 * dt3, "hops_per_s": S * M / dt3,
+                     "kernel_ms_per_step": {k: v["ms"] / 10 for k, v in eng.profile_get_all().items() if v["launches"]}}
+            eng.profile(False)
+            zen_amd.set_option("no_block_fused", 0)
         if rank == 0:
             total_hops = world * S * M * args.steps
             value = total_hops / dt
-            t_launch = 1e-3 * med_ms / max(med_launches, 1)
-            traffic = None          # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot
-            try:                    # run inside this process); only quoted for the shape it was measured on
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_e_hbm_traffic.json")))
-                if tj["shape"]["elements"] == med_elems // max(med_launches, 1):
-                    traffic = tj["kernels"]["median_net_freq_kernel<47,nonneg>"]["hbm_bytes_per_launch"]
-            except (OSError, KeyError, ValueError):
-                pass
-            achieved = 8.0 * med_elems / max(med_launches, 1) / t_launch / 1e9 if t_launch > 0 else 0.0
+            nfft = 4 * HOP
+
+            def traffic_of(fname, kernel, elems):
+                """HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this
+                process); only quoted for the shape it was measured on."""
+                try:
+                    tj = json.load(open(os.path.join(ROOT, "profiles", fname)))
+                    if tj["shape"]["elements"] == elems:
+                        return tj["kernels"][kernel]["hbm_bytes_per_launch"]
+                except (OSError, KeyError, ValueError):
+                    pass
+                return None
+
+            t_med = 1e-3 * med_ms / max(med_launches, 1)
+            el_med = med_elems // max(med_launches, 1)
+            ach_med = 8.0 * el_med / t_med / 1e9 if t_med > 0 else 0.0
+            tr_med = traffic_of("r01_e_hbm_traffic.json", "median_net_freq_kernel<47,nonneg>", el_med)
+            roof_median = {
+                "bound": "hbm", "achieved": ach_med, "peak": 8000.0, "unit": "GB/s", "frac": ach_med / 8000.0,
+                "traffic": tr_med,
+                "traffic_source": "profiles/r01_e_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH "
+                                  "doubled per the gfx950 correction)" if tr_med else None,
+                "kernel": "median_net_freq_kernel<47, nonneg> (frequency direction, 47 taps)",
+                "elements_per_launch": el_med, "algorithmic_bytes_per_element": 8, "avg_launch_ms": 1e3 * t_med,
+                "launches": med_launches,
+                "note": "VALU-bound, not HBM-bound: v_min/v_max/v_med3 issue at half rate on gfx950 "
+                        "(profiles/r01_ubench_valu_rates.txt, profiles/r01_c_median47_pmc.json)"}
+            if fused:
+                fl = breakdown["rt_fused"]
+                t_f = 1e-3 * fl["ms"] / fl["launches"]
+                bytes_per_hop = 24 * (nfft // 2 + 1) + 8 * HOP       # SURVEY 8(d): per-frame minimum, P-only hard mask
+                ach = bytes_per_hop * S * M / t_f / 1e9
+                tr = traffic_of("r01_g_fused_hbm_traffic.json", "rt_fused_kernel<12,47>", S * M * nfft)
+                roof = {
+                    "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                    "traffic": tr,
+                    "traffic_source": "profiles/r01_g_fused_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                      "FETCH doubled per the gfx950 correction)" if tr else None,
+                    "kernel": "rt_fused_kernel<12, 47> (one workgroup per hop: STFT, |S|, 47-tap median, hard mask, iSTFT)",
+                    "hops_per_launch": S * M, "algorithmic_bytes_per_hop": bytes_per_hop,
+                    "algorithmic_bytes_formula": "24*(nfft/2+1) + 8*hop (SURVEY 8(d): per-frame minimum of the batched "
+                                                 "pipeline, percussive-only hard mask)",
+                    "avg_launch_ms": 1e3 * t_f, "launches": fl["launches"],
+                    "share_of_step": (fl["ms"] / 1e3) / dt if dt > 0 else None,
+                    "note": "the spectrum, |S| and P stay in registers/LDS, so the HBM traffic of this kernel is BELOW "
+                            "the algorithmic figure (4*hop read + 8*hop written per hop); it is bound by VALU issue "
+                            "(FFT butterflies at full rate, median min/max at half rate), not by HBM"}
+            else:
+                roof = dict(roof_median, share_of_step=(med_ms / 1e3) / dt if dt > 0 else None)
             out.update({
                 "value": value, "ms_per_step": 1e3 * dt / args.steps,
                 "config": {
@@ -204,21 +271,15 @@ def main():
                                 "OUTPUT_PERCUSSIVE, hard mask, causal; S-music 44.1 kHz mono stream resident "
                                 "in HBM; block mode (zen_hip_hpr_process), %d hops/step/stream" % M,
                     "hops_per_step": M, "streams_per_gpu": S, "fs": FS, "hop": HOP,
-                    "time_mask": 3, "freq_mask": 47, "parallelism": "replicas x%d" % world},
+                    "time_mask": 3, "freq_mask": 47, "parallelism": "replicas x%d" % world,
+                    "path": "fused per-hop kernel + overlap-add" if fused else "STFT / median / iSTFT kernels + overlap-add"},
                 "x_realtime": value * HOP / FS,
                 "checksum": chk,
                 "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in breakdown.items() if v["launches"]},
-                "roofline": {
-                    "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                    "frac": achieved / 8000.0, "traffic": traffic,
-                    "traffic_source": "profiles/r01_e_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                      "FETCH doubled per the gfx950 correction)" if traffic else None,
-                    "kernel": "median_net_freq_kernel<47, nonneg> (frequency direction, 47 taps)",
-                    "elements_per_launch": med_elems / max(med_launches, 1),
-                    "algorithmic_bytes_per_element": 8, "avg_launch_ms": 1e3 * t_launch,
-                    "launches": med_launches, "share_of_step": (med_ms / 1e3) / dt if dt > 0 else None,
-                    "note": "VALU-bound, not HBM-bound: v_min/v_max/v_med3 issue at half rate on gfx950 "
-                            "(profiles/r01_ubench_valu_rates.txt, profiles/r01_c_median47_pmc.json)"}})
+                "roofline": roof})
+            if fused:
+                out["roofline_median"] = roof_median
+                out["three_kernel_path"] = three
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_realtime(x[0])
                 out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

@@ -59,7 +59,9 @@ int zen_hip_device_name(char* buf, size_t n);
 int zen_hip_synchronize(void* stream); /* hipStreamSynchronize; synchronises */
 /* process-wide tuning/debug switches (no reference counterpart).  "median_general" = 1 forces the general
  * wave-cooperative median kernel even where the sorting-network fast path (masks <= 63 taps) applies;
- * "no_rt_fused" = 1 sends single-hop calls through the three-kernel block path instead of rt_fused.hip;
+ * "no_rt_fused" = 1 sends causal calls through the three-kernel path instead of the fused kernel of
+ * rt_fused.hip, "no_block_fused" = 1 does so only for calls of more than one hop; "block_fused_minb" = 1..3
+ * picks the occupancy the fused block kernel is compiled for;
  * "median47_shared" = 1 routes 47-tap frequency masks to the experimental neighbour-sharing kernel
  * (median47.hip; same results, currently not faster), "median47_blocks" = n makes it persistent on n workgroups. */
 int zen_hip_set_option(const char* name, int value);
@@ -157,8 +159,9 @@ int zen_hip_hpr_profile(zen_hip_hpr_t h, int enable);
 int zen_hip_hpr_profile_get(zen_hip_hpr_t h, double* median_ms, unsigned long long* median_launches,
                             unsigned long long* median_elements);
 /* summed milliseconds / launch counts per kernel class:
- * [0] STFT, [1] frequency filter, [2] time filter, [3] iSTFT, [4] overlap-add/copy-out */
-int zen_hip_hpr_profile_get_all(zen_hip_hpr_t h, double ms[5], unsigned long long launches[5]);
+ * [0] STFT, [1] frequency filter, [2] time filter, [3] iSTFT, [4] overlap-add/copy-out,
+ * [5] fused causal kernel (STFT + median + masks + iSTFT of a hop in one workgroup) */
+int zen_hip_hpr_profile_get_all(zen_hip_hpr_t h, double ms[6], unsigned long long launches[6]);
 
 /* ---------------------------------------------------------------------------------------------
  * HPRIOffline<Backend::GPU>   (libzen/hps.cu:21-221): two cascaded HPR passes ("HPR-I").

@@ -511,6 +511,40 @@ def test_realtime_fused_single_launch_hop(z, fs, hop, soft):
         assert np.array_equal(dout[k].download()[:off * hop], ref[k][:off * hop])
 
 
+@pytest.mark.parametrize("fs,hop", [(44100.0, 128), (48000.0, 256), (44100.0, 512), (48000.0, 1024), (44100.0, 1024)])
+@pytest.mark.parametrize("minb", [1, 2, 3])
+def test_block_fused_matches_three_kernel_path(z, fs, hop, minb):
+    """Blocks of causal hops run in the fused one-workgroup-per-hop kernel (rt_fused.hip); same samples as
+    the oracle and as the STFT / median / iSTFT kernels, for several streams, with engine chunks shorter
+    than the call, and when the two paths alternate on one engine (the fused block call leaves the
+    spectrum rings untouched, which a causal stream never reads back)."""
+    n_hops, S = 37, 3
+    x = np.stack([music(hop * n_hops, 500 + hop + s, fs) for s in range(S)])
+    refs = [run_oracle(fs, hop, 2.0, ALL, o.TIME_CAUSAL, x[s])[1] for s in range(S)]
+    ref = {k: np.stack([r[k] for r in refs]) for k in "PHR"}
+    z.set_option("block_fused_minb", minb)
+    try:
+        for chunk in (0, 8):
+            g = z.HPR(fs, hop, 2.0, ALL, z.TIME_CAUSAL, True, S, chunk)
+            assert same(g.process_stream_host(x), ref), chunk
+            assert same(z.HPR(fs, hop, 2.0, ALL, z.TIME_CAUSAL, True, S, chunk).process_stream_host(x, block=5), ref)
+        g = z.HPR(fs, hop, 2.0, ALL, z.TIME_CAUSAL, True, S, 16)
+        din = z.DeviceBuffer.from_host(x)
+        dout = {k: z.DeviceBuffer(x.size) for k in "PHR"}
+        off, n = 0, x.shape[1]
+        for i, m in enumerate((6, 1, 9, 4, 1, 16)):
+            z.set_option("no_block_fused", i & 1)
+            g.process(din.offset(off * hop), m, n, dout["H"].offset(off * hop), dout["P"].offset(off * hop),
+                      dout["R"].offset(off * hop), n)
+            off += m
+        z.synchronize()
+        for k in "PHR":
+            assert np.array_equal(dout[k].download().reshape(S, n)[:, :off * hop], ref[k][:, :off * hop]), k
+    finally:
+        z.set_option("no_block_fused", 0)
+        z.set_option("block_fused_minb", 3)
+
+
 @pytest.mark.parametrize("hop_h,hop_p,n", [(4096, 256, 400000), (1024, 256, 161571), (2048, 512, 90000)])
 def test_offline_time_sharded_equals_whole_clip(z, hop_h, hop_p, n):
     """one clip cut into time ranges, every range computed independently (as different GPUs

@@ -13,6 +13,7 @@ namespace zen_hip_impl {
 static thread_local char g_err[512] = "";
 int g_opt_median_general = 0;
 int g_opt_no_rt_fused = 0;
+int g_opt_no_block_fused = 0;
 int g_opt_median47_shared = 0;
 int g_opt_median47_blocks = 0;
 
@@ -128,6 +129,14 @@ int zen_hip_set_option(const char* name, int value)
 	}
 	if (name && !strcmp(name, "no_rt_fused")) {
 		g_opt_no_rt_fused = value;
+		return ZEN_HIP_OK;
+	}
+	if (name && !strcmp(name, "no_block_fused")) {
+		g_opt_no_block_fused = value;
+		return ZEN_HIP_OK;
+	}
+	if (name && !strcmp(name, "block_fused_minb")) {
+		g_opt_block_fused_minb = value;
 		return ZEN_HIP_OK;
 	}
 	if (name && !strcmp(name, "median47_blocks")) {

@@ -56,10 +56,10 @@ struct zen_hip_hpr {
 	size_t last_frames = 0;
 
 	// profiling hook (bench.py): HIP events around every launch, per kernel class
-	enum { K_STFT = 0, K_FREQ = 1, K_TIME = 2, K_ISTFT = 3, K_FINALIZE = 4, K_COUNT = 5 };
+	enum { K_STFT = 0, K_FREQ = 1, K_TIME = 2, K_ISTFT = 3, K_FINALIZE = 4, K_FUSED = 5, K_COUNT = 6 };
 	bool prof = false;
-	double prof_ms[K_COUNT] = {0, 0, 0, 0, 0};
-	unsigned long long prof_launches[K_COUNT] = {0, 0, 0, 0, 0};
+	double prof_ms[K_COUNT] = {0, 0, 0, 0, 0, 0};
+	unsigned long long prof_launches[K_COUNT] = {0, 0, 0, 0, 0, 0};
 	unsigned long long prof_elements = 0; // elements filtered by the frequency-direction kernel
 	struct Pending {
 		int k;
@@ -165,8 +165,8 @@ int reset_state(zen_hip_hpr* e)
 	return ZEN_HIP_OK;
 }
 
-// M == 1, causal, median path: the whole hop in one launch (rt_fused.hip)
-int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride)
+// causal, median path: M hops of every stream in one launch, one workgroup per hop (rt_fused.hip)
+int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 {
 	RtFusedArgs a;
 	memset(&a, 0, sizeof(a));
@@ -176,12 +176,13 @@ int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride)
 	a.tail_next = e->d_tail[e->tail_sel ^ 1];
 	a.window = e->d_window;
 	a.tw = e->d_tw;
-	a.S = e->d_S;
+	a.S = M == 1 ? e->d_S : nullptr; // causal: no later frame reads the rings (the time median is the identity)
 	a.s_stride = (long long)e->s_stride;
 	a.mag = e->d_mag;
 	a.ring_rows = e->ring_rows;
 	a.row0 = e->abs_frame;
 	a.hop = (int)e->hop;
+	a.n_frames = (int)M;
 	a.n_streams = (int)e->n_streams;
 	a.prev_frames = (int)e->last_frames;
 	a.y_stream_stride = (long long)(e->max_hops * e->nwin);
@@ -200,21 +201,21 @@ int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride)
 	a.out_h = e->out_h ? 1 : 0;
 	a.out_p = e->out_p ? 1 : 0;
 	{
-		ProfScope ps(e, zen_hip_hpr::K_STFT);
+		ProfScope ps(e, zen_hip_hpr::K_FUSED);
 		ZH_TRY(launch_rt_fused(e->log2n, e->mf, a, e->stream));
 	}
 	e->tail_sel ^= 1;
-	e->abs_frame += 1;
-	e->last_frames = 1;
+	e->abs_frame += (long long)M;
+	e->last_frames = M;
 	return ZEN_HIP_OK;
 }
 
 int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 {
 	const size_t S = e->n_streams, N = e->nfft;
-	if (M == 1 && e->causality == ZEN_HIP_TIME_CAUSAL && !e->use_sse && !g_opt_no_rt_fused
+	if (e->causality == ZEN_HIP_TIME_CAUSAL && !e->use_sse && !g_opt_no_rt_fused && (M == 1 || !g_opt_no_block_fused)
 	    && rt_fused_available(e->log2n, e->mf))
-		return run_hop_fused(e, in, in_stride);
+		return run_hop_fused(e, in, in_stride, M);
 	// ---- analysis
 	StftArgs sa;
 	memset(&sa, 0, sizeof(sa));
@@ -617,7 +618,7 @@ int zen_hip_hpr_profile_get(zen_hip_hpr_t h, double* median_ms, unsigned long lo
 	return ZEN_HIP_OK;
 }
 
-int zen_hip_hpr_profile_get_all(zen_hip_hpr_t h, double ms[5], unsigned long long launches[5])
+int zen_hip_hpr_profile_get_all(zen_hip_hpr_t h, double ms[6], unsigned long long launches[6])
 {
 	if (!h || !ms || !launches)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null argument");

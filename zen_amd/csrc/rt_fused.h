@@ -1,22 +1,24 @@
-// rt_fused.h -- launch interface of the one-launch-per-hop realtime kernel (rt_fused.hip).
+// rt_fused.h -- launch interface of the fused causal-realtime kernel (rt_fused.hip): one workgroup per
+// hop, one launch per call (one hop of every stream, or a block of consecutive hops).
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace zen_hip_impl {
 
 struct RtFusedArgs {
-	const float* in;        // stream s: in[s*in_stride .. +hop)
+	const float* in;        // stream s: in[s*in_stride .. +n_frames*hop)
 	long long in_stride;
 	const float* tail_prev; // [n_streams][hop]
 	float* tail_next;
 	const float* window;
 	const float2* tw;
-	float2* S;              // spectrum ring (bins 0..nfft/2 per row)
+	float2* S;              // spectrum ring (bins 0..nfft/2 per row); null: rings are not written
 	long long s_stride;
 	float* mag;             // magnitude ring
 	long long ring_rows;
-	long long row0;         // absolute row of this hop's frame
+	long long row0;         // absolute row of the first frame
 	int hop;
+	int n_frames;           // consecutive hops per stream in this call
 	int n_streams;
 	int prev_frames;        // frames of the previous call (overlap-add carry source)
 	float* carry[3];        // indexed by output id: 0 percussive, 1 harmonic, 2 residual (null = not computed)

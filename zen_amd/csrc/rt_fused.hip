@@ -1,8 +1,9 @@
-// rt_fused.hip -- one launch per hop for the single-stream realtime call path
-// (HPRRealtime<GPU>::process_next_hop, libzen/hps.cu:334-339 -> HPR::process_next_hop :429-486 ->
-// apply_median_filter :488-580).  The reference issues ~21 launches here; the block engine of hpr.hip
-// needs 3 (STFT, median, iSTFT); at one frame per call those are pure launch latency, so this kernel runs
-// the whole hop in one workgroup per stream:
+// rt_fused.hip -- the causal realtime path (HPRRealtime<GPU>::process_next_hop, libzen/hps.cu:334-339 ->
+// HPR::process_next_hop :429-486 -> apply_median_filter :488-580) in ONE launch, one workgroup per hop.
+// The reference issues ~21 launches per hop; the general engine of hpr.hip needs 3 per block of hops (STFT,
+// median, iSTFT) with the spectrum, |S| and P going through HBM in between.  In the causal configuration
+// the time-direction median is the identity, so a hop depends on nothing but its own frame and
+// the whole chain fits in one workgroup:
 //
 //   window + zero-padded forward FFT         -> spectrum stays in REGISTERS (16 bins per thread, the very
 //                                               bins pass 0 of the inverse transform reads: fft_dev.h slot)
@@ -11,8 +12,10 @@
 //   causal time median                       -> identity: H = |S|
 //   per output: mask, S*mask, inverse FFT    -> Y row (the two-term overlap-add is done by copy_output)
 //
-// Same arithmetic, same buffers and same carry protocol as the three-kernel path: the two are
-// interchangeable hop by hop (tests/test_gpu_parity.py::test_hpr_blocking_is_invisible).
+// Used for single-hop calls (latency: 1 launch instead of 3) and for blocks of hops (throughput: the
+// spectrum never leaves the chip; only 4*hop input and 8*hop of Y per output touch HBM).  Same arithmetic,
+// same carry protocol as the three-kernel path: the two are interchangeable call by call
+// (tests/test_gpu_parity.py::test_hpr_blocking_is_invisible, ::test_block_fused_matches_three_kernel_path).
 #include "common.h"
 #include "fft_dev.h"
 #include "masks.h"
@@ -38,8 +41,8 @@ struct RtImage {
 };
 
 struct Regs {
-	float2 S[16];
-	float mag[16];
+	float2 S[16]; // the frame's spectrum, bins tf + slot*TF
+	float mag[16]; // |S| of the same bins: loaded back from the LDS image after the median stage
 };
 
 template <int LOG2N>
@@ -64,13 +67,21 @@ struct FwdOut {
 	int n, mid_al;
 	__device__ __forceinline__ void operator()(int idx, float2 X, bool lower, int slot) const
 	{
-		const float m = zfft::cabs_exact(X.x, X.y); // complex_abs_functor hps.h:82-89
 		r->S[slot] = X;
-		r->mag[slot] = m;
-		if (lower || idx == (n >> 1))
-			S[idx] = X;
-		mag[idx] = m;
-		img[RtImage<T>::addr(idx + mid_al)] = __float_as_int(m); // |S| >= +0: the bits are the ordering key
+		// The spectrum of a real frame is exactly Hermitian (fft_dev.h), so |S[n-k]| == |S[k]| bit for bit:
+		// the owner of bin k <= n/2 computes the double-precision hypot once and stores it for both bins.
+		if (lower || idx == (n >> 1)) {
+			const float m = zfft::cabs_exact(X.x, X.y); // complex_abs_functor hps.h:82-89
+			const int key = __float_as_int(m);          // |S| >= +0: the bits are the ordering key
+			const int mir = (idx == 0 || idx == (n >> 1)) ? idx : n - idx;
+			img[RtImage<T>::addr(idx + mid_al)] = key;
+			img[RtImage<T>::addr(mir + mid_al)] = key;
+			if (S) { // rings are only kept for single-hop calls
+				S[idx] = X;
+				mag[idx] = m;
+				mag[mir] = m;
+			}
+		}
 	}
 };
 
@@ -93,8 +104,10 @@ struct InvOut {
 	__device__ __forceinline__ void operator()(int idx, float2 x, bool, int) const { Y[idx] = x.x * cola; }
 };
 
-template <int LOG2N, int W>
-__global__ __launch_bounds__(Plan<LOG2N>::TF) void rt_fused_kernel(RtFusedArgs a)
+// SINGLE: exactly one output is enabled (the realtime default, percussive only): the spectrum registers die
+// in the first pass of the one inverse transform instead of living through a loop over outputs.
+template <int LOG2N, int W, int MINB, bool SINGLE>
+__global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFusedArgs a)
 {
 	using PL = Plan<LOG2N>;
 	constexpr int N = PL::N, TF = PL::TF;
@@ -111,11 +124,14 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF) void rt_fused_kernel(RtFusedArgs a
 	int* img = reinterpret_cast<int*>(lds);
 	float* Prow = reinterpret_cast<float*>(lds + PL::LDS_FLOAT2);
 
-	const int tf = threadIdx.x, s = blockIdx.x, hop = a.hop;
-	const float* in_s = a.in + (long long)s * a.in_stride;
+	const int tf = threadIdx.x, hop = a.hop;
+	const int s = blockIdx.x / a.n_frames, f = blockIdx.x - s * a.n_frames; // consecutive blocks: consecutive hops
+	const float* cur = a.in + (long long)s * a.in_stride + (long long)f * hop;
 
-	// ---- per-hop housekeeping (as the extra block of stft_kernel): overlap-add carries, input tail
-	if (a.prev_frames > 0) {
+	// ---- housekeeping (as the extra block of stft_kernel): overlap-add carries, input tail.  The carry is
+	// the second half of the previous call's last Y row; the workgroup that will overwrite that row (or, if
+	// this call is shorter, the last one) saves it first.
+	if (a.prev_frames > 0 && f == (a.prev_frames - 1 < a.n_frames - 1 ? a.prev_frames - 1 : a.n_frames - 1)) {
 		for (int o = 0; o < 3; ++o) {
 			if (!a.carry[o])
 				continue;
@@ -124,22 +140,23 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF) void rt_fused_kernel(RtFusedArgs a
 				a.carry[o][(long long)s * hop + i] = y[i];
 		}
 	}
-	for (int i = tf; i < hop; i += TF)
-		a.tail_next[(long long)s * hop + i] = in_s[i];
+	if (f == a.n_frames - 1)
+		for (int i = tf; i < hop; i += TF)
+			a.tail_next[(long long)s * hop + i] = cur[i];
 
 	// ---- analysis: hps.cu:452-472, :492
 	Regs r;
 	{
 		FwdIn<LOG2N> in;
-		in.prev = a.tail_prev + (long long)s * hop;
-		in.cur = in_s;
+		in.prev = f > 0 ? cur - hop : a.tail_prev + (long long)s * hop;
+		in.cur = cur;
 		in.window = a.window;
 		in.hop = hop;
-		const long long row = (a.row0 % a.ring_rows) + (long long)s * a.ring_rows;
+		const long long row = ((a.row0 + f) % a.ring_rows) + (long long)s * a.ring_rows;
 		FwdOut<T> out;
 		out.r = &r;
-		out.S = a.S + row * a.s_stride;
-		out.mag = a.mag + row * N;
+		out.S = a.S ? a.S + row * a.s_stride : nullptr;
+		out.mag = a.S ? a.mag + row * N : nullptr;
 		out.img = img;
 		out.n = N;
 		out.mid_al = MID_AL;
@@ -181,37 +198,72 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF) void rt_fused_kernel(RtFusedArgs a
 			*reinterpret_cast<int4*>(&Prow[ch * T + 4 * v]) =
 			    make_int4(out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]);
 	}
-	__syncthreads(); // P row complete; the magnitude image is dead, the FFT image is free again
+	__syncthreads(); // P row complete
+	// the thread's 16 magnitudes come back from the image (they were not held in registers across the
+	// median stage); after the barrier the image is dead and the FFT image is free again
+#pragma unroll
+	for (int slot = 0; slot < 16; ++slot)
+		r.mag[slot] = __int_as_float(img[IM::addr(tf + slot * TF + MID_AL)]);
+	__syncthreads();
 
 	// ---- synthesis per enabled output: hps.cu:498-579 (H = |S| of the same row: causal)
-	for (int oi = 0; oi < a.n_out; ++oi) {
+	auto synth = [&](int which) {
 		InvIn in;
 		in.r = &r;
 		in.P = Prow;
 		in.cfg = MaskCfg{a.beta, a.beta_h, a.soft, a.power, 0, a.out_h, a.out_p};
-		in.which = a.out_id[oi];
+		in.which = which;
 		InvOut out;
-		out.Y = a.Y[a.out_id[oi]] + (long long)s * a.y_stream_stride;
+		out.Y = a.Y[which] + (long long)s * a.y_stream_stride + (long long)f * (2 * hop);
 		out.cola = a.cola;
 		zfft::fft_frame<LOG2N, true, false, true>(tf, lds, a.tw, in, out, true);
-		__syncthreads();
+	};
+	if constexpr (SINGLE) {
+		synth(a.out_id[0]);
+	}
+	else {
+		for (int oi = 0; oi < a.n_out; ++oi) {
+			synth(a.out_id[oi]);
+			__syncthreads();
+		}
 	}
 }
 
-template <int LOG2N, int W>
-int launch_t(const RtFusedArgs& a, hipStream_t stream)
+template <int LOG2N, int W, int MINB, bool SINGLE>
+int launch_k(const RtFusedArgs& a, hipStream_t stream)
 {
 	using PL = Plan<LOG2N>;
 	const size_t lds = sizeof(float2) * PL::LDS_FLOAT2 + sizeof(float) * PL::N;
-	auto kern = rt_fused_kernel<LOG2N, W>;
+	auto kern = rt_fused_kernel<LOG2N, W, MINB, SINGLE>;
 	if (lds > 64 * 1024)
 		ZH_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-	hipLaunchKernelGGL(kern, dim3((unsigned)a.n_streams), dim3(PL::TF), lds, stream, a);
+	hipLaunchKernelGGL(kern, dim3((unsigned)((long long)a.n_streams * a.n_frames)), dim3(PL::TF), lds, stream, a);
 	ZH_HIP(hipGetLastError());
 	return ZEN_HIP_OK;
 }
 
+// single hops are latency-bound (all the registers the compiler wants); blocks of hops are compiled for
+// BLOCK_MINB workgroups per CU
+template <int LOG2N, int W>
+int launch_t(const RtFusedArgs& a, hipStream_t stream)
+{
+	if (a.n_out == 1) {
+		if (a.n_frames == 1 || g_opt_block_fused_minb <= 1)
+			return launch_k<LOG2N, W, 1, true>(a, stream);
+		if (g_opt_block_fused_minb == 2)
+			return launch_k<LOG2N, W, 2, true>(a, stream);
+		return launch_k<LOG2N, W, 3, true>(a, stream);
+	}
+	if (a.n_frames == 1 || g_opt_block_fused_minb <= 1)
+		return launch_k<LOG2N, W, 1, false>(a, stream);
+	if (g_opt_block_fused_minb == 2)
+		return launch_k<LOG2N, W, 2, false>(a, stream);
+	return launch_k<LOG2N, W, 3, false>(a, stream);
+}
+
 } // namespace
+
+int g_opt_block_fused_minb = 3;
 
 // (transform size, frequency mask) pairs with a fused kernel: hops 128..1024 at 44.1 and 48 kHz
 bool rt_fused_available(int log2n, int freq_len)

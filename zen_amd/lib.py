@@ -325,9 +325,9 @@ class HPR:
         return ms.value, n.value, el.value
 
     def profile_get_all(self):
-        ms, n = (C.c_double * 5)(), (C.c_ulonglong * 5)()
+        ms, n = (C.c_double * 6)(), (C.c_ulonglong * 6)()
         _ck(load().zen_hip_hpr_profile_get_all(self._h, ms, n))
-        names = ("stft", "freq_filter", "time_filter", "istft", "finalize")
+        names = ("stft", "freq_filter", "time_filter", "istft", "finalize", "rt_fused")
         return {k: {"ms": ms[i], "launches": n[i]} for i, k in enumerate(names)}
 
     # ---- host-side convenience for tests ---------------------------------------------------------
