@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py -- hops/sec of the 1024-hop HPR hot path on MI355X, with the median kernel's HBM roofline.
+"""bench.py -- hops/sec of the 1024-hop HPR hot path on MI355X, with the HBM roofline of its kernels.
 
 Metric (BASELINE.json): "hops/sec (1024-hop HPR, 44.1 kHz mono) + median-filter HBM GB/s vs roofline".
 
@@ -9,21 +9,26 @@ Default workload (BASELINE configs[1], the one `value` is quoted on): HPRRealtim
 `--hops` hops (default 25 840 = 10 minutes of audio) of the stream through zen_hip_hpr_process with the
 percussive output written (STFT -> 47-tap frequency median -> hard mask -> iSTFT -> overlap-add).  State
 carries over between steps exactly as consecutive process_next_hop calls leave it, and the samples are
-bit-identical to per-hop calls (tests/test_gpu_parity.py::test_hpr_blocking_is_invisible).
+bit-identical to per-hop calls (tests/test_gpu_parity.py::test_hpr_blocking_is_invisible,
+::test_block_fused_matches_three_kernel_path).
 
 N > 1: a realtime stream is a sequential recurrence and does not shard ("replicas only"):
 every rank runs its own independent stream of the same size (weak scaling), no data-path collective;
 torch.distributed (RCCL) carries the barrier and the max-over-ranks time only.
 
 Also in the JSON line:
-  roofline     -- the frequency-direction median kernel (47 taps over the 25 840 x 4096 magnitude
-                  matrix): algorithmic bytes = 8 B/element (4 read + 4 written) divided by
-                  its mean launch duration, measured with HIP events on the engine's stream inside the
-                  timed region (zen_hip_hpr_profile).
-  cpu_baseline -- the CPU oracle (restatement of the reference's CPU/IPP path, kind "port") timed on this
-                  box's host, one thread, on a bounded prefix of the same stream; rank 0, N = 1 only.
-  realtime     -- the single-stream per-hop call path (process_next_hop + copy_percussive through mapped
-                  host memory, timed like zen/fakert.h:221-247), outside the timed region.
+  roofline        -- the dominant kernel of the timed region, timed with HIP events on the engine's stream
+                     (zen_hip_hpr_profile).  Default path: rt_fused_kernel (one workgroup per hop), priced
+                     with SURVEY 8(d)'s per-frame minimum 24*(nfft/2+1) + 8*hop bytes per hop.  With
+                     --no-block-fused: the 47-tap frequency median kernel, 8 B/element.
+  roofline_median -- BASELINE's second metric: the stand-alone frequency-direction median kernel (47 taps
+                     over the 25 840 x 4096 magnitude matrix, 8 B/element: 4 read + 4 written), timed
+                     with HIP events in a second leg that sends the same stream through the STFT /
+                     median / iSTFT kernels (outside the timed region of `value`).
+  cpu_baseline    -- the CPU oracle (restatement of the reference's CPU/IPP path, kind "port") timed on
+                     this box's host, one thread, on a bounded prefix of the same stream; rank 0, N = 1.
+  realtime        -- the single-stream per-hop call path (process_next_hop + copy_percussive through
+                     mapped host memory, timed like zen/fakert.h:221-247), outside the timed region.
 
 Other workloads (not the headline; `--workload`):
   offline_batch -- BASELINE configs[3]: independent 30 s mono clips, HPRIOffline<GPU> 4096/256 hard mask,
@@ -123,7 +128,7 @@ def realtime_leg(zen_amd, x, n_hops=400):
         rt.copy_percussive(io.device_out)            # synchronises
         _ = io.host_out[0]
     dt = time.perf_counter() - t0
-    return {"us_per_hop": 1e6 * dt / n_hops, "hops_per_s": n_hops / dt, "launches_per_hop": 4,
+    return {"us_per_hop": 1e6 * dt / n_hops, "hops_per_s": n_hops / dt, "launches_per_hop": 2,
             "x_realtime": (n_hops / dt) * HOP / FS,
             "note": "process_next_hop + copy_percussive via mapped host memory, host-timed incl. copies "
                     "(zen/fakert.h:221-247); latency-bound, no roofline quoted"}
