@@ -113,6 +113,30 @@ def cpu_baseline_offline(x, hop_h, hop_p, total_hops_per_clip, seconds=6.0):
             "x_realtime": (n / FS) / dt, "host_cpu": host_cpu_name(), "host_cores_available": os.cpu_count()}
 
 
+def device_copy_bandwidth(zen_amd, n_floats=1 << 28, iters=10):
+    """Device-to-device copy of 1 GiB (read + write bytes per second): the practical HBM roof of this box,
+    quoted next to the nominal 8 TB/s (roofline denominators)."""
+    import ctypes as C
+    a, b = zen_amd.DeviceBuffer(n_floats), zen_amd.DeviceBuffer(n_floats)
+    a.zero()
+    lib = zen_amd.load()
+
+    def cp():
+        lib.zen_hip_memcpy_d2d(C.c_void_p(b.ptr), C.c_void_p(a.ptr), C.c_size_t(4 * n_floats), None)
+
+    for _ in range(3):
+        cp()
+    zen_amd.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        cp()
+    zen_amd.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    a.free()
+    b.free()
+    return 8.0 * n_floats / dt / 1e9
+
+
 def realtime_leg(zen_amd, x, n_hops=400):
     """Per-hop call path through mapped memory; returns dict."""
     rt = zen_amd.HPRRealtime(FS, HOP, BETA, zen_amd.OUTPUT_PERCUSSIVE, False, 1)
@@ -233,12 +257,14 @@ def main():
                     pass
                 return None
 
+            copy_bw = device_copy_bandwidth(zen_amd)
             t_med = 1e-3 * med_ms / max(med_launches, 1)
             el_med = med_elems // max(med_launches, 1)
             ach_med = 8.0 * el_med / t_med / 1e9 if t_med > 0 else 0.0
             tr_med = traffic_of("r01_e_hbm_traffic.json", "median_net_freq_kernel<47,nonneg>", el_med)
             roof_median = {
                 "bound": "hbm", "achieved": ach_med, "peak": 8000.0, "unit": "GB/s", "frac": ach_med / 8000.0,
+                "device_copy_GBps": copy_bw, "frac_of_device_copy": ach_med / copy_bw,
                 "traffic": tr_med,
                 "traffic_source": "profiles/r01_e_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH "
                                   "doubled per the gfx950 correction)" if tr_med else None,
@@ -255,6 +281,7 @@ def main():
                 tr = traffic_of("r01_g_fused_hbm_traffic.json", "rt_fused_kernel<12,47>", S * M * nfft)
                 roof = {
                     "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                    "device_copy_GBps": copy_bw, "frac_of_device_copy": ach / copy_bw,
                     "traffic": tr,
                     "traffic_source": "profiles/r01_g_fused_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                       "FETCH doubled per the gfx950 correction)" if tr else None,

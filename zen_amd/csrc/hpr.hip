@@ -153,12 +153,15 @@ int reset_state(zen_hip_hpr* e)
 	const size_t S = e->n_streams;
 	ZH_HIP(hipMemsetAsync(e->d_tail[0], 0, sizeof(float) * S * e->hop, e->stream));
 	ZH_HIP(hipMemsetAsync(e->d_tail[1], 0, sizeof(float) * S * e->hop, e->stream));
-	ZH_HIP(hipMemsetAsync(e->d_S, 0, sizeof(float2) * S * e->ring_rows * e->s_stride, e->stream));
-	ZH_HIP(hipMemsetAsync(e->d_mag, 0, sizeof(float) * S * e->ring_rows * e->nfft, e->stream));
-	for (int o = 0; o < 3; ++o) {
-		ZH_HIP(hipMemsetAsync(e->d_Y[o], 0, sizeof(float) * S * e->max_hops * e->nwin, e->stream));
-		ZH_HIP(hipMemsetAsync(e->d_carry[o], 0, sizeof(float) * S * e->hop, e->stream));
+	// Only the W-1 history rows of the rings (absolute rows 0..W-2 of every stream) are read before they are
+	// written; every other ring row, and every Y row, is produced by the call that consumes it.
+	if (e->W > 1) {
+		const size_t srow = sizeof(float2) * e->s_stride, mrow = sizeof(float) * e->nfft;
+		ZH_HIP(hipMemset2DAsync(e->d_S, srow * e->ring_rows, 0, srow * (e->W - 1), S, e->stream));
+		ZH_HIP(hipMemset2DAsync(e->d_mag, mrow * e->ring_rows, 0, mrow * (e->W - 1), S, e->stream));
 	}
+	for (int o = 0; o < 3; ++o)
+		ZH_HIP(hipMemsetAsync(e->d_carry[o], 0, sizeof(float) * S * e->hop, e->stream));
 	e->tail_sel = 0;
 	e->abs_frame = (long long)e->W - 1; // rows 0..W-2 are the all-zero history of a fresh stream
 	e->last_frames = 0;
@@ -458,6 +461,11 @@ int zen_hip_hpr_create(float fs, size_t hop, float beta, unsigned output_flags, 
 		ZH_FAIL(ZEN_HIP_E_HIP, "hpr_create: device allocation failed (nfft %zu, streams %zu, chunk %zu hops)",
 		        nfft, n_streams, max_hops_per_chunk);
 	}
+	// once, so that no kernel can ever see uninitialised memory; reset_buffers() clears only what is read
+	(void)hipMemsetAsync(e->d_S, 0, sizeof(float2) * S * e->ring_rows * e->s_stride, e->stream);
+	(void)hipMemsetAsync(e->d_mag, 0, sizeof(float) * S * e->ring_rows * nfft, e->stream);
+	for (int o = 0; o < 3; ++o)
+		(void)hipMemsetAsync(e->d_Y[o], 0, sizeof(float) * S * MH * nwin, e->stream);
 	int rc = reset_state(e);
 	if (rc != ZEN_HIP_OK) {
 		free_all(e);
