@@ -5,6 +5,7 @@
 //   libzen/fftw.test.cu   : forward / inverse within 2e-4 of another FFT, n = 64 / 1024 / 16384
 //   libzen/hps.test.cu    : ProcessingModifiesInput, PercOnlyOutputsPerc, ResettingDoesTheRightThing
 //   libzen/hps_gpu_public.test.cu : HPRIOffline Basic / WithPadding, HPRRealtime
+//   demos/pitch-tracking/main.cu:90-118, demos/beat-tracking/main.cu:92-127 : the HPR front ends of the demos
 #include <cmath>
 #include <complex>
 #include <cstdio>
@@ -222,6 +223,39 @@ static void test_public_api(std::size_t extra) // hps_gpu_public.test.cu (Basic 
 	CHECK(thrown);
 }
 
+// The two downstream demos drive HPRRealtime<GPU> exactly like this: pitch tracking takes
+// the harmonic output at hop 4096 / beta 2.5 (demos/pitch-tracking/main.cu:90-118), beat tracking the
+// percussive output at hop 256 / beta 2.5 (demos/beat-tracking/main.cu:92-127), both through IOGPU's
+// mapped buffers, one hop per call.  Only the HPR front half is in scope; it must equal the CPU path.
+static void test_demo_front_end(float fs, std::size_t hop, float beta, unsigned what, std::size_t n_hops)
+{
+	auto x = generate_data_normalized(n_hops * hop);
+	zen::hps::HPRRealtime<Backend::GPU> rt(fs, hop, beta, what);
+	zen::io::IOGPU io(hop);
+	rt.warmup(io);
+	int err = 0;
+	zo_hpr* o = zo_hpr_create(fs, hop, beta, what == zen::hps::OUTPUT_HARMONIC ? ZO_OUTPUT_HARMONIC : ZO_OUTPUT_PERCUSSIVE,
+	                          ZO_TIME_CAUSAL, 1, &err);
+	CHECK(o != nullptr);
+	bool any = false;
+	for (std::size_t i = 0; i < n_hops; ++i) {
+		std::copy(x.begin() + i * hop, x.begin() + (i + 1) * hop, io.host_in);
+		rt.process_next_hop(io.device_in);
+		if (what == zen::hps::OUTPUT_HARMONIC)
+			rt.copy_harmonic(io.device_out);
+		else
+			rt.copy_percussive(io.device_out);
+		zo_hpr_process_next_hop(o, x.data() + i * hop);
+		const float* ref = what == zen::hps::OUTPUT_HARMONIC ? zo_hpr_harmonic_out(o) : zo_hpr_percussive_out(o);
+		for (std::size_t j = 0; j < hop; ++j) {
+			CHECK(io.host_out[j] == ref[j]);
+			any = any || io.host_out[j] != 0.0F;
+		}
+	}
+	CHECK(any);
+	zo_hpr_destroy(o);
+}
+
 int main()
 {
 	if (zen_hip_init(0) != ZEN_HIP_OK) {
@@ -239,6 +273,10 @@ int main()
 	test_hpr_properties();
 	test_public_api(0);
 	test_public_api(11);
+	test_demo_front_end(48000.0F, 4096, 2.5F, zen::hps::OUTPUT_HARMONIC, 12);   // pitch-tracking front end
+	test_demo_front_end(44100.0F, 4096, 2.5F, zen::hps::OUTPUT_HARMONIC, 12);
+	test_demo_front_end(44100.0F, 256, 2.5F, zen::hps::OUTPUT_PERCUSSIVE, 80);  // beat-tracking front end
+	test_demo_front_end(48000.0F, 256, 2.5F, zen::hps::OUTPUT_PERCUSSIVE, 80);
 	std::printf("%d checks, %d failures\n", g_checks, g_fail);
 	return g_fail ? 1 : 0;
 }
