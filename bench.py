@@ -170,6 +170,8 @@ def main():
     ap.add_argument("--clip-seconds", type=float, default=30.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-realtime", action="store_true")
+    ap.add_argument("--outputs", default="P", choices=["P", "HPR"],
+                    help="realtime_block: percussive only (the headline config) or all three outputs")
     ap.add_argument("--no-block-fused", action="store_true",
                     help="realtime_block: STFT / median / iSTFT kernels instead of the fused per-hop kernel")
     ap.add_argument("--fused-minb", type=int, default=0, help="tuning: occupancy the fused kernel is built for")
@@ -203,10 +205,15 @@ def main():
         x = np.stack([s_music(n, seed=1000 * rank + s) for s in range(S)])
         d_in = zen_amd.DeviceBuffer.from_host(x)
         d_out = zen_amd.DeviceBuffer(S * n)
-        eng = zen_amd.HPR(FS, HOP, BETA, zen_amd.OUTPUT_PERCUSSIVE, zen_amd.TIME_CAUSAL, True, S, M)
+        all_out = args.outputs == "HPR"
+        flags = (zen_amd.OUTPUT_PERCUSSIVE | zen_amd.OUTPUT_HARMONIC | zen_amd.OUTPUT_RESIDUAL) if all_out \
+            else zen_amd.OUTPUT_PERCUSSIVE
+        d_h = zen_amd.DeviceBuffer(S * n) if all_out else None
+        d_r = zen_amd.DeviceBuffer(S * n) if all_out else None
+        eng = zen_amd.HPR(FS, HOP, BETA, flags, zen_amd.TIME_CAUSAL, True, S, M)
 
         def step():
-            eng.process(d_in.ptr, M, n, None, d_out.ptr, None, n)
+            eng.process(d_in.ptr, M, n, d_h.ptr if all_out else None, d_out.ptr, d_r.ptr if all_out else None, n)
 
         for _ in range(args.warmup):
             step()
@@ -300,8 +307,9 @@ def main():
                 "value": value, "ms_per_step": 1e3 * dt / args.steps,
                 "config": {
                     "workload": "HPRRealtime<GPU> semantics: hop 1024, nwin 2048, transform 4096, beta 2.0, "
-                                "OUTPUT_PERCUSSIVE, hard mask, causal; S-music 44.1 kHz mono stream resident "
-                                "in HBM; block mode (zen_hip_hpr_process), %d hops/step/stream" % M,
+                                "%s, hard mask, causal; S-music 44.1 kHz mono stream resident "
+                                "in HBM; block mode (zen_hip_hpr_process), %d hops/step/stream"
+                                % ("OUTPUT_HARMONIC|PERCUSSIVE|RESIDUAL" if all_out else "OUTPUT_PERCUSSIVE", M),
                     "hops_per_step": M, "streams_per_gpu": S, "fs": FS, "hop": HOP,
                     "time_mask": 3, "freq_mask": 47, "parallelism": "replicas x%d" % world,
                     "path": "fused per-hop kernel + overlap-add" if fused else "STFT / median / iSTFT kernels + overlap-add"},

@@ -511,6 +511,24 @@ def test_realtime_fused_single_launch_hop(z, fs, hop, soft):
         assert np.array_equal(dout[k].download()[:off * hop], ref[k][:off * hop])
 
 
+@pytest.mark.parametrize("scale", [1e-10, 1e-20, 1e-30, 1e-38, 1e15, 1e30])
+@pytest.mark.parametrize("soft", [False, True])
+def test_hpr_extreme_amplitudes(z, scale, soft):
+    """Denormal products in the soft mask, |S|^2 beyond float range (the hypot is evaluated in double),
+    ratios against Eps: same bits as the CPU path on the fused kernel (causal) and on the general engine
+    (anticausal).  The device code must neither flush denormals nor contract multiply-adds."""
+    hop, n_hops = 256, 40
+    x = (np.random.default_rng(5).uniform(-1, 1, hop * n_hops) * scale).astype(np.float32)
+    for caus in (o.TIME_CAUSAL, o.TIME_ANTICAUSAL):
+        _, ref = run_oracle(44100.0, hop, 2.0, ALL, caus, x, soft=soft)
+        g = z.HPR(44100.0, hop, 2.0, ALL, caus)
+        if soft:
+            g.use_soft_mask()
+        got = g.process_stream_host(x)
+        for k in "PHR":
+            assert np.array_equal(got[k], ref[k], equal_nan=True), (caus, k)
+
+
 @pytest.mark.parametrize("fs,hop", [(44100.0, 128), (48000.0, 256), (44100.0, 512), (48000.0, 1024), (44100.0, 1024)])
 @pytest.mark.parametrize("minb", [1, 2, 3])
 def test_block_fused_matches_three_kernel_path(z, fs, hop, minb):
