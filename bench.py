@@ -113,6 +113,39 @@ def cpu_baseline_offline(x, hop_h, hop_p, total_hops_per_clip, seconds=6.0):
             "x_realtime": (n / FS) / dt, "host_cpu": host_cpu_name(), "host_cores_available": os.cpu_count()}
 
 
+def _cpu_clip_worker(job):
+    """One oracle HPRIOffline run on the first `seconds` of clip `clip_id` (forked worker, CPU only)."""
+    clip_id, seconds, hop_h, hop_p = job
+    from oracle import oracle as o
+    n = int(seconds * FS)
+    x = s_music(n, seed=7000 + clip_id)
+    eng = o.HPRIOffline(FS, hop_h, hop_p, BETA, BETA)
+    t0 = time.perf_counter()
+    eng.process(x)
+    dt = time.perf_counter() - t0
+    n1, _ = o.chunk_padder(n, hop_h, 1)
+    n2, _ = o.chunk_padder(n, hop_p, 11)
+    return n1 + n2, dt
+
+
+def cpu_baseline_offline_all_cores(hop_h, hop_p, seconds=4.0):
+    """one clip per host core, all cores at once.  Must run BEFORE the GPU is
+    initialised: the workers are plain forks of this process."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    ctx = mp.get_context("fork")
+    with ctx.Pool(cores) as pool:
+        pool.map(_cpu_clip_worker, [(i, 0.5, hop_h, hop_p) for i in range(cores)])       # start-up, page-in
+        t0 = time.perf_counter()
+        res = pool.map(_cpu_clip_worker, [(i, seconds, hop_h, hop_p) for i in range(cores)], chunksize=1)
+        wall = time.perf_counter() - t0
+    hops = sum(r[0] for r in res)
+    return {"value": hops / wall, "unit": "hops/s", "cores": cores, "kind": "port",
+            "sample": "first %.1f s of %d clips, one per core at the same time, oracle HPRIOffline %d/%d hard mask"
+                      % (seconds, cores, hop_h, hop_p),
+            "x_realtime": cores * seconds / wall, "wall_s": wall, "host_cpu": host_cpu_name()}
+
+
 def device_copy_bandwidth(zen_amd, n_floats=1 << 28, iters=10):
     """Device-to-device copy of 1 GiB (read + write bytes per second): the practical HBM roof of this box,
     quoted next to the nominal 8 TB/s (roofline denominators)."""
@@ -177,9 +210,12 @@ def main():
     ap.add_argument("--fused-minb", type=int, default=0, help="tuning: occupancy the fused kernel is built for")
     args = ap.parse_args()
 
-    import torch
+    cpu_all = None
+    if args.workload == "offline_batch" and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
+        cpu_all = cpu_baseline_offline_all_cores(4096, 256)      # forks: before anything loads or touches the GPU
     from zen_amd import dist as zdist
     rank, local_rank, world = zdist.env_world()
+    import torch
     torch.cuda.set_device(local_rank)
     grp = zdist.Group("nccl", torch.device("cuda", local_rank))
 
@@ -363,6 +399,7 @@ def main():
                 "checksum": chk})
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_offline(x[0], hop_h, hop_p, n1 + n2)
+                out["cpu_baseline_all_cores"] = cpu_all
     if args.workload == "offline_long":
         # BASELINE configs[2]: one 10-minute stereo clip = 2 mono channels, HPR-I 4096/256, soft mask p = 2.
         # N > 1: every channel is cut into N time ranges, rank r computes range r of both
