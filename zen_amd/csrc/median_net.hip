@@ -304,13 +304,65 @@ int launch_freq(const FilterArgs& a, const RowMap& rm, hipStream_t stream)
 	return ZEN_HIP_OK;
 }
 
+// 3- and 5-tap frequency masks (hops <= 128: l_perc = 500 / (fs / nfft) is 1..5 bins): one thread per four
+// outputs straight from global memory (the 2*mid halo samples come out of L1), med3 / the 5-input median
+// identity med3(e, max(min(a,b), min(c,d)), min(max(a,b), max(c,d))).
+template <int W, bool NONNEG>
+__global__ __launch_bounds__(256) void median_tiny_freq_kernel(FilterArgs a, RowMap rm, int groups_per_row)
+{
+	constexpr int mid = W / 2;
+	const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+	const int row = (int)(gid / groups_per_row), g = (int)(gid - (long long)row * groups_per_row);
+	if (row >= a.n_out_rows)
+		return;
+	const int cols = a.cols, c0 = 4 * g;
+	const float* __restrict__ srow =
+	    a.src + (long long)blockIdx.y * a.src_stream_stride + (long long)map_row(rm, row) * cols;
+	float* __restrict__ drow = a.dst + (long long)blockIdx.y * a.dst_stream_stride + (long long)row * cols;
+	int k[4 + 2 * mid];
+#pragma unroll
+	for (int i = 0; i < 4 + 2 * mid; ++i) {
+		int c = c0 - mid + i;
+		c = c < 0 ? 0 : (c > cols - 1 ? cols - 1 : c); // replicate border (ippBorderRepl)
+		k[i] = to_key<NONNEG>(srow[c]);
+	}
+#pragma unroll
+	for (int o = 0; o < 4; ++o) {
+		int m;
+		if constexpr (W == 3) {
+			m = znet::med3i(k[o], k[o + 1], k[o + 2]);
+		}
+		else {
+			const int lo = max(min(k[o], k[o + 1]), min(k[o + 2], k[o + 3]));
+			const int hi = min(max(k[o], k[o + 1]), max(k[o + 2], k[o + 3]));
+			m = znet::med3i(k[o + 4], lo, hi);
+		}
+		if (c0 + o < cols)
+			drow[c0 + o] = from_key<NONNEG>(m);
+	}
+}
+
+template <int W>
+int launch_tiny_freq(const FilterArgs& a, const RowMap& rm, hipStream_t stream)
+{
+	const int groups = (a.cols + 3) / 4;
+	const long long threads = (long long)a.n_out_rows * groups;
+	dim3 grid((unsigned)((threads + 255) / 256), (unsigned)a.n_streams);
+	if (a.nonneg)
+		hipLaunchKernelGGL((median_tiny_freq_kernel<W, true>), grid, dim3(256), 0, stream, a, rm, groups);
+	else
+		hipLaunchKernelGGL((median_tiny_freq_kernel<W, false>), grid, dim3(256), 0, stream, a, rm, groups);
+	ZH_HIP(hipGetLastError());
+	return ZEN_HIP_OK;
+}
+
 template <int W>
 int launch_freq_guard(const FilterArgs& a, const RowMap& rm, hipStream_t stream)
 {
 	if constexpr (W >= 7)
 		return launch_freq<W>(a, rm, stream);
 	else
-		return ZEN_HIP_E_BAD_ARG; // never reached: masks < 7 taps are routed to the general kernel
+		return launch_tiny_freq<W>(a, rm, stream);
 }
 
 template <int W, int VC>
@@ -354,8 +406,8 @@ int launch_median_net(const FilterArgs& a, hipStream_t stream, bool* handled)
 	if (a.len < 3 || a.len > 63 || !prepare(a, &rm))
 		return ZEN_HIP_OK;
 	const bool freq = a.direction == ZEN_HIP_FREQUENCY;
-	if (freq && a.len < 7)
-		return ZEN_HIP_OK; // T < 4: the 16-byte LDS path does not apply; tiny masks go the general way
+	if ((long long)a.n_out_rows * ((a.cols + 3) / 4) > 0x7fffffffLL * 256)
+		return ZEN_HIP_OK;
 	*handled = true;
 	switch (a.len) {
 #define X(W) \
