@@ -1,0 +1,433 @@
+// hpri.hip -- HPRIOffline<Backend::GPU> behind the C-ABI: two cascaded HPR passes ("HPR-I") on two streaming
+// engines (hpr.hip), everything resident in HBM.
+//
+//   zen_hip_hpri_* : HPRIOffline<GPU>::process (libzen/hps.cu:128-221): pass 1 (hop_h; H, P, R) ->
+//                    P+R shifted by lag_h*hop_h -> pass 2 (hop_p; P).  The reference walks the clip hop by hop
+//                    through two IOGPU buffers (hps.cu:146-166,189-204); here each pass is a handful of
+//                    block calls on the engine.  Also: a batch of equal-length clips per call, and any time
+//                    range of one clip from its own warm-up halo.
+#include "common.h"
+#include "hpr_engine.h"
+
+#include <cfloat>
+#include <climits>
+#include <cmath>
+
+using namespace zen_hip_impl;
+
+// =================================================================================================
+// HPRIOffline<GPU>
+// =================================================================================================
+struct zen_hip_hpri {
+	zen_hip_hpr* eh = nullptr; // p_impl_h : hop_h, H+P+R, anticausal (hps.cu:38-43)
+	zen_hip_hpr* ep = nullptr; // p_impl_p : hop_p, P only, anticausal (hps.cu:45-48)
+	size_t hop_h, hop_p, n_clips;
+	hipStream_t stream = nullptr;
+	// scratch, grown on demand
+	size_t cap1 = 0, cap2 = 0;
+	float *a1 = nullptr, *H1 = nullptr, *P1 = nullptr, *R1 = nullptr, *in2 = nullptr, *P2 = nullptr;
+	float *stage_in = nullptr, *stage_out[3] = {nullptr, nullptr, nullptr};
+	size_t stage_cap = 0;
+};
+
+namespace {
+
+// hps.cu:109-126 hpss_chunk_padder: float ceil of a float quotient, plus `lag` chunks
+int chunk_padder(size_t audio_size, size_t hop, size_t lag, size_t* padded)
+{
+	int n = (int)(ceilf((float)audio_size / (float)hop));
+	n += (int)lag;
+	*padded = (size_t)n * hop;
+	return n;
+}
+
+__global__ __launch_bounds__(256) void pad_clips_kernel(const float* __restrict__ in, long long in_stride,
+                                                        size_t n, float* __restrict__ out, size_t padded)
+{
+	const float* src = in + (long long)blockIdx.y * in_stride;
+	float* dst = out + (size_t)blockIdx.y * padded;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < padded; i += (size_t)gridDim.x * blockDim.x)
+		dst[i] = i < n ? src[i] : 0.0F; // audio.resize(size + pad, 0.0F)  hps.cu:123
+}
+
+// hps.cu:153-160 (xp1 + xr1), :171-176 (shift left by lag_h*hop_h in place; the tail keeps its old
+// contents) and :186-190 (pass 2 reads `intermediate` up to n2*hop_p, past size() -- SURVEY Q9).
+__global__ __launch_bounds__(256) void intermediate_kernel(const float* __restrict__ P1, const float* __restrict__ R1,
+                                                           size_t padded1, size_t sh1, float* __restrict__ in2,
+                                                           size_t padded2)
+{
+	const float* p = P1 + (size_t)blockIdx.y * padded1;
+	const float* r = R1 + (size_t)blockIdx.y * padded1;
+	float* dst = in2 + (size_t)blockIdx.y * padded2;
+	for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < padded2; j += (size_t)gridDim.x * blockDim.x) {
+		float v = 0.0F; // beyond the reference's allocation (undefined there)
+		if (j < padded1) {
+			const size_t q = (j < padded1 - sh1) ? j + sh1 : j;
+			v = p[q] + r[q]; // sum_vectors_functor hps.h:142-150
+		}
+		dst[j] = v;
+	}
+}
+
+// hps.cu:171-178, :209-217 : drop the lag*hop delay, truncate to the clip length
+__global__ __launch_bounds__(256) void unshift_kernel(const float* __restrict__ full, size_t padded, size_t sh,
+                                                      float* __restrict__ out, long long out_stride, size_t n)
+{
+	const float* src = full + (size_t)blockIdx.y * padded;
+	float* dst = out + (long long)blockIdx.y * out_stride;
+	for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
+		float v = 0.0F;
+		if (j < padded)
+			v = (j < padded - sh) ? src[j + sh] : src[j];
+		dst[j] = v;
+	}
+}
+
+unsigned grid_for(size_t n)
+{
+	size_t b = (n + 255) / 256;
+	return (unsigned)(b > 4096 ? 4096 : (b ? b : 1));
+}
+
+void hpri_free_scratch(zen_hip_hpri* o)
+{
+	(void)hipFree(o->a1);
+	(void)hipFree(o->H1);
+	(void)hipFree(o->P1);
+	(void)hipFree(o->R1);
+	(void)hipFree(o->in2);
+	(void)hipFree(o->P2);
+	o->a1 = o->H1 = o->P1 = o->R1 = o->in2 = o->P2 = nullptr;
+	o->cap1 = o->cap2 = 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int zen_hip_hpri_create(float fs, size_t hop_h, size_t hop_p, float beta_h, float beta_p, int nocopybord,
+                        size_t n_clips, zen_hip_hpri_t* h)
+{
+	if (!h || n_clips == 0)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_create: null handle or zero clips");
+	if (hop_p == 0 || hop_h % hop_p != 0) // hps.cu:33-36
+		ZH_FAIL(ZEN_HIP_E_HOPS_NOT_DIVISIBLE, "hop_h and hop_p should be evenly divisible");
+	zen_hip_hpri* o = new zen_hip_hpri;
+	o->hop_h = hop_h;
+	o->hop_p = hop_p;
+	o->n_clips = n_clips;
+	int rc = zen_hip_hpr_create(fs, hop_h, beta_h,
+	                            ZEN_HIP_OUTPUT_HARMONIC | ZEN_HIP_OUTPUT_PERCUSSIVE | ZEN_HIP_OUTPUT_RESIDUAL,
+	                            ZEN_HIP_TIME_ANTICAUSAL, !nocopybord, n_clips, 0, &o->eh);
+	if (rc == ZEN_HIP_OK)
+		rc = zen_hip_hpr_create(fs, hop_p, beta_p, ZEN_HIP_OUTPUT_PERCUSSIVE, ZEN_HIP_TIME_ANTICAUSAL,
+		                        !nocopybord, n_clips, 0, &o->ep);
+	if (rc != ZEN_HIP_OK) {
+		zen_hip_hpr_destroy(o->eh);
+		delete o;
+		return rc;
+	}
+	*h = o;
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpri_destroy(zen_hip_hpri_t h)
+{
+	if (h) {
+		zen_hip_hpr_destroy(h->eh);
+		zen_hip_hpr_destroy(h->ep);
+		hpri_free_scratch(h);
+		(void)hipFree(h->stage_in);
+		for (int i = 0; i < 3; ++i)
+			(void)hipFree(h->stage_out[i]);
+		delete h;
+	}
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpri_set_stream(zen_hip_hpri_t h, void* stream)
+{
+	if (!h)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null handle");
+	ZH_TRY(zen_hip_hpr_set_stream(h->eh, stream));
+	ZH_TRY(zen_hip_hpr_set_stream(h->ep, stream));
+	h->stream = (hipStream_t)stream;
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpri_use_sse_filter(zen_hip_hpri_t h)
+{
+	if (!h)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null handle");
+	zen_hip_hpr_use_sse_filter(h->eh);
+	zen_hip_hpr_use_sse_filter(h->ep);
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpri_use_soft_mask(zen_hip_hpri_t h)
+{
+	if (!h)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null handle");
+	zen_hip_hpr_use_soft_mask(h->eh);
+	zen_hip_hpr_use_soft_mask(h->ep);
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpri_hop_counts(zen_hip_hpri_t h, size_t n, size_t* n_hops_h, size_t* n_hops_p)
+{
+	if (!h)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null handle");
+	size_t p1, p2;
+	const int n1 = chunk_padder(n, h->hop_h, (size_t)h->eh->lag, &p1);
+	const int n2 = chunk_padder(n, h->hop_p, (size_t)h->ep->lag, &p2);
+	if (n_hops_h)
+		*n_hops_h = (size_t)n1;
+	if (n_hops_p)
+		*n_hops_p = (size_t)n2;
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpri_process_device(zen_hip_hpri_t h, const float* audio_dev, size_t n, size_t stride,
+                                float* harm_dev, float* perc_dev, float* resid_dev, size_t out_stride)
+{
+	if (!h || !audio_dev || n == 0)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_process: null argument or empty clip");
+	const size_t C = h->n_clips;
+	size_t padded1, padded2;
+	const int n1 = chunk_padder(n, h->hop_h, (size_t)h->eh->lag, &padded1); // hps.cu:133-134
+	const int n2 = chunk_padder(n, h->hop_p, (size_t)h->ep->lag, &padded2); // hps.cu:180-181
+	if (n1 <= 0 || n2 <= 0)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_process: clip too short");
+	if (padded1 > h->cap1 || padded2 > h->cap2) {
+		ZH_HIP(hipStreamSynchronize(h->stream));
+		hpri_free_scratch(h);
+		ZH_HIP(hipMalloc((void**)&h->a1, sizeof(float) * C * padded1));
+		ZH_HIP(hipMalloc((void**)&h->H1, sizeof(float) * C * padded1));
+		ZH_HIP(hipMalloc((void**)&h->P1, sizeof(float) * C * padded1));
+		ZH_HIP(hipMalloc((void**)&h->R1, sizeof(float) * C * padded1));
+		ZH_HIP(hipMalloc((void**)&h->in2, sizeof(float) * C * padded2));
+		ZH_HIP(hipMalloc((void**)&h->P2, sizeof(float) * C * padded2));
+		h->cap1 = padded1;
+		h->cap2 = padded2;
+	}
+	ZH_TRY(zen_hip_hpr_reset_buffers(h->eh)); // each process() call is a fresh pair of HPR objects' state
+	ZH_TRY(zen_hip_hpr_reset_buffers(h->ep));
+
+	hipLaunchKernelGGL(pad_clips_kernel, dim3(grid_for(padded1), (unsigned)C), dim3(256), 0, h->stream, audio_dev,
+	                   (long long)stride, n, h->a1, padded1);
+	ZH_HIP(hipGetLastError());
+	// pass 1: large hop, harmonic + percussive + residual (hps.cu:142-167)
+	ZH_TRY(zen_hip_hpr_process(h->eh, h->a1, (size_t)n1, padded1, h->H1, h->P1, h->R1, padded1));
+	const size_t sh1 = (size_t)h->eh->lag * h->hop_h;
+	hipLaunchKernelGGL(intermediate_kernel, dim3(grid_for(padded2), (unsigned)C), dim3(256), 0, h->stream, h->P1,
+	                   h->R1, padded1, sh1, h->in2, padded2);
+	ZH_HIP(hipGetLastError());
+	// pass 2: small hop on xp1 + xr1, percussive only (hps.cu:185-205)
+	ZH_TRY(zen_hip_hpr_process(h->ep, h->in2, (size_t)n2, padded2, nullptr, h->P2, nullptr, padded2));
+	const size_t sh2 = (size_t)h->ep->lag * h->hop_p;
+	if (harm_dev) {
+		hipLaunchKernelGGL(unshift_kernel, dim3(grid_for(n), (unsigned)C), dim3(256), 0, h->stream, h->H1, padded1,
+		                   sh1, harm_dev, (long long)out_stride, n);
+		ZH_HIP(hipGetLastError());
+	}
+	if (perc_dev) {
+		hipLaunchKernelGGL(unshift_kernel, dim3(grid_for(n), (unsigned)C), dim3(256), 0, h->stream, h->P2, padded2,
+		                   sh2, perc_dev, (long long)out_stride, n);
+		ZH_HIP(hipGetLastError());
+	}
+	if (resid_dev) // pass 2's residual_out is never written: zeros (hps.cu:45-48, :200-204)
+		ZH_HIP(hipMemset2DAsync(resid_dev, sizeof(float) * out_stride, 0, sizeof(float) * n, C, h->stream));
+	return ZEN_HIP_OK;
+}
+
+// ---- time-sharding one long clip ---------------------------------------------------
+// Output samples [begin, end) of an n-sample clip, bit-identical to the same range of
+// zen_hip_hpri_process.  Both passes are streaming recurrences whose state (input tail, the last W-1
+// spectra, the overlap-add carry) is a function of the last <= W+1 hops only, so a shard that starts
+// 2W+2 hops early from zero state reaches exactly the serial state before its first kept sample.  The
+// shard therefore needs only a halo of input: (2W_p+2)*hop_p + lag_p*hop_p for pass 2 on top of
+// (2W_h+2)*hop_h + lag_h*hop_h for pass 1; ranks exchange nothing.
+namespace {
+
+struct RangePlan {
+	size_t padded1, padded2, sh1, sh2;
+	size_t q1, k1;   // pass-1 hops [q1, k1) are run
+	size_t q2, m1;   // pass-2 hops [q2, m1) are run
+	size_t in_begin, in_end; // input samples read (clipped to n; beyond n is zero padding)
+};
+
+int plan_range(zen_hip_hpri* h, size_t n, size_t begin, size_t end, RangePlan* p)
+{
+	if (!(begin < end) || end > n)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri range [%zu, %zu) outside the clip of %zu samples", begin, end, n);
+	const size_t hop_h = h->hop_h, hop_p = h->hop_p;
+	const int n1 = chunk_padder(n, hop_h, (size_t)h->eh->lag, &p->padded1);
+	const int n2 = chunk_padder(n, hop_p, (size_t)h->ep->lag, &p->padded2);
+	if (n1 <= 0 || n2 <= 0)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri range: clip too short");
+	p->sh1 = (size_t)h->eh->lag * hop_h;
+	p->sh2 = (size_t)h->ep->lag * hop_p;
+	const size_t warm_p = 2 * h->ep->W + 2, warm_h = 2 * h->eh->W + 2;
+	// pass-2 output positions [begin + sh2, end + sh2) (or unshifted near the very end: Q9-style tail)
+	size_t m0 = begin / hop_p;                       // conservative: positions j or j + sh2
+	p->m1 = ceil_div(end + p->sh2, hop_p);
+	if (p->m1 > (size_t)n2)
+		p->m1 = (size_t)n2;
+	if (m0 > p->m1)
+		m0 = p->m1;
+	p->q2 = m0 > warm_p ? m0 - warm_p : 0;
+	// pass-1 output positions: pass-2 input j in [q2*hop_p, m1*hop_p) reads position j or j + sh1;
+	// the harmonic output reads [begin, end + sh1)
+	size_t a1 = p->q2 * hop_p < begin ? p->q2 * hop_p : begin;
+	size_t b1 = p->m1 * hop_p + p->sh1;
+	if (end + p->sh1 > b1)
+		b1 = end + p->sh1;
+	if (b1 > p->padded1)
+		b1 = p->padded1;
+	const size_t k0 = a1 / hop_h;
+	p->k1 = ceil_div(b1, hop_h);
+	if (p->k1 > (size_t)n1)
+		p->k1 = (size_t)n1;
+	p->q1 = k0 > warm_h ? k0 - warm_h : 0;
+	p->in_begin = p->q1 * hop_h;
+	p->in_end = p->k1 * hop_h < n ? p->k1 * hop_h : n;
+	if (p->in_begin > p->in_end)
+		p->in_begin = p->in_end;
+	return ZEN_HIP_OK;
+}
+
+// a1[i] = audio[off + i] (zero beyond n), i < count
+__global__ __launch_bounds__(256) void range_input_kernel(const float* __restrict__ audio, size_t n, size_t off,
+                                                          float* __restrict__ dst, size_t count)
+{
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
+		dst[i] = (off + i < n) ? audio[off + i] : 0.0F;
+}
+
+// pass-2 input positions j in [j0, j0+count): intermediate'[j] as intermediate_kernel defines it;
+// P1/R1 hold pass-1 output positions [base1, ...)
+__global__ __launch_bounds__(256) void range_intermediate_kernel(const float* __restrict__ P1, const float* __restrict__ R1,
+                                                                 size_t base1, size_t padded1, size_t sh1, size_t j0,
+                                                                 float* __restrict__ dst, size_t count)
+{
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+		const size_t j = j0 + i;
+		float v = 0.0F;
+		if (j < padded1) {
+			const size_t q = (j < padded1 - sh1) ? j + sh1 : j;
+			v = P1[q - base1] + R1[q - base1];
+		}
+		dst[i] = v;
+	}
+}
+
+// out[i] = full'[begin + i] where full' is `full` with the lag*hop delay removed (unshift_kernel);
+// `full` holds positions [base, ...)
+__global__ __launch_bounds__(256) void range_unshift_kernel(const float* __restrict__ full, size_t base, size_t padded,
+                                                            size_t sh, size_t begin, float* __restrict__ out, size_t count)
+{
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+		const size_t j = begin + i;
+		float v = 0.0F;
+		if (j < padded) {
+			const size_t q = (j < padded - sh) ? j + sh : j;
+			v = full[q - base];
+		}
+		out[i] = v;
+	}
+}
+
+} // namespace
+
+int zen_hip_hpri_range_halo(zen_hip_hpri_t h, size_t n, size_t begin, size_t end, size_t* in_begin, size_t* in_end)
+{
+	if (!h)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null handle");
+	RangePlan p;
+	ZH_TRY(plan_range(h, n, begin, end, &p));
+	if (in_begin)
+		*in_begin = p.in_begin;
+	if (in_end)
+		*in_end = p.in_end;
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpri_process_range(zen_hip_hpri_t h, const float* audio_dev, size_t n, size_t begin, size_t end,
+                               float* harm_dev, float* perc_dev)
+{
+	if (!h || !audio_dev)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_process_range: null argument");
+	if (h->n_clips != 1)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_process_range needs a handle created with n_clips == 1");
+	RangePlan p;
+	ZH_TRY(plan_range(h, n, begin, end, &p));
+	const size_t hop_h = h->hop_h, hop_p = h->hop_p;
+	const size_t c1 = (p.k1 - p.q1) * hop_h, c2 = (p.m1 - p.q2) * hop_p;
+	if (c1 > h->cap1 || c2 > h->cap2) {
+		ZH_HIP(hipStreamSynchronize(h->stream));
+		hpri_free_scratch(h);
+		ZH_HIP(hipMalloc((void**)&h->a1, sizeof(float) * c1));
+		ZH_HIP(hipMalloc((void**)&h->H1, sizeof(float) * c1));
+		ZH_HIP(hipMalloc((void**)&h->P1, sizeof(float) * c1));
+		ZH_HIP(hipMalloc((void**)&h->R1, sizeof(float) * c1));
+		ZH_HIP(hipMalloc((void**)&h->in2, sizeof(float) * (c2 ? c2 : 1)));
+		ZH_HIP(hipMalloc((void**)&h->P2, sizeof(float) * (c2 ? c2 : 1)));
+		h->cap1 = c1;
+		h->cap2 = c2;
+	}
+	ZH_TRY(zen_hip_hpr_reset_buffers(h->eh));
+	ZH_TRY(zen_hip_hpr_reset_buffers(h->ep));
+	const size_t base1 = p.q1 * hop_h, base2 = p.q2 * hop_p;
+	hipLaunchKernelGGL(range_input_kernel, dim3(grid_for(c1)), dim3(256), 0, h->stream, audio_dev, n, base1, h->a1, c1);
+	ZH_HIP(hipGetLastError());
+	ZH_TRY(zen_hip_hpr_process(h->eh, h->a1, p.k1 - p.q1, c1, h->H1, h->P1, h->R1, c1));
+	if (c2) {
+		hipLaunchKernelGGL(range_intermediate_kernel, dim3(grid_for(c2)), dim3(256), 0, h->stream, h->P1, h->R1, base1,
+		                   p.padded1, p.sh1, base2, h->in2, c2);
+		ZH_HIP(hipGetLastError());
+		ZH_TRY(zen_hip_hpr_process(h->ep, h->in2, p.m1 - p.q2, c2, nullptr, h->P2, nullptr, c2));
+	}
+	const size_t cnt = end - begin;
+	if (harm_dev) {
+		hipLaunchKernelGGL(range_unshift_kernel, dim3(grid_for(cnt)), dim3(256), 0, h->stream, h->H1, base1, p.padded1,
+		                   p.sh1, begin, harm_dev, cnt);
+		ZH_HIP(hipGetLastError());
+	}
+	if (perc_dev) {
+		hipLaunchKernelGGL(range_unshift_kernel, dim3(grid_for(cnt)), dim3(256), 0, h->stream, h->P2, base2, p.padded2,
+		                   p.sh2, begin, perc_dev, cnt);
+		ZH_HIP(hipGetLastError());
+	}
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpri_process(zen_hip_hpri_t h, const float* audio_host, size_t n, float* harm_host,
+                         float* perc_host, float* resid_host)
+{
+	if (!h || !audio_host || n == 0)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_process: null argument or empty clip");
+	if (h->n_clips != 1)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_process(host) needs a handle created with n_clips == 1");
+	if (n > h->stage_cap) {
+		ZH_HIP(hipStreamSynchronize(h->stream));
+		(void)hipFree(h->stage_in);
+		for (int i = 0; i < 3; ++i)
+			(void)hipFree(h->stage_out[i]);
+		ZH_HIP(hipMalloc((void**)&h->stage_in, sizeof(float) * n));
+		for (int i = 0; i < 3; ++i)
+			ZH_HIP(hipMalloc((void**)&h->stage_out[i], sizeof(float) * n));
+		h->stage_cap = n;
+	}
+	ZH_HIP(hipMemcpyAsync(h->stage_in, audio_host, sizeof(float) * n, hipMemcpyHostToDevice, h->stream));
+	ZH_TRY(zen_hip_hpri_process_device(h, h->stage_in, n, n, harm_host ? h->stage_out[0] : nullptr,
+	                                   perc_host ? h->stage_out[1] : nullptr,
+	                                   resid_host ? h->stage_out[2] : nullptr, n));
+	float* hosts[3] = {harm_host, perc_host, resid_host};
+	for (int i = 0; i < 3; ++i)
+		if (hosts[i])
+			ZH_HIP(hipMemcpyAsync(hosts[i], h->stage_out[i], sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
+	ZH_HIP(hipStreamSynchronize(h->stream));
+	return ZEN_HIP_OK;
+}
+
+} // extern "C"
