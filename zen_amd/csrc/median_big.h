@@ -7,11 +7,12 @@
 //   * a thread produces 16 consecutive outputs.  The samples common to its 16 windows are NB whole blocks
 //     plus rl + rr <= 30 loose samples.  It merges the first 2^k sorted blocks pairwise (Batcher odd-even
 //     merges, 16 -> 32 -> 64 -> 128) into one sorted list A, sorts the loose samples and merges them with
-//     the remaining blocks into a second sorted list R, and reads the 16 candidate order statistics
-//     off the two lists with the selection identity merge(A,R)[p] = min_q max(A[p-q], R[q-1]);
+//     the remaining blocks into a second sorted list R, and gets the 16 candidate order statistics from
+//     one more (heavily pruned) odd-even merge of the relevant window of A with R (or, where that merge
+//     overflows the register file, from the selection identity merge(A,R)[p] = min_q max(A[p-q], R[q-1]));
 //   * the 15 + 15 flank samples then go through the same selection tree as for small windows.
 //
-// ~250 min/max per output at 187 taps, all with compile-time indices (no data-dependent addressing),
+// 210-250 min/max per output at 171/187 taps, all with compile-time indices (no data-dependent addressing),
 // instead of ~60 wave-wide instructions per output in the sliding wave-window kernel.
 #pragma once
 #include "median_net.h"
@@ -36,6 +37,9 @@ struct Geo {
 	static constexpr int RREAL = 32 + 16 * REST; // R slots in use: 32 for the loose samples + the blocks
 	static constexpr int NRP = RREAL <= 32 ? 32 : (RREAL <= 64 ? 64 : (RREAL <= 128 ? 128 : 256));
 	static constexpr bool supported = (W & 1) && W >= 65 && W <= 255;
+	// candidates by a pruned odd-even merge (fewer instructions) unless both lists are long: with
+	// NA = 128 and NR > 32 (187 taps) that version spills ~60 registers and loses to the selection identity
+	static constexpr bool use_merge = !(NA >= 128 && NR > 32);
 };
 
 template <int N, int TOTAL, int OFF = 0>
@@ -143,27 +147,48 @@ __device__ __forceinline__ void medians_big(const LD& ld, int (&out)[16])
 		if constexpr (NRP >= 256)
 			MergeLevelR<256, NRP, G::RREAL, 0>::run(R);
 	}
-	// ---- candidates = ranks m-15 .. m of A u R:  merge(A,R)[p] = min_q max(A[p-q], R[q-1])
+	// ---- candidates = ranks m-15 .. m of A u R.  At most NR samples of R precede any of them, so only the
+	// window An = A[ALO..AHI] of A matters, and the ranks are m-15-ALO .. m-ALO of An u R.
 	int cand[16];
+	constexpr int NAN_ = AHI - ALO + 1;
+	constexpr int HALF = (NAN_ <= 64 && NRP <= 64) ? 64 : 128;
+	if constexpr (NAN_ <= HALF && NRP <= HALF && G::use_merge) {
+		// one odd-even merge of the two lists, each padded with +inf to HALF; the compiler prunes the
+		// comparators that cannot reach the 16 outputs read below (~235 comparators at HALF = 64 instead of
+		// 16 * NR max/min terms)
+		int X[2 * HALF];
 #pragma unroll
-	for (int i = 0; i < 16; ++i) {
-		const int p = G::m - 15 + i;
-		int best = KEY_INF;
-#pragma unroll
-		for (int q = 0; q <= G::NR; ++q) { // q samples from R, p + 1 - q from A
-			const int ia = p - q;          // last sample taken from A
-			if (ia > G::NA - 1 || ia < -1)
-				continue;                  // A or R cannot supply that many
-			int term;
-			if (ia < 0)
-				term = R[q - 1];
-			else if (q == 0)
-				term = An[ia - ALO];
-			else
-				term = max(An[ia - ALO], R[q - 1]);
-			best = min(best, term);
+		for (int j = 0; j < HALF; ++j) {
+			X[j] = j < NAN_ ? An[j < NAN_ ? j : 0] : KEY_INF;
+			X[HALF + j] = j < NRP ? R[j < NRP ? j : 0] : KEY_INF;
 		}
-		cand[i] = best;
+		znet::oe_merge<2 * HALF, 0>(X);
+#pragma unroll
+		for (int i = 0; i < 16; ++i)
+			cand[i] = X[G::m - 15 - ALO + i];
+	}
+	else {
+		// selection identity merge(A,R)[p] = min_q max(A[p-q], R[q-1])
+#pragma unroll
+		for (int i = 0; i < 16; ++i) {
+			const int p = G::m - 15 + i;
+			int best = KEY_INF;
+#pragma unroll
+			for (int q = 0; q <= G::NR; ++q) { // q samples from R, p + 1 - q from A
+				const int ia = p - q;          // last sample taken from A
+				if (ia > G::NA - 1 || ia < -1)
+					continue;                  // A or R cannot supply that many
+				int term;
+				if (ia < 0)
+					term = R[q - 1];
+				else if (q == 0)
+					term = An[ia - ALO];
+				else
+					term = max(An[ia - ALO], R[q - 1]);
+				best = min(best, term);
+			}
+			cand[i] = best;
+		}
 	}
 	phase_fence();
 	// ---- flanks and the selection tree
