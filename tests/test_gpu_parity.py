@@ -511,6 +511,23 @@ def test_realtime_fused_single_launch_hop(z, fs, hop, soft):
         assert np.array_equal(dout[k].download()[:off * hop], ref[k][:off * hop])
 
 
+@pytest.mark.parametrize("fs,hop,n_hops", [(44100.0, 256, 60), (44100.0, 1024, 24), (44100.0, 4096, 8), (48000.0, 64, 130)])
+@pytest.mark.parametrize("flags", [7, 3, 6, 5])
+def test_hard_mask_outputs_in_one_workgroup(z, fs, hop, n_hops, flags):
+    """Hard masks, several outputs (H|P|R subsets, incl. the residual without one of its masks): the synthesis
+    kernel that keeps the two binary masks of a frame in a register and loops over the outputs equals the
+    one-workgroup-per-output kernel and the oracle."""
+    x = music(hop * n_hops, seed=hop + flags, fs=fs)
+    _, ref = run_oracle(fs, hop, 2.0, flags, o.TIME_ANTICAUSAL, x)
+    for off in (0, 1):
+        z.set_option("no_istft_multi", off)
+        try:
+            got = z.HPR(fs, hop, 2.0, flags, z.TIME_ANTICAUSAL).process_stream_host(x)
+        finally:
+            z.set_option("no_istft_multi", 0)
+        assert same(got, ref), off
+
+
 @pytest.mark.parametrize("scale", [1e-10, 1e-20, 1e-30, 1e-38, 1e15, 1e30])
 @pytest.mark.parametrize("soft", [False, True])
 def test_hpr_extreme_amplitudes(z, scale, soft):
