@@ -33,46 +33,8 @@ constexpr int NCH = 259;  // chunks per row segment: blocks u = -1 .. 257  <->  
 constexpr int RSTR = 20;  // raw image: 16 words + 4 pad per chunk (5c mod 16 distinct: ds_read_b128 conflict free)
 constexpr int OUTS = 4096;
 
-template <bool NONNEG>
-__device__ __forceinline__ int to_key(float f)
-{
-	return NONNEG ? __float_as_int(f) : znet::f2key(f);
-}
-template <bool NONNEG>
-__device__ __forceinline__ float from_key(int k)
-{
-	return NONNEG ? __int_as_float(k) : znet::key2f(k);
-}
-
-__device__ __forceinline__ void ld16(const int* p, int (&v)[16])
-{
-#pragma unroll
-	for (int i = 0; i < 4; ++i) {
-		const int4 q = *reinterpret_cast<const int4*>(p + 4 * i);
-		v[4 * i] = q.x;
-		v[4 * i + 1] = q.y;
-		v[4 * i + 2] = q.z;
-		v[4 * i + 3] = q.w;
-	}
-}
-__device__ __forceinline__ void st16(int* p, const int (&v)[16])
-{
-#pragma unroll
-	for (int i = 0; i < 4; ++i)
-		*reinterpret_cast<int4*>(p + 4 * i) = make_int4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
-}
-template <int N>
-__device__ __forceinline__ void ldn(const int* p, int (&v)[N])
-{
-#pragma unroll
-	for (int i = 0; i < N / 4; ++i) {
-		const int4 q = *reinterpret_cast<const int4*>(p + 4 * i);
-		v[4 * i] = q.x;
-		v[4 * i + 1] = q.y;
-		v[4 * i + 2] = q.z;
-		v[4 * i + 3] = q.w;
-	}
-}
+using znet::from_key;
+using znet::to_key;
 
 // Preconditions (checked by the launcher): cols % 4 == 0, rows and pointers 16-byte aligned.
 template <bool NONNEG>
@@ -147,8 +109,8 @@ __global__ __launch_bounds__(256) void median47_shared_kernel(FilterArgs a, int 
 		int A[16];
 		{
 			int lo[16], hi[16];
-			ld16(&raw[tid * RSTR], lo);       // B(t-1) = x[16t-24 .. 16t-9]
-			ld16(&raw[(tid + 3) * RSTR], hi); // B(t+2) = x[16t+24 .. 16t+39]
+			znet::lds_load<16>(&raw[tid * RSTR], lo);       // B(t-1) = x[16t-24 .. 16t-9]
+			znet::lds_load<16>(&raw[(tid + 3) * RSTR], hi); // B(t+2) = x[16t+24 .. 16t+39]
 #pragma unroll
 			for (int q = 0; q < 15; ++q) {
 				e[q] = lo[q + 1];
@@ -157,28 +119,28 @@ __global__ __launch_bounds__(256) void median47_shared_kernel(FilterArgs a, int 
 #pragma unroll
 			for (int q = 15; q < 47; ++q)
 				e[q] = 0; // the 32 common samples come from the sorted blocks instead
-			ld16(&raw[(tid + 1) * RSTR], A);
+			znet::lds_load<16>(&raw[(tid + 1) * RSTR], A);
 		}
 		int extra[16];
 		if (tid == 0)
-			ld16(&raw[257 * RSTR], extra); // B(256): right neighbour of the last thread
+			znet::lds_load<16>(&raw[257 * RSTR], extra); // B(256): right neighbour of the last thread
 		__syncthreads();
 		znet::sort_net<16>(A);
-		st16(&raw[(tid + 1) * RSTR], A);
+		znet::lds_store<16>(&raw[(tid + 1) * RSTR], A);
 		if (tid == 0) {
 			znet::sort_net<16>(extra);
-			st16(&raw[257 * RSTR], extra);
+			znet::lds_store<16>(&raw[257 * RSTR], extra);
 		}
 		__syncthreads();
 		int cand[16], out[16];
 		{
 			int B[16];
-			ld16(&raw[(tid + 2) * RSTR], B);
+			znet::lds_load<16>(&raw[(tid + 2) * RSTR], B);
 			znet::mid16_of_two_sorted16(A, B, cand);
 		}
 		__syncthreads(); // sorted blocks are consumed: the image now collects the results
 		znet::Node<W, T, 0, NE, T>::run(e, cand, out);
-		st16(&raw[tid * RSTR], out);
+		znet::lds_store<16>(&raw[tid * RSTR], out);
 		__syncthreads();
 
 #pragma unroll

@@ -15,35 +15,8 @@ namespace {
 constexpr int RSTR = 20; // 16 words + 4 pad per block: ds_read_b128 of consecutive blocks is conflict free
 constexpr int OUTS = 4096;
 
-template <bool NONNEG>
-__device__ __forceinline__ int to_key(float f)
-{
-	return NONNEG ? __float_as_int(f) : znet::f2key(f);
-}
-template <bool NONNEG>
-__device__ __forceinline__ float from_key(int k)
-{
-	return NONNEG ? __int_as_float(k) : znet::key2f(k);
-}
-
-template <int N>
-__device__ __forceinline__ void ldn(const int* p, int* v)
-{
-#pragma unroll
-	for (int i = 0; i < N / 4; ++i) {
-		const int4 q = *reinterpret_cast<const int4*>(p + 4 * i);
-		v[4 * i] = q.x;
-		v[4 * i + 1] = q.y;
-		v[4 * i + 2] = q.z;
-		v[4 * i + 3] = q.w;
-	}
-}
-__device__ __forceinline__ void st16(int* p, const int (&v)[16])
-{
-#pragma unroll
-	for (int i = 0; i < 4; ++i)
-		*reinterpret_cast<int4*>(p + 4 * i) = make_int4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
-}
+using znet::from_key;
+using znet::to_key;
 
 // Preconditions (checked by the launcher): cols % 4 == 0, rows and pointers 16-byte aligned.
 #ifndef ZEN_BIG_MINB
@@ -93,9 +66,9 @@ __global__ __launch_bounds__(256, ZEN_BIG_MINB) void median_big_kernel(FilterArg
 	// ---- every block sorted once
 	for (int s = tid; s < NSORT; s += 256) {
 		int v[16];
-		ldn<16>(&raw[(s + 2) * RSTR], v);
+		znet::lds_load<16>(&raw[(s + 2) * RSTR], v);
 		znet::sort_net<16>(v);
-		st16(&srt[s * RSTR], v);
+		znet::lds_store<16>(&srt[s * RSTR], v);
 	}
 	__syncthreads();
 	// ---- 16 outputs per thread
@@ -104,14 +77,14 @@ __global__ __launch_bounds__(256, ZEN_BIG_MINB) void median_big_kernel(FilterArg
 		struct Loader {
 			const int* srt_t; // sorted block t-a
 			const int* raw_t; // raw block t-a-2
-			__device__ __forceinline__ void sorted(int i, int* v) const { ldn<16>(srt_t + i * RSTR, v); }
-			__device__ __forceinline__ void rawl(int j, int* v) const { ldn<16>(raw_t + j * RSTR, v); }
-			__device__ __forceinline__ void rawr(int j, int* v) const { ldn<16>(raw_t + (G::a + G::b + 2 + j) * RSTR, v); }
+			__device__ __forceinline__ void sorted(int i, int* v) const { znet::lds_load<16>(srt_t + i * RSTR, v); }
+			__device__ __forceinline__ void rawl(int j, int* v) const { znet::lds_load<16>(raw_t + j * RSTR, v); }
+			__device__ __forceinline__ void rawr(int j, int* v) const { znet::lds_load<16>(raw_t + (G::a + G::b + 2 + j) * RSTR, v); }
 		} ld{&srt[tid * RSTR], &raw[tid * RSTR]};
 		zbig::medians_big<W>(ld, out);
 	}
 	__syncthreads(); // all reads of the images done: the raw image now collects the results
-	st16(&raw[tid * RSTR], out);
+	znet::lds_store<16>(&raw[tid * RSTR], out);
 	__syncthreads();
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {

@@ -30,6 +30,39 @@ __device__ __forceinline__ int f2key(float f)
 }
 __device__ __forceinline__ float key2f(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
 
+// NONNEG: every sample is >= +0 (spectrogram magnitudes), whose bit patterns already order like the values
+template <bool NONNEG>
+__device__ __forceinline__ int to_key(float f)
+{
+	return NONNEG ? __float_as_int(f) : f2key(f);
+}
+template <bool NONNEG>
+__device__ __forceinline__ float from_key(int k)
+{
+	return NONNEG ? __int_as_float(k) : key2f(k);
+}
+
+// N keys (a multiple of 4) between registers and 16-byte aligned LDS
+template <int N>
+__device__ __forceinline__ void lds_load(const int* p, int* v)
+{
+#pragma unroll
+	for (int i = 0; i < N / 4; ++i) {
+		const int4 q = *reinterpret_cast<const int4*>(p + 4 * i);
+		v[4 * i] = q.x;
+		v[4 * i + 1] = q.y;
+		v[4 * i + 2] = q.z;
+		v[4 * i + 3] = q.w;
+	}
+}
+template <int N>
+__device__ __forceinline__ void lds_store(int* p, const int* v)
+{
+#pragma unroll
+	for (int i = 0; i < N / 4; ++i)
+		*reinterpret_cast<int4*>(p + 4 * i) = make_int4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+}
+
 __device__ __forceinline__ int med3i(int a, int b, int c)
 {
 	int r;

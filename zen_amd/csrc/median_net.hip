@@ -59,17 +59,8 @@ struct RowImage {
 	static constexpr int words(int n) { return ((n + T - 1) / T) * STRIDE; }
 };
 
-template <bool NONNEG>
-__device__ __forceinline__ int to_key(float f)
-{
-	// non-negative floats (spectrogram magnitudes) already order like their bit patterns
-	return NONNEG ? __float_as_int(f) : f2key(f);
-}
-template <bool NONNEG>
-__device__ __forceinline__ float from_key(int k)
-{
-	return NONNEG ? __int_as_float(k) : key2f(k);
-}
+using znet::from_key;
+using znet::to_key;
 
 template <int W, bool NONNEG>
 __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowMap rm, int segs_per_row, int vec_ok)
