@@ -63,6 +63,7 @@ int zen_hip_synchronize(void* stream); /* hipStreamSynchronize; synchronises */
  * rt_fused.hip, "no_block_fused" = 1 does so only for calls of more than one hop; "block_fused_minb" = 1..3
  * picks the occupancy the fused block kernel is compiled for; "no_istft_multi" = 1 synthesises hard-mask
  * outputs in separate workgroups instead of one per frame;
+ * "no_median47_neighbour" = 1 runs the 47-tap frequency kernel without the DPP exchange of sorted blocks;
  * "median47_shared" = 1 routes 47-tap frequency masks to the experimental neighbour-sharing kernel
  * (median47.hip; same results, currently not faster), "median47_blocks" = n makes it persistent on n workgroups. */
 int zen_hip_set_option(const char* name, int value);

@@ -18,15 +18,18 @@ def z():
     return zen_amd
 
 
-@pytest.fixture(params=["net", "general", "shared47", "shared47_persistent"])
+@pytest.fixture(params=["net", "net_plain47", "general", "shared47", "shared47_persistent"])
 def zk(z, request):
-    """All median kernels: sorting networks (default), the general wave kernel, and the experimental
-    neighbour-sharing 47-tap kernel (one workgroup per row / persistent)."""
+    """All median kernels: sorting networks (default; 47 taps with the DPP neighbour exchange, or without:
+    net_plain47), the general wave kernel, and the experimental LDS neighbour-sharing 47-tap kernel (one
+    workgroup per row / persistent)."""
     z.set_option("median_general", 1 if request.param == "general" else 0)
+    z.set_option("no_median47_neighbour", 1 if request.param == "net_plain47" else 0)
     z.set_option("median47_shared", 1 if request.param.startswith("shared47") else 0)
     z.set_option("median47_blocks", 7 if request.param == "shared47_persistent" else 0)
     yield z
     z.set_option("median_general", 0)
+    z.set_option("no_median47_neighbour", 0)
     z.set_option("median47_shared", 0)
     z.set_option("median47_blocks", 0)
 

@@ -14,6 +14,7 @@ static thread_local char g_err[512] = "";
 int g_opt_median_general = 0;
 int g_opt_no_rt_fused = 0;
 int g_opt_no_block_fused = 0;
+int g_opt_no_median47_neighbour = 0;
 int g_opt_no_istft_multi = 0;
 int g_opt_median47_shared = 0;
 int g_opt_median47_blocks = 0;
@@ -134,6 +135,10 @@ int zen_hip_set_option(const char* name, int value)
 	}
 	if (name && !strcmp(name, "no_block_fused")) {
 		g_opt_no_block_fused = value;
+		return ZEN_HIP_OK;
+	}
+	if (name && !strcmp(name, "no_median47_neighbour")) {
+		g_opt_no_median47_neighbour = value;
 		return ZEN_HIP_OK;
 	}
 	if (name && !strcmp(name, "no_istft_multi")) {

@@ -15,6 +15,7 @@ extern int g_opt_no_rt_fused;      // zen_hip_set_option("no_rt_fused"): single 
 extern int g_opt_no_block_fused;   // zen_hip_set_option("no_block_fused"): blocks of causal hops use the 3-kernel path
 extern int g_opt_block_fused_minb; // zen_hip_set_option("block_fused_minb"): fused block kernel built for n workgroups/CU
 extern int g_opt_no_istft_multi;   // zen_hip_set_option("no_istft_multi"): one workgroup per (frame, output) also for hard masks
+extern int g_opt_no_median47_neighbour; // zen_hip_set_option("no_median47_neighbour"): 47 taps without the DPP block sharing
 extern int g_opt_median_general; // zen_hip_set_option("median_general")
 extern int g_opt_median47_blocks;  // zen_hip_set_option("median47_blocks"): persistent grid size (0 = one block per row)
 extern int g_opt_median47_shared; // zen_hip_set_option("median47_shared"): use the experimental block-sharing 47-tap kernel

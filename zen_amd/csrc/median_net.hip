@@ -62,7 +62,13 @@ struct RowImage {
 using znet::from_key;
 using znet::to_key;
 
-template <int W, bool NONNEG>
+// NEIGHBOUR (47 taps only): the 32 samples common to a thread's 16 windows are exactly two aligned
+// 16-sample blocks, its own and its right neighbour's own (mid + 1 = 24 = 8 mod 16).  Each thread sorts
+// its own block once and receives the neighbour's sorted block through a wave-wide DPP shift (lane i <-
+// lane i+1; the last lane of a wave through LDS), then takes the 16 middle ranks of the two sorted
+// blocks with one bitonic half-merge: 63 + 48 comparators instead of a 191-comparator 32-sort, no extra
+// LDS traffic.  Same results.
+template <int W, bool NONNEG, bool NEIGHBOUR>
 __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowMap rm, int segs_per_row, int vec_ok)
 {
 	constexpr int T = znet::outputs_per_thread(W), mid = W / 2;
@@ -116,21 +122,64 @@ __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowM
 	}
 	__syncthreads();
 
-	int ld[NE], e[W + T - 1], out[T];
+	int out[T];
 	const int* mine = &tile[tid * IM::STRIDE];
+	if constexpr (NEIGHBOUR) {
+		static_assert(W == 47 && T == 16 && DELTA == 1, "block alignment of the 47-tap mask");
+		__shared__ __attribute__((aligned(16))) int edge[4][16]; // sorted block of lane 0 of waves 1..3, and of block 256
+		// e[q] = x[16t-23+q]: chunk tid = left flank (words 1..15), chunk tid+1 = own block B(t),
+		// chunk tid+2 = B(t+1) (comes sorted from the neighbour), chunk tid+3 = right flank (words 0..14)
+		int e[W + T - 1], A[16], B[16];
+		{
+			int lo[16], hi[16];
+			znet::lds_load<16>(mine + IM::caddr(0), lo);
+			znet::lds_load<16>(mine + IM::caddr(16), A);
+			znet::lds_load<16>(mine + IM::caddr(48), hi);
 #pragma unroll
-	for (int v = 0; v < NV; ++v) {
-		const int4 q = *reinterpret_cast<const int4*>(mine + IM::caddr(4 * v));
-		ld[4 * v] = q.x;
-		ld[4 * v + 1] = q.y;
-		ld[4 * v + 2] = q.z;
-		ld[4 * v + 3] = q.w;
+			for (int q = 0; q < W + T - 1; ++q)
+				e[q] = 0;
+#pragma unroll
+			for (int q = 0; q < 15; ++q) {
+				e[q] = lo[q + 1];
+				e[47 + q] = hi[q];
+			}
+		}
+		znet::sort_net<16>(A);
+		const int lane = tid & 63, wave = tid >> 6;
+		if (lane == 0 && wave > 0)
+			znet::lds_store<16>(edge[wave - 1], A);
+		if (tid == 255) { // the right neighbour of the last block belongs to nobody
+			int X[16];
+			znet::lds_load<16>(mine + IM::caddr(32), X);
+			znet::sort_net<16>(X);
+			znet::lds_store<16>(edge[3], X);
+		}
+#pragma unroll
+		for (int i = 0; i < 16; ++i) // lane i <- lane i+1 (lane 63 keeps its own value: replaced below)
+			B[i] = __builtin_amdgcn_update_dpp(A[i], A[i], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+		__syncthreads(); // edge blocks published; every window is in registers: the image can take the results
+		if (lane == 63)
+			znet::lds_load<16>(edge[wave], B);
+		int cand[16];
+		znet::mid16_of_two_sorted16(A, B, cand);
+		znet::Node<W, T, 0, W + T - 1, T>::run(e, cand, out);
 	}
+	else {
+		int ld[NE], e[W + T - 1];
 #pragma unroll
-	for (int q = 0; q < W + T - 1; ++q)
-		e[q] = ld[q + DELTA];
-	__syncthreads(); // every window is in registers: the image can take the results
-	znet::medians<W, T, W + T - 1>(e, out);
+		for (int v = 0; v < NV; ++v) {
+			const int4 q = *reinterpret_cast<const int4*>(mine + IM::caddr(4 * v));
+			ld[4 * v] = q.x;
+			ld[4 * v + 1] = q.y;
+			ld[4 * v + 2] = q.z;
+			ld[4 * v + 3] = q.w;
+		}
+#pragma unroll
+		for (int q = 0; q < W + T - 1; ++q)
+			e[q] = ld[q + DELTA];
+		__syncthreads(); // every window is in registers: the image can take the results
+		znet::medians<W, T, W + T - 1>(e, out);
+	}
 #pragma unroll
 	for (int v = 0; v < T / 4; ++v)
 		*reinterpret_cast<int4*>(&tile[tid * IM::STRIDE + 4 * v]) =
@@ -287,10 +336,20 @@ int launch_freq(const FilterArgs& a, const RowMap& rm, hipStream_t stream)
 	                   && ((reinterpret_cast<uintptr_t>(a.dst) & 15) == 0) && (a.src_stream_stride % 4 == 0)
 	                   && (a.dst_stream_stride % 4 == 0);
 	dim3 grid((unsigned)((long long)a.n_out_rows * segs), (unsigned)a.n_streams);
+	if constexpr (W == 47) {
+		if (!g_opt_no_median47_neighbour) {
+			if (a.nonneg)
+				hipLaunchKernelGGL((median_net_freq_kernel<W, true, true>), grid, dim3(256), 0, stream, a, rm, segs, vec_ok);
+			else
+				hipLaunchKernelGGL((median_net_freq_kernel<W, false, true>), grid, dim3(256), 0, stream, a, rm, segs, vec_ok);
+			ZH_HIP(hipGetLastError());
+			return ZEN_HIP_OK;
+		}
+	}
 	if (a.nonneg)
-		hipLaunchKernelGGL((median_net_freq_kernel<W, true>), grid, dim3(256), 0, stream, a, rm, segs, vec_ok);
+		hipLaunchKernelGGL((median_net_freq_kernel<W, true, false>), grid, dim3(256), 0, stream, a, rm, segs, vec_ok);
 	else
-		hipLaunchKernelGGL((median_net_freq_kernel<W, false>), grid, dim3(256), 0, stream, a, rm, segs, vec_ok);
+		hipLaunchKernelGGL((median_net_freq_kernel<W, false, false>), grid, dim3(256), 0, stream, a, rm, segs, vec_ok);
 	ZH_HIP(hipGetLastError());
 	return ZEN_HIP_OK;
 }

@@ -118,6 +118,10 @@ def _ck(rc):
 
 def init(device=0):
     _ck(load().zen_hip_init(device))
+    # A/B timing hook: ZEN_HIP_OPTIONS="no_block_fused=1,no_median47_neighbour=1" -> zen_hip_set_option
+    for item in filter(None, os.environ.get("ZEN_HIP_OPTIONS", "").split(",")):
+        name, _, val = item.partition("=")
+        set_option(name.strip(), int(val or 1))
 
 
 def synchronize(stream=None):
