@@ -633,3 +633,17 @@ def test_full_size_offline_batch_config4_properties(z):
     halo = 4 * 4096 + 30 * 256
     rh, rp, _ = o.HPRIOffline(44100.0, 4096, 256, 2.0, 2.0).process(x[0][:m + halo])
     assert np.array_equal(P[0][:m], rp[:m]) and np.array_equal(H[0][:m], rh[:m])
+
+
+def test_random_configurations_differential(z):
+    """A short run of tools/fuzz_parity.py: random sample rates, hops, output flags, causality, mask types,
+    stream counts, blockings and chunk sizes against the oracle (a 150 s run covers ~340 distinct
+    configurations with no mismatch; this one a few dozen)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(root, "tools", "fuzz_parity.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    n_ok, n_bad, _, n_seen = fuzz.run(12.0, 7)
+    assert n_bad == 0 and n_ok >= 10 and n_seen >= 10
