@@ -213,6 +213,8 @@ static void test_public_api(std::size_t extra) // hps_gpu_public.test.cu (Basic 
 		}
 	}
 	zo_hpr_destroy(ort);
+	auto none = hpri_offline.process(std::vector<float>()); // an empty clip gives three empty vectors
+	CHECK(none[0].empty() && none[1].empty() && none[2].empty());
 	bool thrown = false;
 	try {
 		zen::hps::HPRIOffline<Backend::GPU> bad(48000.0F, 4096, 300, 2.0, 2.0);

@@ -402,9 +402,10 @@ def test_full_size_stream_linearity_of_blocks(z):
 
 
 # ---------------------------------------------------------------------------- edge cases
-@pytest.mark.parametrize("n", [1, 7, 255, 256, 257, 4095, 4096, 4097, 10000])
+@pytest.mark.parametrize("n", [0, 1, 7, 255, 256, 257, 4095, 4096, 4097, 10000])
 def test_offline_ragged_and_tiny_clips(z, n):
-    """Clip lengths around the hop sizes, down to a single sample (hps.cu:109-126 padding arithmetic)."""
+    """Clip lengths around the hop sizes, down to a single sample and the empty clip (hps.cu:109-126 padding
+    arithmetic)."""
     x = noise(n, 40 + n)
     h, p, r = z.HPRIOffline(44100.0, 1024, 256, 2.0, 2.0).process(x)
     rh, rp, rr = o.HPRIOffline(44100.0, 1024, 256, 2.0, 2.0).process(x)

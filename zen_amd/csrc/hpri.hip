@@ -190,8 +190,12 @@ int zen_hip_hpri_hop_counts(zen_hip_hpri_t h, size_t n, size_t* n_hops_h, size_t
 int zen_hip_hpri_process_device(zen_hip_hpri_t h, const float* audio_dev, size_t n, size_t stride,
                                 float* harm_dev, float* perc_dev, float* resid_dev, size_t out_stride)
 {
-	if (!h || !audio_dev || n == 0)
-		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_process: null argument or empty clip");
+	if (!h)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_process: null handle");
+	if (n == 0)
+		return ZEN_HIP_OK; // empty clips: nothing to write
+	if (!audio_dev)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_process: null argument");
 	const size_t C = h->n_clips;
 	size_t padded1, padded2;
 	const int n1 = chunk_padder(n, h->hop_h, (size_t)h->eh->lag, &padded1); // hps.cu:133-134
@@ -404,8 +408,12 @@ int zen_hip_hpri_process_range(zen_hip_hpri_t h, const float* audio_dev, size_t 
 int zen_hip_hpri_process(zen_hip_hpri_t h, const float* audio_host, size_t n, float* harm_host,
                          float* perc_host, float* resid_host)
 {
-	if (!h || !audio_host || n == 0)
-		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_process: null argument or empty clip");
+	if (!h)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_process: null handle");
+	if (n == 0)
+		return ZEN_HIP_OK; // the reference returns three empty vectors (hps.cu:128-221 on an empty input)
+	if (!audio_host)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_process: null argument");
 	if (h->n_clips != 1)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_process(host) needs a handle created with n_clips == 1");
 	if (n > h->stage_cap) {
