@@ -19,10 +19,14 @@
  *     tests/test_oracle_golden.py; cross-checked against scipy.ndimage.median_filter(mode="nearest").
  *   - FFT: pinned only to the tolerance the reference itself uses (2e-4 abs vs another FFT,
  *     libzen/fftw.test.cu:16,83-101); checked here against numpy float64 FFTs at n = 64/1024/16384.
- *   - box filter: PARITY UNPINNED (reference suite disabled, libzen/CMakeLists.txt:82); restated from the
- *     IPP contract, summation order is this file's choice (ascending tap index, then divide).
+ *   - box filter: PARITY UNPINNED (reference suite disabled, libzen/CMakeLists.txt:82, and mostly commented
+ *     out); restated from the IPP contract, summation order is this file's choice (ascending tap index,
+ *     then divide).  Its three enabled cases (box.test.cu:124-199, a constant column) are carried over but
+ *     cannot distinguish summation orders.
  *   - separated waveforms (HPRRealtime / HPRIOffline): PARITY UNPINNED -- the reference tests hold only
  *     EXPECT_NE / EXPECT_EQ properties (libzen/hps.test.cu:160-372), which are carried over as tests.
+ *     Cross-checked against an independent float64 numpy model of the causal path (tests/test_oracle.py)
+ *     and frozen as regression vectors in tests/golden/hpr_waveforms.npz.
  *
  * Arithmetic is IEEE binary32, round-to-nearest-even, no FMA contraction (compile with
  * -ffp-contract=off).  Every float operation is written out so that the HIP engine can reproduce it

@@ -114,6 +114,19 @@ def test_median_reference_stripe_vectors(zk, x, y, f):
     assert np.array_equal(zk.MedianFilterGPU(x, y, f, zk.FREQUENCY, True).filter_host(d), exp_f)  # copy_bord
 
 
+@pytest.mark.parametrize("x,y,f", [(9, 9, 3), (10, 20, 5), (1024, 128, 5)])
+def test_box_reference_column_vectors(z, x, y, f):
+    """The enabled cases of libzen/box.test.cu (:124-199): reciprocal, time-direction box, reciprocal of a
+    matrix whose middle column is 8 -> 8*(f+1) on the column, 0 (from +inf) elsewhere."""
+    from test_oracle_golden import box_column_case
+    rec, exp = box_column_case(x, y, f)
+    res = z.BoxFilterGPU(x, y, f, z.TIME_CAUSAL).filter_host(rec)
+    with np.errstate(divide="ignore"):
+        back = (np.float32(f + 1.0) / res).astype(np.float32)
+    assert np.array_equal(back, exp)
+    assert np.array_equal(res, o.box_filter(rec, f, o.TIME_CAUSAL))
+
+
 def test_median_filter_too_big_throws(z):
     for direction in (z.FREQUENCY, z.TIME_CAUSAL, z.TIME_ANTICAUSAL):   # mfilt.test.cu:525-534
         with pytest.raises(z.ZgException):

@@ -125,3 +125,26 @@ def test_fft_huge_range_finiteness(n):
 def test_fft_rejects_non_power_of_two():
     with pytest.raises(o.OracleError):
         o.fft_c2c(np.zeros(48, np.complex64))
+
+
+# ---------------------------------------------------------------- box filter: the reference's own vectors
+def box_column_case(x, y, f):
+    """libzen/box.test.cu:30-60, :124-199 (the three enabled BoxFilter*UnitTestGPU.CausalTime cases): a zero
+    matrix whose middle column is 8, reciprocal (1/x: the zeros become +inf), time-direction box filter,
+    reciprocal again ((f+1)/x).  Expected: 8*(f+1) on the column (32 for f = 3, 48 for f = 5), 0 elsewhere."""
+    d = np.zeros((x, y), np.float32)
+    d[:, y // 2] = 8
+    with np.errstate(divide="ignore"):
+        rec = (np.float32(1.0) / d).astype(np.float32)
+    exp = np.zeros((x, y), np.float32)
+    exp[:, y // 2] = 8 * (f + 1)
+    return rec, exp
+
+
+@pytest.mark.parametrize("x,y,f", SHAPES)
+def test_box_reference_column_vectors(x, y, f):
+    rec, exp = box_column_case(x, y, f)
+    res = o.box_filter(rec, f, o.TIME_CAUSAL)
+    with np.errstate(divide="ignore"):
+        back = (np.float32(f + 1.0) / res).astype(np.float32)
+    assert np.array_equal(back, exp)
