@@ -1,0 +1,86 @@
+// ubench_copy.hip -- practical HBM roof of the box: streaming copy / read / write kernels with 16-byte
+// accesses over 1 GiB, several grid shapes.  hipcc --offload-arch=gfx950 -O3 tools/ubench_copy.hip -o tools/bin/ubench_copy
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+__global__ __launch_bounds__(256) void copy_k(const float4* __restrict__ a, float4* __restrict__ b, size_t n)
+{
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+		b[i] = a[i];
+}
+template <int U>
+__global__ __launch_bounds__(256) void copy_u(const float4* __restrict__ a, float4* __restrict__ b, size_t n)
+{
+	const size_t base = (size_t)blockIdx.x * 256 * U + threadIdx.x;
+	float4 v[U];
+#pragma unroll
+	for (int u = 0; u < U; ++u)
+		v[u] = a[base + (size_t)u * 256];
+#pragma unroll
+	for (int u = 0; u < U; ++u)
+		b[base + (size_t)u * 256] = v[u];
+}
+__global__ __launch_bounds__(256) void read_k(const float4* __restrict__ a, float* out, size_t n)
+{
+	float s = 0;
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+		const float4 v = a[i];
+		s += v.x + v.y + v.z + v.w;
+	}
+	if (s == 123.456f)
+		out[0] = s;
+}
+__global__ __launch_bounds__(256) void write_k(float4* __restrict__ b, size_t n)
+{
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+		b[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+}
+
+template <class F>
+float timeit(F f, int iters = 10)
+{
+	hipEvent_t e0, e1;
+	(void)hipEventCreate(&e0);
+	(void)hipEventCreate(&e1);
+	for (int i = 0; i < 3; ++i)
+		f();
+	(void)hipDeviceSynchronize();
+	(void)hipEventRecord(e0);
+	for (int i = 0; i < iters; ++i)
+		f();
+	(void)hipEventRecord(e1);
+	(void)hipEventSynchronize(e1);
+	float ms;
+	(void)hipEventElapsedTime(&ms, e0, e1);
+	return ms / iters;
+}
+
+int main()
+{
+	const size_t n = (size_t)1 << 26; // float4 elements: 1 GiB per buffer
+	float4 *a, *b;
+	float* o;
+	(void)hipMalloc(&a, n * 16);
+	(void)hipMalloc(&b, n * 16);
+	(void)hipMalloc(&o, 4);
+	(void)hipMemset(a, 0, n * 16);
+	for (int grid : {2048, 4096, 8192, 16384, 65536}) {
+		float ms = timeit([&] { copy_k<<<grid, 256>>>(a, b, n); });
+		printf("copy  grid-stride %6d blocks: %.3f ms  %.0f GB/s (read+write)\n", grid, ms, 2.0 * n * 16 / ms / 1e6);
+	}
+	{
+		float ms = timeit([&] { copy_u<4><<<(unsigned)(n / (256 * 4)), 256>>>(a, b, n); });
+		printf("copy  4 x 16 B per thread, one shot: %.3f ms  %.0f GB/s\n", ms, 2.0 * n * 16 / ms / 1e6);
+		ms = timeit([&] { copy_u<8><<<(unsigned)(n / (256 * 8)), 256>>>(a, b, n); });
+		printf("copy  8 x 16 B per thread, one shot: %.3f ms  %.0f GB/s\n", ms, 2.0 * n * 16 / ms / 1e6);
+		ms = timeit([&] { (void)hipMemcpyAsync(b, a, n * 16, hipMemcpyDeviceToDevice, 0); });
+		printf("hipMemcpy device-to-device:          %.3f ms  %.0f GB/s\n", ms, 2.0 * n * 16 / ms / 1e6);
+	}
+	for (int grid : {4096, 16384}) {
+		float ms = timeit([&] { read_k<<<grid, 256>>>(a, o, n); });
+		printf("read  grid-stride %6d blocks: %.3f ms  %.0f GB/s\n", grid, ms, 1.0 * n * 16 / ms / 1e6);
+		ms = timeit([&] { write_k<<<grid, 256>>>(b, n); });
+		printf("write grid-stride %6d blocks: %.3f ms  %.0f GB/s\n", grid, ms, 1.0 * n * 16 / ms / 1e6);
+	}
+	return 0;
+}
