@@ -194,16 +194,21 @@ def test_median_bench_squares_iota(zk):
 
 
 # ---------------------------------------------------------------------------- box filter
-@pytest.mark.parametrize("shape,flen", [((12, 2048), 23), ((12, 2048), 7), ((22, 1024), 13), ((2, 4096), 187)])
+@pytest.mark.parametrize("shape,flen", [
+    ((12, 2048), 23), ((12, 2048), 7), ((22, 1024), 13), ((2, 4096), 187), ((300, 70), 21), ((513, 1030), 5),
+    ((260, 33), 255), ((200, 200), 179), ((700, 130), 65), ((5, 5000), 93), ((40, 1), 7), ((1, 40), 9), ((64, 64), 1)])
 def test_box_bit_exact(z, shape, flen):
+    """Tiled kernels (row segments of 1024 / 64-column tiles with halo rows), ragged widths, tile seams,
+    masks up to 255 taps and the direct kernel behind them, against the oracle's ascending-order sums."""
     rng = np.random.default_rng(flen)
     d = rng.uniform(0, 10, shape).astype(np.float32)
     if flen <= shape[1]:
         assert np.array_equal(z.BoxFilterGPU(shape[0], shape[1], flen, z.FREQUENCY).filter_host(d),
                               o.box_filter(d, flen, o.FREQUENCY))
     if flen <= shape[0]:
-        assert np.array_equal(z.BoxFilterGPU(shape[0], shape[1], flen, z.TIME_CAUSAL).filter_host(d),
-                              o.box_filter(d, flen, o.TIME_CAUSAL))
+        for direction in (o.TIME_CAUSAL, o.TIME_ANTICAUSAL):
+            assert np.array_equal(z.BoxFilterGPU(shape[0], shape[1], flen, direction).filter_host(d),
+                                  o.box_filter(d, flen, direction))
 
 
 # ---------------------------------------------------------------------------- HPR engine

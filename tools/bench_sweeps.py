@@ -7,6 +7,7 @@
            forward, inverse, round trip; per-call latency and batched throughput.
   hpr   -- libzen/hps.bench.cu:62-64: HPRRealtime<GPU>(48000, hop, 2.0, P) for hop = 2^5 .. 2^12: per-hop
            call path through mapped memory (the figure docs/cpu_vs_gpu.png plots), and block-mode hops/s.
+  sse   -- BASELINE configs[4]: the SSE (box-filter) variant at hop 512 and 2048, per-hop and block mode.
   copy  -- device-to-device copy bandwidth of the box: the practical HBM roof next to the nominal 8 TB/s.
 """
 import argparse
@@ -109,6 +110,40 @@ def suite_hpr(fs):
         dout.free()
 
 
+def suite_sse(fs=44100.0):
+    """BASELINE configs[4]: HPRRealtime<GPU>(44100, 512, 2.0, P, nocopybord) + use_sse_filter(): box filters
+    7 / 23 taps instead of medians; also hop 2048 as the config's second reading."""
+    rng = np.random.default_rng(2)
+    for hop in (512, 2048):
+        n_hops = 300
+        x = rng.uniform(-1, 1, hop * n_hops).astype(np.float32)
+        rt = zen_amd.HPRRealtime(fs, hop, 2.0, zen_amd.OUTPUT_PERCUSSIVE, True)
+        rt.use_sse_filter()
+        io = zen_amd.IOGPU(hop)
+        for i in range(30):
+            io.host_in[:] = x[i * hop:(i + 1) * hop]
+            rt.process_next_hop(io.device_in)
+            rt.copy_percussive(io.device_out)
+        t0 = time.perf_counter()
+        for i in range(n_hops):
+            io.host_in[:] = x[i * hop:(i + 1) * hop]
+            rt.process_next_hop(io.device_in)
+            rt.copy_percussive(io.device_out)
+            _ = io.host_out[0]
+        per_hop = (time.perf_counter() - t0) / n_hops
+        M = (1 << 25) // (4 * hop)
+        xb = rng.uniform(-1, 1, hop * M).astype(np.float32)
+        eng = zen_amd.HPR(fs, hop, 2.0, zen_amd.OUTPUT_PERCUSSIVE, zen_amd.TIME_CAUSAL, False, 1, M)
+        eng.use_sse_filter()
+        din, dout = zen_amd.DeviceBuffer.from_host(xb), zen_amd.DeviceBuffer(xb.size)
+        bt = timed(lambda: eng.process(din.ptr, M, xb.size, None, dout.ptr, None, xb.size), 10)
+        yield {"suite": "sse", "fs": fs, "hop": hop, "nfft": 4 * hop, "time_box": rt.p_impl.time_len,
+               "freq_box": rt.p_impl.freq_len, "per_hop_us": 1e6 * per_hop, "block_hops": M,
+               "block_hops_per_s": M / bt, "block_x_realtime": (M / bt) * hop / fs}
+        din.free()
+        dout.free()
+
+
 def suite_copy():
     n = 1 << 28                                                             # 1 GiB of floats each way
     a, b = zen_amd.DeviceBuffer(n), zen_amd.DeviceBuffer(n)
@@ -120,11 +155,11 @@ def suite_copy():
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--suite", default="all", choices=["all", "mfilt", "fft", "hpr", "copy"])
+    ap.add_argument("--suite", default="all", choices=["all", "mfilt", "fft", "hpr", "sse", "copy"])
     ap.add_argument("--fs", type=float, default=48000.0)
     args = ap.parse_args()
     zen_amd.init(0)
-    gens = {"copy": suite_copy, "mfilt": suite_mfilt, "fft": suite_fft, "hpr": lambda: suite_hpr(args.fs)}
+    gens = {"copy": suite_copy, "mfilt": suite_mfilt, "fft": suite_fft, "hpr": lambda: suite_hpr(args.fs), "sse": suite_sse}
     for name, g in gens.items():
         if args.suite in ("all", name):
             for rec in g():

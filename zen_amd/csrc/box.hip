@@ -6,8 +6,12 @@
 //
 // The sum is taken tap by tap in ascending index order, in float, then divided by the mask length:
 // the same order as oracle/zen_oracle.c zo_box_filter, so results are bit-identical (a running sum
-// would be faster and differently rounded).  Neighbouring threads read neighbouring addresses, the
-// taps of a thread are served by L1/L2; masks are <= 23 taps on the BASELINE configs.
+// would be faster and differently rounded).  Both tiled kernels stage their source samples in LDS once,
+// with sse_pre already applied (one division per sample instead of one per tap), and every thread adds
+// its taps from there:
+//   frequency : a workgroup owns 1024 consecutive outputs of one row (+ the mask halo);
+//   time      : a workgroup owns 64 columns x RB rows (+ the halo rows); lanes are consecutive columns.
+// Masks too long for the time tile fall back to the direct kernel.
 #include "common.h"
 #include "filters.h"
 
@@ -16,8 +20,89 @@
 namespace zen_hip_impl {
 namespace {
 
+__device__ __forceinline__ float pre_of(float v, int sse_pre)
+{
+	return sse_pre ? (1.0f / (v * v)) * 1.0F : v; // hps.h:91-98 powf(abs,2) then hps.h:45-56 (1/x)*1
+}
+__device__ __forceinline__ float post_of(float acc, float flen, int sse_post, float post_factor)
+{
+	const float res = acc / flen;
+	return sse_post ? (1.0f / res) * post_factor : res; // hps.cu:599-604
+}
+
+constexpr int FREQ_OUTS = 1024;   // outputs per workgroup (4 per thread)
+constexpr int MAX_LEN = 255;
+
+__global__ __launch_bounds__(256) void box_freq_kernel(FilterArgs a, int segs_per_row)
+{
+	__shared__ float tile[FREQ_OUTS + MAX_LEN - 1];
+	const int tid = threadIdx.x;
+	const int row = blockIdx.x / segs_per_row, seg = blockIdx.x - row * segs_per_row;
+	const int cols = a.cols, len = a.len, mid = len >> 1, col0 = seg * FREQ_OUTS;
+	const long long ring_row = (a.first_row + row) % a.ring_rows; // wave-uniform
+	const float* __restrict__ srow = a.src + (long long)blockIdx.y * a.src_stream_stride + ring_row * cols;
+	float* __restrict__ drow = a.dst + (long long)blockIdx.y * a.dst_stream_stride + (long long)row * cols;
+	const int span = FREQ_OUTS + len - 1;
+	for (int g = tid; g < span; g += 256) {
+		int c = col0 - mid + g;
+		c = c < 0 ? 0 : (c > cols - 1 ? cols - 1 : c); // replicate border (ippBorderRepl)
+		tile[g] = pre_of(srow[c], a.sse_pre);
+	}
+	__syncthreads();
+	const float flen = (float)len;
+#pragma unroll
+	for (int k = 0; k < FREQ_OUTS / 256; ++k) {
+		const int o = tid + 256 * k; // lanes read consecutive words: no bank conflicts
+		if (col0 + o >= cols)
+			break;
+		float acc = tile[o];
+		for (int j = 1; j < len; ++j)
+			acc = acc + tile[o + j];
+		drow[col0 + o] = post_of(acc, flen, a.sse_post, a.post_factor);
+	}
+}
+
+constexpr int TIME_COLS = 64;
+constexpr int TIME_TILE_ROWS = 192; // 48 KB of LDS
+
+// rows_per_block output rows x 64 columns per workgroup; tile row i holds absolute source row
+// clamp(first + i - mid) of the block's first output row `first`.
+__global__ __launch_bounds__(256) void box_time_kernel(FilterArgs a, int rows_per_block)
+{
+	__shared__ float tile[TIME_TILE_ROWS * TIME_COLS];
+	const int tid = threadIdx.x, lane_col = tid & (TIME_COLS - 1), rl = tid >> 6;
+	const int cols = a.cols, len = a.len, mid = len >> 1;
+	const int col = blockIdx.x * TIME_COLS + lane_col;
+	const int q0 = blockIdx.y * rows_per_block; // first output row of the block
+	const int nq = min(rows_per_block, a.n_out_rows - q0);
+	const float* __restrict__ src = a.src + (long long)blockIdx.z * a.src_stream_stride;
+	float* __restrict__ dst = a.dst + (long long)blockIdx.z * a.dst_stream_stride;
+	const long long ar0 = a.first_row + q0;
+	const int nrows = nq + len - 1;
+	if (col < cols) {
+		for (int i = rl; i < nrows; i += 4) {
+			long long r = ar0 - mid + i;
+			r = r < a.clamp_lo ? a.clamp_lo : (r > a.clamp_hi ? a.clamp_hi : r);
+			tile[i * TIME_COLS + lane_col] = pre_of(src[(r % a.ring_rows) * cols + col], a.sse_pre);
+		}
+	}
+	__syncthreads();
+	if (col >= cols)
+		return;
+	const float flen = (float)len;
+	// causal_self: taps beyond the output's own row are that row again (hps.h:265-268): tile row q + mid
+	const int jmax = a.causal_self ? mid : len - 1;
+	for (int q = rl; q < nq; q += 4) {
+		float acc = tile[q * TIME_COLS + lane_col];
+		for (int j = 1; j < len; ++j)
+			acc = acc + tile[(q + (j < jmax ? j : jmax)) * TIME_COLS + lane_col];
+		dst[(long long)(q0 + q) * cols + col] = post_of(acc, flen, a.sse_post, a.post_factor);
+	}
+}
+
+// direct form: every output gathers its taps from global memory (any mask length)
 template <int DIR>
-__global__ __launch_bounds__(256) void box_kernel(FilterArgs a)
+__global__ __launch_bounds__(256) void box_direct_kernel(FilterArgs a)
 {
 	const float* __restrict__ src = a.src + (long long)blockIdx.y * a.src_stream_stride;
 	float* __restrict__ dst = a.dst + (long long)blockIdx.y * a.dst_stream_stride;
@@ -44,14 +129,10 @@ __global__ __launch_bounds__(256) void box_kernel(FilterArgs a)
 					r = ar;
 				v = src[(r % a.ring_rows) * cols + col];
 			}
-			if (a.sse_pre)
-				v = (1.0f / (v * v)) * 1.0F; // hps.h:91-98 powf(abs,2) then hps.h:45-56 (1/x)*1
+			v = pre_of(v, a.sse_pre);
 			acc = (j == 0) ? v : acc + v;
 		}
-		float res = acc / flen;
-		if (a.sse_post)
-			res = (1.0f / res) * a.post_factor; // hps.cu:599-604
-		dst[i] = res;
+		dst[i] = post_of(acc, flen, a.sse_post, a.post_factor);
 	}
 }
 
@@ -63,15 +144,40 @@ int launch_box(const FilterArgs& a, hipStream_t stream)
 		return ZEN_HIP_OK;
 	if (a.len < 1 || !(a.len & 1))
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "box: mask length %d must be odd and positive", a.len);
+	if (a.direction == ZEN_HIP_FREQUENCY && a.len <= MAX_LEN) {
+		const int segs = (a.cols + FREQ_OUTS - 1) / FREQ_OUTS;
+		const long long blocks = (long long)a.n_out_rows * segs;
+		if (blocks <= 0x7fffffffLL) {
+			hipLaunchKernelGGL(box_freq_kernel, dim3((unsigned)blocks, (unsigned)a.n_streams), dim3(256), 0, stream, a, segs);
+			ZH_HIP(hipGetLastError());
+			return ZEN_HIP_OK;
+		}
+	}
+	if (a.direction != ZEN_HIP_FREQUENCY && a.len - 1 + 16 <= TIME_TILE_ROWS) {
+		int rpb = TIME_TILE_ROWS - (a.len - 1);
+		if (rpb > 128)
+			rpb = 128;
+		const int col_blocks = (a.cols + TIME_COLS - 1) / TIME_COLS;
+		// enough workgroups to fill the chip when the matrix is small
+		while (rpb > 16 && (long long)col_blocks * ((a.n_out_rows + rpb - 1) / rpb) * a.n_streams < 1024)
+			rpb >>= 1;
+		const long long row_blocks = (a.n_out_rows + rpb - 1) / rpb;
+		if (row_blocks <= 65535 && a.n_streams <= 65535) {
+			hipLaunchKernelGGL(box_time_kernel, dim3((unsigned)col_blocks, (unsigned)row_blocks, (unsigned)a.n_streams),
+			                   dim3(256), 0, stream, a, rpb);
+			ZH_HIP(hipGetLastError());
+			return ZEN_HIP_OK;
+		}
+	}
 	const long long n = (long long)a.n_out_rows * a.cols;
 	long long blocks = (n + 255) / 256;
 	if (blocks > 8192)
 		blocks = 8192;
 	dim3 grid((unsigned)blocks, (unsigned)a.n_streams);
 	if (a.direction == ZEN_HIP_FREQUENCY)
-		hipLaunchKernelGGL(box_kernel<0>, grid, dim3(256), 0, stream, a);
+		hipLaunchKernelGGL(box_direct_kernel<0>, grid, dim3(256), 0, stream, a);
 	else
-		hipLaunchKernelGGL(box_kernel<1>, grid, dim3(256), 0, stream, a);
+		hipLaunchKernelGGL(box_direct_kernel<1>, grid, dim3(256), 0, stream, a);
 	ZH_HIP(hipGetLastError());
 	return ZEN_HIP_OK;
 }
