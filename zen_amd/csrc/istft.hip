@@ -1,0 +1,175 @@
+// istft.hip -- synthesis kernels of the HPSS engine for gfx950, built on fft_dev.h.
+//
+//   istft_kernel            : hps.cu:498-579 per consumed row: mask from (H, P), complex*real, inverse FFT
+//                             (only the nwin real outputs that are used are computed), *COLA.
+//   istft_hard_multi_kernel : the same for hard masks with several outputs, one workgroup per frame.
+// Its own translation unit because it is compiled with the max-ILP scheduling strategy (build.py), which
+// helps these kernels (-4 %) and hurts the analysis kernel of stft.hip.
+#include "common.h"
+#include "fft_dev.h"
+#include "fft_launch.h"
+#include "masks.h"
+#include "stft.h"
+
+#include <cfloat>
+
+#pragma clang fp contract(off)
+
+namespace zen_hip_impl {
+namespace {
+
+using zfft::Plan;
+
+// ------------------------------------------------------------------------------------------------
+struct IstftIn {
+	const float2* S;
+	const float* H;
+	const float* P;
+	MaskCfg cfg;
+	int which;
+	int n;
+	__device__ __forceinline__ float2 operator()(int idx, int) const
+	{
+		const bool mirror = idx > (n >> 1); // upper half: S[n-k] = conj(S[k])
+		float2 z = S[mirror ? n - idx : idx];
+		if (mirror)
+			z.y = -z.y;
+		const float m = mask_value(which, H[idx], P[idx], cfg);
+		return make_float2(z.x * m, z.y * m); // apply_mask_functor hps.h:58-66
+	}
+};
+
+struct IstftOut {
+	float* Y;
+	float cola;
+	__device__ __forceinline__ void operator()(int idx, float2 x, bool, int) const
+	{
+		Y[idx] = x.x * cola; // the product of overlap_add_functor hps.h:68-80; the sum is in finalize
+	}
+};
+
+template <int LOG2N>
+__global__ __launch_bounds__(Plan<LOG2N>::THREADS) void istft_kernel(IstftArgs a)
+{
+	using PL = Plan<LOG2N>;
+	extern __shared__ float2 lds[];
+	const int tid = threadIdx.x, s = blockIdx.z, oi = blockIdx.y;
+	const int slot = tid / PL::TF, tf = tid - slot * PL::TF;
+	const int f = blockIdx.x * PL::FRAMES_PER_BLOCK + slot;
+	const bool active = f < a.n_frames;
+	const long long ring_row = ((a.crow0 + f) % a.ring_rows) + (long long)s * a.ring_rows;
+	IstftIn in;
+	in.S = a.S + ring_row * a.s_stride;
+	in.n = PL::N;
+	in.H = a.h_is_ring ? a.H + ring_row * PL::N : a.H + (long long)s * a.h_stream_stride + (long long)f * PL::N;
+	in.P = a.P + (long long)s * a.p_stream_stride + (long long)f * PL::N;
+	in.cfg = MaskCfg{a.beta, a.beta_h, a.soft, a.power, a.sse, a.out_h, a.out_p};
+	in.which = a.out_id[oi];
+	IstftOut out;
+	out.Y = a.Y[oi] + (long long)s * a.y_stream_stride + (long long)f * (PL::N / 2);
+	out.cola = a.cola;
+	zfft::fft_frame<LOG2N, true, false, true>(tf, lds + slot * PL::LDS_FLOAT2, a.tw, in, out, active);
+}
+
+// Hard masks with more than one output (HPRIOffline pass 1: H, P and R of every frame): one workgroup
+// synthesises all outputs of its frame.  The two binary masks of a bin are compared once, while the first
+// output loads S, H and P, and kept as two bits per bin in one register; the other outputs re-read only S
+// (from L2) instead of S, H and P, and repeat no division.  Same values as mask_value().
+struct IstftHardIn {
+	const float2* S;
+	const float* H;
+	const float* P;
+	MaskCfg cfg;
+	unsigned* bits; // bit 2*slot: percussive mask, bit 2*slot + 1: harmonic mask
+	int which;
+	int first;
+	int n;
+	__device__ __forceinline__ float2 operator()(int idx, int slot) const
+	{
+		const bool mirror = idx > (n >> 1);
+		float2 z = S[mirror ? n - idx : idx];
+		if (mirror)
+			z.y = -z.y;
+		if (first) {
+			const float h = H[idx], p = P[idx];
+			const unsigned pm = cfg.out_p || which == 0 ? (unsigned)(pmask_value(h, p, cfg) != 0.0f) : 0u;
+			const unsigned hm = cfg.out_h || which == 1 ? (unsigned)(hmask_value(h, p, cfg) != 0.0f) : 0u;
+			*bits |= (pm | (hm << 1)) << (2 * slot);
+		}
+		const float pm = (float)((*bits >> (2 * slot)) & 1u), hm = (float)((*bits >> (2 * slot + 1)) & 1u);
+		const float m = which == 0 ? pm : (which == 1 ? hm : 1 - (hm + pm)); // residual_mask_functor hps.h:35-43
+		return make_float2(z.x * m, z.y * m);
+	}
+};
+
+template <int LOG2N>
+__global__ __launch_bounds__(Plan<LOG2N>::THREADS) void istft_hard_multi_kernel(IstftArgs a)
+{
+	using PL = Plan<LOG2N>;
+	extern __shared__ float2 lds[];
+	const int tid = threadIdx.x, s = blockIdx.z;
+	const int slot = tid / PL::TF, tf = tid - slot * PL::TF;
+	const int f = blockIdx.x * PL::FRAMES_PER_BLOCK + slot;
+	const bool active = f < a.n_frames;
+	const long long ring_row = ((a.crow0 + f) % a.ring_rows) + (long long)s * a.ring_rows;
+	unsigned bits = 0;
+	IstftHardIn in;
+	in.S = a.S + ring_row * a.s_stride;
+	in.n = PL::N;
+	in.H = a.h_is_ring ? a.H + ring_row * PL::N : a.H + (long long)s * a.h_stream_stride + (long long)f * PL::N;
+	in.P = a.P + (long long)s * a.p_stream_stride + (long long)f * PL::N;
+	in.cfg = MaskCfg{a.beta, a.beta_h, 0, a.power, 0, a.out_h, a.out_p};
+	in.bits = &bits;
+	for (int oi = 0; oi < a.n_out; ++oi) {
+		in.which = a.out_id[oi];
+		in.first = oi == 0;
+		IstftOut out;
+		out.Y = a.Y[oi] + (long long)s * a.y_stream_stride + (long long)f * (PL::N / 2);
+		out.cola = a.cola;
+		// The thread index and the table pointer are made opaque per output: otherwise every LDS address and
+		// twiddle index of the transform (all functions of tf alone) is hoisted out of this loop and kept
+		// in registers (226 VGPRs instead of 90 at nfft 4096, 128 spilled at nfft 16384).
+		int tf_o = tf;
+		const float2* tw_o = a.tw;
+		asm volatile("" : "+v"(tf_o));
+		asm volatile("" : "+s"(tw_o));
+		zfft::fft_frame<LOG2N, true, false, true>(tf_o, lds + slot * PL::LDS_FLOAT2, tw_o, in, out, active);
+		__syncthreads(); // the frame image is reused by the next output
+	}
+}
+
+template <int LOG2N>
+int launch_istft_t(const IstftArgs& a, hipStream_t stream)
+{
+	using PL = Plan<LOG2N>;
+	// all outputs of a frame in one workgroup; not at nfft 8192/16384, where a CU holds one or two frames and
+	// three short workgroups per frame schedule better than one long one (measured)
+	if (LOG2N <= 12 && a.n_out > 1 && !a.soft && !a.sse && !g_opt_no_istft_multi) {
+		auto kern = istft_hard_multi_kernel<LOG2N>;
+		ZH_TRY(set_lds(kern, lds_bytes<LOG2N>()));
+		dim3 grid((unsigned)ceil_div((size_t)a.n_frames, (size_t)PL::FRAMES_PER_BLOCK), 1, (unsigned)a.n_streams);
+		hipLaunchKernelGGL(kern, grid, dim3(PL::THREADS), lds_bytes<LOG2N>(), stream, a);
+		ZH_HIP(hipGetLastError());
+		return ZEN_HIP_OK;
+	}
+	auto kern = istft_kernel<LOG2N>;
+	ZH_TRY(set_lds(kern, lds_bytes<LOG2N>()));
+	dim3 grid((unsigned)ceil_div((size_t)a.n_frames, (size_t)PL::FRAMES_PER_BLOCK), (unsigned)a.n_out, (unsigned)a.n_streams);
+	hipLaunchKernelGGL(kern, grid, dim3(PL::THREADS), lds_bytes<LOG2N>(), stream, a);
+	ZH_HIP(hipGetLastError());
+	return ZEN_HIP_OK;
+}
+
+
+} // namespace
+
+int launch_istft(int log2n, const IstftArgs& a, hipStream_t stream)
+{
+	if (a.n_frames <= 0 || a.n_out <= 0)
+		return ZEN_HIP_OK;
+#define CALL(L) launch_istft_t<L>(a, stream)
+	ZH_DISPATCH_LOG2N(log2n, CALL)
+#undef CALL
+}
+
+} // namespace zen_hip_impl
