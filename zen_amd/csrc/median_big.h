@@ -8,11 +8,11 @@
 //     plus rl + rr <= 30 loose samples.  It merges the first 2^k sorted blocks pairwise (Batcher odd-even
 //     merges, 16 -> 32 -> 64 -> 128) into one sorted list A, sorts the loose samples and merges them with
 //     the remaining blocks into a second sorted list R, and gets the 16 candidate order statistics from
-//     one more (heavily pruned) odd-even merge of the relevant window of A with R (or, where that merge
-//     overflows the register file, from the selection identity merge(A,R)[p] = min_q max(A[p-q], R[q-1]));
+//     one more (heavily pruned) odd-even merge of the relevant window of A with R (255 taps, whose second
+//     list is too long for that, uses the selection identity merge(A,R)[p] = min_q max(A[p-q], R[q-1]));
 //   * the 15 + 15 flank samples then go through the same selection tree as for small windows.
 //
-// 210-250 min/max per output at 171/187 taps, all with compile-time indices (no data-dependent addressing),
+// ~210 min/max per output at 171/187 taps, all with compile-time indices (no data-dependent addressing),
 // instead of ~60 wave-wide instructions per output in the sliding wave-window kernel.
 #pragma once
 #include "median_net.h"
@@ -37,9 +37,6 @@ struct Geo {
 	static constexpr int RREAL = 32 + 16 * REST; // R slots in use: 32 for the loose samples + the blocks
 	static constexpr int NRP = RREAL <= 32 ? 32 : (RREAL <= 64 ? 64 : (RREAL <= 128 ? 128 : 256));
 	static constexpr bool supported = (W & 1) && W >= 65 && W <= 255;
-	// candidates by a pruned odd-even merge (fewer instructions) unless both lists are long: with
-	// NA = 128 and NR > 32 (187 taps) that version spills ~60 registers and loses to the selection identity
-	static constexpr bool use_merge = !(NA >= 128 && NR > 32);
 };
 
 template <int N, int TOTAL, int OFF = 0>
@@ -152,7 +149,7 @@ __device__ __forceinline__ void medians_big(const LD& ld, int (&out)[16])
 	int cand[16];
 	constexpr int NAN_ = AHI - ALO + 1;
 	constexpr int HALF = (NAN_ <= 64 && NRP <= 64) ? 64 : 128;
-	if constexpr (NAN_ <= HALF && NRP <= HALF && G::use_merge) {
+	if constexpr (NAN_ <= HALF && NRP <= HALF) {
 		// one odd-even merge of the two lists, each padded with +inf to HALF; the compiler prunes the
 		// comparators that cannot reach the 16 outputs read below (~235 comparators at HALF = 64 instead of
 		// 16 * NR max/min terms)
