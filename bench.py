@@ -191,6 +191,41 @@ def realtime_leg(zen_amd, x, n_hops=400):
                     "(zen/fakert.h:221-247); latency-bound, no roofline quoted"}
 
 
+def dry_main(args, zdist):
+    """The N-rank plumbing without a GPU: rendezvous, sharding of the workload's units, empty timed steps
+    between barriers, max-over-ranks time, summed counters, one JSON line from rank 0.  What tests/ run on
+    CPU with gloo; never a measurement."""
+    rank, _, world = zdist.env_world()
+    grp = zdist.Group(args.backend if args.backend == "gloo" else "gloo")
+    if args.workload == "offline_batch":
+        units = len(zdist.shard_units(args.clips * world, world, rank))
+        par = "clips sharded x%d, no data-path collective" % world
+    elif args.workload == "offline_long":
+        b, e = zdist.time_shards(int(600 * FS), world, 4096)[rank]
+        units = (e - b) // 4096
+        par = "each channel time-sharded x%d with warm-up halos, no exchange" % world
+    else:
+        units = args.hops * args.streams
+        par = "replicas x%d" % world
+    grp.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    grp.barrier()
+    dt = grp.max(time.perf_counter() - t0)
+    tot_units, ranks = grp.sum([units, 1])
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (launch / sharding plumbing only)", "dry": True, "value": None,
+                          "unit": "hops/s", "n_gpus": world, "ranks_reported": int(ranks), "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1),
+                          "higher_is_better": True, "scaling": "strong" if args.workload == "offline_long" else "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "none",
+                          "config": {"workload": args.workload, "units_all_ranks": int(tot_units),
+                                     "units_rank0": units, "parallelism": par, "backend": "gloo"}}))
+    grp.close()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -208,16 +243,31 @@ def main():
     ap.add_argument("--no-block-fused", action="store_true",
                     help="realtime_block: STFT / median / iSTFT kernels instead of the fused per-hop kernel")
     ap.add_argument("--fused-minb", type=int, default=0, help="tuning: occupancy the fused kernel is built for")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo for the CPU plumbing test)")
+    ap.add_argument("--dry", action="store_true",
+                    help="no GPU: run only the launch / sharding / aggregation plumbing with empty steps "
+                         "(CPU tests; the line says dry: true and is not a measurement)")
     args = ap.parse_args()
 
-    cpu_all = None
-    if args.workload == "offline_batch" and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
-        cpu_all = cpu_baseline_offline_all_cores(4096, 256)      # forks: before anything loads or touches the GPU
     from zen_amd import dist as zdist
+    if args.gpus > 1 and not zdist.launched_by_torchrun():
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing above has imported torch, loaded the
+        # HIP library or touched a GPU; the ranks are fresh interpreters (one per GPU), rank 0's line is relayed.
+        sys.exit(zdist.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
     rank, local_rank, world = zdist.env_world()
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d from the launcher; using WORLD_SIZE" % (args.gpus, world),
+              file=sys.stderr)
+    if args.dry:
+        return dry_main(args, zdist)
+
+    cpu_all = None
+    if args.workload == "offline_batch" and world == 1 and not args.no_cpu_baseline:
+        cpu_all = cpu_baseline_offline_all_cores(4096, 256)      # forks: before anything loads or touches the GPU
     import torch
     torch.cuda.set_device(local_rank)
-    grp = zdist.Group("nccl", torch.device("cuda", local_rank))
+    grp = zdist.Group(args.backend, torch.device("cuda", local_rank) if args.backend == "nccl" else None)
 
     import zen_amd
     zen_amd.init(local_rank)

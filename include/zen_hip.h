@@ -53,19 +53,21 @@ typedef struct zen_hip_hpri* zen_hip_hpri_t;
  * runtime   (replaces libzen/core.cu:4-6, the cudaSetDeviceFlags(cudaDeviceMapHost) constructor)
  * ------------------------------------------------------------------------------------------- */
 int zen_hip_init(int device);          /* hipSetDevice + mapped-host flag; idempotent */
+int zen_hip_device_count(int* n);      /* GPUs visible to this process (one process per GPU: `zen batch --gpus`) */
 const char* zen_hip_last_error(void);  /* thread-local text of the last failure */
 const char* zen_hip_version(void);
 int zen_hip_device_name(char* buf, size_t n);
 int zen_hip_synchronize(void* stream); /* hipStreamSynchronize; synchronises */
-/* process-wide tuning/debug switches (no reference counterpart).  "median_general" = 1 forces the general
- * wave-cooperative median kernel even where the sorting-network fast path (masks <= 63 taps) applies;
- * "no_rt_fused" = 1 sends causal calls through the three-kernel path instead of the fused kernel of
- * rt_fused.hip, "no_block_fused" = 1 does so only for calls of more than one hop; "block_fused_minb" = 1..3
- * picks the occupancy the fused block kernel is compiled for; "no_istft_multi" = 1 synthesises hard-mask
- * outputs in separate workgroups instead of one per frame;
- * "no_median47_neighbour" = 1 runs the 47-tap frequency kernel without the DPP exchange of sorted blocks;
- * "median47_shared" = 1 routes 47-tap frequency masks to the experimental neighbour-sharing kernel
- * (median47.hip; same results, currently not faster), "median47_blocks" = n makes it persistent on n workgroups. */
+/* process-wide tuning/debug switches (no reference counterpart; atomics, may be set from any thread).
+ * "median_general" = 1 forces the general wave-cooperative median kernel even where the sorting-network
+ * fast paths apply; "no_rt_fused" = 1 sends causal calls through the three-kernel path instead of the fused
+ * kernel of rt_fused.hip, "no_block_fused" = 1 does so only for calls of more than one hop;
+ * "block_fused_minb" = 1..3 picks the occupancy the fused block kernel is compiled for; "no_istft_multi" = 1
+ * synthesises hard-mask outputs in separate workgroups instead of one per frame; "no_median47_dpp" = 1 sends
+ * 47-tap frequency masks on 4096-bin rows through the generic sorting-network kernel instead of
+ * median47_dpp_kernel, "no_median47_neighbour" = 1 additionally switches off that kernel's DPP exchange of
+ * sorted blocks; "median47_variant" = 1 lets median47_dpp_kernel store results without the LDS transpose (2, 3: timing
+ * diagnostics whose outputs are not medians). */
 int zen_hip_set_option(const char* name, int value);
 
 /* device memory + copies: what thrust::device_vector / thrust::copy are to the reference

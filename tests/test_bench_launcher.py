@@ -1,0 +1,77 @@
+"""bench.py --gpus N must really start N ranks.
+
+CPU tier: the launch / rendezvous / sharding / aggregation plumbing with the gloo backend and empty steps
+(`--dry`); the GPU path differs only in the backend name ("nccl" = RCCL) and in what a step does."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def run(cmd, timeout=240):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    return r.returncode, lines, r.stderr.decode()
+
+
+def test_plain_launch_spawns_one_rank_per_gpu():
+    rc, lines, err = run([sys.executable, BENCH, "--gpus", "2", "--dry", "--backend", "gloo",
+                          "--workload", "offline_batch", "--steps", "2"])
+    assert rc == 0, err
+    assert len(lines) == 1                       # only rank 0 prints
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["ranks_reported"] == 2 and j["dry"] is True
+    assert j["config"]["parallelism"].startswith("clips sharded x2")
+    assert j["config"]["units_all_ranks"] == 128 and j["config"]["units_rank0"] == 64
+
+
+def test_plain_launch_time_shards_and_replicas():
+    rc, lines, err = run([sys.executable, BENCH, "--gpus", "2", "--dry", "--backend", "gloo",
+                          "--workload", "offline_long", "--steps", "1"])
+    assert rc == 0, err
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and "time-sharded x2" in j["config"]["parallelism"]
+    rc, lines, err = run([sys.executable, BENCH, "--gpus", "3", "--dry", "--backend", "gloo", "--hops", "100",
+                          "--steps", "1"])
+    assert rc == 0, err
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 3 and j["ranks_reported"] == 3 and j["config"]["units_all_ranks"] == 300
+    assert j["config"]["parallelism"] == "replicas x3"
+
+
+def test_torchrun_launch_is_not_respawned():
+    """The driver's own launch line: the environment already names the ranks, bench.py must not spawn again."""
+    rc, lines, err = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29631", BENCH, "--gpus", "2", "--dry",
+                          "--backend", "gloo", "--steps", "1"])
+    assert rc == 0, err
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["ranks_reported"] == 2
+
+
+def test_single_gpu_line_has_no_launcher():
+    rc, lines, err = run([sys.executable, BENCH, "--dry", "--steps", "1"])
+    assert rc == 0, err
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["ranks_reported"] == 1
+
+
+def test_spawn_ranks_reports_a_dead_rank_and_stops_the_others():
+    sys.path.insert(0, ROOT)
+    from zen_amd import dist as zdist
+    code = ("import os, sys, time\n"
+            "r = int(os.environ['RANK'])\n"
+            "assert os.environ['WORLD_SIZE'] == '3' and os.environ['LOCAL_RANK'] == str(r)\n"
+            "assert os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0\n"
+            "if r == 1: sys.exit(7)\n"
+            "time.sleep(60)\n")
+    import time
+    t0 = time.monotonic()
+    rc = zdist.spawn_ranks([sys.executable, "-c", code], 3, timeout=50)
+    assert rc == 7
+    assert time.monotonic() - t0 < 30            # ranks 0 and 2 were terminated, not waited for

@@ -138,3 +138,14 @@ def test_cli_batch_directory(tmp_path):
             a = open(str(outdir / (nm + suffix)), "rb").read()
             b = open(str(tmp_path / (nm + suffix)), "rb").read()
             assert a == b, nm + suffix
+
+
+def test_median_networks_on_the_host(tmp_path):
+    """zen_amd/csrc/median_net.h compiled as plain C++ (tests/cpp/test_median_net_host.cpp): every sorting /
+    selection network the kernels instantiate, and the 47-tap block scheme of median47_dpp_kernel with its
+    neighbours' sorted pieces, against a brute-force replicate-border median (mfilt.h:270-342 semantics)."""
+    exe = str(tmp_path / "test_median_net_host")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cpp", "test_median_net_host.cpp"),
+                           "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "passed" in r.stdout, r.stdout[-2000:]

@@ -18,20 +18,20 @@ def z():
     return zen_amd
 
 
-@pytest.fixture(params=["net", "net_plain47", "general", "shared47", "shared47_persistent"])
+@pytest.fixture(params=["net", "net_plain47", "general", "dpp47_direct", "net47"])
 def zk(z, request):
-    """All median kernels: sorting networks (default; 47 taps with the DPP neighbour exchange, or without:
-    net_plain47), the general wave kernel, and the experimental LDS neighbour-sharing 47-tap kernel (one
-    workgroup per row / persistent)."""
+    """All median kernels: the defaults (sorting networks; median47_dpp_kernel for 47 taps on 4096-bin rows),
+    the same with direct stores (dpp47_direct), the generic network kernel for that shape too (net47: with
+    its own DPP exchange of sorted blocks, net_plain47: without), and the general wave kernel."""
     z.set_option("median_general", 1 if request.param == "general" else 0)
+    z.set_option("no_median47_dpp", 1 if request.param in ("net47", "net_plain47") else 0)
     z.set_option("no_median47_neighbour", 1 if request.param == "net_plain47" else 0)
-    z.set_option("median47_shared", 1 if request.param.startswith("shared47") else 0)
-    z.set_option("median47_blocks", 7 if request.param == "shared47_persistent" else 0)
+    z.set_option("median47_variant", 1 if request.param == "dpp47_direct" else 0)
     yield z
     z.set_option("median_general", 0)
+    z.set_option("no_median47_dpp", 0)
     z.set_option("no_median47_neighbour", 0)
-    z.set_option("median47_shared", 0)
-    z.set_option("median47_blocks", 0)
+    z.set_option("median47_variant", 0)
 
 
 def noise(n, seed=0):

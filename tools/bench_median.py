@@ -18,6 +18,8 @@ def run(rows, cols, flen, direction, iters, general=False, nonneg=True):
     zen_amd.set_option("median_general", int(general))
     rng = np.random.default_rng(0)
     d = rng.uniform(0, 1, (rows, cols)).astype(np.float32)
+    if os.environ.get("ZEN_BENCH_SIGNED"):
+        d -= 0.5
     src, dst = zen_amd.DeviceBuffer.from_host(d), zen_amd.DeviceBuffer(d.size)
     f = zen_amd.MedianFilterGPU(rows, cols, flen, direction)
     for _ in range(3):

@@ -20,6 +20,62 @@ __global__ __launch_bounds__(256) void copy_u(const float4* __restrict__ a, floa
 	for (int u = 0; u < U; ++u)
 		b[base + (size_t)u * 256] = v[u];
 }
+// nontemporal variants: streaming data that will not be re-read should not displace cache lines
+template <int U, bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void copy_nt(const float4* __restrict__ a, float4* __restrict__ b, size_t n)
+{
+	const size_t base = (size_t)blockIdx.x * 256 * U + threadIdx.x;
+	float4 v[U];
+#pragma unroll
+	for (int u = 0; u < U; ++u) {
+		const float* p = reinterpret_cast<const float*>(a + base + (size_t)u * 256);
+		if (NTL) {
+			v[u].x = __builtin_nontemporal_load(p);
+			v[u].y = __builtin_nontemporal_load(p + 1);
+			v[u].z = __builtin_nontemporal_load(p + 2);
+			v[u].w = __builtin_nontemporal_load(p + 3);
+		}
+		else
+			v[u] = a[base + (size_t)u * 256];
+	}
+#pragma unroll
+	for (int u = 0; u < U; ++u) {
+		float* q = reinterpret_cast<float*>(b + base + (size_t)u * 256);
+		if (NTS) {
+			__builtin_nontemporal_store(v[u].x, q);
+			__builtin_nontemporal_store(v[u].y, q + 1);
+			__builtin_nontemporal_store(v[u].z, q + 2);
+			__builtin_nontemporal_store(v[u].w, q + 3);
+		}
+		else
+			b[base + (size_t)u * 256] = v[u];
+	}
+}
+// persistent copy with the next tile's loads in flight while the current tile is stored
+__global__ __launch_bounds__(256) void copy_pipe(const float4* __restrict__ a, float4* __restrict__ b, size_t ntiles)
+{
+	float4 v[4], w[4];
+	size_t t = blockIdx.x;
+	if (t >= ntiles)
+		return;
+#pragma unroll
+	for (int u = 0; u < 4; ++u)
+		v[u] = a[t * 1024 + threadIdx.x + u * 256];
+	for (; t < ntiles; t += gridDim.x) {
+		const size_t tn = t + gridDim.x;
+		if (tn < ntiles) {
+#pragma unroll
+			for (int u = 0; u < 4; ++u)
+				w[u] = a[tn * 1024 + threadIdx.x + u * 256];
+		}
+#pragma unroll
+		for (int u = 0; u < 4; ++u)
+			b[t * 1024 + threadIdx.x + u * 256] = v[u];
+#pragma unroll
+		for (int u = 0; u < 4; ++u)
+			v[u] = w[u];
+	}
+}
 __global__ __launch_bounds__(256) void read_k(const float4* __restrict__ a, float* out, size_t n)
 {
 	float s = 0;
@@ -73,6 +129,24 @@ int main()
 		printf("copy  4 x 16 B per thread, one shot: %.3f ms  %.0f GB/s\n", ms, 2.0 * n * 16 / ms / 1e6);
 		ms = timeit([&] { copy_u<8><<<(unsigned)(n / (256 * 8)), 256>>>(a, b, n); });
 		printf("copy  8 x 16 B per thread, one shot: %.3f ms  %.0f GB/s\n", ms, 2.0 * n * 16 / ms / 1e6);
+		ms = timeit([&] { copy_nt<4, true, false><<<(unsigned)(n / (256 * 4)), 256>>>(a, b, n); });
+		printf("copy  4 x 16 B, nontemporal loads:   %.3f ms  %.0f GB/s\n", ms, 2.0 * n * 16 / ms / 1e6);
+		ms = timeit([&] { copy_nt<4, false, true><<<(unsigned)(n / (256 * 4)), 256>>>(a, b, n); });
+		printf("copy  4 x 16 B, nontemporal stores:  %.3f ms  %.0f GB/s\n", ms, 2.0 * n * 16 / ms / 1e6);
+		ms = timeit([&] { copy_nt<4, true, true><<<(unsigned)(n / (256 * 4)), 256>>>(a, b, n); });
+		printf("copy  4 x 16 B, nontemporal both:    %.3f ms  %.0f GB/s\n", ms, 2.0 * n * 16 / ms / 1e6);
+		for (int g : {1024, 1792, 2048, 4096}) {
+			ms = timeit([&] { copy_pipe<<<g, 256>>>(a, b, n / 1024); });
+			printf("copy  persistent pipelined %5d WGs: %.3f ms  %.0f GB/s\n", g, ms, 2.0 * n * 16 / ms / 1e6);
+		}
+		// the median kernel's working set: 25 840 x 4096 floats in, the same out
+		{
+			const size_t m = (size_t)25840 * 1024;
+			ms = timeit([&] { copy_u<4><<<(unsigned)(m / (256 * 4)), 256>>>(a, b, m); }, 50);
+			printf("copy  4 x 16 B, 25840 x 4096 floats: %.3f ms  %.0f GB/s\n", ms, 2.0 * m * 16 / ms / 1e6);
+			ms = timeit([&] { copy_nt<4, true, true><<<(unsigned)(m / (256 * 4)), 256>>>(a, b, m); }, 50);
+			printf("copy  same, nontemporal both:        %.3f ms  %.0f GB/s\n", ms, 2.0 * m * 16 / ms / 1e6);
+		}
 		ms = timeit([&] { (void)hipMemcpyAsync(b, a, n * 16, hipMemcpyDeviceToDevice, 0); });
 		printf("hipMemcpy device-to-device:          %.3f ms  %.0f GB/s\n", ms, 2.0 * n * 16 / ms / 1e6);
 	}

@@ -13,6 +13,9 @@
 #include <string>
 #include <vector>
 
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include <libzen/hps.h>
 #include <libzen/io.h>
 #include <libzen/zen.h>
@@ -42,7 +45,9 @@ void usage(std::ostream& os)
 	      "      [--sse] [--only-percussive] [--soft-mask] [--nocopybord]\n"
 	      "  zen fakert -i <infile> [--hps [<hop> [<beta>]]] [-o <outfile>] [--sse] [--soft-mask] [--nocopybord]\n"
 	      "  zen batch -i <indir> -o <outdir> [--hps [<hop-h> [<beta-h> [<hop-p> [<beta-p>]]]]] [--sse] [--soft-mask]\n"
-	      "      (MI355X extension: every .wav of <indir>, equal-length clips separated together in one batch)\n"
+	      "      [--gpus <n>]\n"
+	      "      (MI355X extension: every .wav of <indir>, equal-length clips separated together in one batch;\n"
+	      "       --gpus n deals the files round-robin to n processes, one per GPU, no exchange between them)\n"
 	      "  zen help|-h|--help\n"
 	      "  zen version|-v|--version\n";
 }
@@ -140,8 +145,85 @@ int run_offline(const OfflineParams& p)
 			throw std::runtime_error(std::string(#call ": ") + zen_hip_last_error()); \
 	} while (0)
 
-int run_batch(const OfflineParams& p, const std::string& outdir)
+// Rank / world of this process inside `zen batch --gpus N` (set by run_batch_multi for its children).
+struct BatchRank {
+	int rank = 0, world = 1, report_fd = -1;
+};
+
+BatchRank batch_rank_from_env()
 {
+	BatchRank b;
+	if (const char* r = std::getenv("ZEN_BATCH_RANK"))
+		b.rank = std::atoi(r);
+	if (const char* w = std::getenv("ZEN_BATCH_WORLD"))
+		b.world = std::max(1, std::atoi(w));
+	if (const char* f = std::getenv("ZEN_BATCH_REPORT_FD"))
+		b.report_fd = std::atoi(f);
+	return b;
+}
+
+// `zen batch --gpus N` (BASELINE configs[3]): clips are independent units, so the parent only
+// starts N copies of itself -- one per GPU, before anything in this process has touched a GPU -- and adds
+// up what they report through a pipe.  Child r separates files r, r+N, r+2N, ... of the sorted directory
+// listing on device r.  No collective: every child reads its own inputs and writes its own outputs.
+int run_batch_multi(int gpus, char* argv[])
+{
+	struct Child {
+		pid_t pid;
+		int fd;
+	};
+	std::vector<Child> kids;
+	const auto t1 = std::chrono::high_resolution_clock::now();
+	for (int r = 0; r < gpus; ++r) {
+		int fds[2];
+		if (pipe(fds) != 0)
+			throw std::runtime_error("pipe failed");
+		const pid_t pid = fork();
+		if (pid < 0)
+			throw std::runtime_error("fork failed");
+		if (pid == 0) {
+			close(fds[0]);
+			setenv("ZEN_BATCH_RANK", std::to_string(r).c_str(), 1);
+			setenv("ZEN_BATCH_WORLD", std::to_string(gpus).c_str(), 1);
+			setenv("ZEN_BATCH_REPORT_FD", std::to_string(fds[1]).c_str(), 1);
+			execv("/proc/self/exe", argv);
+			_exit(127);
+		}
+		close(fds[1]);
+		kids.push_back({pid, fds[0]});
+	}
+	double audio_s = 0, gpu_ms_max = 0;
+	long files = 0;
+	int rc = 0;
+	for (auto& k : kids) {
+		std::string text;
+		char buf[256];
+		ssize_t got;
+		while ((got = read(k.fd, buf, sizeof(buf))) > 0)
+			text.append(buf, (size_t)got);
+		close(k.fd);
+		int status = 0;
+		waitpid(k.pid, &status, 0);
+		if (!WIFEXITED(status) || WEXITSTATUS(status) != 0)
+			rc = WIFEXITED(status) ? WEXITSTATUS(status) : 1;
+		double a = 0, ms = 0;
+		long f = 0;
+		if (std::sscanf(text.c_str(), "%lf %lf %ld", &a, &ms, &f) == 3) {
+			audio_s += a;
+			gpu_ms_max = std::max(gpu_ms_max, ms);
+			files += f;
+		}
+	}
+	const auto t2 = std::chrono::high_resolution_clock::now();
+	const long wall = (long)std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count();
+	std::cout << "zen batch: " << gpus << " GPUs: " << files << " files, " << audio_s << " s of audio separated; "
+	          << gpu_ms_max << " ms of GPU time on the busiest GPU, " << wall << " ms wall incl. file I/O" << std::endl;
+	return rc;
+}
+
+int run_batch(const OfflineParams& p, const std::string& outdir, const BatchRank& br)
+{
+	const std::string tag = br.world > 1 ? "[gpu " + std::to_string(br.rank) + "] " : "";
 	std::vector<std::string> files;
 	if (DIR* d = opendir(p.infile.c_str())) {
 		while (dirent* e = readdir(d)) {
@@ -155,6 +237,12 @@ int run_batch(const OfflineParams& p, const std::string& outdir)
 		throw std::runtime_error("cannot open directory " + p.infile);
 	}
 	std::sort(files.begin(), files.end());
+	if (br.world > 1) { // this rank's share: files rank, rank + world, ... (same deal as zen_amd/dist.py shard_units)
+		std::vector<std::string> mine;
+		for (std::size_t i = (std::size_t)br.rank; i < files.size(); i += (std::size_t)br.world)
+			mine.push_back(files[i]);
+		files.swap(mine);
+	}
 	struct Clip {
 		std::string stem;
 		std::vector<float> mono;
@@ -175,7 +263,7 @@ int run_batch(const OfflineParams& p, const std::string& outdir)
 		if (!c.mono.empty())
 			groups[{fd.sampleRate, c.mono.size()}].push_back(std::move(c));
 	}
-	std::cout << "zen batch: " << files.size() << " wav files in " << groups.size() << " (rate, length) groups"
+	std::cout << tag << "zen batch: " << files.size() << " wav files in " << groups.size() << " (rate, length) groups"
 	          << std::endl;
 	const std::size_t max_batch = 64;
 	double total_audio_s = 0;
@@ -208,7 +296,7 @@ int run_batch(const OfflineParams& p, const std::string& outdir)
 			const long ms = (long)std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count();
 			total_ms += ms;
 			total_audio_s += (double)C * n / fs;
-			std::cout << "GPU/HIP/gfx950: 2-pass HPR-I-Offline of " << C << " clips x " << n << " samples took " << ms
+			std::cout << tag << "GPU/HIP/gfx950: 2-pass HPR-I-Offline of " << C << " clips x " << n << " samples took " << ms
 			          << " ms" << std::endl;
 			std::vector<float> out(n);
 			for (std::size_t c = 0; c < C; ++c) {
@@ -224,8 +312,15 @@ int run_batch(const OfflineParams& p, const std::string& outdir)
 			zen_hip_hpri_destroy(eng);
 		}
 	}
-	std::cout << "zen batch: " << total_audio_s << " s of audio separated in " << total_ms << " ms of GPU time"
+	std::cout << tag << "zen batch: " << total_audio_s << " s of audio separated in " << total_ms << " ms of GPU time"
 	          << std::endl;
+	if (br.report_fd >= 0) { // to run_batch_multi
+		const std::string line = std::to_string(total_audio_s) + " " + std::to_string(total_ms) + " "
+		                         + std::to_string(files.size()) + "\n";
+		if (write(br.report_fd, line.data(), line.size()) < 0)
+			std::cerr << tag << "zen batch: report pipe closed" << std::endl;
+		close(br.report_fd);
+	}
 	return 0;
 }
 
@@ -329,6 +424,7 @@ int main(int argc, char* argv[])
 	OfflineParams op;
 	FakeRtParams fp;
 	bool cpu = false, have_input = false;
+	int gpus = 1;
 	for (std::size_t i = 1; i < a.size(); ++i) {
 		const std::string& s = a[i];
 		auto next_is_number = [&]() { return i + 1 < a.size() && is_number(a[i + 1].c_str()); };
@@ -353,6 +449,7 @@ int main(int argc, char* argv[])
 		         && i + 1 < a.size()) {
 			op.outfile_prefix = fp.outfile = a[++i];
 		}
+		else if (s == "--gpus" && cmd == "batch" && next_is_number()) gpus = std::max(1, std::atoi(a[++i].c_str()));
 		else if (s == "--cpu") cpu = true;
 		else if (s == "--sse") op.use_sse = fp.use_sse = true;
 		else if (s == "--soft-mask") op.soft_mask = fp.soft_mask = true;
@@ -372,17 +469,25 @@ int main(int argc, char* argv[])
 		return 2;
 	}
 	try {
-		if (zen_hip_init(0) != ZEN_HIP_OK) {
+		const BatchRank br = batch_rank_from_env();
+		if (cmd == "batch" && op.outfile_prefix == "") {
+			usage(std::cerr);
+			return 0;
+		}
+		if (cmd == "batch" && gpus > 1 && br.world == 1)
+			return run_batch_multi(gpus, argv); // before zen_hip_init: the parent never touches a GPU
+		int device = cmd == "batch" ? br.rank : 0;
+		if (cmd == "batch" && br.world > 1 && std::getenv("ZEN_ALLOW_GPU_SHARING")) {
+			int n_dev = 0; // testing on a box with fewer GPUs than ranks: ranks share devices
+			if (zen_hip_device_count(&n_dev) == ZEN_HIP_OK && n_dev > 0)
+				device = br.rank % n_dev;
+		}
+		if (zen_hip_init(device) != ZEN_HIP_OK) {
 			std::cerr << "zen: " << zen_hip_last_error() << std::endl;
 			return 1;
 		}
-		if (cmd == "batch") {
-			if (op.outfile_prefix == "") {
-				usage(std::cerr);
-				return 0;
-			}
-			return run_batch(op, op.outfile_prefix);
-		}
+		if (cmd == "batch")
+			return run_batch(op, op.outfile_prefix, br);
 		return cmd == "offline" ? run_offline(op) : run_fakert(fp);
 	}
 	catch (const std::exception& e) {

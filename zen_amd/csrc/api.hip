@@ -11,13 +11,13 @@
 namespace zen_hip_impl {
 
 static thread_local char g_err[512] = "";
-int g_opt_median_general = 0;
-int g_opt_no_rt_fused = 0;
-int g_opt_no_block_fused = 0;
-int g_opt_no_median47_neighbour = 0;
-int g_opt_no_istft_multi = 0;
-int g_opt_median47_shared = 0;
-int g_opt_median47_blocks = 0;
+opt_t g_opt_median_general{0};
+opt_t g_opt_no_rt_fused{0};
+opt_t g_opt_no_block_fused{0};
+opt_t g_opt_no_median47_neighbour{0};
+opt_t g_opt_no_istft_multi{0};
+opt_t g_opt_no_median47_dpp{0};
+opt_t g_opt_median47_variant{0};
 
 void set_error(const char* fmt, ...)
 {
@@ -123,39 +123,32 @@ int zen_hip_init(int device)
 	return ZEN_HIP_OK;
 }
 
+int zen_hip_device_count(int* n)
+{
+	if (!n)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "zen_hip_device_count: null argument");
+	ZH_HIP(hipGetDeviceCount(n));
+	return ZEN_HIP_OK;
+}
+
 int zen_hip_set_option(const char* name, int value)
 {
-	if (name && !strcmp(name, "median_general")) {
-		g_opt_median_general = value;
-		return ZEN_HIP_OK;
-	}
-	if (name && !strcmp(name, "no_rt_fused")) {
-		g_opt_no_rt_fused = value;
-		return ZEN_HIP_OK;
-	}
-	if (name && !strcmp(name, "no_block_fused")) {
-		g_opt_no_block_fused = value;
-		return ZEN_HIP_OK;
-	}
-	if (name && !strcmp(name, "no_median47_neighbour")) {
-		g_opt_no_median47_neighbour = value;
-		return ZEN_HIP_OK;
-	}
-	if (name && !strcmp(name, "no_istft_multi")) {
-		g_opt_no_istft_multi = value;
-		return ZEN_HIP_OK;
-	}
-	if (name && !strcmp(name, "block_fused_minb")) {
-		g_opt_block_fused_minb = value;
-		return ZEN_HIP_OK;
-	}
-	if (name && !strcmp(name, "median47_blocks")) {
-		g_opt_median47_blocks = value;
-		return ZEN_HIP_OK;
-	}
-	if (name && !strcmp(name, "median47_shared")) {
-		g_opt_median47_shared = value;
-		return ZEN_HIP_OK;
+	static const struct {
+		const char* name;
+		opt_t* var;
+	} table[] = {{"median_general", &g_opt_median_general},
+	             {"no_rt_fused", &g_opt_no_rt_fused},
+	             {"no_block_fused", &g_opt_no_block_fused},
+	             {"no_median47_neighbour", &g_opt_no_median47_neighbour},
+	             {"no_istft_multi", &g_opt_no_istft_multi},
+	             {"block_fused_minb", &g_opt_block_fused_minb},
+	             {"no_median47_dpp", &g_opt_no_median47_dpp},
+	             {"median47_variant", &g_opt_median47_variant}};
+	for (const auto& t : table) {
+		if (name && !strcmp(name, t.name)) {
+			t.var->store(value, std::memory_order_relaxed);
+			return ZEN_HIP_OK;
+		}
 	}
 	ZH_FAIL(ZEN_HIP_E_BAD_ARG, "zen_hip_set_option: unknown option '%s'", name ? name : "(null)");
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -11,14 +12,17 @@
 namespace zen_hip_impl {
 
 void set_error(const char* fmt, ...);
-extern int g_opt_no_rt_fused;      // zen_hip_set_option("no_rt_fused"): single hops go through the 3-kernel path
-extern int g_opt_no_block_fused;   // zen_hip_set_option("no_block_fused"): blocks of causal hops use the 3-kernel path
-extern int g_opt_block_fused_minb; // zen_hip_set_option("block_fused_minb"): fused block kernel built for n workgroups/CU
-extern int g_opt_no_istft_multi;   // zen_hip_set_option("no_istft_multi"): one workgroup per (frame, output) also for hard masks
-extern int g_opt_no_median47_neighbour; // zen_hip_set_option("no_median47_neighbour"): 47 taps without the DPP block sharing
-extern int g_opt_median_general; // zen_hip_set_option("median_general")
-extern int g_opt_median47_blocks;  // zen_hip_set_option("median47_blocks"): persistent grid size (0 = one block per row)
-extern int g_opt_median47_shared; // zen_hip_set_option("median47_shared"): use the experimental block-sharing 47-tap kernel
+// Process-wide tuning / debug switches (zen_hip_set_option).  Atomics: a host with one thread per GPU may
+// flip one while another thread launches; every launch reads each switch once.
+typedef std::atomic<int> opt_t;
+extern opt_t g_opt_no_rt_fused;          // "no_rt_fused": single hops go through the 3-kernel path
+extern opt_t g_opt_no_block_fused;       // "no_block_fused": blocks of causal hops use the 3-kernel path
+extern opt_t g_opt_block_fused_minb;     // "block_fused_minb": fused block kernel built for n workgroups/CU
+extern opt_t g_opt_no_istft_multi;       // "no_istft_multi": one workgroup per (frame, output) also for hard masks
+extern opt_t g_opt_no_median47_neighbour; // "no_median47_neighbour": generic 47-tap kernel without its DPP block exchange
+extern opt_t g_opt_median_general;       // "median_general": force the general wave kernel
+extern opt_t g_opt_no_median47_dpp;      // "no_median47_dpp": 4096-bin rows / 47 taps through the generic kernel
+extern opt_t g_opt_median47_variant;    // "median47_variant": median47_dpp_kernel build (0 default, 1 direct stores, 2/3 diagnostics)
 
 // Evaluate a HIP call; on failure record file:line + hipGetErrorString and return ZEN_HIP_E_HIP.
 #define ZH_HIP(call)                                                                                  \

@@ -36,7 +36,7 @@ struct FilterArgs {
 
 int launch_median(const FilterArgs& a, hipStream_t stream);
 int launch_median_net(const FilterArgs& a, hipStream_t stream, bool* handled); // masks <= 63 taps
-int launch_median47_shared(const FilterArgs& a, hipStream_t stream, bool* handled); // 47 taps, frequency
+int launch_median47_dpp(const FilterArgs& a, hipStream_t stream, bool* handled);  // 47 taps, frequency, 4096-bin rows
 int launch_median_big(const FilterArgs& a, hipStream_t stream, bool* handled); // 65/85/93/129/171/187/255 taps, frequency
 int launch_box(const FilterArgs& a, hipStream_t stream);
 

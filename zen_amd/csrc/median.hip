@@ -281,7 +281,7 @@ int launch_median(const FilterArgs& a, hipStream_t stream)
 	}
 	if (!a.force_general && !g_opt_median_general) { // sorting-network fast path (median_net.hip) for masks <= 63 taps
 		bool handled = false;
-		ZH_TRY(launch_median47_shared(a, stream, &handled)); // experimental neighbour-sharing kernel, off by default
+		ZH_TRY(launch_median47_dpp(a, stream, &handled)); // headline shape: 47 taps on whole 4096-bin rows
 		if (handled)
 			return ZEN_HIP_OK;
 		ZH_TRY(launch_median_net(a, stream, &handled));

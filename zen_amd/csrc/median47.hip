@@ -1,25 +1,32 @@
 // median47.hip -- the 47-tap frequency-direction median of the headline config (hop 1024: l_perc = 46,
-// mask 47, libzen/hps.h:229 + libzen/mfilt.h:89), with the sorting work shared between neighbouring
-// threads.  Same results as median_net_freq_kernel<47> (and as MedianFilterCPU, mfilt.h:270-342).
+// mask 47, libzen/hps.h:229 + libzen/mfilt.h:89) on whole 4096-bin rows: median47_dpp_kernel.
+// Same results as median_net_freq_kernel<47> (and as MedianFilterCPU, libzen/mfilt.h:270-342).
 //
-// Why a second kernel: on gfx950 v_min/v_max/v_min3/v_max3/v_med3 issue at half rate (~4 cycles per
-// wave64 instruction), and the generic kernel spends 85 % of all SIMD cycles on ~52 of them per output
-// (profiles/r01_c_median47_pmc.json).  Nearly half of those sort samples that the neighbouring threads
-// sort as well.  With 47 taps and 16 outputs per thread every chunk the selection tree consumes is an
-// aligned dyadic block of the row (mid + 1 = 24 is a multiple of 8):
+// Why a second kernel.  On gfx950 v_min/v_max/v_min3/v_max3/v_med3 issue at half rate (~1.7 ns per wave
+// instruction per SIMD against 1.0 ns for v_mov/v_add/v_fma, profiles/r01_ubench_valu_rates.txt), and the
+// generic kernel is bound by exactly those (profiles/r01_c_median47_pmc.json).  With 47 taps and 16 outputs
+// per thread every chunk the selection tree of median_net.h consumes is an aligned dyadic piece of the row
+// (mid + 1 = 24 is a multiple of 8):
 //
-//   B(u) = x[16u-8 .. 16u+7]                      one 16-sample block per thread u
-//   thread t needs  B(t), B(t+1) sorted            (its 32 common samples)
+//   B(u) = x[16u-8 .. 16u+7]                       one 16-sample block per thread u
+//   thread t needs  B(t), B(t+1) sorted             (the 32 samples common to its 16 windows)
 //                   upper half / 2nd, 4th quarter of B(t-1), sorted;  B(t-1) raw (pairs, singles)
 //                   lower half / 1st, 3rd quarter of B(t+2), sorted;  B(t+2) raw
 //
-// so each thread sorts ONE block (63 comparators), publishes it in place of its raw samples, and gets
-// the 16 middle ranks of its 32 common samples from its own and its right neighbour's sorted block by
-// one bitonic half-merge (48 comparator-equivalents) instead of a 191-comparator 32-sort.  The flanks
-// (15 samples on either side) are read before the in-place publication and go through the same
-// selection tree as the generic kernel.  ~44 min/max per output instead of ~52, same LDS footprint.
-// (A variant that also shared the sorted halves/quarters needed 75 KB of LDS per workgroup and lost
-// more to occupancy than it saved in instructions.)
+// and the sorted halves and quarters of a block are the intermediate stages of its own Batcher merge sort
+// (znet::pyramid16).  So every thread sorts ONE block (63 comparators), and everything else it needs
+// sorted arrives from lanes t-1, t+1, t+2 through wave-wide DPP shifts (v_mov_b32_dpp wave_shl/shr:1, full
+// rate, no LDS): 64 moves replace 58 comparators (116 half-rate instructions) of re-sorting.  The three
+// lanes at a wave's ends take their neighbours' pieces from a 256-byte LDS edge record per wave, passed as
+// the `old` operand of the same DPP moves (a lane whose DPP source lies outside the wave keeps `old`), so
+// there is no lane-dependent code at all.  Blocks that hang over the row ends are (partly) border replicas
+// (ippBorderRepl): B(-1) and B(257) are constant, B(256) is eight samples and eight copies of the last one,
+// whose sorted pieces cost 19 comparators + 16 min/max in thread 255 instead of a 63-comparator sort.
+//
+// Per thread of 16 outputs: 126 (own sort) + 96 (middle 16 of two sorted blocks) + 304 (selection tree
+// below the shared pieces) = 526 min/max/med3 against 642 + 126/4 in median_net_freq_kernel<47>, and a
+// prologue without integer division, clamps or branches (whole rows only; other geometries use the generic
+// kernel).  HBM traffic is unchanged: 4 B read + 4 B written per element.
 #include "common.h"
 #include "filters.h"
 #include "median_net.h"
@@ -29,159 +36,285 @@
 namespace zen_hip_impl {
 namespace {
 
-constexpr int NCH = 259;  // chunks per row segment: blocks u = -1 .. 257  <->  chunk c = u + 1
-constexpr int RSTR = 20;  // raw image: 16 words + 4 pad per chunk (5c mod 16 distinct: ds_read_b128 conflict free)
-constexpr int OUTS = 4096;
+constexpr int NCH = 259;  // image chunks: blocks u = -1 .. 257  <->  chunk c = u + 1
+constexpr int RSTR = 20;  // 16 words + 4 pad per chunk (5c mod 16 distinct: ds_read_b128 is conflict free)
+constexpr int COLS = 4096;
 
 using znet::from_key;
 using znet::to_key;
 
-// Preconditions (checked by the launcher): cols % 4 == 0, rows and pointers 16-byte aligned.
-template <bool NONNEG>
-__global__ __launch_bounds__(256) void median47_shared_kernel(FilterArgs a, int row_base, int ring, int segs_per_row)
+struct M47Args {
+	const float* src;
+	float* dst;
+	long long src_stream_stride, dst_stream_stride;
+	int row_base, ring; // source row of output row r: (row_base + r) % ring, with row_base < ring, r < ring
+};
+
+__device__ __forceinline__ int dpp_from_next(int old, int v) // lane i <- lane i+1; lane 63 keeps `old`
 {
-	__shared__ __attribute__((aligned(16))) int raw[NCH * RSTR];
+	return __builtin_amdgcn_update_dpp(old, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int dpp_from_prev(int old, int v) // lane i <- lane i-1; lane 0 keeps `old`
+{
+	return __builtin_amdgcn_update_dpp(old, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
 
-	const int tid = threadIdx.x;
-	const int cols = a.cols;
-	const long long total = (long long)a.n_out_rows * segs_per_row * a.n_streams;
-	constexpr int NVEC = NCH * 4, NLD = (NVEC + 255) / 256;
+// Streaming accesses: every input is read once and every output written once, so both bypass the caches'
+// retention ("nt"): the plain copy of this shape runs 154 us, the nontemporal one 139 us
+// (profiles/r02_ubench_copy.txt).
+__device__ __forceinline__ float4 load_nt(const float* p)
+{
+	return make_float4(__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1), __builtin_nontemporal_load(p + 2),
+	                   __builtin_nontemporal_load(p + 3));
+}
+__device__ __forceinline__ void store_nt(float* p, float4 v)
+{
+	__builtin_nontemporal_store(v.x, p);
+	__builtin_nontemporal_store(v.y, p + 1);
+	__builtin_nontemporal_store(v.z, p + 2);
+	__builtin_nontemporal_store(v.w, p + 3);
+}
 
-	const float* srow = nullptr;
-	float* drow = nullptr;
-	int col0 = 0;
-	auto locate = [&](long long sg) {
-		const long long rowg = sg / segs_per_row;
-		const int seg = (int)(sg - rowg * segs_per_row);
-		const int st = (int)(rowg / a.n_out_rows), row = (int)(rowg - (long long)st * a.n_out_rows);
-		col0 = seg * OUTS;
-		srow = a.src + (long long)st * a.src_stream_stride + (long long)((row_base + row) % ring) * cols;
-		drow = a.dst + (long long)st * a.dst_stream_stride + (long long)row * cols;
-	};
-	float4 x[NLD];
-	auto issue_loads = [&]() {
-		const int c_lo = col0 - 24; // column of raw chunk 0, word 0 (block u = -1)
+__device__ __forceinline__ int* unit_ptr(int* img, int u) // 16-byte unit u of the row image (word 4u)
+{
+	return img + (u >> 2) * RSTR + (u & 3) * 4;
+}
+
+// VARIANT 0: results are transposed through the LDS image and stored 1 KB-contiguous per wave instruction.
+// VARIANT 1: every thread stores its 16 consecutive results straight to global memory (four 16-byte stores,
+//            64 bytes apart between lanes): two barriers and eight LDS instructions fewer (measured slower).
+// VARIANT 2, 3 (diagnostics for tools/bench_median.py, results are NOT medians): 2 = the data movement
+//            alone (HBM -> image -> transposed store, no sorting), 3 = everything but the global stores.
+template <bool NONNEG, int VARIANT>
+__global__ __launch_bounds__(256) void median47_dpp_kernel(M47Args p)
+{
+	constexpr bool DIRECT = VARIANT == 1;
+	constexpr bool NT = VARIANT != 4; // VARIANT 4 (diagnostic): the default kernel with plain loads / stores
+	__shared__ __attribute__((aligned(16))) int img[NCH * RSTR];
+	// per wave: [0,16) pieces of the block left of lane 0; [16,32) sorted block right of lane 63,
+	// [32,48) its pieces; [48,64) pieces of the block after that
+	__shared__ __attribute__((aligned(16))) int edge[4][64];
+
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int row = blockIdx.x;
+	int srow_idx = p.row_base + row; // < 2 * ring: one conditional subtraction instead of a division
+	if (srow_idx >= p.ring)
+		srow_idx -= p.ring;
+	const float* __restrict__ srow = p.src + (long long)blockIdx.y * p.src_stream_stride + (long long)srow_idx * COLS;
+	float* __restrict__ drow = p.dst + (long long)blockIdx.y * p.dst_stream_stride + (long long)row * COLS;
+
+	// ---- HBM -> LDS image.  Column c is image word c + 24; thread tid holds columns 4*tid + 1024*i.
+	{
+		float4 x[4];
 #pragma unroll
-		for (int i = 0; i < NLD; ++i) {
-			int vc = c_lo + 4 * (tid + 256 * i);
-			vc = vc < 0 ? 0 : (vc > cols - 4 ? cols - 4 : vc);
-			x[i] = *reinterpret_cast<const float4*>(srow + vc);
+		for (int i = 0; i < 4; ++i)
+			x[i] = NT ? load_nt(srow + 4 * tid + 1024 * i) : *reinterpret_cast<const float4*>(srow + 4 * tid + 1024 * i);
+		int* wr = unit_ptr(img, tid + 6);
+#pragma unroll
+		for (int i = 0; i < 4; ++i)
+			*reinterpret_cast<int4*>(wr + i * 64 * RSTR) = make_int4(to_key<NONNEG>(x[i].x), to_key<NONNEG>(x[i].y),
+			                                                         to_key<NONNEG>(x[i].z), to_key<NONNEG>(x[i].w));
+		// replicate border (ippBorderRepl): words 0..23 = x[0], words 4120..4143 = x[4095]
+		if (wave == 0) {
+			const int b = __builtin_amdgcn_readfirstlane(to_key<NONNEG>(x[0].x));
+			if (lane < 6)
+				*reinterpret_cast<int4*>(unit_ptr(img, lane)) = make_int4(b, b, b, b);
 		}
-	};
-
-	// persistent: a workgroup walks over row segments; the HBM loads of the next segment are in flight
-	// while the current one is sorted.
-	long long sg = blockIdx.x;
-	if (sg < total) {
-		locate(sg);
-		issue_loads();
+		if (wave == 3) {
+			const int b = __builtin_amdgcn_readlane(to_key<NONNEG>(x[3].w), 63);
+			if (lane < 6)
+				*reinterpret_cast<int4*>(unit_ptr(img, 1030 + lane)) = make_int4(b, b, b, b);
+		}
 	}
-	while (sg < total) {
-		float* const drow_cur = drow;
-		const int col0_cur = col0;
-		{
-			const int c_lo = col0 - 24;
-#pragma unroll
-			for (int i = 0; i < NLD; ++i) {
-				const int vi = tid + 256 * i;
-				const int vc = c_lo + 4 * vi;
-				if (vi < NVEC) {
-					int4 k = make_int4(to_key<NONNEG>(x[i].x), to_key<NONNEG>(x[i].y), to_key<NONNEG>(x[i].z),
-					                   to_key<NONNEG>(x[i].w));
-					if (vc < 0) // replicate border (ippBorderRepl)
-						k = make_int4(k.x, k.x, k.x, k.x);
-					else if (vc >= cols)
-						k = make_int4(k.w, k.w, k.w, k.w);
-					*reinterpret_cast<int4*>(&raw[(vi >> 2) * RSTR + 4 * (vi & 3)]) = k;
-				}
-			}
-		}
-		const long long next = sg + gridDim.x;
-		if (next < total) {
-			locate(next);
-			issue_loads();
-		}
-		__syncthreads();
+	__syncthreads();
 
-		// ---- own block + both flanks into registers, then the sorted block replaces the raw one
-		constexpr int W = 47, T = 16, NE = W + T - 1;
-		int e[NE]; // e[q] = x[16t-23+q]; only the flanks e[0..14], e[47..61] are filled
-		int A[16];
-		{
-			int lo[16], hi[16];
-			znet::lds_load<16>(&raw[tid * RSTR], lo);       // B(t-1) = x[16t-24 .. 16t-9]
-			znet::lds_load<16>(&raw[(tid + 3) * RSTR], hi); // B(t+2) = x[16t+24 .. 16t+39]
+	int out[16];
+	if constexpr (VARIANT == 2) {
+		znet::lds_load<16>(&img[(tid + 1) * RSTR + 8], out);
+		znet::lds_load<8>(&img[(tid + 2) * RSTR], *reinterpret_cast<int(*)[8]>(&out[8]));
+	}
+	else {
+	// ---- own block B(tid) = chunk tid + 1: sorted, with its sorted halves and quarters
+	int s16[16], oct[16], quad[16];
+	{
+		int raw[16];
+		znet::lds_load<16>(&img[(tid + 1) * RSTR], raw);
+		znet::pyramid16(raw, s16, oct, quad);
+	}
+	// pieces wanted by the lanes to the left (they sit two and one blocks below this one) ...
+	int up[16], dn[16];
 #pragma unroll
-			for (int q = 0; q < 15; ++q) {
-				e[q] = lo[q + 1];
-				e[47 + q] = hi[q];
-			}
+	for (int i = 0; i < 8; ++i) {
+		up[i] = oct[i];     // lower half
+		dn[i] = oct[8 + i]; // upper half
+	}
 #pragma unroll
-			for (int q = 15; q < 47; ++q)
-				e[q] = 0; // the 32 common samples come from the sorted blocks instead
-			znet::lds_load<16>(&raw[(tid + 1) * RSTR], A);
-		}
-		int extra[16];
-		if (tid == 0)
-			znet::lds_load<16>(&raw[257 * RSTR], extra); // B(256): right neighbour of the last thread
-		__syncthreads();
-		znet::sort_net<16>(A);
-		znet::lds_store<16>(&raw[(tid + 1) * RSTR], A);
-		if (tid == 0) {
-			znet::sort_net<16>(extra);
-			znet::lds_store<16>(&raw[257 * RSTR], extra);
-		}
-		__syncthreads();
-		int cand[16], out[16];
-		{
-			int B[16];
-			znet::lds_load<16>(&raw[(tid + 2) * RSTR], B);
-			znet::mid16_of_two_sorted16(A, B, cand);
-		}
-		__syncthreads(); // sorted blocks are consumed: the image now collects the results
-		znet::Node<W, T, 0, NE, T>::run(e, cand, out);
-		znet::lds_store<16>(&raw[tid * RSTR], out);
-		__syncthreads();
-
+	for (int i = 0; i < 4; ++i) {
+		up[8 + i] = quad[i];      // 1st quarter
+		up[12 + i] = quad[8 + i]; // 3rd quarter
+		dn[8 + i] = quad[4 + i];  // ... and by the lane to the right: 2nd and 4th quarter
+		dn[12 + i] = quad[12 + i];
+	}
+	// ---- wave edges through LDS
+	if (wave > 0 && lane < 2) {
+		int* e = &edge[wave - 1][32 + 16 * lane];
+		znet::lds_store<16>(e, up);
+		if (lane == 0)
+			znet::lds_store<16>(&edge[wave - 1][16], s16);
+	}
+	if (wave < 3 && lane == 63)
+		znet::lds_store<16>(&edge[wave + 1][0], dn);
+	if (tid == 0) { // B(-1) = 16 copies of x[0]
+		const int b = img[0];
+		const int4 q = make_int4(b, b, b, b);
+#pragma unroll
+		for (int i = 0; i < 4; ++i)
+			*reinterpret_cast<int4*>(&edge[0][4 * i]) = q;
+	}
+	if (tid == 255) { // B(256) = x[4088..4095] and eight copies of c = x[4095]; B(257) = 16 copies of c
+		int w[8];
+		znet::lds_load<8>(&img[257 * RSTR], w);
+		const int c = w[7];
+		znet::oe_merge<2, 0>(w);
+		znet::oe_merge<2, 2>(w);
+		znet::oe_merge<2, 4>(w);
+		znet::oe_merge<2, 6>(w);
+		znet::oe_merge<4, 0>(w);
+		znet::oe_merge<4, 4>(w);
+		int pc[16], s[16];
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
-			const int g = 4 * tid + 1024 * i;
-			const int c = col0_cur + g;
-			if (c < cols) {
-				const int4 k = *reinterpret_cast<const int4*>(&raw[(g >> 4) * RSTR + (g & 15)]);
-				*reinterpret_cast<float4*>(drow_cur + c) = make_float4(from_key<NONNEG>(k.x), from_key<NONNEG>(k.y),
-				                                                       from_key<NONNEG>(k.z), from_key<NONNEG>(k.w));
-			}
+			pc[8 + i] = w[i]; // 1st quarter sorted
+			pc[12 + i] = c;   // 3rd quarter
 		}
-		__syncthreads(); // results are out of the image before the next segment is staged
-		sg = next;
+		znet::oe_merge<8, 0>(w);
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			pc[i] = w[i];            // lower half sorted
+			s[i] = min(w[i], c);     // the block sorted: the eight samples with eight copies of c spliced in
+			s[8 + i] = max(w[i], c);
+		}
+		znet::lds_store<16>(&edge[3][16], s);
+		znet::lds_store<16>(&edge[3][32], pc);
+		const int4 q = make_int4(c, c, c, c);
+#pragma unroll
+		for (int i = 0; i < 4; ++i)
+			*reinterpret_cast<int4*>(&edge[3][48 + 4 * i]) = q;
+	}
+	__syncthreads();
+
+	// ---- neighbours' pieces: DPP shifts, the wave's edge record as `old`
+	znet::Shared47 sh;
+	{
+		const int* ed = edge[wave];
+		int eb[16], B[16];
+		znet::lds_load<16>(ed + 16, eb);
+#pragma unroll
+		for (int i = 0; i < 16; ++i)
+			B[i] = dpp_from_next(eb[i], s16[i]);
+		znet::mid16_of_two_sorted16(s16, B, sh.cand);
+		int e0[16], e1[16], el[16], hi[16], lo[16];
+		znet::lds_load<16>(ed + 32, e0);
+		znet::lds_load<16>(ed + 48, e1);
+		znet::lds_load<16>(ed, el);
+#pragma unroll
+		for (int i = 0; i < 16; ++i) {
+			const int x1 = dpp_from_next(e0[i], up[i]); // pieces of B(t+1)
+			hi[i] = dpp_from_next(e1[i], x1);           // pieces of B(t+2)
+			lo[i] = dpp_from_prev(el[i], dn[i]);        // pieces of B(t-1)
+		}
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			sh.lo_oct[i] = lo[i];
+			sh.hi_oct[i] = hi[i];
+		}
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			sh.lo_q[0][i] = lo[8 + i];
+			sh.lo_q[1][i] = lo[12 + i];
+			sh.hi_q[0][i] = hi[8 + i];
+			sh.hi_q[1][i] = hi[12 + i];
+		}
+	}
+	znet::lds_load<16>(&img[tid * RSTR], sh.lo_raw);       // B(t-1) as it stands
+	znet::lds_load<16>(&img[(tid + 3) * RSTR], sh.hi_raw); // B(t+2)
+
+	znet::medians47_shared(sh, out);
+	}
+
+	if constexpr (DIRECT) {
+#pragma unroll
+		for (int v = 0; v < 4; ++v)
+			*reinterpret_cast<float4*>(drow + 16 * tid + 4 * v) =
+			    make_float4(from_key<NONNEG>(out[4 * v]), from_key<NONNEG>(out[4 * v + 1]),
+			                from_key<NONNEG>(out[4 * v + 2]), from_key<NONNEG>(out[4 * v + 3]));
+	}
+	else {
+		__syncthreads(); // every flank is in registers: the image can take the results
+		znet::lds_store<16>(&img[tid * RSTR], out);
+		__syncthreads();
+		const int* rd = unit_ptr(img, tid);
+		if (VARIANT == 3 && p.ring > 0) // always true: the host never passes ring <= 0
+			return;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const int4 k = *reinterpret_cast<const int4*>(rd + i * 64 * RSTR);
+			const float4 r = make_float4(from_key<NONNEG>(k.x), from_key<NONNEG>(k.y), from_key<NONNEG>(k.z), from_key<NONNEG>(k.w));
+			if (NT)
+				store_nt(drow + 4 * tid + 1024 * i, r);
+			else
+				*reinterpret_cast<float4*>(drow + 4 * tid + 1024 * i) = r;
+		}
 	}
 }
 
 } // namespace
 
-// 47 taps, frequency direction, vector-aligned geometry.  *handled = false: use the generic kernel.
-int launch_median47_shared(const FilterArgs& a, hipStream_t stream, bool* handled)
+// 47 taps, frequency direction, whole 4096-bin rows, 16-byte aligned.  *handled = false: generic kernel.
+int launch_median47_dpp(const FilterArgs& a, hipStream_t stream, bool* handled)
 {
 	*handled = false;
-	if (a.len != 47 || a.direction != ZEN_HIP_FREQUENCY || !g_opt_median47_shared)
+	if (a.len != 47 || a.direction != ZEN_HIP_FREQUENCY || a.cols != COLS || g_opt_no_median47_dpp)
 		return ZEN_HIP_OK;
-	const bool vec_ok = (a.cols % 4 == 0) && a.cols >= 4 && ((reinterpret_cast<uintptr_t>(a.src) & 15) == 0)
-	                    && ((reinterpret_cast<uintptr_t>(a.dst) & 15) == 0) && (a.src_stream_stride % 4 == 0)
-	                    && (a.dst_stream_stride % 4 == 0);
-	if (!vec_ok || a.ring_rows <= 0 || a.ring_rows > 0x3fffffff || a.n_out_rows > 0x3fffffff)
+	const bool vec_ok = ((reinterpret_cast<uintptr_t>(a.src) & 15) == 0) && ((reinterpret_cast<uintptr_t>(a.dst) & 15) == 0)
+	                    && (a.src_stream_stride % 4 == 0) && (a.dst_stream_stride % 4 == 0);
+	if (!vec_ok || a.ring_rows <= 0 || a.ring_rows > 0x3fffffff || a.n_out_rows > a.ring_rows)
+		return ZEN_HIP_OK;
+	// the row clamp of the time direction never acts on a frequency filter's own rows; if a caller asks for
+	// rows outside [clamp_lo, clamp_hi] anyway, the generic kernel (which clamps) takes the call
+	if (a.first_row < a.clamp_lo || a.first_row + a.n_out_rows - 1 > a.clamp_hi)
 		return ZEN_HIP_OK;
 	*handled = true;
-	const int segs = (a.cols + OUTS - 1) / OUTS;
-	const int row_base = (int)(a.first_row % a.ring_rows);
-	long long blocks = (long long)a.n_out_rows * segs * a.n_streams;
-	if (g_opt_median47_blocks > 0 && blocks > g_opt_median47_blocks)
-		blocks = g_opt_median47_blocks; // persistent: a few workgroups per CU
-	dim3 grid((unsigned)blocks);
-	if (a.nonneg)
-		hipLaunchKernelGGL((median47_shared_kernel<true>), grid, dim3(256), 0, stream, a, row_base, (int)a.ring_rows, segs);
-	else
-		hipLaunchKernelGGL((median47_shared_kernel<false>), grid, dim3(256), 0, stream, a, row_base, (int)a.ring_rows, segs);
+	M47Args p;
+	p.src = a.src;
+	p.dst = a.dst;
+	p.src_stream_stride = a.src_stream_stride;
+	p.dst_stream_stride = a.dst_stream_stride;
+	p.ring = (int)a.ring_rows;
+	p.row_base = (int)(((a.first_row % a.ring_rows) + a.ring_rows) % a.ring_rows);
+	dim3 grid((unsigned)a.n_out_rows, (unsigned)a.n_streams);
+	const int variant = g_opt_median47_variant;
+#define ZH_M47(NN, V) hipLaunchKernelGGL((median47_dpp_kernel<NN, V>), grid, dim3(256), 0, stream, p)
+	if (a.nonneg) {
+		switch (variant) {
+		case 1: ZH_M47(true, 1); break;
+		case 2: ZH_M47(true, 2); break;
+		case 3: ZH_M47(true, 3); break;
+		case 4: ZH_M47(true, 4); break;
+		default: ZH_M47(true, 0); break;
+		}
+	}
+	else {
+		switch (variant) {
+		case 1: ZH_M47(false, 1); break;
+		case 2: ZH_M47(false, 2); break;
+		case 3: ZH_M47(false, 3); break;
+		case 4: ZH_M47(false, 4); break;
+		default: ZH_M47(false, 0); break;
+		}
+	}
+#undef ZH_M47
 	ZH_HIP(hipGetLastError());
 	return ZEN_HIP_OK;
 }

@@ -19,7 +19,9 @@
 // integer min/max per output instead of ~250 for a per-window selection network.  Samples are ordered
 // through the monotone float->int key, so the output is the bit pattern of an input sample.
 #pragma once
+#ifndef ZNET_HOST_TEST // tests/cpp/test_median_net_host.cpp runs the networks on the CPU with its own shims
 #include <hip/hip_runtime.h>
+#endif
 
 namespace znet {
 
@@ -65,9 +67,13 @@ __device__ __forceinline__ void lds_store(int* p, const int* v)
 
 __device__ __forceinline__ int med3i(int a, int b, int c)
 {
+#ifdef ZNET_HOST_TEST
+	return max(min(a, b), min(max(a, b), c));
+#else
 	int r;
 	asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
 	return r;
+#endif
 }
 
 // Batcher's merge exchange (Knuth 5.2.2 Algorithm M) for any N, as a compile-time comparator list.
@@ -231,7 +237,7 @@ __device__ __forceinline__ void medians(const int (&e)[NE], int (&out)[T])
 } // namespace znet
 
 // ---------------------------------------------------------------------------------------------------
-// Pieces of the block-sharing 47-tap kernel (median_net.hip: median47_shared_kernel).
+// Pieces of the block-sharing 47-tap kernel (median47.hip: median47_dpp_kernel; rt_fused.hip).
 namespace znet {
 
 // Batcher odd-even merge of the two sorted halves of a[0..N) (N a power of two), as a comparator list.

@@ -263,7 +263,7 @@ int launch_t(const RtFusedArgs& a, hipStream_t stream)
 
 } // namespace
 
-int g_opt_block_fused_minb = 3;
+opt_t g_opt_block_fused_minb{3};
 
 // (transform size, frequency mask) pairs with a fused kernel: hops 128..1024 at 44.1 and 48 kHz
 bool rt_fused_available(int log2n, int freq_len)

@@ -6,12 +6,83 @@ process group (RCCL on GPUs, gloo in the CPU tests) carries a barrier and a few 
 wall time, unit counts and an output checksum so that rank 0 can print the whole-job figure.
 """
 import os
+import socket
+import subprocess
+import sys
 
 
 def env_world():
     """(rank, local_rank, world_size) from the torchrun environment; (0, 0, 1) when launched plainly."""
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
             int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def launched_by_torchrun():
+    """True when RANK / WORLD_SIZE are already in the environment (torch.distributed.run, or spawn_ranks)."""
+    return "RANK" in os.environ and "WORLD_SIZE" in os.environ
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(argv, n, timeout=None, env_extra=None):
+    """Run `argv` as n fresh child processes, one per GPU of this node (RANK = LOCAL_RANK = 0..n-1,
+    WORLD_SIZE = n, MASTER_ADDR = 127.0.0.1, a free MASTER_PORT), the same environment torch.distributed.run
+    would give them.  The caller must not have touched the GPU: nothing here imports torch or loads the HIP
+    library, and the children are new interpreters (no fork of a GPU context, no exec from one).
+
+    Rank 0's stdout is relayed to ours (the one JSON line of bench.py); every rank's stderr goes to ours.
+    Returns 0 when every rank exited 0, else the first non-zero exit code (the remaining ranks are
+    terminated so that a dead rank cannot leave the others waiting in a collective forever)."""
+    if n < 1:
+        raise ValueError("spawn_ranks: n must be >= 1")
+    import tempfile
+    import time
+    port = _free_port()
+    procs = []
+    rc = 0
+    with tempfile.TemporaryFile() as out0:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
+            if env_extra:
+                env.update(env_extra)
+            procs.append(subprocess.Popen(argv, env=env, stdout=out0 if r == 0 else subprocess.DEVNULL))
+        deadline = None if timeout is None else time.monotonic() + timeout
+        try:
+            while True:
+                codes = [p.poll() for p in procs]
+                bad = [c for c in codes if c not in (None, 0)]
+                if bad:
+                    rc = bad[0]
+                    break
+                if all(c == 0 for c in codes):
+                    break
+                if deadline is not None and time.monotonic() > deadline:
+                    rc = 124
+                    break
+                time.sleep(0.05)
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+        out0.seek(0)
+        data = out0.read()
+    if data:
+        sys.stdout.write(data.decode(errors="replace"))
+        sys.stdout.flush()
+    return rc
 
 
 def shard_units(n_units, world, rank, lengths=None):

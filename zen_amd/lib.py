@@ -40,6 +40,7 @@ _vp, _sz, _i, _u, _f = C.c_void_p, C.c_size_t, C.c_int, C.c_uint, C.c_float
 _pvp = C.POINTER(C.c_void_p)
 SYMBOLS = [
     ("zen_hip_init", _i, [_i]),
+    ("zen_hip_device_count", _i, [C.POINTER(C.c_int)]),
     ("zen_hip_last_error", C.c_char_p, []),
     ("zen_hip_version", C.c_char_p, []),
     ("zen_hip_device_name", _i, [C.c_char_p, _sz]),
