@@ -306,6 +306,25 @@ def test_hpr_sse_filter(z, hop, caus):
     assert same(got, ref)
 
 
+@pytest.mark.parametrize("hop,first,block", [(512, 16, 16), (1024, 12, 5), (256, 30, 30), (512, 7, 1)])
+def test_hpr_switch_to_sse_after_block_calls(z, hop, first, block):
+    """use_sse_filter() may be called at any time (hps.h:289).  The causal median path runs blocks of hops
+    through the fused kernel, which keeps no rings; the hop after the switch filters the magnitudes of the
+    stft_width-1 frames before it (causal time box filter), so those rows must be there all the same."""
+    n_hops = first + 14
+    x = music(hop * n_hops, 21)
+    h = o.HPR(44100.0, hop, 2.0, ALL, o.TIME_CAUSAL)
+    ref_a = h.process_stream(x[:first * hop])
+    h.use_sse_filter()
+    ref_b = h.process_stream(x[first * hop:])
+    g = z.HPR(44100.0, hop, 2.0, ALL, z.TIME_CAUSAL)
+    got_a = g.process_stream_host(x[:first * hop], block=block)
+    g.use_sse_filter()
+    got_b = g.process_stream_host(x[first * hop:], block=3)
+    assert same(got_a, ref_a)
+    assert same(got_b, ref_b)
+
+
 def test_hpr_multi_stream_matches_single(z):
     fs, hop, n_hops, S = 44100.0, 256, 40, 5
     x = np.stack([noise(hop * n_hops, 100 + s) for s in range(S)])

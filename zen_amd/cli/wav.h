@@ -41,27 +41,37 @@ namespace wav {
 		int format = 0, bits = 0;
 		const unsigned char* data = nullptr;
 		std::size_t data_bytes = 0;
+		// Chunk sizes come from the file: every read below is bounded by what the buffer really holds.
 		while (pos + 8 <= buf.size()) {
-			const uint32_t sz = rd32(&buf[pos + 4]);
-			const unsigned char* body = &buf[pos + 8];
+			const std::size_t sz = rd32(&buf[pos + 4]);
+			const std::size_t avail = buf.size() - (pos + 8); // bytes of this chunk's body that exist
+			const unsigned char* body = buf.data() + pos + 8;
 			if (!memcmp(&buf[pos], "fmt ", 4) && sz >= 16) {
+				if (avail < 16)
+					throw std::runtime_error(path + ": truncated fmt chunk");
 				format = rd16(body);
 				out.channelCount = rd16(body + 2);
 				out.sampleRate = (int)rd32(body + 4);
 				out.frameSize = rd16(body + 12);
 				bits = rd16(body + 14);
-				if (format == 0xFFFE && sz >= 26) // WAVE_FORMAT_EXTENSIBLE: sub-format GUID's first word
+				if (format == 0xFFFE && sz >= 26 && avail >= 26) // WAVE_FORMAT_EXTENSIBLE: sub-format GUID's first word
 					format = rd16(body + 24);
 			}
 			else if (!memcmp(&buf[pos], "data", 4)) {
 				data = body;
-				data_bytes = std::min<std::size_t>(sz, buf.size() - (pos + 8));
+				data_bytes = std::min<std::size_t>(sz, avail);
 			}
+			if (sz > avail)
+				break; // the last chunk runs past the end of the file
 			pos += 8 + sz + (sz & 1);
 		}
-		if (!data || !out.channelCount || !bits)
+		if (!data || !bits)
 			throw std::runtime_error(path + ": missing fmt/data chunk");
-		const std::size_t n = data_bytes / (bits / 8);
+		if (out.channelCount <= 0 || out.sampleRate <= 0)
+			throw std::runtime_error(path + ": bad channel count or sample rate");
+		if (bits % 8 != 0 || bits < 8)
+			throw std::runtime_error(path + ": unsupported WAV encoding (bits per sample must be a multiple of 8)");
+		const std::size_t n = data_bytes / (std::size_t)(bits / 8);
 		out.samples.resize(n);
 		if (format == 1 && bits == 16) {
 			for (std::size_t i = 0; i < n; ++i)

@@ -18,6 +18,7 @@ opt_t g_opt_no_median47_neighbour{0};
 opt_t g_opt_no_istft_multi{0};
 opt_t g_opt_no_median47_dpp{0};
 opt_t g_opt_median47_variant{0};
+opt_t g_opt_rt_fused_diag{0};
 
 void set_error(const char* fmt, ...)
 {
@@ -143,7 +144,8 @@ int zen_hip_set_option(const char* name, int value)
 	             {"no_istft_multi", &g_opt_no_istft_multi},
 	             {"block_fused_minb", &g_opt_block_fused_minb},
 	             {"no_median47_dpp", &g_opt_no_median47_dpp},
-	             {"median47_variant", &g_opt_median47_variant}};
+	             {"median47_variant", &g_opt_median47_variant},
+	             {"rt_fused_diag", &g_opt_rt_fused_diag}};
 	for (const auto& t : table) {
 		if (name && !strcmp(name, t.name)) {
 			t.var->store(value, std::memory_order_relaxed);
@@ -235,6 +237,8 @@ int zen_hip_fft_create(size_t nfft, zen_hip_fft_t* h)
 	make_twiddles(tw.data(), nfft);
 	if (hipMalloc((void**)&f->tw, sizeof(float) * nfft) != hipSuccess
 	    || hipMemcpy(f->tw, tw.data(), sizeof(float) * nfft, hipMemcpyHostToDevice) != hipSuccess) {
+		(void)hipFree(f->tw);
+		(void)hipGetLastError();
 		delete f;
 		ZH_FAIL(ZEN_HIP_E_HIP, "fft_create: device allocation failed");
 	}

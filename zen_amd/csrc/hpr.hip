@@ -143,6 +143,7 @@ int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 	a.S = M == 1 ? e->d_S : nullptr; // causal: no later frame reads the rings (the time median is the identity)
 	a.s_stride = (long long)e->s_stride;
 	a.mag = e->d_mag;
+	a.keep_mag_rows = (int)e->W - 1;
 	a.ring_rows = e->ring_rows;
 	a.row0 = e->abs_frame;
 	a.hop = (int)e->hop;
@@ -164,6 +165,7 @@ int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 	a.power = (int)e->beta;
 	a.out_h = e->out_h ? 1 : 0;
 	a.out_p = e->out_p ? 1 : 0;
+	a.diag = g_opt_rt_fused_diag;
 	{
 		ProfScope ps(e, zen_hip_hpr::K_FUSED);
 		ZH_TRY(launch_rt_fused(e->log2n, e->mf, a, e->stream));

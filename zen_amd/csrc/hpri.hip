@@ -419,8 +419,12 @@ int zen_hip_hpri_process(zen_hip_hpri_t h, const float* audio_host, size_t n, fl
 	if (n > h->stage_cap) {
 		ZH_HIP(hipStreamSynchronize(h->stream));
 		(void)hipFree(h->stage_in);
-		for (int i = 0; i < 3; ++i)
+		h->stage_in = nullptr; // a failed allocation below must not leave freed pointers behind a stale capacity
+		for (int i = 0; i < 3; ++i) {
 			(void)hipFree(h->stage_out[i]);
+			h->stage_out[i] = nullptr;
+		}
+		h->stage_cap = 0;
 		ZH_HIP(hipMalloc((void**)&h->stage_in, sizeof(float) * n));
 		for (int i = 0; i < 3; ++i)
 			ZH_HIP(hipMalloc((void**)&h->stage_out[i], sizeof(float) * n));

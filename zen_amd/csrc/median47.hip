@@ -29,7 +29,7 @@
 // kernel).  HBM traffic is unchanged: 4 B read + 4 B written per element.
 #include "common.h"
 #include "filters.h"
-#include "median_net.h"
+#include "median47_core.h"
 
 #pragma clang fp contract(off)
 
@@ -37,7 +37,7 @@ namespace zen_hip_impl {
 namespace {
 
 constexpr int NCH = 259;  // image chunks: blocks u = -1 .. 257  <->  chunk c = u + 1
-constexpr int RSTR = 20;  // 16 words + 4 pad per chunk (5c mod 16 distinct: ds_read_b128 is conflict free)
+using zm47::RSTR;
 constexpr int COLS = 4096;
 
 using znet::from_key;
@@ -49,15 +49,6 @@ struct M47Args {
 	long long src_stream_stride, dst_stream_stride;
 	int row_base, ring; // source row of output row r: (row_base + r) % ring, with row_base < ring, r < ring
 };
-
-__device__ __forceinline__ int dpp_from_next(int old, int v) // lane i <- lane i+1; lane 63 keeps `old`
-{
-	return __builtin_amdgcn_update_dpp(old, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-}
-__device__ __forceinline__ int dpp_from_prev(int old, int v) // lane i <- lane i-1; lane 0 keeps `old`
-{
-	return __builtin_amdgcn_update_dpp(old, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-}
 
 // Streaming accesses: every input is read once and every output written once, so both bypass the caches'
 // retention ("nt"): the plain copy of this shape runs 154 us, the nontemporal one 139 us
@@ -135,112 +126,11 @@ __global__ __launch_bounds__(256) void median47_dpp_kernel(M47Args p)
 		znet::lds_load<8>(&img[(tid + 2) * RSTR], *reinterpret_cast<int(*)[8]>(&out[8]));
 	}
 	else {
-	// ---- own block B(tid) = chunk tid + 1: sorted, with its sorted halves and quarters
-	int s16[16], oct[16], quad[16];
-	{
-		int raw[16];
-		znet::lds_load<16>(&img[(tid + 1) * RSTR], raw);
-		znet::pyramid16(raw, s16, oct, quad);
-	}
-	// pieces wanted by the lanes to the left (they sit two and one blocks below this one) ...
-	int up[16], dn[16];
-#pragma unroll
-	for (int i = 0; i < 8; ++i) {
-		up[i] = oct[i];     // lower half
-		dn[i] = oct[8 + i]; // upper half
-	}
-#pragma unroll
-	for (int i = 0; i < 4; ++i) {
-		up[8 + i] = quad[i];      // 1st quarter
-		up[12 + i] = quad[8 + i]; // 3rd quarter
-		dn[8 + i] = quad[4 + i];  // ... and by the lane to the right: 2nd and 4th quarter
-		dn[12 + i] = quad[12 + i];
-	}
-	// ---- wave edges through LDS
-	if (wave > 0 && lane < 2) {
-		int* e = &edge[wave - 1][32 + 16 * lane];
-		znet::lds_store<16>(e, up);
-		if (lane == 0)
-			znet::lds_store<16>(&edge[wave - 1][16], s16);
-	}
-	if (wave < 3 && lane == 63)
-		znet::lds_store<16>(&edge[wave + 1][0], dn);
-	if (tid == 0) { // B(-1) = 16 copies of x[0]
-		const int b = img[0];
-		const int4 q = make_int4(b, b, b, b);
-#pragma unroll
-		for (int i = 0; i < 4; ++i)
-			*reinterpret_cast<int4*>(&edge[0][4 * i]) = q;
-	}
-	if (tid == 255) { // B(256) = x[4088..4095] and eight copies of c = x[4095]; B(257) = 16 copies of c
-		int w[8];
-		znet::lds_load<8>(&img[257 * RSTR], w);
-		const int c = w[7];
-		znet::oe_merge<2, 0>(w);
-		znet::oe_merge<2, 2>(w);
-		znet::oe_merge<2, 4>(w);
-		znet::oe_merge<2, 6>(w);
-		znet::oe_merge<4, 0>(w);
-		znet::oe_merge<4, 4>(w);
-		int pc[16], s[16];
-#pragma unroll
-		for (int i = 0; i < 4; ++i) {
-			pc[8 + i] = w[i]; // 1st quarter sorted
-			pc[12 + i] = c;   // 3rd quarter
-		}
-		znet::oe_merge<8, 0>(w);
-#pragma unroll
-		for (int i = 0; i < 8; ++i) {
-			pc[i] = w[i];            // lower half sorted
-			s[i] = min(w[i], c);     // the block sorted: the eight samples with eight copies of c spliced in
-			s[8 + i] = max(w[i], c);
-		}
-		znet::lds_store<16>(&edge[3][16], s);
-		znet::lds_store<16>(&edge[3][32], pc);
-		const int4 q = make_int4(c, c, c, c);
-#pragma unroll
-		for (int i = 0; i < 4; ++i)
-			*reinterpret_cast<int4*>(&edge[3][48 + 4 * i]) = q;
-	}
-	__syncthreads();
-
-	// ---- neighbours' pieces: DPP shifts, the wave's edge record as `old`
-	znet::Shared47 sh;
-	{
-		const int* ed = edge[wave];
-		int eb[16], B[16];
-		znet::lds_load<16>(ed + 16, eb);
-#pragma unroll
-		for (int i = 0; i < 16; ++i)
-			B[i] = dpp_from_next(eb[i], s16[i]);
-		znet::mid16_of_two_sorted16(s16, B, sh.cand);
-		int e0[16], e1[16], el[16], hi[16], lo[16];
-		znet::lds_load<16>(ed + 32, e0);
-		znet::lds_load<16>(ed + 48, e1);
-		znet::lds_load<16>(ed, el);
-#pragma unroll
-		for (int i = 0; i < 16; ++i) {
-			const int x1 = dpp_from_next(e0[i], up[i]); // pieces of B(t+1)
-			hi[i] = dpp_from_next(e1[i], x1);           // pieces of B(t+2)
-			lo[i] = dpp_from_prev(el[i], dn[i]);        // pieces of B(t-1)
-		}
-#pragma unroll
-		for (int i = 0; i < 8; ++i) {
-			sh.lo_oct[i] = lo[i];
-			sh.hi_oct[i] = hi[i];
-		}
-#pragma unroll
-		for (int i = 0; i < 4; ++i) {
-			sh.lo_q[0][i] = lo[8 + i];
-			sh.lo_q[1][i] = lo[12 + i];
-			sh.hi_q[0][i] = hi[8 + i];
-			sh.hi_q[1][i] = hi[12 + i];
-		}
-	}
-	znet::lds_load<16>(&img[tid * RSTR], sh.lo_raw);       // B(t-1) as it stands
-	znet::lds_load<16>(&img[(tid + 3) * RSTR], sh.hi_raw); // B(t+2)
-
-	znet::medians47_shared(sh, out);
+		// ---- own block sorted, wave edges published; then the neighbours' pieces and the selection tree
+		zm47::Pieces pc;
+		zm47::m47_sort_and_publish(img, edge, tid, lane, wave, tid == 0, tid == 255, pc);
+		__syncthreads();
+		zm47::m47_select(img, edge, tid, wave, pc, out);
 	}
 
 	if constexpr (DIRECT) {

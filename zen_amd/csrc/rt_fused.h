@@ -15,6 +15,7 @@ struct RtFusedArgs {
 	float2* S;              // spectrum ring (bins 0..nfft/2 per row); null: rings are not written
 	long long s_stride;
 	float* mag;             // magnitude ring
+	int keep_mag_rows;      // block calls (S == null) still write the magnitude rows of their last keep_mag_rows frames
 	long long ring_rows;
 	long long row0;         // absolute row of the first frame
 	int hop;
@@ -28,6 +29,7 @@ struct RtFusedArgs {
 	int out_id[3];
 	float beta, beta_h, cola;
 	int soft, power, out_h, out_p;
+	int diag;               // 0; 1 / 2: timing diagnostics of rt_fused_kernel (results are not valid)
 };
 
 bool rt_fused_available(int log2n, int freq_len);

@@ -19,6 +19,7 @@
 #include "common.h"
 #include "fft_dev.h"
 #include "masks.h"
+#include "median47_core.h"
 #include "median_net.h"
 #include "rt_fused.h"
 
@@ -76,8 +77,9 @@ struct FwdOut {
 			const int mir = (idx == 0 || idx == (n >> 1)) ? idx : n - idx;
 			img[RtImage<T>::addr(idx + mid_al)] = key;
 			img[RtImage<T>::addr(mir + mid_al)] = key;
-			if (S) { // rings are only kept for single-hop calls
+			if (S) // the spectrum ring is only kept for single-hop calls
 				S[idx] = X;
+			if (mag) { // the magnitude ring: single-hop calls and the last stft_width-1 frames of a block
 				mag[idx] = m;
 				mag[mir] = m;
 			}
@@ -85,6 +87,11 @@ struct FwdOut {
 	}
 };
 
+// HALF: only bins 0..N/2 and the last MID bins of the P row were filtered.  |S| is exactly Hermitian, so for
+// MID < k < N/2 the window of bin N-k is the mirror image of the window of bin k and P[N-k] == P[k] bit for
+// bit; the MID bins next to either end see different replicate borders (|S[0]| against |S[N-1]| = |S[1]|,
+// SURVEY Q7) and are filtered on both sides.
+template <int N, int TF, int MID, bool HALF>
 struct InvIn {
 	const Regs* r;
 	const float* P; // LDS, natural bin order
@@ -92,8 +99,18 @@ struct InvIn {
 	int which;
 	__device__ __forceinline__ float2 operator()(int idx, int slot) const
 	{
+		int pi = idx; // idx = tf + slot*TF; `slot` is a constant after unrolling, so the first two tests fold
+		if (HALF) {
+			const int lo = slot * TF, hi = lo + TF - 1;
+			if (hi <= N / 2)
+				pi = idx;
+			else if (lo > N / 2 && hi < N - MID)
+				pi = N - idx;
+			else
+				pi = (idx > N / 2 && idx < N - MID) ? N - idx : idx;
+		}
 		const float2 z = r->S[slot];
-		const float m = mask_value(which, r->mag[slot], P[idx], cfg);
+		const float m = mask_value(which, r->mag[slot], P[pi], cfg);
 		return make_float2(z.x * m, z.y * m); // apply_mask_functor hps.h:58-66
 	}
 };
@@ -119,6 +136,9 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 	constexpr int NCHUNK = N / T, CPT = 16 / T; // median chunks in the row / per thread
 	constexpr int IMG_WORDS = IM::words((NCHUNK - 1) * T + NE);
 	static_assert(IMG_WORDS * 4 <= PL::LDS_FLOAT2 * 8, "magnitude image must fit in the FFT image");
+	// 47 taps on 4096 bins (hop 1024 at 44.1 kHz, the headline configuration): the block scheme of
+	// median47_core.h on the half spectrum
+	constexpr bool BLOCK47 = (W == 47 && LOG2N == 12);
 
 	extern __shared__ float2 lds[];       // [FFT image | P row]; the magnitude image aliases the FFT image
 	int* img = reinterpret_cast<int*>(lds);
@@ -156,7 +176,9 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		FwdOut<T> out;
 		out.r = &r;
 		out.S = a.S ? a.S + row * a.s_stride : nullptr;
-		out.mag = a.S ? a.mag + row * N : nullptr;
+		// A later use_sse_filter() (allowed at any time, hps.h:289) makes the next hop's causal time box filter
+		// read the magnitudes of the stft_width-1 frames before it: a block keeps those rows up to date too.
+		out.mag = (a.S || f >= a.n_frames - a.keep_mag_rows) ? a.mag + row * N : nullptr;
 		out.img = img;
 		out.n = N;
 		out.mid_al = MID_AL;
@@ -176,6 +198,32 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 	__syncthreads();
 
 	// ---- percussive estimate: frequency-direction median of the new row (hps.cu:496)
+	if (a.diag == 1) { // timing diagnostic (zen_hip_set_option "rt_fused_diag"): no median, P = |S|
+		for (int k = tf; k < N; k += TF)
+			Prow[k] = __int_as_float(img[IM::addr(k + MID_AL)]);
+	}
+	else if constexpr (BLOCK47) {
+		// Waves 0 and 1 filter bins 0..2047 (blocks 0..127).  Wave 2 supplies what is left: lanes 0..31 take
+		// blocks 128..159 (bin 2048 is wanted, and blocks 128/129 feed wave 1's last lanes), lanes 32..63
+		// blocks 224..255 (the last MID bins).  Wave 3 sits the stage out.  P[N-k] is read as P[k] (InvIn).
+		static_assert(IM::STRIDE == zm47::RSTR && MID_AL == 24 && TF == 256, "image layout of median47_core.h");
+		int(*edge)[64] = reinterpret_cast<int(*)[64]>(Prow + N);
+		const int lane = tf & 63, wave = __builtin_amdgcn_readfirstlane(tf >> 6);
+		const int blk = wave < 2 ? tf : (lane < 32 ? 128 + lane : 192 + lane);
+		zm47::Pieces pc;
+		if (wave < 3)
+			zm47::m47_sort_and_publish(img, edge, blk, lane, wave, tf == 0, blk == 255, pc);
+		__syncthreads();
+		if (wave < 3) {
+			int out[16];
+			zm47::m47_select(img, edge, blk, wave, pc, out);
+#pragma unroll
+			for (int v = 0; v < 4; ++v)
+				*reinterpret_cast<int4*>(&Prow[blk * 16 + 4 * v]) =
+				    make_int4(out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]);
+		}
+	}
+	else {
 #pragma unroll
 	for (int ci = 0; ci < CPT; ++ci) {
 		const int ch = tf * CPT + ci;
@@ -198,6 +246,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 			*reinterpret_cast<int4*>(&Prow[ch * T + 4 * v]) =
 			    make_int4(out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]);
 	}
+	}
 	__syncthreads(); // P row complete
 	// the thread's 16 magnitudes come back from the image (they were not held in registers across the
 	// median stage); after the barrier the image is dead and the FFT image is free again
@@ -208,7 +257,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 
 	// ---- synthesis per enabled output: hps.cu:498-579 (H = |S| of the same row: causal)
 	auto synth = [&](int which) {
-		InvIn in;
+		InvIn<N, TF, mid, BLOCK47> in;
 		in.r = &r;
 		in.P = Prow;
 		in.cfg = MaskCfg{a.beta, a.beta_h, a.soft, a.power, 0, a.out_h, a.out_p};
@@ -218,6 +267,11 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		out.cola = a.cola;
 		zfft::fft_frame<LOG2N, true, false, true>(tf, lds, a.tw, in, out, true);
 	};
+	if (a.diag == 2) { // timing diagnostic: no synthesis
+		if (tf == 0)
+			a.Y[a.out_id[0]][(long long)s * a.y_stream_stride + (long long)f * (2 * hop)] = Prow[tf] + r.mag[3] + r.S[5].x;
+		return;
+	}
 	if constexpr (SINGLE) {
 		synth(a.out_id[0]);
 	}
@@ -233,7 +287,7 @@ template <int LOG2N, int W, int MINB, bool SINGLE>
 int launch_k(const RtFusedArgs& a, hipStream_t stream)
 {
 	using PL = Plan<LOG2N>;
-	const size_t lds = sizeof(float2) * PL::LDS_FLOAT2 + sizeof(float) * PL::N;
+	const size_t lds = sizeof(float2) * PL::LDS_FLOAT2 + sizeof(float) * PL::N + (W == 47 && LOG2N == 12 ? 1024 : 0);
 	auto kern = rt_fused_kernel<LOG2N, W, MINB, SINGLE>;
 	if (lds > 64 * 1024)
 		ZH_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
