@@ -80,7 +80,9 @@ int zen_hip_memcpy_d2h(void* host, const void* dev, size_t bytes); /* synchronis
 int zen_hip_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
 
 /* zen::io::IOGPU (libzen/libzen/io.h:16-81): pinned, mapped, portable host buffer and its device
- * alias; write_combined != 0 for host_in (io.h:33-35). */
+ * alias; write_combined != 0 for host_in (io.h:33-35), the buffer the host only writes: on a large-BAR system
+ * that one is placed in device memory the host can write directly (*host == *dev), so the kernel reads the hop
+ * locally instead of pulling it over the host link (ZEN_HIP_INPUT_IN_HOST_MEMORY=1: always pinned host memory). */
 int zen_hip_host_alloc_mapped(size_t bytes, int write_combined, void** host, void** dev);
 int zen_hip_host_free(void* host);
 
@@ -163,6 +165,9 @@ int zen_hip_hpr_process(zen_hip_hpr_t h, const float* in_dev, size_t n_hops, siz
 int zen_hip_hpr_profile(zen_hip_hpr_t h, int enable);
 int zen_hip_hpr_profile_get(zen_hip_hpr_t h, double* median_ms, unsigned long long* median_launches,
                             unsigned long long* median_elements);
+/* diagnostic: after this call single-hop launches of the fused causal kernel leave s_memrealtime stamps (100 MHz)
+ * of their phases in the returned mapped host array of 8 words (tools/rt_latency.cpp --stamps). */
+int zen_hip_hpr_debug_stamps(zen_hip_hpr_t h, unsigned long long** host_stamps);
 /* summed milliseconds / launch counts per kernel class:
  * [0] STFT, [1] frequency filter, [2] time filter, [3] iSTFT, [4] overlap-add/copy-out,
  * [5] fused causal kernel (STFT + median + masks + iSTFT of a hop in one workgroup) */

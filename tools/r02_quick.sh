@@ -1,5 +1,8 @@
 #!/bin/bash
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
-for opt in "" "rt_fused_diag=1" "rt_fused_diag=2" "no_median47_dpp=1"; do
-ZEN_HIP_OPTIONS="$opt" python3 bench.py --no-cpu-baseline --no-realtime | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); print('$opt', j['value'], j['kernel_ms_per_step'])"
-done
+OUT=gpurun_out/r02_p; mkdir -p $OUT
+g++ -O2 -std=c++17 -I include tools/rt_latency.cpp -o /tmp/rt_latency -L zen_amd -lzen_hip -Wl,-rpath,$PWD/zen_amd
+/tmp/rt_latency 3000 --stamps
+echo "-- input in host memory:"; ZEN_HIP_INPUT_IN_HOST_MEMORY=1 /tmp/rt_latency 2000 | head -3
+timeout 2700 python3 -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; echo "rc=$?" >> $OUT/pytest_gpu.log
+tail -4 $OUT/pytest_gpu.log

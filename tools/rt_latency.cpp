@@ -1,0 +1,84 @@
+// rt_latency.cpp -- per-hop latency of the realtime call path through the C-ABI, timed as zen/fakert.h:221-247
+// does (copy the hop into the mapped input buffer, process_next_hop, copy_percussive, copy the hop out),
+// without an interpreter in the loop.  Prints one JSON line per hop size.
+//   g++ -O2 -std=c++17 -I include tools/rt_latency.cpp -o /tmp/rt_latency -L zen_amd -lzen_hip -Wl,-rpath,$PWD/zen_amd
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "zen_hip.h"
+
+#define CK(x)                                                                  \
+	do {                                                                       \
+		if ((x) != ZEN_HIP_OK) {                                               \
+			std::fprintf(stderr, "%s: %s\n", #x, zen_hip_last_error());        \
+			std::exit(1);                                                      \
+		}                                                                      \
+	} while (0)
+
+static double now_us()
+{
+	return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int main(int argc, char** argv)
+{
+	const int n_hops = argc > 1 ? std::atoi(argv[1]) : 2000;
+	CK(zen_hip_init(0));
+	for (int sse = 0; sse < 2; ++sse) {
+		for (size_t hop : {256, 512, 1024, 2048, 4096}) {
+			if (sse && hop != 512 && hop != 2048)
+				continue;
+			zen_hip_hpr_t h = nullptr;
+			CK(zen_hip_hpr_create(44100.f, hop, 2.0f, ZEN_HIP_OUTPUT_PERCUSSIVE, ZEN_HIP_TIME_CAUSAL, 1, 1, 64, &h));
+			if (sse)
+				CK(zen_hip_hpr_use_sse_filter(h));
+			void *hin, *din, *hout, *dout;
+			CK(zen_hip_host_alloc_mapped(hop * 4, 1, &hin, &din));
+			CK(zen_hip_host_alloc_mapped(hop * 4, 0, &hout, &dout));
+			std::vector<float> x(hop * 64), y(hop);
+			for (size_t i = 0; i < x.size(); ++i)
+				x[i] = (float)((i * 2654435761u) % 20001) / 10000.f - 1.f;
+			double t_proc = 0, t_copy = 0, t_all = 0;
+			for (int i = -200; i < n_hops; ++i) { // 200 warm-up hops
+				const float* src = x.data() + (size_t)(i & 63) * hop;
+				const double t0 = now_us();
+				std::memcpy(hin, src, hop * 4);
+				CK(zen_hip_hpr_process_next_hop(h, (const float*)din));
+				const double t1 = now_us();
+				CK(zen_hip_hpr_copy_output(h, ZEN_HIP_OUTPUT_PERCUSSIVE, (float*)dout));
+				const double t2 = now_us();
+				std::memcpy(y.data(), hout, hop * 4);
+				const double t3 = now_us();
+				if (i >= 0) {
+					t_proc += t1 - t0;
+					t_copy += t2 - t1;
+					t_all += t3 - t0;
+				}
+			}
+			if (argc > 2 && !sse && hop <= 1024) { // --stamps: phase times of the last single-hop launch
+				unsigned long long* st = nullptr;
+				CK(zen_hip_hpr_debug_stamps(h, &st));
+				std::memcpy(hin, x.data(), hop * 4);
+				for (int rep = 0; rep < 3; ++rep) {
+					CK(zen_hip_hpr_process_next_hop(h, (const float*)din));
+					CK(zen_hip_hpr_copy_output(h, ZEN_HIP_OUTPUT_PERCUSSIVE, (float*)dout));
+				}
+				std::printf("{\"hop\": %zu, \"phase_us\": {\"housekeeping\": %.2f, \"forward_fft_abs\": %.2f, \"border_median\": %.2f, "
+				            "\"reload\": %.2f, \"mask_inverse_fft_store\": %.2f}}\n",
+				            hop, (st[1] - st[0]) / 100.0, (st[2] - st[1]) / 100.0, (st[3] - st[2]) / 100.0,
+				            (st[4] - st[3]) / 100.0, (st[5] - st[4]) / 100.0);
+			}
+			std::printf("{\"hop\": %zu, \"sse\": %d, \"us_per_hop\": %.2f, \"us_process_call\": %.2f, \"us_copy_call\": %.2f, "
+			            "\"hops\": %d, \"pct_of_hop_period\": %.4f}\n",
+			            hop, sse, t_all / n_hops, t_proc / n_hops, t_copy / n_hops, n_hops,
+			            100.0 * (t_all / n_hops) / (1e6 * hop / 44100.0));
+			zen_hip_host_free(hin);
+			zen_hip_host_free(hout);
+			zen_hip_hpr_destroy(h);
+		}
+	}
+	return 0;
+}

@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 namespace zen_hip_impl {
@@ -118,9 +119,14 @@ int zen_hip_init(int device)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "zen_hip_init: device %d of %d", device, n);
 	// core.cu:4-6 sets cudaDeviceMapHost before a context exists; on ROCm mapped host memory needs
 	// no device flag, the call is kept for symmetry and its "already active" status is ignored.
-	(void)hipSetDeviceFlags(hipDeviceMapHost);
-	(void)hipGetLastError();
+	// hipDeviceScheduleSpin: a synchronising call polls instead of sleeping on an interrupt; the realtime path
+	// synchronises once per hop and the wake-up would cost more than the hop's kernel (ZEN_HIP_SCHEDULE=auto
+	// in the environment keeps the runtime's default).
+	const char* sched = getenv("ZEN_HIP_SCHEDULE");
+	const unsigned spin = (sched && !strcmp(sched, "auto")) ? 0u : (unsigned)hipDeviceScheduleSpin;
 	ZH_HIP(hipSetDevice(device));
+	(void)hipSetDeviceFlags(hipDeviceMapHost | spin);
+	(void)hipGetLastError();
 	return ZEN_HIP_OK;
 }
 
@@ -203,9 +209,37 @@ int zen_hip_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream)
 	return ZEN_HIP_OK;
 }
 
+// Input buffers that live in HBM (see zen_hip_host_alloc_mapped): remembered so that zen_hip_host_free can
+// tell them from pinned host memory.
+static std::mutex g_bar_mu;
+static std::vector<void*> g_bar_bufs;
+
 int zen_hip_host_alloc_mapped(size_t bytes, int write_combined, void** host, void** dev)
 {
-	// io.h:24-66 : cudaHostAllocMapped | cudaHostAllocPortable (| WriteCombined for host_in)
+	if (!host || !dev)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "host_alloc_mapped: null argument");
+	// io.h:24-66 : cudaHostAllocMapped | cudaHostAllocPortable (| WriteCombined for host_in).
+	// write_combined marks the buffer the host only ever WRITES (IOGPU::host_in, io.h:33-35).  On a large-BAR
+	// system the device's own memory can be written by the host directly, so that buffer is placed in HBM
+	// (fine-grained): the host pushes a hop with posted writes (0.5 us per 4 KB measured) and the kernel reads
+	// local memory, instead of pulling the hop over the host link (4-5 us of the 1024-hop call, measured).
+	// Same contract for the caller: write through `host`, hand `dev` to the engine.
+	// ZEN_HIP_INPUT_IN_HOST_MEMORY=1 keeps the reference's placement.
+	if (write_combined && !getenv("ZEN_HIP_INPUT_IN_HOST_MEMORY")) {
+		int devid = 0, large_bar = 0;
+		if (hipGetDevice(&devid) == hipSuccess
+		    && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, devid) == hipSuccess && large_bar) {
+			void* p = nullptr;
+			if (hipExtMallocWithFlags(&p, bytes ? bytes : 1, hipDeviceMallocFinegrained) == hipSuccess) {
+				std::lock_guard<std::mutex> lk(g_bar_mu);
+				g_bar_bufs.push_back(p);
+				*host = p;
+				*dev = p;
+				return ZEN_HIP_OK;
+			}
+		}
+		(void)hipGetLastError();
+	}
 	unsigned flags = hipHostMallocMapped | hipHostMallocPortable;
 	if (write_combined)
 		flags |= hipHostMallocWriteCombined;
@@ -215,8 +249,19 @@ int zen_hip_host_alloc_mapped(size_t bytes, int write_combined, void** host, voi
 }
 int zen_hip_host_free(void* host)
 {
-	if (host)
-		ZH_HIP(hipHostFree(host));
+	if (!host)
+		return ZEN_HIP_OK;
+	{
+		std::lock_guard<std::mutex> lk(g_bar_mu);
+		for (size_t i = 0; i < g_bar_bufs.size(); ++i) {
+			if (g_bar_bufs[i] == host) {
+				g_bar_bufs.erase(g_bar_bufs.begin() + (long)i);
+				ZH_HIP(hipFree(host));
+				return ZEN_HIP_OK;
+			}
+		}
+	}
+	ZH_HIP(hipHostFree(host));
 	return ZEN_HIP_OK;
 }
 

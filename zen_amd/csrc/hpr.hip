@@ -98,7 +98,13 @@ void free_all(zen_hip_hpr* e)
 	for (int o = 0; o < 3; ++o) {
 		(void)hipFree(e->d_Y[o]);
 		(void)hipFree(e->d_carry[o]);
+		if (e->ready_host[o])
+			(void)hipHostFree(e->ready_host[o]);
+		else
+			(void)hipFree(e->ready_dev[o]);
 	}
+	if (e->dbg_stamps_host)
+		(void)hipHostFree(e->dbg_stamps_host);
 	for (auto& p : e->prof_pending) {
 		(void)hipEventDestroy(p.e0);
 		(void)hipEventDestroy(p.e1);
@@ -126,6 +132,8 @@ int reset_state(zen_hip_hpr* e)
 	e->tail_sel = 0;
 	e->abs_frame = (long long)e->W - 1; // rows 0..W-2 are the all-zero history of a fresh stream
 	e->last_frames = 0;
+	e->drain[0] = e->drain[1] = e->drain[2] = false;
+	e->ready_valid[0] = e->ready_valid[1] = e->ready_valid[2] = false;
 	return ZEN_HIP_OK;
 }
 
@@ -153,11 +161,17 @@ int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 	a.y_stream_stride = (long long)(e->max_hops * e->nwin);
 	for (int o = 0; o < 3; ++o) {
 		a.Y[o] = e->d_Y[o];
+		e->ready_valid[o] = false;
 		if (output_computed(e, o)) {
 			a.carry[o] = e->d_carry[o];
 			a.out_id[a.n_out++] = o;
+			a.ready[o] = e->ready_dev[o];
+			e->ready_valid[o] = (M == 1);
 		}
 	}
+	if (M == 1)
+		a.seq = ++e->hop_seq;
+	a.publish_seq = e->ready_host[0] != nullptr;
 	a.beta = e->beta;
 	a.beta_h = e->beta - FLT_EPSILON;
 	a.cola = e->cola;
@@ -166,6 +180,7 @@ int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 	a.out_h = e->out_h ? 1 : 0;
 	a.out_p = e->out_p ? 1 : 0;
 	a.diag = g_opt_rt_fused_diag;
+	a.stamps = e->dbg_stamps;
 	{
 		ProfScope ps(e, zen_hip_hpr::K_FUSED);
 		ZH_TRY(launch_rt_fused(e->log2n, e->mf, a, e->stream));
@@ -287,13 +302,21 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 	ia.n_frames = (int)M;
 	ia.n_streams = (int)S;
 	ia.n_out = 0;
+	ia.hop = (int)e->hop;
 	for (int o = 0; o < 3; ++o) {
+		e->ready_valid[o] = false;
 		if (output_computed(e, o)) {
 			ia.Y[ia.n_out] = e->d_Y[o];
 			ia.out_id[ia.n_out] = o;
+			ia.ready[ia.n_out] = e->ready_dev[o];
+			ia.carry[ia.n_out] = e->d_carry[o];
+			e->ready_valid[o] = (M == 1);
 			++ia.n_out;
 		}
 	}
+	if (M == 1)
+		ia.seq = ++e->hop_seq;
+	ia.publish_seq = e->ready_host[0] != nullptr;
 	ia.beta = e->beta;
 	ia.beta_h = e->beta - FLT_EPSILON; // hps.cu:540 hard_mask_functor(beta - Eps)
 	ia.soft = e->soft ? 1 : 0;
@@ -312,12 +335,35 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 	return ZEN_HIP_OK;
 }
 
+// Called when use_sse_filter / use_soft_mask switch an output off in mid-stream: park the second half of its
+// last frame in the carry buffer, from where the next copy-out drains it.
+int park_dropped_outputs(zen_hip_hpr* e, const bool (&before)[3])
+{
+	for (int o = 0; o < 3; ++o) {
+		if (!before[o] || output_computed(e, o))
+			continue;
+		if (e->last_frames > 0) {
+			const float* y = e->d_Y[o] + (e->last_frames - 1) * e->nwin + e->hop;
+			ZH_HIP(hipMemcpy2DAsync(e->d_carry[o], sizeof(float) * e->hop, y, sizeof(float) * e->max_hops * e->nwin,
+			                        sizeof(float) * e->hop, e->n_streams, hipMemcpyDeviceToDevice, e->stream));
+		}
+		e->drain[o] = true;
+	}
+	return ZEN_HIP_OK;
+}
+
 int finalize_output(zen_hip_hpr* e, int o, float* out, size_t out_stride, size_t M)
 {
 	if (!output_computed(e, o)) {
-		// the reference's accumulator for a disabled output stays all zero (hps.test.cu:321-343)
+		// the reference's accumulator for a disabled output stays all zero (hps.test.cu:321-343) ...
 		ZH_HIP(hipMemset2DAsync(out, sizeof(float) * out_stride, 0, sizeof(float) * M * e->hop, e->n_streams,
 		                        e->stream));
+		if (e->drain[o]) { // ... except for the tail of the last frame computed before it was switched off
+			ZH_HIP(hipMemcpy2DAsync(out, sizeof(float) * out_stride, e->d_carry[o], sizeof(float) * e->hop,
+			                        sizeof(float) * e->hop, e->n_streams, hipMemcpyDeviceToDevice, e->stream));
+			ZH_HIP(hipMemsetAsync(e->d_carry[o], 0, sizeof(float) * e->n_streams * e->hop, e->stream));
+			e->drain[o] = false;
+		}
 		return ZEN_HIP_OK;
 	}
 	FinalizeArgs fa;
@@ -414,6 +460,19 @@ int zen_hip_hpr_create(float fs, size_t hop, float beta, unsigned output_flags, 
 	for (int o = 0; o < 3 && ok; ++o)
 		ok = hipMalloc((void**)&e->d_Y[o], sizeof(float) * S * MH * nwin) == hipSuccess
 		     && hipMalloc((void**)&e->d_carry[o], sizeof(float) * S * hop) == hipSuccess;
+	for (int o = 0; o < 3 && ok; ++o) {
+		if (S == 1) { // io.h:24-66 style: pinned, mapped; the kernel writes it over the host link
+			void* dev = nullptr;
+			ok = hipHostMalloc((void**)&e->ready_host[o], sizeof(float) * (hop + 16), hipHostMallocMapped | hipHostMallocPortable) == hipSuccess
+			     && hipHostGetDevicePointer(&dev, e->ready_host[o], 0) == hipSuccess;
+			e->ready_dev[o] = (float*)dev;
+			if (ok)
+				memset(e->ready_host[o], 0, sizeof(float) * (hop + 16)); // [hop] = sequence word
+		}
+		else {
+			ok = hipMalloc((void**)&e->ready_dev[o], sizeof(float) * S * hop) == hipSuccess;
+		}
+	}
 	if (ok)
 		ok = hipMemcpy(e->d_window, win.data(), sizeof(float) * nwin, hipMemcpyHostToDevice) == hipSuccess
 		     && hipMemcpy(e->d_tw, tw.data(), sizeof(float) * nfft, hipMemcpyHostToDevice) == hipSuccess;
@@ -481,16 +540,18 @@ int zen_hip_hpr_use_sse_filter(zen_hip_hpr_t h)
 {
 	if (!h)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null handle");
+	const bool before[3] = {output_computed(h, 0), output_computed(h, 1), output_computed(h, 2)};
 	h->use_sse = true;
-	return ZEN_HIP_OK;
+	return park_dropped_outputs(h, before);
 }
 
 int zen_hip_hpr_use_soft_mask(zen_hip_hpr_t h)
 {
 	if (!h)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null handle");
+	const bool before[3] = {output_computed(h, 0), output_computed(h, 1), output_computed(h, 2)};
 	h->soft = true;
-	return ZEN_HIP_OK;
+	return park_dropped_outputs(h, before);
 }
 
 int zen_hip_hpr_reset_buffers(zen_hip_hpr_t h)
@@ -523,26 +584,72 @@ int zen_hip_hpr_process_next_hop(zen_hip_hpr_t h, const float* in_dev)
 	return run_chunk(h, in_dev, h->hop, 1);
 }
 
-int zen_hip_hpr_copy_output_async(zen_hip_hpr_t h, unsigned which, float* out_dev)
+// host address of a copy_* destination if it is (mapped) host memory, else null; one lookup per distinct pointer
+static void* host_alias_of(zen_hip_hpr_t h, const void* out_dev)
+{
+	if (h->out_query_dev == out_dev)
+		return h->out_query_host;
+	hipPointerAttribute_t at;
+	void* host = nullptr;
+	if (hipPointerGetAttributes(&at, out_dev) == hipSuccess && at.type == hipMemoryTypeHost)
+		host = at.hostPointer;
+	else
+		(void)hipGetLastError();
+	h->out_query_dev = out_dev;
+	h->out_query_host = host;
+	return host;
+}
+
+static int copy_output_impl(zen_hip_hpr_t h, unsigned which, float* out_dev, bool sync)
 {
 	if (!h || !out_dev)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpr_copy_output: null argument");
 	const int o = which_index(which);
 	if (o < 0)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpr_copy_output: `which` must be exactly one ZEN_HIP_OUTPUT_* flag");
-	const size_t M = h->last_frames ? h->last_frames : 1; // before any hop: the zero accumulator
-	if (h->last_frames == 0) {
+	if (h->last_frames == 0) { // before any hop: the zero accumulator
 		ZH_HIP(hipMemsetAsync(out_dev, 0, sizeof(float) * h->hop * h->n_streams, h->stream));
-		return ZEN_HIP_OK;
 	}
-	return finalize_output(h, o, out_dev, M * h->hop, M);
+	else if (h->last_frames == 1 && h->ready_valid[o] && output_computed(h, o)) {
+		// the hop was finished by the synthesis kernel itself (InvOut / IstftOut): no launch here
+		const size_t bytes = sizeof(float) * h->hop * h->n_streams;
+		void* host = (sync && h->ready_host[o]) ? host_alias_of(h, out_dev) : nullptr;
+		if (host) { // mapped host destination (zen::io::IOGPU::device_out): wait for the hop, host copy
+			// The kernel publishes the call's sequence number behind the hop once every sample of it is visible
+			// system-wide; polling that word saves the completion-signal round trip of a stream synchronise.
+			const unsigned* flag = reinterpret_cast<const unsigned*>(h->ready_host[o] + h->hop);
+			bool seen = false;
+			for (long spin = 0; spin < 50000000L; ++spin) {
+				if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == h->hop_seq) {
+					seen = true;
+					break;
+				}
+				__builtin_ia32_pause();
+			}
+			if (!seen) // a fault or a hang: let the runtime report it
+				ZH_HIP(hipStreamSynchronize(h->stream));
+			memcpy(host, h->ready_host[o], bytes);
+			return ZEN_HIP_OK;
+		}
+		ZH_HIP(hipMemcpyAsync(out_dev, h->ready_dev[o], bytes, hipMemcpyDefault, h->stream));
+	}
+	else {
+		const size_t M = h->last_frames;
+		ZH_TRY(finalize_output(h, o, out_dev, M * h->hop, M));
+	}
+	if (sync)
+		ZH_HIP(hipStreamSynchronize(h->stream));
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpr_copy_output_async(zen_hip_hpr_t h, unsigned which, float* out_dev)
+{
+	return copy_output_impl(h, which, out_dev, false);
 }
 
 int zen_hip_hpr_copy_output(zen_hip_hpr_t h, unsigned which, float* out_dev)
 {
-	ZH_TRY(zen_hip_hpr_copy_output_async(h, which, out_dev));
-	ZH_HIP(hipStreamSynchronize(h->stream));
-	return ZEN_HIP_OK;
+	return copy_output_impl(h, which, out_dev, true);
 }
 
 static int prof_drain(zen_hip_hpr_t h)
@@ -555,6 +662,22 @@ static int prof_drain(zen_hip_hpr_t h)
 		h->prof_pool.emplace_back(p.e0, p.e1);
 	}
 	h->prof_pending.clear();
+	return ZEN_HIP_OK;
+}
+
+// diagnostic (tools/rt_latency.cpp): mapped host buffer that receives the fused kernel's phase stamps
+int zen_hip_hpr_debug_stamps(zen_hip_hpr_t h, unsigned long long** host_stamps)
+{
+	if (!h || !host_stamps)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null argument");
+	if (!h->dbg_stamps_host) {
+		void* dev = nullptr;
+		ZH_HIP(hipHostMalloc((void**)&h->dbg_stamps_host, 8 * sizeof(unsigned long long), hipHostMallocMapped));
+		ZH_HIP(hipHostGetDevicePointer(&dev, h->dbg_stamps_host, 0));
+		h->dbg_stamps = (unsigned long long*)dev;
+		memset(h->dbg_stamps_host, 0, 8 * sizeof(unsigned long long));
+	}
+	*host_stamps = h->dbg_stamps_host;
 	return ZEN_HIP_OK;
 }
 

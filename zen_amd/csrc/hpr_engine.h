@@ -32,6 +32,20 @@ struct zen_hip_hpr {
 	float* d_carry[3] = {nullptr, nullptr, nullptr};
 	long long abs_frame = 0;
 	size_t last_frames = 0;
+	// An output that stops being computed (residual after use_soft_mask / use_sse_filter, hps.cu:562, :582-652)
+	// still owes the second half of its last frame: the reference's accumulator is shifted, not cleared.
+	bool drain[3] = {false, false, false};
+	// Single-hop calls (the realtime API): the synthesis kernel itself adds the two overlapping halves and
+	// leaves the finished hop in `ready` -- host-mapped staging memory for a single stream, so that copy_*
+	// is a fence plus a 4*hop-byte host copy instead of a second launch; device memory otherwise.
+	float* ready_dev[3] = {nullptr, nullptr, nullptr};  // device-visible address the kernels write to
+	float* ready_host[3] = {nullptr, nullptr, nullptr}; // host address of the same memory (single stream only)
+	bool ready_valid[3] = {false, false, false};
+	unsigned hop_seq = 0; // number of the last single-hop call; the kernels publish it behind the finished hop
+	unsigned long long* dbg_stamps = nullptr;      // device alias of ...
+	unsigned long long* dbg_stamps_host = nullptr; // ... the mapped stamp buffer of zen_hip_hpr_debug_stamps
+	const void* out_query_dev = nullptr; // last copy_* destination looked up with hipPointerGetAttributes ...
+	void* out_query_host = nullptr;      // ... and its host address (null: not host memory)
 
 	// profiling hook (bench.py): HIP events around every launch, per kernel class
 	enum { K_STFT = 0, K_FREQ = 1, K_TIME = 2, K_ISTFT = 3, K_FINALIZE = 4, K_FUSED = 5, K_COUNT = 6 };

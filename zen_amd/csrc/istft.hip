@@ -42,9 +42,15 @@ struct IstftIn {
 struct IstftOut {
 	float* Y;
 	float cola;
+	float* ready;       // single-frame calls: the finished hop = carry + first half of this frame
+	const float* carry; // saved by the housekeeping block of the analysis kernel of the same call
+	int hop;
 	__device__ __forceinline__ void operator()(int idx, float2 x, bool, int) const
 	{
-		Y[idx] = x.x * cola; // the product of overlap_add_functor hps.h:68-80; the sum is in finalize
+		const float y = x.x * cola; // the product of overlap_add_functor hps.h:68-80; the sum is in finalize ...
+		Y[idx] = y;
+		if (ready && idx < hop) // ... or here, when the call is a single hop (hps.cu:341-363 hands out [0, hop))
+			ready[idx] = carry[idx] + y;
 	}
 };
 
@@ -68,7 +74,17 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void istft_kernel(IstftArgs a
 	IstftOut out;
 	out.Y = a.Y[oi] + (long long)s * a.y_stream_stride + (long long)f * (PL::N / 2);
 	out.cola = a.cola;
+	out.ready = (a.n_frames == 1 && a.ready[oi]) ? a.ready[oi] + (long long)s * a.hop : nullptr;
+	out.carry = a.carry[oi] + (long long)s * a.hop;
+	out.hop = a.hop;
 	zfft::fft_frame<LOG2N, true, false, true>(tf, lds + slot * PL::LDS_FLOAT2, a.tw, in, out, active);
+	if (a.n_frames == 1 && a.publish_seq && a.ready[oi]) { // see rt_fused.hip publish_ready (a.n_frames == 1: one frame per block)
+		__threadfence_system();
+		__syncthreads();
+		if (tid == 0)
+			__hip_atomic_store(reinterpret_cast<unsigned*>(a.ready[oi] + (long long)s * a.hop + a.hop), a.seq, __ATOMIC_RELEASE,
+			                   __HIP_MEMORY_SCOPE_SYSTEM);
+	}
 }
 
 // Hard masks with more than one output (HPRIOffline pass 1: H, P and R of every frame): one workgroup
@@ -126,6 +142,9 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void istft_hard_multi_kernel(
 		IstftOut out;
 		out.Y = a.Y[oi] + (long long)s * a.y_stream_stride + (long long)f * (PL::N / 2);
 		out.cola = a.cola;
+		out.ready = (a.n_frames == 1 && a.ready[oi]) ? a.ready[oi] + (long long)s * a.hop : nullptr;
+		out.carry = a.carry[oi] + (long long)s * a.hop;
+		out.hop = a.hop;
 		// The thread index and the table pointer are made opaque per output: otherwise every LDS address and
 		// twiddle index of the transform (all functions of tf alone) is hoisted out of this loop and kept
 		// in registers (226 VGPRs instead of 90 at nfft 4096, 128 spilled at nfft 16384).
@@ -134,6 +153,13 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void istft_hard_multi_kernel(
 		asm volatile("" : "+v"(tf_o));
 		asm volatile("" : "+s"(tw_o));
 		zfft::fft_frame<LOG2N, true, false, true>(tf_o, lds + slot * PL::LDS_FLOAT2, tw_o, in, out, active);
+		if (a.n_frames == 1 && a.publish_seq && a.ready[oi]) {
+			__threadfence_system();
+			__syncthreads();
+			if (tid == 0)
+				__hip_atomic_store(reinterpret_cast<unsigned*>(a.ready[oi] + (long long)s * a.hop + a.hop), a.seq,
+				                   __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
 		__syncthreads(); // the frame image is reused by the next output
 	}
 }

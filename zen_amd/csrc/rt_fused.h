@@ -25,11 +25,15 @@ struct RtFusedArgs {
 	float* carry[3];        // indexed by output id: 0 percussive, 1 harmonic, 2 residual (null = not computed)
 	float* Y[3];            // indexed by output id
 	long long y_stream_stride;
+	float* ready[3];        // indexed by output id; single-hop calls: receives carry + first half of the new frame
+	unsigned seq;           // single-hop calls: written to ready[o][hop] (as an integer) once ready[o] is complete,
+	int publish_seq;        // when publish_seq != 0 (ready is host-mapped: the host polls it instead of synchronising)
 	int n_out;              // enabled outputs
 	int out_id[3];
 	float beta, beta_h, cola;
 	int soft, power, out_h, out_p;
 	int diag;               // 0; 1 / 2: timing diagnostics of rt_fused_kernel (results are not valid)
+	unsigned long long* stamps; // diagnostic: 8 s_memrealtime stamps (100 MHz) of workgroup 0's phases, or null
 };
 
 bool rt_fused_available(int log2n, int freq_len);

@@ -51,10 +51,15 @@ struct FwdIn {
 	const float* prev;
 	const float* cur;
 	const float* window;
+	float* tail; // the call's last frame: receives its new hop (the next call's `prev`), else null
 	int hop;
 	__device__ __forceinline__ float2 operator()(int idx, int) const
 	{
 		const float x = idx < hop ? prev[idx] : cur[idx - hop];
+		// every sample of the new hop is loaded here exactly once: the input tail is stored from the same
+		// registers instead of being read again (over the host link, when `cur` is mapped host memory)
+		if (tail && idx >= hop)
+			tail[idx - hop] = x;
 		return make_float2(x * window[idx], 0.0f); // window_functor hps.h:24-33
 	}
 };
@@ -118,8 +123,28 @@ struct InvIn {
 struct InvOut {
 	float* Y;
 	float cola;
-	__device__ __forceinline__ void operator()(int idx, float2 x, bool, int) const { Y[idx] = x.x * cola; }
+	float* ready;       // single-hop calls: the finished hop = carry + first half of this frame (hps.cu:526-528 + :341-363)
+	const float* carry; // second half of the previous frame, saved by this workgroup's housekeeping
+	int hop;
+	__device__ __forceinline__ void operator()(int idx, float2 x, bool, int) const
+	{
+		const float y = x.x * cola;
+		Y[idx] = y;
+		if (ready && idx < hop)
+			ready[idx] = carry[idx] + y;
+	}
 };
+
+// Single-hop calls whose `ready` buffer is mapped host memory: the host does not wait for the launch to retire, it
+// polls the word behind the hop.  Every thread makes its stores visible system-wide, the workgroup meets, one
+// thread publishes the sequence number.
+__device__ __forceinline__ void publish_ready(unsigned* flag, unsigned seq, int tf)
+{
+	__threadfence_system();
+	__syncthreads();
+	if (tf == 0)
+		__hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // SINGLE: exactly one output is enabled (the realtime default, percussive only): the spectrum registers die
 // in the first pass of the one inverse transform instead of living through a loop over outputs.
@@ -146,24 +171,35 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 
 	const int tf = threadIdx.x, hop = a.hop;
 	const int s = blockIdx.x / a.n_frames, f = blockIdx.x - s * a.n_frames; // consecutive blocks: consecutive hops
+	// diagnostic build hook (tools/rt_latency.cpp --stamps): phase times of a single-hop call.  The stamps go
+	// to a buffer nothing else reads.
+	auto stamp = [&](int k) {
+		if (a.stamps && blockIdx.x == 0 && tf == 0)
+			a.stamps[k] = __builtin_amdgcn_s_memrealtime();
+	};
+	stamp(0);
 	const float* cur = a.in + (long long)s * a.in_stride + (long long)f * hop;
 
 	// ---- housekeeping (as the extra block of stft_kernel): overlap-add carries, input tail.  The carry is
 	// the second half of the previous call's last Y row; the workgroup that will overwrite that row (or, if
 	// this call is shorter, the last one) saves it first.
+	// (hop == 4*TF: four elements per thread, all loads in flight together, then the stores)
 	if (a.prev_frames > 0 && f == (a.prev_frames - 1 < a.n_frames - 1 ? a.prev_frames - 1 : a.n_frames - 1)) {
 		for (int o = 0; o < 3; ++o) {
 			if (!a.carry[o])
 				continue;
 			const float* y = a.Y[o] + (long long)s * a.y_stream_stride + (long long)(a.prev_frames - 1) * (2 * hop) + hop;
-			for (int i = tf; i < hop; i += TF)
-				a.carry[o][(long long)s * hop + i] = y[i];
+			float v[4];
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+				v[i] = y[tf + i * TF];
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+				a.carry[o][(long long)s * hop + tf + i * TF] = v[i];
 		}
 	}
-	if (f == a.n_frames - 1)
-		for (int i = tf; i < hop; i += TF)
-			a.tail_next[(long long)s * hop + i] = cur[i];
 
+	stamp(1);
 	// ---- analysis: hps.cu:452-472, :492
 	Regs r;
 	{
@@ -171,6 +207,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		in.prev = f > 0 ? cur - hop : a.tail_prev + (long long)s * hop;
 		in.cur = cur;
 		in.window = a.window;
+		in.tail = f == a.n_frames - 1 ? a.tail_next + (long long)s * hop : nullptr;
 		in.hop = hop;
 		const long long row = ((a.row0 + f) % a.ring_rows) + (long long)s * a.ring_rows;
 		FwdOut<T> out;
@@ -187,6 +224,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		zfft::fft_frame<LOG2N, false, true, false>(tf, lds, a.tw, in, out, true);
 	}
 	__syncthreads();
+	stamp(2);
 	// replicate border of the magnitude row (ippBorderRepl)
 	{
 		const int v0 = img[IM::addr(MID_AL)], v1 = img[IM::addr(N - 1 + MID_AL)];
@@ -248,6 +286,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 	}
 	}
 	__syncthreads(); // P row complete
+	stamp(3);
 	// the thread's 16 magnitudes come back from the image (they were not held in registers across the
 	// median stage); after the barrier the image is dead and the FFT image is free again
 #pragma unroll
@@ -265,15 +304,22 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		InvOut out;
 		out.Y = a.Y[which] + (long long)s * a.y_stream_stride + (long long)f * (2 * hop);
 		out.cola = a.cola;
+		out.ready = (a.n_frames == 1 && a.ready[which]) ? a.ready[which] + (long long)s * hop : nullptr;
+		out.carry = a.carry[which] + (long long)s * hop;
+		out.hop = hop;
 		zfft::fft_frame<LOG2N, true, false, true>(tf, lds, a.tw, in, out, true);
+		if (out.ready && a.publish_seq)
+			publish_ready(reinterpret_cast<unsigned*>(out.ready + hop), a.seq, tf);
 	};
 	if (a.diag == 2) { // timing diagnostic: no synthesis
 		if (tf == 0)
 			a.Y[a.out_id[0]][(long long)s * a.y_stream_stride + (long long)f * (2 * hop)] = Prow[tf] + r.mag[3] + r.S[5].x;
 		return;
 	}
+	stamp(4);
 	if constexpr (SINGLE) {
 		synth(a.out_id[0]);
+		stamp(5);
 	}
 	else {
 		for (int oi = 0; oi < a.n_out; ++oi) {

@@ -46,6 +46,12 @@ struct IstftArgs {
 	long long y_stream_stride;
 	int n_frames;
 	int n_streams;
+	// single-frame calls: ready[i] (may be null) receives carry[i][k] + Y[i][k], k < hop: the finished hop
+	float* ready[3];
+	const float* carry[3];
+	int hop;
+	unsigned seq;           // see RtFusedArgs
+	int publish_seq;
 	int n_out;              // enabled outputs
 	int out_id[3];          // 0 = percussive, 1 = harmonic, 2 = residual (order of Y[])
 	float beta, beta_h;     // hps.cu:505 / :540 (beta - Eps)

@@ -75,6 +75,7 @@ SYMBOLS = [
     ("zen_hip_hpr_copy_output", _i, [_vp, _u, _vp]),
     ("zen_hip_hpr_copy_output_async", _i, [_vp, _u, _vp]),
     ("zen_hip_hpr_process", _i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _sz]),
+    ("zen_hip_hpr_debug_stamps", _i, [_vp, C.POINTER(C.POINTER(C.c_ulonglong))]),
     ("zen_hip_hpr_profile", _i, [_vp, _i]),
     ("zen_hip_hpr_profile_get", _i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong),
                                      C.POINTER(C.c_ulonglong)]),
