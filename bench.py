@@ -51,6 +51,9 @@ if ROOT not in sys.path:
 FS = 44100.0
 HOP = 1024
 BETA = 2.0
+# HBM bytes per launch measured with rocprofv3 --pmc (tools/pmc_cmd.sh); re-collected whenever a kernel changes
+FUSED_TRAFFIC_FILE = "r02_fused_hbm_traffic.json"
+MEDIAN_TRAFFIC_FILE = "r02_median47_hbm_traffic.json"
 
 
 def s_music(n, seed=0, fs=FS):
@@ -64,6 +67,31 @@ def s_music(n, seed=0, fs=FS):
         m = min(env.size, n - s)
         x[s:s + m] += 0.9 * env[:m] * rng.uniform(-1, 1, m)
     return (x + 0.01 * rng.uniform(-1, 1, n)).astype(np.float32)
+
+
+def usable_cores():
+    """Hardware threads this process may really use: the smaller of the affinity mask and the cgroup CPU quota
+    (a container on a 256-thread host may be allowed a few CPUs' worth of time only)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
 
 
 def host_cpu_name():
@@ -98,18 +126,21 @@ def cpu_baseline_realtime(x, budget_s=12.0):
             "ms_per_hop": 1e3 * dt / n, "host_cpu": host_cpu_name(), "host_cores_available": os.cpu_count()}
 
 
-def cpu_baseline_offline(x, hop_h, hop_p, total_hops_per_clip, seconds=6.0):
+def cpu_baseline_offline(x, hop_h, hop_p, total_hops_per_clip, seconds=6.0, beta=BETA, soft=False):
     """Oracle HPRIOffline on a prefix of one clip (what zen/offline.h:141-147 times), one thread."""
     from oracle import oracle as o
     n = int(min(x.size, seconds * FS))
-    eng = o.HPRIOffline(FS, hop_h, hop_p, BETA, BETA)
+    eng = o.HPRIOffline(FS, hop_h, hop_p, beta, beta)
+    if soft:
+        eng.use_soft_mask()
     t0 = time.perf_counter()
     eng.process(x[:n])
     dt = time.perf_counter() - t0
     n1, _ = o.chunk_padder(n, hop_h, 1)
     n2, _ = o.chunk_padder(n, hop_p, 11)
     return {"value": (n1 + n2) / dt, "unit": "hops/s", "cores": 1, "kind": "port",
-            "sample": "first %.1f s of clip 0, oracle HPRIOffline %d/%d hard mask, 1 thread" % (n / FS, hop_h, hop_p),
+            "sample": "first %.1f s of clip 0, oracle HPRIOffline %d/%d %s mask, 1 thread"
+                      % (n / FS, hop_h, hop_p, "soft" if soft else "hard"),
             "x_realtime": (n / FS) / dt, "host_cpu": host_cpu_name(), "host_cores_available": os.cpu_count()}
 
 
@@ -136,7 +167,7 @@ def cpu_baseline_offline_all_cores(hop_h, hop_p, seconds=4.0):
     timed region: every worker prepares its clip, all meet at a barrier, and the wall time is taken from the
     first start to the last finish of the process() calls (time.perf_counter is system-wide on Linux)."""
     import multiprocessing as mp
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     ctx = mp.get_context("fork")
     barrier, q = ctx.Barrier(cores), ctx.Queue()
     procs = [ctx.Process(target=_cpu_clip_proc, args=(i, seconds, hop_h, hop_p, barrier, q)) for i in range(cores)]
@@ -150,7 +181,43 @@ def cpu_baseline_offline_all_cores(hop_h, hop_p, seconds=4.0):
     return {"value": hops / wall, "unit": "hops/s", "cores": cores, "kind": "port",
             "sample": "first %.1f s of %d clips, one per core at the same time, oracle HPRIOffline %d/%d hard mask; "
                       "input synthesis outside the timed region" % (seconds, cores, hop_h, hop_p),
-            "x_realtime": cores * seconds / wall, "wall_s": wall, "host_cpu": host_cpu_name()}
+            "x_realtime": cores * seconds / wall, "wall_s": wall, "host_cpu": host_cpu_name(),
+            "host_threads_visible": os.cpu_count(), "host_threads_usable": cores}
+
+
+def offline_rooflines(prof, steps, frames, nfft, hop, n_out1, copy_bw, time_mask2):
+    """Per-kernel HBM rooflines of the two offline passes from the engines' HIP-event timings.
+
+    Algorithmic bytes per frame (SURVEY 8(d) accounting: compulsory traffic of each
+    kernel as a stand-alone stage, half spectrum nfft/2+1 bins where the data is Hermitian):
+      stft        : 4*hop in + 8*(nfft/2+1) spectrum + 4*(nfft/2+1) magnitude out
+      freq_filter : 8 B per element of the frames x nfft matrix (4 read + 4 written)
+      time_filter : 8 B per element
+      istft       : per output 8*(nfft/2+1) spectrum + 8*(nfft/2+1) H and P in + 4*nwin out
+      finalize    : per output 12*hop (two half frames in, one hop out)"""
+    out = {}
+    for ps in ("pass1", "pass2"):
+        N, h, F = nfft[ps], hop[ps], frames[ps]
+        nout = n_out1 if ps == "pass1" else 1
+        per_frame = {"stft": 4 * h + 12 * (N // 2 + 1), "freq_filter": 8 * N, "time_filter": 8 * N,
+                     "istft": nout * (16 * (N // 2 + 1) + 8 * h), "finalize": nout * 12 * h}
+        for k, v in prof[ps].items():
+            if not v["launches"] or k not in per_frame:
+                continue
+            ms = v["ms"] / steps
+            ach = per_frame[k] * F / (ms * 1e-3) / 1e9
+            out["%s.%s" % (ps, k)] = {"ms_per_step": ms, "launches_per_step": v["launches"] / steps,
+                                      "algorithmic_bytes_per_frame": per_frame[k], "frames_per_step": F,
+                                      "achieved": ach, "frac": ach / 8000.0}
+    dom = max(out, key=lambda k: out[k]["ms_per_step"])
+    d = out[dom]
+    roof = {"bound": "hbm", "achieved": d["achieved"], "peak": 8000.0, "unit": "GB/s", "frac": d["frac"],
+            "traffic": None, "kernel": dom, "avg_launch_ms": d["ms_per_step"] / max(d["launches_per_step"], 1),
+            "algorithmic_bytes_per_frame": d["algorithmic_bytes_per_frame"], "frames_per_step": d["frames_per_step"],
+            "device_copy_GBps": copy_bw, "frac_of_device_copy": d["achieved"] / copy_bw,
+            "share_of_kernel_time": d["ms_per_step"] / sum(v["ms_per_step"] for v in out.values()),
+            "note": "dominant kernel of the step by HIP-event time; every kernel's line is in `kernels`"}
+    return roof, out
 
 
 def device_copy_bandwidth(zen_amd, n_floats=1 << 28, iters=10):
@@ -178,7 +245,8 @@ def device_copy_bandwidth(zen_amd, n_floats=1 << 28, iters=10):
 
 
 def realtime_leg(zen_amd, x, n_hops=400):
-    """Per-hop call path through mapped memory; returns dict."""
+    """Per-hop call path through mapped memory, timed like zen/fakert.h:221-247: this interpreter's loop, and
+    the same loop without an interpreter (tools/rt_latency.cpp through the C-ABI) for hops 256...4096."""
     rt = zen_amd.HPRRealtime(FS, HOP, BETA, zen_amd.OUTPUT_PERCUSSIVE, False, 1)
     io = zen_amd.IOGPU(HOP)
     for i in range(50):                              # warm-up
@@ -189,13 +257,40 @@ def realtime_leg(zen_amd, x, n_hops=400):
     for i in range(n_hops):
         io.host_in[:] = x[i * HOP:(i + 1) * HOP]
         rt.process_next_hop(io.device_in)
-        rt.copy_percussive(io.device_out)            # synchronises
+        rt.copy_percussive(io.device_out)            # returns when the hop is in host_out
         _ = io.host_out[0]
     dt = time.perf_counter() - t0
-    return {"us_per_hop": 1e6 * dt / n_hops, "hops_per_s": n_hops / dt, "launches_per_hop": 2,
-            "x_realtime": (n_hops / dt) * HOP / FS,
-            "note": "process_next_hop + copy_percussive via mapped host memory, host-timed incl. copies "
-                    "(zen/fakert.h:221-247); latency-bound, no roofline quoted"}
+    res = {"us_per_hop_python_loop": 1e6 * dt / n_hops, "launches_per_hop": 1,
+           "note": "process_next_hop + copy_percussive via IOGPU buffers, host-timed incl. the host copies "
+                   "(zen/fakert.h:221-247); one launch per hop, the overlap-add happens in the kernel and copy_* "
+                   "polls a sequence word behind the finished hop; latency-bound, no roofline quoted"}
+    # the same loop in C++ through the C-ABI (no interpreter between the calls), hops 256...4096 + SSE
+    try:
+        import subprocess
+        import tempfile
+        exe = os.path.join(tempfile.gettempdir(), "zen_rt_latency_%d" % os.getpid())
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "tools", "rt_latency.cpp"), "-o", exe, "-L",
+                               os.path.join(ROOT, "zen_amd"), "-lzen_hip", "-Wl,-rpath," + os.path.join(ROOT, "zen_amd")],
+                              stderr=subprocess.DEVNULL)
+        lines = subprocess.run([exe, "2000"], capture_output=True, text=True, timeout=120).stdout.splitlines()
+        os.remove(exe)
+        sweep = [json.loads(ln) for ln in lines if ln.startswith("{")]
+        res["per_hop_us_by_hop"] = {("sse_" if r["sse"] else "") + str(r["hop"]): r["us_per_hop"] for r in sweep}
+        at = [r for r in sweep if r["hop"] == HOP and not r["sse"]]
+        if at:
+            res["us_per_hop"] = at[0]["us_per_hop"]
+            res["hops_per_s"] = 1e6 / at[0]["us_per_hop"]
+            res["x_realtime"] = (1e6 / at[0]["us_per_hop"]) * HOP / FS
+            res["timed_by"] = "tools/rt_latency.cpp (C++ loop through the C-ABI, 2000 hops after 200 warm-up hops)"
+    except Exception as exc:                         # no compiler on the box: keep the interpreter's figure
+        res["cpp_loop_error"] = str(exc)[:200]
+    if "us_per_hop" not in res:
+        res["us_per_hop"] = res["us_per_hop_python_loop"]
+        res["hops_per_s"] = 1e6 / res["us_per_hop"]
+        res["x_realtime"] = res["hops_per_s"] * HOP / FS
+        res["timed_by"] = "this interpreter's loop"
+    return res
 
 
 def dry_main(args, zdist):
@@ -372,39 +467,47 @@ def main():
             t_med = 1e-3 * med_ms / max(med_launches, 1)
             el_med = med_elems // max(med_launches, 1)
             ach_med = 8.0 * el_med / t_med / 1e9 if t_med > 0 else 0.0
-            tr_med = traffic_of("r01_e_hbm_traffic.json", "median_net_freq_kernel<47,nonneg>", el_med)
+            tr_med = traffic_of(MEDIAN_TRAFFIC_FILE, "median47_dpp_kernel<nonneg>", el_med)
             roof_median = {
                 "bound": "hbm", "achieved": ach_med, "peak": 8000.0, "unit": "GB/s", "frac": ach_med / 8000.0,
                 "device_copy_GBps": copy_bw, "frac_of_device_copy": ach_med / copy_bw,
                 "traffic": tr_med,
-                "traffic_source": "profiles/r01_e_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH "
-                                  "doubled per the gfx950 correction)" if tr_med else None,
-                "kernel": "median_net_freq_kernel<47, nonneg> (frequency direction, 47 taps)",
+                "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in passes of their own, FETCH "
+                                  "doubled per the gfx950 correction)" % MEDIAN_TRAFFIC_FILE if tr_med else None,
+                "kernel": "median47_dpp_kernel<nonneg> (frequency direction, 47 taps, whole 4096-bin rows)",
                 "elements_per_launch": el_med, "algorithmic_bytes_per_element": 8, "avg_launch_ms": 1e3 * t_med,
                 "launches": med_launches,
-                "note": "VALU-bound, not HBM-bound: v_min/v_max/v_med3 issue at half rate on gfx950 "
-                        "(profiles/r01_ubench_valu_rates.txt, profiles/r01_c_median47_pmc.json)"}
+                "note": "stand-alone kernel of the three-kernel path (second leg, outside the timed region of `value`); "
+                        "its data movement alone (same loads, LDS image, transposed stores, no sorting) takes 0.145 ms, "
+                        "the nontemporal copy of the same bytes 0.139 ms (profiles/r02_median47_variants.txt, "
+                        "profiles/r02_ubench_copy.txt)"}
             if fused:
                 fl = breakdown["rt_fused"]
                 t_f = 1e-3 * fl["ms"] / fl["launches"]
                 bytes_per_hop = 24 * (nfft // 2 + 1) + 8 * HOP       # per-frame minimum, P-only hard mask
                 ach = bytes_per_hop * S * M / t_f / 1e9
-                tr = traffic_of("r01_g_fused_hbm_traffic.json", "rt_fused_kernel<12,47>", S * M * nfft)
+                tr = traffic_of(FUSED_TRAFFIC_FILE, "rt_fused_kernel<12,47>", S * M * nfft)
+                moved = 4 * HOP + 8 * HOP                              # what the kernel itself must move per hop
                 roof = {
                     "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                    "limiter": "valu-issue",
                     "device_copy_GBps": copy_bw, "frac_of_device_copy": ach / copy_bw,
                     "traffic": tr,
-                    "traffic_source": "profiles/r01_g_fused_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                      "FETCH doubled per the gfx950 correction)" if tr else None,
+                    "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in passes of their own, "
+                                      "FETCH doubled per the gfx950 correction)" % FUSED_TRAFFIC_FILE if tr else None,
                     "kernel": "rt_fused_kernel<12, 47> (one workgroup per hop: STFT, |S|, 47-tap median, hard mask, iSTFT)",
                     "hops_per_launch": S * M, "algorithmic_bytes_per_hop": bytes_per_hop,
                     "algorithmic_bytes_formula": "24*(nfft/2+1) + 8*hop (SURVEY 8(d): per-frame minimum of the batched "
                                                  "pipeline, percussive-only hard mask)",
+                    "hbm_bytes_moved_per_hop_by_design": moved,
+                    "moved_GBps": moved * S * M / t_f / 1e9,
                     "avg_launch_ms": 1e3 * t_f, "launches": fl["launches"],
                     "share_of_step": (fl["ms"] / 1e3) / dt if dt > 0 else None,
-                    "note": "the spectrum, |S| and P stay in registers/LDS, so the HBM traffic of this kernel is BELOW "
-                            "the algorithmic figure (4*hop read + 8*hop written per hop); it is bound by VALU issue "
-                            "(FFT butterflies at full rate, median min/max at half rate), not by HBM"}
+                    "note": "`achieved`/`frac` price the launch with SURVEY 8(d)'s ALGORITHMIC bytes as the bench contract "
+                            "asks; the kernel does not move them: the spectrum, |S| and P stay in registers/LDS, its own HBM "
+                            "traffic is 4*hop read + 8*hop written per hop (`moved_GBps`, `traffic`), far from the HBM roof. "
+                            "Its limiter is VALU issue (FFT butterflies at full rate; median min/max, DPP moves, double-"
+                            "precision |z| at half rate): see DESIGN.md section 5 and profiles/r02_*fused*"}
             else:
                 roof = dict(roof_median, share_of_step=(med_ms / 1e3) / dt if dt > 0 else None)
             out.update({
@@ -447,15 +550,22 @@ def main():
         for _ in range(args.warmup):
             step()
         barrier()
+        eng.profile(True)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         barrier()
         dt = grp.max(time.perf_counter() - t0)
+        prof = eng.profile_get_all()
+        eng.profile(False)
         chk = grp.sum([float(np.abs(d_p.download(4096)).sum())])[0]
         if rank == 0:
             total_hops = world * C * (n1 + n2) * args.steps
             value = total_hops / dt
+            roof, kern = offline_rooflines(prof, args.steps, {"pass1": C * n1, "pass2": C * n2},
+                                           {"pass1": 4 * hop_h, "pass2": 4 * hop_p}, {"pass1": hop_h, "pass2": hop_p},
+                                           3, device_copy_bandwidth(zen_amd), 11)
+            out.update({"roofline": roof, "kernels": kern})
             out.update({
                 "metric": "hops/sec (HPR-I offline, hops of both passes)", "value": value,
                 "ms_per_step": 1e3 * dt / args.steps,
@@ -492,13 +602,24 @@ def main():
         for _ in range(args.warmup):
             step()
         barrier()
+        eng.profile(True)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         barrier()
         dt = grp.max(time.perf_counter() - t0)
+        prof = eng.profile_get_all()
+        eng.profile(False)
         chk = grp.sum([float(np.abs(d_p.download(min(4096, max(e - b, 1)))).sum())])[0]
         if rank == 0:
+            if world == 1:
+                roof, kern = offline_rooflines(prof, args.steps, {"pass1": 2 * n1, "pass2": 2 * n2},
+                                               {"pass1": 4 * hop_h, "pass2": 4 * hop_p},
+                                               {"pass1": hop_h, "pass2": hop_p}, 2, device_copy_bandwidth(zen_amd), 11)
+                out.update({"roofline": roof, "kernels": kern})
+                if not args.no_cpu_baseline:
+                    out["cpu_baseline"] = cpu_baseline_offline(chans[0], hop_h, hop_p, n1 + n2, seconds=4.0, beta=2.5,
+                                                               soft=True)
             out.update({
                 "metric": "hops/sec (HPR-I offline, hops of both passes)", "scaling": "strong",
                 "value": 2 * (n1 + n2) * args.steps / dt, "ms_per_step": 1e3 * dt / args.steps,

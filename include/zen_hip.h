@@ -202,6 +202,9 @@ int zen_hip_hpri_process_device(zen_hip_hpri_t h, const float* audio_dev, size_t
 int zen_hip_hpri_range_halo(zen_hip_hpri_t h, size_t n, size_t begin, size_t end, size_t* in_begin, size_t* in_end);
 int zen_hip_hpri_process_range(zen_hip_hpri_t h, const float* audio_dev, size_t n, size_t begin, size_t end,
                                float* harm_dev, float* perc_dev);
+/* profiling hooks for bench.py, as zen_hip_hpr_profile / _get_all, per pass (1: hop_h, 2: hop_p) */
+int zen_hip_hpri_profile(zen_hip_hpri_t h, int enable);
+int zen_hip_hpri_profile_get_all(zen_hip_hpri_t h, int pass, double ms[6], unsigned long long launches[6]);
 /* hops the two passes run for an n-sample clip (hps.cu:109-126), for throughput accounting */
 int zen_hip_hpri_hop_counts(zen_hip_hpri_t h, size_t n, size_t* n_hops_h, size_t* n_hops_p);
 

@@ -1,8 +1,8 @@
 #!/bin/bash
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
-OUT=gpurun_out/r02_p; mkdir -p $OUT
-g++ -O2 -std=c++17 -I include tools/rt_latency.cpp -o /tmp/rt_latency -L zen_amd -lzen_hip -Wl,-rpath,$PWD/zen_amd
-/tmp/rt_latency 3000 --stamps
-echo "-- input in host memory:"; ZEN_HIP_INPUT_IN_HOST_MEMORY=1 /tmp/rt_latency 2000 | head -3
+OUT=gpurun_out/r02_s; mkdir -p $OUT
 timeout 2700 python3 -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; echo "rc=$?" >> $OUT/pytest_gpu.log
 tail -4 $OUT/pytest_gpu.log
+for w in offline_batch offline_long; do python3 bench.py --workload $w --no-cpu-baseline | python3 -c "
+import json,sys; j=json.loads(sys.stdin.read()); print('$w', j['value'], j['x_realtime'], j['ms_per_step']); [print('   ',k, round(v['ms_per_step'],3), round(v['frac'],3)) for k,v in j['kernels'].items()]"; done
+python3 bench.py --no-cpu-baseline --no-realtime | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); print(j['value'], j['kernel_ms_per_step'], j['roofline_median']['avg_launch_ms'], j['three_kernel_path'])"

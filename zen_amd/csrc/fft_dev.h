@@ -110,7 +110,9 @@ __device__ __forceinline__ void butterfly(float2 (&a)[R], int k, int log2L, int 
 	}
 }
 
-template <int LOG2N, int PASS, bool INV, bool ZU, bool HALF_OUT, class In, class Out>
+// SYNC_FIRST: in() of the first pass reads LDS that the pass's own stores may overwrite (the fused kernel
+// keeps |S| and P inside the frame image): a barrier separates the two, as in every later pass.
+template <int LOG2N, int PASS, bool INV, bool ZU, bool HALF_OUT, class In, class Out, bool SYNC_FIRST = false>
 struct PassRunner {
 	using PL = Plan<LOG2N>;
 	static __device__ __forceinline__ void run(int tf, float2* __restrict__ lds,
@@ -141,7 +143,7 @@ struct PassRunner {
 				}
 			}
 		}
-		if (!FIRST)
+		if (!FIRST || SYNC_FIRST)
 			__syncthreads(); // every thread has its inputs in registers: LDS may be overwritten
 #pragma unroll
 		for (int i = 0; i < NB; ++i) {
@@ -164,7 +166,7 @@ struct PassRunner {
 		}
 		if constexpr (!LAST) {
 			__syncthreads();
-			PassRunner<LOG2N, PASS + 1, INV, ZU, HALF_OUT, In, Out>::run(tf, lds, tw, in, out, active);
+			PassRunner<LOG2N, PASS + 1, INV, ZU, HALF_OUT, In, Out, SYNC_FIRST>::run(tf, lds, tw, in, out, active);
 		}
 	}
 };
@@ -176,11 +178,11 @@ struct PassRunner {
 // the first pass's inputs and the last pass's outputs, so a spectrum can stay in registers between a
 // forward and an inverse transform (rt_fused.hip).  All threads of the block must call this
 // together (it contains block barriers); inactive frames pass active = false.
-template <int LOG2N, bool INV, bool ZU, bool HALF_OUT, class In, class Out>
+template <int LOG2N, bool INV, bool ZU, bool HALF_OUT, class In, class Out, bool SYNC_FIRST = false>
 __device__ __forceinline__ void fft_frame(int tf, float2* __restrict__ lds, const float2* __restrict__ tw,
                                           In& in, Out& out, bool active)
 {
-	PassRunner<LOG2N, 0, INV, ZU, HALF_OUT, In, Out>::run(tf, lds, tw, in, out, active);
+	PassRunner<LOG2N, 0, INV, ZU, HALF_OUT, In, Out, SYNC_FIRST>::run(tf, lds, tw, in, out, active);
 }
 
 // |z| exactly as the oracle's zo_cabs: (float)sqrt((double)re*re + (double)im*im)

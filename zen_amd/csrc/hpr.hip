@@ -297,6 +297,9 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 	ia.h_is_ring = h_is_ring ? 1 : 0;
 	ia.P = e->d_P;
 	ia.p_stream_stride = (long long)(e->max_hops * N);
+	// The median is an order statistic: P[k] == P[nfft-k] bit for bit away from the borders.  The SSE box mean
+	// adds its taps in ascending bin order, which the mirrored window reverses: rounding differs, no symmetry.
+	ia.p_mid = e->use_sse ? (int)(N / 2) : e->mf / 2;
 	ia.tw = e->d_tw;
 	ia.y_stream_stride = (long long)(e->max_hops * e->nwin);
 	ia.n_frames = (int)M;

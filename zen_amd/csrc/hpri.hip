@@ -405,6 +405,22 @@ int zen_hip_hpri_process_range(zen_hip_hpri_t h, const float* audio_dev, size_t 
 	return ZEN_HIP_OK;
 }
 
+// profiling hooks for bench.py: the two passes are zen_hip_hpr engines with HIP events around every launch
+int zen_hip_hpri_profile(zen_hip_hpri_t h, int enable)
+{
+	if (!h)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null handle");
+	ZH_TRY(zen_hip_hpr_profile(h->eh, enable));
+	return zen_hip_hpr_profile(h->ep, enable);
+}
+
+int zen_hip_hpri_profile_get_all(zen_hip_hpri_t h, int pass, double ms[6], unsigned long long launches[6])
+{
+	if (!h || (pass != 1 && pass != 2))
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_profile_get_all: pass must be 1 or 2");
+	return zen_hip_hpr_profile_get_all(pass == 1 ? h->eh : h->ep, ms, launches);
+}
+
 int zen_hip_hpri_process(zen_hip_hpri_t h, const float* audio_host, size_t n, float* harm_host,
                          float* perc_host, float* resid_host)
 {

@@ -21,6 +21,9 @@ namespace {
 using zfft::Plan;
 
 // ------------------------------------------------------------------------------------------------
+// |S| is exactly Hermitian (fft_dev.h), so H (|S| or its time median / box mean) is mirror symmetric, and so is P
+// except for the p_mid bins next to either end of the row, where the replicate border differs.
+// The upper halves of the H and P rows are therefore never read: they cost no HBM traffic.
 struct IstftIn {
 	const float2* S;
 	const float* H;
@@ -28,13 +31,16 @@ struct IstftIn {
 	MaskCfg cfg;
 	int which;
 	int n;
+	int p_mid;
 	__device__ __forceinline__ float2 operator()(int idx, int) const
 	{
 		const bool mirror = idx > (n >> 1); // upper half: S[n-k] = conj(S[k])
-		float2 z = S[mirror ? n - idx : idx];
+		const int lo = mirror ? n - idx : idx;
+		float2 z = S[lo];
 		if (mirror)
 			z.y = -z.y;
-		const float m = mask_value(which, H[idx], P[idx], cfg);
+		const int pi = (mirror && idx >= n - p_mid) ? idx : lo;
+		const float m = mask_value(which, H[lo], P[pi], cfg);
 		return make_float2(z.x * m, z.y * m); // apply_mask_functor hps.h:58-66
 	}
 };
@@ -71,6 +77,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void istft_kernel(IstftArgs a
 	in.P = a.P + (long long)s * a.p_stream_stride + (long long)f * PL::N;
 	in.cfg = MaskCfg{a.beta, a.beta_h, a.soft, a.power, a.sse, a.out_h, a.out_p};
 	in.which = a.out_id[oi];
+	in.p_mid = a.p_mid;
 	IstftOut out;
 	out.Y = a.Y[oi] + (long long)s * a.y_stream_stride + (long long)f * (PL::N / 2);
 	out.cola = a.cola;
@@ -100,14 +107,16 @@ struct IstftHardIn {
 	int which;
 	int first;
 	int n;
+	int p_mid;
 	__device__ __forceinline__ float2 operator()(int idx, int slot) const
 	{
 		const bool mirror = idx > (n >> 1);
-		float2 z = S[mirror ? n - idx : idx];
+		const int lo = mirror ? n - idx : idx;
+		float2 z = S[lo];
 		if (mirror)
 			z.y = -z.y;
 		if (first) {
-			const float h = H[idx], p = P[idx];
+			const float h = H[lo], p = P[(mirror && idx >= n - p_mid) ? idx : lo]; // see IstftIn
 			const unsigned pm = cfg.out_p || which == 0 ? (unsigned)(pmask_value(h, p, cfg) != 0.0f) : 0u;
 			const unsigned hm = cfg.out_h || which == 1 ? (unsigned)(hmask_value(h, p, cfg) != 0.0f) : 0u;
 			*bits |= (pm | (hm << 1)) << (2 * slot);
@@ -136,6 +145,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void istft_hard_multi_kernel(
 	in.P = a.P + (long long)s * a.p_stream_stride + (long long)f * PL::N;
 	in.cfg = MaskCfg{a.beta, a.beta_h, 0, a.power, 0, a.out_h, a.out_p};
 	in.bits = &bits;
+	in.p_mid = a.p_mid;
 	for (int oi = 0; oi < a.n_out; ++oi) {
 		in.which = a.out_id[oi];
 		in.first = oi == 0;

@@ -120,6 +120,37 @@ struct InvIn {
 	}
 };
 
+// LEAN build (47 taps, 4096 bins, one output -- the realtime default): |S| is read back from the magnitude
+// image and P from a compact half row, both INSIDE the frame image, so a workgroup needs 34 KB of LDS (four
+// per CU) and no |S| registers.  pc: P of bins 0..2048 at pc[bin], of bins 3584..4095 at pc[2052 + bin - 3584].
+constexpr int LEAN_PC_WORD = 5184;   // first word of the compact P row (behind the 259 * 20-word magnitude image)
+constexpr int LEAN_PC_TAIL = 2052;   // pc index of bin 3584
+constexpr int LEAN_EDGE_WORD = LEAN_PC_WORD + LEAN_PC_TAIL + 512 + 4; // wave-edge records of median47_core.h
+template <int N, int TF, int MID>
+struct InvInLean {
+	const Regs* r;
+	const int* img; // magnitude image (word = bin + 24, 16-word chunks 20 apart)
+	const float* pc;
+	MaskCfg cfg;
+	int which;
+	__device__ __forceinline__ float2 operator()(int idx, int slot) const
+	{
+		const int lo = slot * TF, hi = lo + TF - 1;
+		int pi;
+		if (hi <= N / 2)
+			pi = idx;
+		else if (lo > N / 2 && hi < N - MID)
+			pi = N - idx;
+		else
+			pi = (idx > N / 2 && idx < N - MID) ? N - idx : (idx > N / 2 ? idx - (N - 512) + LEAN_PC_TAIL : idx);
+		const int g = idx + 24;
+		const float mag = __int_as_float(img[(g >> 4) * 20 + (g & 15)]);
+		const float2 z = r->S[slot];
+		const float m = mask_value(which, mag, pc[pi], cfg);
+		return make_float2(z.x * m, z.y * m); // apply_mask_functor hps.h:58-66
+	}
+};
+
 struct InvOut {
 	float* Y;
 	float cola;
@@ -148,7 +179,7 @@ __device__ __forceinline__ void publish_ready(unsigned* flag, unsigned seq, int 
 
 // SINGLE: exactly one output is enabled (the realtime default, percussive only): the spectrum registers die
 // in the first pass of the one inverse transform instead of living through a loop over outputs.
-template <int LOG2N, int W, int MINB, bool SINGLE>
+template <int LOG2N, int W, int MINB, bool SINGLE, bool LEAN = false>
 __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFusedArgs a)
 {
 	using PL = Plan<LOG2N>;
@@ -164,10 +195,12 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 	// 47 taps on 4096 bins (hop 1024 at 44.1 kHz, the headline configuration): the block scheme of
 	// median47_core.h on the half spectrum
 	constexpr bool BLOCK47 = (W == 47 && LOG2N == 12);
+	static_assert(!LEAN || (BLOCK47 && SINGLE), "the lean layout is the one-output 47-tap kernel");
+	static_assert(!LEAN || (LEAN_EDGE_WORD + 256) * 4 <= PL::LDS_FLOAT2 * 8, "lean layout must fit in the frame image");
 
 	extern __shared__ float2 lds[];       // [FFT image | P row]; the magnitude image aliases the FFT image
 	int* img = reinterpret_cast<int*>(lds);
-	float* Prow = reinterpret_cast<float*>(lds + PL::LDS_FLOAT2);
+	float* Prow = LEAN ? reinterpret_cast<float*>(img + LEAN_PC_WORD) : reinterpret_cast<float*>(lds + PL::LDS_FLOAT2);
 
 	const int tf = threadIdx.x, hop = a.hop;
 	const int s = blockIdx.x / a.n_frames, f = blockIdx.x - s * a.n_frames; // consecutive blocks: consecutive hops
@@ -237,7 +270,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 
 	// ---- percussive estimate: frequency-direction median of the new row (hps.cu:496)
 	if (a.diag == 1) { // timing diagnostic (zen_hip_set_option "rt_fused_diag"): no median, P = |S|
-		for (int k = tf; k < N; k += TF)
+		for (int k = tf; k < (LEAN ? 2048 : N); k += TF)
 			Prow[k] = __int_as_float(img[IM::addr(k + MID_AL)]);
 	}
 	else if constexpr (BLOCK47) {
@@ -245,7 +278,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		// blocks 128..159 (bin 2048 is wanted, and blocks 128/129 feed wave 1's last lanes), lanes 32..63
 		// blocks 224..255 (the last MID bins).  Wave 3 sits the stage out.  P[N-k] is read as P[k] (InvIn).
 		static_assert(IM::STRIDE == zm47::RSTR && MID_AL == 24 && TF == 256, "image layout of median47_core.h");
-		int(*edge)[64] = reinterpret_cast<int(*)[64]>(Prow + N);
+		int(*edge)[64] = LEAN ? reinterpret_cast<int(*)[64]>(img + LEAN_EDGE_WORD) : reinterpret_cast<int(*)[64]>(Prow + N);
 		const int lane = tf & 63, wave = __builtin_amdgcn_readfirstlane(tf >> 6);
 		const int blk = wave < 2 ? tf : (lane < 32 ? 128 + lane : 192 + lane);
 		zm47::Pieces pc;
@@ -255,10 +288,24 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		if (wave < 3) {
 			int out[16];
 			zm47::m47_select(img, edge, blk, wave, pc, out);
+			if constexpr (LEAN) { // compact half row: bins 0..2051 and 3584..4095
+				const int at = blk >= 224 ? LEAN_PC_TAIL + (blk - 224) * 16 : blk * 16;
+				if (blk <= 127 || blk >= 224) {
 #pragma unroll
-			for (int v = 0; v < 4; ++v)
-				*reinterpret_cast<int4*>(&Prow[blk * 16 + 4 * v]) =
-				    make_int4(out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]);
+					for (int v = 0; v < 4; ++v)
+						*reinterpret_cast<int4*>(&Prow[at + 4 * v]) =
+						    make_int4(out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]);
+				}
+				else if (blk == 128) {
+					*reinterpret_cast<int4*>(&Prow[at]) = make_int4(out[0], out[1], out[2], out[3]);
+				}
+			}
+			else {
+#pragma unroll
+				for (int v = 0; v < 4; ++v)
+					*reinterpret_cast<int4*>(&Prow[blk * 16 + 4 * v]) =
+					    make_int4(out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]);
+			}
 		}
 	}
 	else {
@@ -287,6 +334,26 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 	}
 	__syncthreads(); // P row complete
 	stamp(3);
+	if constexpr (LEAN) { // |S| and P are read inside the first inverse pass, which then meets at a barrier
+		if (a.diag == 2)
+			return;
+		InvInLean<N, TF, mid> in;
+		in.r = &r;
+		in.img = img;
+		in.pc = Prow;
+		in.cfg = MaskCfg{a.beta, a.beta_h, a.soft, a.power, 0, a.out_h, a.out_p};
+		in.which = a.out_id[0];
+		InvOut out;
+		out.Y = a.Y[in.which] + (long long)s * a.y_stream_stride + (long long)f * (2 * hop);
+		out.cola = a.cola;
+		out.ready = (a.n_frames == 1 && a.ready[in.which]) ? a.ready[in.which] + (long long)s * hop : nullptr;
+		out.carry = a.carry[in.which] + (long long)s * hop;
+		out.hop = hop;
+		zfft::fft_frame<LOG2N, true, false, true, InvInLean<N, TF, mid>, InvOut, true>(tf, lds, a.tw, in, out, true);
+		if (out.ready && a.publish_seq)
+			publish_ready(reinterpret_cast<unsigned*>(out.ready + hop), a.seq, tf);
+		return;
+	}
 	// the thread's 16 magnitudes come back from the image (they were not held in registers across the
 	// median stage); after the barrier the image is dead and the FFT image is free again
 #pragma unroll
@@ -329,12 +396,13 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 	}
 }
 
-template <int LOG2N, int W, int MINB, bool SINGLE>
+template <int LOG2N, int W, int MINB, bool SINGLE, bool LEAN = false>
 int launch_k(const RtFusedArgs& a, hipStream_t stream)
 {
 	using PL = Plan<LOG2N>;
-	const size_t lds = sizeof(float2) * PL::LDS_FLOAT2 + sizeof(float) * PL::N + (W == 47 && LOG2N == 12 ? 1024 : 0);
-	auto kern = rt_fused_kernel<LOG2N, W, MINB, SINGLE>;
+	const size_t lds = LEAN ? sizeof(float2) * PL::LDS_FLOAT2
+	                        : sizeof(float2) * PL::LDS_FLOAT2 + sizeof(float) * PL::N + (W == 47 && LOG2N == 12 ? 1024 : 0);
+	auto kern = rt_fused_kernel<LOG2N, W, MINB, SINGLE, LEAN>;
 	if (lds > 64 * 1024)
 		ZH_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	hipLaunchKernelGGL(kern, dim3((unsigned)((long long)a.n_streams * a.n_frames)), dim3(PL::TF), lds, stream, a);
@@ -347,14 +415,27 @@ int launch_k(const RtFusedArgs& a, hipStream_t stream)
 template <int LOG2N, int W>
 int launch_t(const RtFusedArgs& a, hipStream_t stream)
 {
+	if constexpr (LOG2N == 12 && W == 47) {
+		// the headline configuration with one output: the lean layout (34 KB of LDS, no |S| registers).  Built for
+		// three workgroups per CU: a fourth would fit in LDS but not in registers (128 VGPRs spill 60 of them:
+		// 0.74 ms against 0.60 ms per 25 840 hops, measured); "block_fused_minb" = 4 selects that build, 5 the
+		// roomy layout below, for comparison.
+		if (a.n_out == 1 && g_opt_block_fused_minb != 5) {
+			if (a.n_frames == 1)
+				return launch_k<LOG2N, W, 1, true, true>(a, stream);
+			if (g_opt_block_fused_minb == 4)
+				return launch_k<LOG2N, W, 4, true, true>(a, stream);
+			return launch_k<LOG2N, W, 3, true, true>(a, stream);
+		}
+	}
 	if (a.n_out == 1) {
-		if (a.n_frames == 1 || g_opt_block_fused_minb <= 1)
+		if (a.n_frames == 1 || g_opt_block_fused_minb == 1)
 			return launch_k<LOG2N, W, 1, true>(a, stream);
 		if (g_opt_block_fused_minb == 2)
 			return launch_k<LOG2N, W, 2, true>(a, stream);
 		return launch_k<LOG2N, W, 3, true>(a, stream);
 	}
-	if (a.n_frames == 1 || g_opt_block_fused_minb <= 1)
+	if (a.n_frames == 1 || g_opt_block_fused_minb == 1)
 		return launch_k<LOG2N, W, 1, false>(a, stream);
 	if (g_opt_block_fused_minb == 2)
 		return launch_k<LOG2N, W, 2, false>(a, stream);
@@ -363,7 +444,7 @@ int launch_t(const RtFusedArgs& a, hipStream_t stream)
 
 } // namespace
 
-opt_t g_opt_block_fused_minb{3};
+opt_t g_opt_block_fused_minb{0}; // 0: default (three workgroups per CU)
 
 // (transform size, frequency mask) pairs with a fused kernel: hops 128..1024 at 44.1 and 48 kHz
 bool rt_fused_available(int log2n, int freq_len)

@@ -41,6 +41,9 @@ struct IstftArgs {
 	int h_is_ring;          // 1: H is the magnitude ring itself (causal median)
 	const float* P;         // [n_streams][max_frames][nfft]
 	long long p_stream_stride;
+	int p_mid;              // half length of the frequency mask: P[k] == P[nfft-k] for p_mid < k < nfft/2, so the
+	                        // synthesis reads only bins 0..nfft/2 and the last p_mid bins of a P row (and bins
+	                        // 0..nfft/2 of an H row, which is symmetric throughout)
 	const float2* tw;
 	float* Y[3];
 	long long y_stream_stride;

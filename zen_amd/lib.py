@@ -90,6 +90,8 @@ SYMBOLS = [
     ("zen_hip_hpri_range_halo", _i, [_vp, _sz, _sz, _sz, C.POINTER(_sz), C.POINTER(_sz)]),
     ("zen_hip_hpri_process_range", _i, [_vp, _vp, _sz, _sz, _sz, _vp, _vp]),
     ("zen_hip_hpri_hop_counts", _i, [_vp, _sz, C.POINTER(_sz), C.POINTER(_sz)]),
+    ("zen_hip_hpri_profile", _i, [_vp, _i]),
+    ("zen_hip_hpri_profile_get_all", _i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong)]),
 ]
 
 _lib = None
@@ -420,6 +422,19 @@ class HPRIOffline:
 
     def set_stream(self, stream):
         _ck(load().zen_hip_hpri_set_stream(self._h, stream))
+
+    def profile(self, enable):
+        _ck(load().zen_hip_hpri_profile(self._h, int(bool(enable))))
+
+    def profile_get_all(self):
+        """{"pass1": {kernel class: {"ms", "launches"}}, "pass2": {...}} since profile(True)."""
+        names = ("stft", "freq_filter", "time_filter", "istft", "finalize", "rt_fused")
+        out = {}
+        for ps in (1, 2):
+            ms, n = (C.c_double * 6)(), (C.c_ulonglong * 6)()
+            _ck(load().zen_hip_hpri_profile_get_all(self._h, ps, ms, n))
+            out["pass%d" % ps] = {k: {"ms": ms[i], "launches": n[i]} for i, k in enumerate(names)}
+        return out
 
     def hop_counts(self, n):
         a, b = C.c_size_t(), C.c_size_t()
