@@ -185,21 +185,26 @@ def cpu_baseline_offline_all_cores(hop_h, hop_p, seconds=4.0):
             "host_threads_visible": os.cpu_count(), "host_threads_usable": cores}
 
 
-def offline_rooflines(prof, steps, frames, nfft, hop, n_out1, copy_bw, time_mask2):
+def offline_rooflines(prof, steps, frames, nfft, hop, n_out1, copy_bw, freq_mask):
     """Per-kernel HBM rooflines of the two offline passes from the engines' HIP-event timings.
 
     Algorithmic bytes per frame (SURVEY 8(d) accounting: compulsory traffic of each
     kernel as a stand-alone stage, half spectrum nfft/2+1 bins where the data is Hermitian):
       stft        : 4*hop in + 8*(nfft/2+1) spectrum + 4*(nfft/2+1) magnitude out
-      freq_filter : 8 B per element of the frames x nfft matrix (4 read + 4 written)
-      time_filter : 8 B per element
+      freq_filter : 8 B per element (4 read + 4 written) of the frames x nfft matrix; where the engine filters
+                    half rows (masks <= 63 taps) of the frames x (nfft/2 + 1 + mask/2) it needs
+      time_filter : 8 B per element of frames x nfft, or of frames x (nfft/2 + 1) with half rows
       istft       : per output 8*(nfft/2+1) spectrum + 8*(nfft/2+1) H and P in + 4*nwin out
       finalize    : per output 12*hop (two half frames in, one hop out)"""
     out = {}
     for ps in ("pass1", "pass2"):
         N, h, F = nfft[ps], hop[ps], frames[ps]
         nout = n_out1 if ps == "pass1" else 1
-        per_frame = {"stft": 4 * h + 12 * (N // 2 + 1), "freq_filter": 8 * N, "time_filter": 8 * N,
+        mf = freq_mask[ps]
+        half = mf <= 63                                           # hpr.hip run_chunk: half rows on the median path
+        per_frame = {"stft": 4 * h + 12 * (N // 2 + 1),
+                     "freq_filter": 8 * (N // 2 + 1 + mf // 2) if half else 8 * N,
+                     "time_filter": 8 * (N // 2 + 1) if half else 8 * N,
                      "istft": nout * (16 * (N // 2 + 1) + 8 * h), "finalize": nout * 12 * h}
         for k, v in prof[ps].items():
             if not v["launches"] or k not in per_frame:
@@ -433,19 +438,31 @@ def main():
             # second leg, outside the timed region: the same stream through the general engine (STFT / median /
             # iSTFT kernels) for the stand-alone median kernel's roofline, BASELINE's second metric
             zen_amd.set_option("no_block_fused", 1)
-            for _ in range(3):
-                step()
-            zen_amd.synchronize()
-            eng.profile(True)
-            t1 = time.perf_counter()
-            for _ in range(10):
-                step()
-            zen_amd.synchronize()
-            dt3 = (time.perf_counter() - t1) / 10
-            med_ms, med_launches, med_elems = eng.profile_get()
-            three = {"ms_per_step": 1e3 * dt3, "hops_per_s": S * M / dt3,
-                     "kernel_ms_per_step": {k: v["ms"] / 10 for k, v in eng.profile_get_all().items() if v["launches"]}}
-            eng.profile(False)
+
+            def leg():
+                for _ in range(3):
+                    step()
+                zen_amd.synchronize()
+                eng.profile(True)
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    step()
+                zen_amd.synchronize()
+                dt3 = (time.perf_counter() - t1) / 10
+                r = eng.profile_get()
+                kern = {k: v["ms"] / 10 for k, v in eng.profile_get_all().items() if v["launches"]}
+                eng.profile(False)
+                return dt3, r, kern
+
+            # the path as the engine runs it (half rows: bins 0..nfft/2 and the last 23 of every magnitude / P row)
+            dt3, _, kern3 = leg()
+            three = {"ms_per_step": 1e3 * dt3, "hops_per_s": S * M / dt3, "kernel_ms_per_step": kern3,
+                     "rows": "half (bins 0..2048 and 4073..4095 filtered)"}
+            # BASELINE's median metric is the kernel over the whole 25 840 x 4096 matrix: whole rows
+            zen_amd.set_option("no_half_rows", 1)
+            dt3f, (med_ms, med_launches, med_elems), kern3f = leg()
+            three["whole_rows"] = {"ms_per_step": 1e3 * dt3f, "hops_per_s": S * M / dt3f, "kernel_ms_per_step": kern3f}
+            zen_amd.set_option("no_half_rows", 0)
             zen_amd.set_option("no_block_fused", 0)
         if rank == 0:
             total_hops = world * S * M * args.steps
@@ -564,7 +581,7 @@ def main():
             value = total_hops / dt
             roof, kern = offline_rooflines(prof, args.steps, {"pass1": C * n1, "pass2": C * n2},
                                            {"pass1": 4 * hop_h, "pass2": 4 * hop_p}, {"pass1": hop_h, "pass2": hop_p},
-                                           3, device_copy_bandwidth(zen_amd), 11)
+                                           3, device_copy_bandwidth(zen_amd), {"pass1": 187, "pass2": 13})
             out.update({"roofline": roof, "kernels": kern})
             out.update({
                 "metric": "hops/sec (HPR-I offline, hops of both passes)", "value": value,
@@ -615,7 +632,8 @@ def main():
             if world == 1:
                 roof, kern = offline_rooflines(prof, args.steps, {"pass1": 2 * n1, "pass2": 2 * n2},
                                                {"pass1": 4 * hop_h, "pass2": 4 * hop_p},
-                                               {"pass1": hop_h, "pass2": hop_p}, 2, device_copy_bandwidth(zen_amd), 11)
+                                               {"pass1": hop_h, "pass2": hop_p}, 2, device_copy_bandwidth(zen_amd),
+                                               {"pass1": 187, "pass2": 13})
                 out.update({"roofline": roof, "kernels": kern})
                 if not args.no_cpu_baseline:
                     out["cpu_baseline"] = cpu_baseline_offline(chans[0], hop_h, hop_p, n1 + n2, seconds=4.0, beta=2.5,

@@ -66,7 +66,8 @@ int zen_hip_synchronize(void* stream); /* hipStreamSynchronize; synchronises */
  * synthesises hard-mask outputs in separate workgroups instead of one per frame; "no_median47_dpp" = 1 sends
  * 47-tap frequency masks on 4096-bin rows through the generic sorting-network kernel instead of
  * median47_dpp_kernel, "no_median47_neighbour" = 1 additionally switches off that kernel's DPP exchange of
- * sorted blocks; "median47_variant" = 1 lets median47_dpp_kernel store results without the LDS transpose (2, 3: timing
+ * sorted blocks; "no_half_rows" = 1 makes the three-kernel path store and filter whole magnitude rows instead of the
+ * non-redundant half (bins 0..nfft/2); "median47_variant" = 1 lets median47_dpp_kernel store results without the LDS transpose (2, 3: timing
  * diagnostics whose outputs are not medians). */
 int zen_hip_set_option(const char* name, int value);
 

@@ -20,6 +20,7 @@ opt_t g_opt_no_istft_multi{0};
 opt_t g_opt_no_median47_dpp{0};
 opt_t g_opt_median47_variant{0};
 opt_t g_opt_rt_fused_diag{0};
+opt_t g_opt_no_half_rows{0};
 
 void set_error(const char* fmt, ...)
 {
@@ -151,7 +152,8 @@ int zen_hip_set_option(const char* name, int value)
 	             {"block_fused_minb", &g_opt_block_fused_minb},
 	             {"no_median47_dpp", &g_opt_no_median47_dpp},
 	             {"median47_variant", &g_opt_median47_variant},
-	             {"rt_fused_diag", &g_opt_rt_fused_diag}};
+	             {"rt_fused_diag", &g_opt_rt_fused_diag},
+	             {"no_half_rows", &g_opt_no_half_rows}};
 	for (const auto& t : table) {
 		if (name && !strcmp(name, t.name)) {
 			t.var->store(value, std::memory_order_relaxed);

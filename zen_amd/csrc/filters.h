@@ -32,7 +32,17 @@ struct FilterArgs {
 	float post_factor;
 	int nonneg;             // every source sample is >= +0 (magnitudes): ordering keys are the raw bits
 	int force_general;      // tests: skip the sorting-network fast path, use the general wave kernel
+	int hermitian;          // frequency direction, engine only: the source row is the magnitude of a Hermitian
+	                        // spectrum of which only bins 0..cols/2 are stored (bin c > cols/2 is read as bin
+	                        // cols-c); only bins 0..cols/2 and the last len/2 bins of the output are wanted, the
+	                        // rest of the output row is left untouched (P[c] == P[cols-c] there, see stft.h).
+	                        // Kernels that do not know the flag are not offered such rows (filter_supports_hermitian)
+	int pitch;              // floats between consecutive rows of src and dst (0: cols) -- the time-direction
+	                        // kernels filter only the stored half of such rows (cols = nfft/2 + 4, pitch = nfft)
 };
+
+// true if launch_median(a) with a.hermitian = 1 is implemented for this (direction, mask, row length)
+bool filter_supports_hermitian(int len, int cols);
 
 int launch_median(const FilterArgs& a, hipStream_t stream);
 int launch_median_net(const FilterArgs& a, hipStream_t stream, bool* handled); // masks <= 63 taps

@@ -197,6 +197,14 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 	if (e->causality == ZEN_HIP_TIME_CAUSAL && !e->use_sse && !g_opt_no_rt_fused && (M == 1 || !g_opt_no_block_fused)
 	    && rt_fused_available(e->log2n, e->mf))
 		return run_hop_fused(e, in, in_stride, M);
+	// Half rows: |S| is exactly Hermitian, so the median path stores and filters bins 0..nfft/2 only (and the
+	// last mf/2 bins of P, whose replicate border differs): half the magnitude / H / P traffic, half the
+	// median work.  Not for the SSE box mean (its ascending summation is not mirror symmetric), nor where a
+	// kernel on the way does not know such rows.  The last W-1 frames of a chunk keep whole magnitude rows: a
+	// later use_sse_filter() (hps.h:289) reads them.
+	const bool time_identity = (e->causality == ZEN_HIP_TIME_CAUSAL || e->mt == 1);
+	const bool half = !e->use_sse && !g_opt_no_half_rows && !g_opt_median_general
+	                  && filter_supports_hermitian(e->mf, (int)N) && (time_identity || e->mt <= 63);
 	// ---- analysis
 	StftArgs sa;
 	memset(&sa, 0, sizeof(sa));
@@ -209,6 +217,7 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 	sa.S = e->d_S;
 	sa.s_stride = (long long)e->s_stride;
 	sa.mag = e->d_mag;
+	sa.mag_full_from = half ? (int)M - ((int)e->W - 1) : 0;
 	sa.ring_rows = e->ring_rows;
 	sa.row0 = e->abs_frame;
 	sa.n_frames = (int)M;
@@ -246,6 +255,7 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 	ff.dst = e->d_P;
 	ff.len = e->mf;
 	ff.direction = ZEN_HIP_FREQUENCY;
+	ff.hermitian = half ? 1 : 0;
 	{
 		ProfScope ps(e, zen_hip_hpr::K_FREQ);
 		if (e->use_sse) {
@@ -257,8 +267,8 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 		else {
 			ZH_TRY(launch_median(ff, e->stream));
 		}
-		if (e->prof)
-			e->prof_elements += (unsigned long long)(M * N * S);
+		if (e->prof) // elements the kernel is asked for: whole rows, or bins 0..nfft/2 and the last mf/2
+			e->prof_elements += (unsigned long long)(M * (half ? N / 2 + 1 + (size_t)(e->mf / 2) : N) * S);
 	}
 
 	bool h_is_ring = false; // time direction -> H   (hps.cu:495 / :596)
@@ -266,6 +276,10 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 	ft.dst = e->d_H;
 	ft.len = e->mt;
 	ft.direction = e->causality;
+	if (half) { // only the stored half of every row (rounded up to whole 16-byte vectors)
+		ft.cols = (int)N / 2 + 4;
+		ft.pitch = (int)N;
+	}
 	if (e->use_sse) {
 		ft.sse_pre = 1;
 		ft.sse_post = 1;

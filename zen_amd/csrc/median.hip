@@ -291,6 +291,9 @@ int launch_median(const FilterArgs& a, hipStream_t stream)
 		if (handled)
 			return ZEN_HIP_OK;
 	}
+	if (a.hermitian || a.pitch)
+		ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "median: half rows (hermitian / pitch) are not implemented for mask %d on %d columns",
+		        a.len, a.cols); // the engine asks filter_supports_hermitian() first
 	if (a.direction == ZEN_HIP_FREQUENCY)
 		return launch_dir<0>(a, stream);
 	return launch_dir<1>(a, stream);

@@ -48,6 +48,7 @@ struct M47Args {
 	float* dst;
 	long long src_stream_stride, dst_stream_stride;
 	int row_base, ring; // source row of output row r: (row_base + r) % ring, with row_base < ring, r < ring
+	int herm;           // FilterArgs::hermitian: bins 0..2048 stored, bins 0..2048 and 4073..4095 wanted
 };
 
 // Streaming accesses: every input is read once and every output written once, so both bypass the caches'
@@ -76,7 +77,7 @@ __device__ __forceinline__ int* unit_ptr(int* img, int u) // 16-byte unit u of t
 //            64 bytes apart between lanes): two barriers and eight LDS instructions fewer (measured slower).
 // VARIANT 2, 3 (diagnostics for tools/bench_median.py, results are NOT medians): 2 = the data movement
 //            alone (HBM -> image -> transposed store, no sorting), 3 = everything but the global stores.
-template <bool NONNEG, int VARIANT>
+template <bool NONNEG, int VARIANT, bool HERM = false>
 __global__ __launch_bounds__(256) void median47_dpp_kernel(M47Args p)
 {
 	constexpr bool DIRECT = VARIANT == 1;
@@ -99,8 +100,16 @@ __global__ __launch_bounds__(256) void median47_dpp_kernel(M47Args p)
 	{
 		float4 x[4];
 #pragma unroll
-		for (int i = 0; i < 4; ++i)
-			x[i] = NT ? load_nt(srow + 4 * tid + 1024 * i) : *reinterpret_cast<const float4*>(srow + 4 * tid + 1024 * i);
+		for (int i = 0; i < 4; ++i) {
+			if (HERM && i >= 2) { // columns 2048 + ...: the mirror image of the stored half, back to front
+				const int mc = COLS - (4 * tid + 1024 * i); // columns mc, mc-1, mc-2, mc-3
+				const float4 v = *reinterpret_cast<const float4*>(srow + mc - 4);
+				x[i] = make_float4(srow[mc], v.w, v.z, v.y);
+			}
+			else {
+				x[i] = NT ? load_nt(srow + 4 * tid + 1024 * i) : *reinterpret_cast<const float4*>(srow + 4 * tid + 1024 * i);
+			}
+		}
 		int* wr = unit_ptr(img, tid + 6);
 #pragma unroll
 		for (int i = 0; i < 4; ++i)
@@ -121,16 +130,139 @@ __global__ __launch_bounds__(256) void median47_dpp_kernel(M47Args p)
 	__syncthreads();
 
 	int out[16];
+	int out_blk = tid;     // the block whose 16 outputs this thread holds
+	bool out_valid = true;
 	if constexpr (VARIANT == 2) {
 		znet::lds_load<16>(&img[(tid + 1) * RSTR + 8], out);
 		znet::lds_load<8>(&img[(tid + 2) * RSTR], *reinterpret_cast<int(*)[8]>(&out[8]));
 	}
 	else {
-		// ---- own block sorted, wave edges published; then the neighbours' pieces and the selection tree
+		// ---- own block sorted, wave edges published; then the neighbours' pieces and the selection tree.
+		// Hermitian rows: P[4096-k] == P[k] for 23 < k < 2048, so waves 0 and 1 take blocks 0..127, wave 2 the
+		// leftovers (lanes 0..31 blocks 128..159: bin 2048, and the pieces wave 1's last lanes need; lanes 32..63
+		// blocks 224..255: the last 23 bins) and wave 3 sits the stage out -- as in rt_fused.hip.
 		zm47::Pieces pc;
-		zm47::m47_sort_and_publish(img, edge, tid, lane, wave, tid == 0, tid == 255, pc);
+		if constexpr (HERM) {
+			const int blk = wave < 2 ? tid : (lane < 32 ? 128 + lane : 192 + lane);
+			if (wave < 3)
+				zm47::m47_sort_and_publish(img, edge, blk, lane, wave, tid == 0, blk == 255, pc);
+			__syncthreads();
+			if (wave < 3)
+				zm47::m47_select(img, edge, blk, wave, pc, out);
+			out_blk = blk;
+			out_valid = wave < 3;
+		}
+		else {
+			// (the same steps as median47_core.h, written out: as one scope the compiler keeps this kernel at 72
+			// registers and seven workgroups per CU, through the shared functions it needs 92)
+		// ---- own block B(tid) = chunk tid + 1: sorted, with its sorted halves and quarters
+		int s16[16], oct[16], quad[16];
+		{
+			int raw[16];
+			znet::lds_load<16>(&img[(tid + 1) * RSTR], raw);
+			znet::pyramid16(raw, s16, oct, quad);
+		}
+		// pieces wanted by the lanes to the left (they sit two and one blocks below this one) ...
+		int up[16], dn[16];
+	#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			up[i] = oct[i];     // lower half
+			dn[i] = oct[8 + i]; // upper half
+		}
+	#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			up[8 + i] = quad[i];      // 1st quarter
+			up[12 + i] = quad[8 + i]; // 3rd quarter
+			dn[8 + i] = quad[4 + i];  // ... and by the lane to the right: 2nd and 4th quarter
+			dn[12 + i] = quad[12 + i];
+		}
+		// ---- wave edges through LDS
+		if (wave > 0 && lane < 2) {
+			int* e = &edge[wave - 1][32 + 16 * lane];
+			znet::lds_store<16>(e, up);
+			if (lane == 0)
+				znet::lds_store<16>(&edge[wave - 1][16], s16);
+		}
+		if (wave < 3 && lane == 63)
+			znet::lds_store<16>(&edge[wave + 1][0], dn);
+		if (tid == 0) { // B(-1) = 16 copies of x[0]
+			const int b = img[0];
+			const int4 q = make_int4(b, b, b, b);
+	#pragma unroll
+			for (int i = 0; i < 4; ++i)
+				*reinterpret_cast<int4*>(&edge[0][4 * i]) = q;
+		}
+		if (tid == 255) { // B(256) = x[4088..4095] and eight copies of c = x[4095]; B(257) = 16 copies of c
+			int w[8];
+			znet::lds_load<8>(&img[257 * RSTR], w);
+			const int c = w[7];
+			znet::oe_merge<2, 0>(w);
+			znet::oe_merge<2, 2>(w);
+			znet::oe_merge<2, 4>(w);
+			znet::oe_merge<2, 6>(w);
+			znet::oe_merge<4, 0>(w);
+			znet::oe_merge<4, 4>(w);
+			int pc[16], s[16];
+	#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				pc[8 + i] = w[i]; // 1st quarter sorted
+				pc[12 + i] = c;   // 3rd quarter
+			}
+			znet::oe_merge<8, 0>(w);
+	#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				pc[i] = w[i];            // lower half sorted
+				s[i] = min(w[i], c);     // the block sorted: the eight samples with eight copies of c spliced in
+				s[8 + i] = max(w[i], c);
+			}
+			znet::lds_store<16>(&edge[3][16], s);
+			znet::lds_store<16>(&edge[3][32], pc);
+			const int4 q = make_int4(c, c, c, c);
+	#pragma unroll
+			for (int i = 0; i < 4; ++i)
+				*reinterpret_cast<int4*>(&edge[3][48 + 4 * i]) = q;
+		}
 		__syncthreads();
-		zm47::m47_select(img, edge, tid, wave, pc, out);
+
+		// ---- neighbours' pieces: DPP shifts, the wave's edge record as `old`
+		znet::Shared47 sh;
+		{
+			const int* ed = edge[wave];
+			int eb[16], B[16];
+			znet::lds_load<16>(ed + 16, eb);
+	#pragma unroll
+			for (int i = 0; i < 16; ++i)
+				B[i] = zm47::dpp_from_next(eb[i], s16[i]);
+			znet::mid16_of_two_sorted16(s16, B, sh.cand);
+			int e0[16], e1[16], el[16], hi[16], lo[16];
+			znet::lds_load<16>(ed + 32, e0);
+			znet::lds_load<16>(ed + 48, e1);
+			znet::lds_load<16>(ed, el);
+	#pragma unroll
+			for (int i = 0; i < 16; ++i) {
+				const int x1 = zm47::dpp_from_next(e0[i], up[i]); // pieces of B(t+1)
+				hi[i] = zm47::dpp_from_next(e1[i], x1);           // pieces of B(t+2)
+				lo[i] = zm47::dpp_from_prev(el[i], dn[i]);        // pieces of B(t-1)
+			}
+	#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				sh.lo_oct[i] = lo[i];
+				sh.hi_oct[i] = hi[i];
+			}
+	#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				sh.lo_q[0][i] = lo[8 + i];
+				sh.lo_q[1][i] = lo[12 + i];
+				sh.hi_q[0][i] = hi[8 + i];
+				sh.hi_q[1][i] = hi[12 + i];
+			}
+		}
+		znet::lds_load<16>(&img[tid * RSTR], sh.lo_raw);       // B(t-1) as it stands
+		znet::lds_load<16>(&img[(tid + 3) * RSTR], sh.hi_raw); // B(t+2)
+
+		znet::medians47_shared(sh, out);
+
+		}
 	}
 
 	if constexpr (DIRECT) {
@@ -142,13 +274,17 @@ __global__ __launch_bounds__(256) void median47_dpp_kernel(M47Args p)
 	}
 	else {
 		__syncthreads(); // every flank is in registers: the image can take the results
-		znet::lds_store<16>(&img[tid * RSTR], out);
+		if (!HERM || out_valid)
+			znet::lds_store<16>(&img[(HERM ? out_blk : tid) * RSTR], out);
 		__syncthreads();
 		const int* rd = unit_ptr(img, tid);
 		if (VARIANT == 3 && p.ring > 0) // always true: the host never passes ring <= 0
 			return;
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
+			const int c = 4 * tid + 1024 * i;
+			if (HERM && c > 2048 && c < 4064) // Hermitian rows: nobody reads these columns
+				continue;
 			const int4 k = *reinterpret_cast<const int4*>(rd + i * 64 * RSTR);
 			const float4 r = make_float4(from_key<NONNEG>(k.x), from_key<NONNEG>(k.y), from_key<NONNEG>(k.z), from_key<NONNEG>(k.w));
 			if (NT)
@@ -181,12 +317,19 @@ int launch_median47_dpp(const FilterArgs& a, hipStream_t stream, bool* handled)
 	p.dst = a.dst;
 	p.src_stream_stride = a.src_stream_stride;
 	p.dst_stream_stride = a.dst_stream_stride;
+	p.herm = a.hermitian;
 	p.ring = (int)a.ring_rows;
 	p.row_base = (int)(((a.first_row % a.ring_rows) + a.ring_rows) % a.ring_rows);
 	dim3 grid((unsigned)a.n_out_rows, (unsigned)a.n_streams);
-	const int variant = g_opt_median47_variant;
+	const int variant = a.hermitian ? 0 : (int)g_opt_median47_variant; // the diagnostic builds know whole rows only
 #define ZH_M47(NN, V) hipLaunchKernelGGL((median47_dpp_kernel<NN, V>), grid, dim3(256), 0, stream, p)
-	if (a.nonneg) {
+	if (a.hermitian) {
+		if (a.nonneg)
+			hipLaunchKernelGGL((median47_dpp_kernel<true, 0, true>), grid, dim3(256), 0, stream, p);
+		else
+			hipLaunchKernelGGL((median47_dpp_kernel<false, 0, true>), grid, dim3(256), 0, stream, p);
+	}
+	else if (a.nonneg) {
 		switch (variant) {
 		case 1: ZH_M47(true, 1); break;
 		case 2: ZH_M47(true, 2); break;

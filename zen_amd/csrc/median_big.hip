@@ -124,7 +124,7 @@ bool median_big_available(int len)
 int launch_median_big(const FilterArgs& a, hipStream_t stream, bool* handled)
 {
 	*handled = false;
-	if (a.direction != ZEN_HIP_FREQUENCY || !median_big_available(a.len))
+	if (a.direction != ZEN_HIP_FREQUENCY || !median_big_available(a.len) || a.hermitian)
 		return ZEN_HIP_OK;
 	const bool vec_ok = (a.cols % 4 == 0) && a.cols >= 4 && ((reinterpret_cast<uintptr_t>(a.src) & 15) == 0)
 	                    && ((reinterpret_cast<uintptr_t>(a.dst) & 15) == 0) && (a.src_stream_stride % 4 == 0)

@@ -62,6 +62,32 @@ struct RowImage {
 using znet::from_key;
 using znet::to_key;
 
+// Four consecutive logical columns vc..vc+3 (vc a multiple of 4, the row 16-byte aligned and a multiple of 4
+// long) of a source row as ordering keys: replicate border (ippBorderRepl) outside [0, cols); `herm`: only
+// columns 0..cols/2 are stored, column c > cols/2 is column cols - c (FilterArgs::hermitian).
+template <bool NONNEG>
+__device__ __forceinline__ int4 row_vec_keys(const float* __restrict__ srow, int vc, int cols, int herm)
+{
+	if (herm && vc >= (cols >> 1)) {
+		if (vc >= cols) { // beyond the row: column cols-1, which is column 1
+			const int b = to_key<NONNEG>(srow[1]);
+			return make_int4(b, b, b, b);
+		}
+		// columns cols-vc, cols-vc-1, cols-vc-2, cols-vc-3: one aligned vector and the scalar above it
+		const int mc = cols - vc;
+		const float4 v = *reinterpret_cast<const float4*>(srow + mc - 4);
+		return make_int4(to_key<NONNEG>(srow[mc]), to_key<NONNEG>(v.w), to_key<NONNEG>(v.z), to_key<NONNEG>(v.y));
+	}
+	const int vcl = vc < 0 ? 0 : (vc > cols - 4 ? cols - 4 : vc);
+	const float4 x = *reinterpret_cast<const float4*>(srow + vcl);
+	int4 k = make_int4(to_key<NONNEG>(x.x), to_key<NONNEG>(x.y), to_key<NONNEG>(x.z), to_key<NONNEG>(x.w));
+	if (vc < 0)
+		k = make_int4(k.x, k.x, k.x, k.x);
+	else if (vc >= cols)
+		k = make_int4(k.w, k.w, k.w, k.w);
+	return k;
+}
+
 // NEIGHBOUR (47 taps only): the 32 samples common to a thread's 16 windows are exactly two aligned
 // 16-sample blocks, its own and its right neighbour's own (mid + 1 = 24 = 8 mod 16).  Each thread sorts
 // its own block once and receives the neighbour's sorted block through a wave-wide DPP shift (lane i <-
@@ -89,28 +115,21 @@ __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowM
 	float* __restrict__ drow = a.dst + (long long)blockIdx.y * a.dst_stream_stride + (long long)row * cols;
 	const int c_lo = col0 - MID_AL; // column of image word 0
 
+	// Hermitian rows: only the outputs of columns 0..cols/2 and of the last `mid` columns are wanted
+	const int herm = a.hermitian;
+	const int o0 = col0 + tid * T; // this thread's first output column
+	const bool wanted = !herm || o0 <= (cols >> 1) || o0 + T > cols - mid;
 	if (vec_ok) { // cols % 4 == 0 and 16-byte aligned rows: a vector is wholly inside or wholly outside
 		constexpr int NLD = (SPANV + 255) / 256;
-		float4 x[NLD];
+		int4 k[NLD];
 #pragma unroll
-		for (int i = 0; i < NLD; ++i) { // all loads in flight before the first use
-			int vc = c_lo + 4 * (tid + 256 * i);
-			vc = vc < 0 ? 0 : (vc > cols - 4 ? cols - 4 : vc);
-			x[i] = *reinterpret_cast<const float4*>(srow + vc);
-		}
+		for (int i = 0; i < NLD; ++i) // all loads in flight before the first use
+			k[i] = row_vec_keys<NONNEG>(srow, c_lo + 4 * (tid + 256 * i), cols, herm);
 #pragma unroll
 		for (int i = 0; i < NLD; ++i) {
 			const int vi = tid + 256 * i;
-			const int vc = c_lo + 4 * vi;
-			if (vi < SPANV) {
-				int4 k = make_int4(to_key<NONNEG>(x[i].x), to_key<NONNEG>(x[i].y), to_key<NONNEG>(x[i].z),
-				                   to_key<NONNEG>(x[i].w));
-				if (vc < 0) // replicate border (ippBorderRepl): the clamped vector starts at column 0
-					k = make_int4(k.x, k.x, k.x, k.x);
-				else if (vc >= cols) // ... or ends at column cols-1
-					k = make_int4(k.w, k.w, k.w, k.w);
-				*reinterpret_cast<int4*>(&tile[IM::addr(4 * vi)]) = k;
-			}
+			if (vi < SPANV)
+				*reinterpret_cast<int4*>(&tile[IM::addr(4 * vi)]) = k[i];
 		}
 	}
 	else {
@@ -123,6 +142,9 @@ __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowM
 	__syncthreads();
 
 	int out[T];
+#pragma unroll
+	for (int i = 0; i < T; ++i)
+		out[i] = 0; // threads whose outputs nobody wants (Hermitian rows) skip the network
 	const int* mine = &tile[tid * IM::STRIDE];
 	if constexpr (NEIGHBOUR) {
 		static_assert(W == 47 && T == 16 && DELTA == 1, "block alignment of the 47-tap mask");
@@ -178,7 +200,8 @@ __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowM
 		for (int q = 0; q < W + T - 1; ++q)
 			e[q] = ld[q + DELTA];
 		__syncthreads(); // every window is in registers: the image can take the results
-		znet::medians<W, T, W + T - 1>(e, out);
+		if (wanted)
+			znet::medians<W, T, W + T - 1>(e, out);
 	}
 #pragma unroll
 	for (int v = 0; v < T / 4; ++v)
@@ -191,7 +214,7 @@ __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowM
 		for (int i = 0; i < T / 4; ++i) {
 			const int g = 4 * tid + 1024 * i;
 			const int c = col0 + g;
-			if (c < cols) {
+			if (c < cols && (!herm || c <= (cols >> 1) || c + 4 > cols - mid)) {
 				const int4 k = *reinterpret_cast<const int4*>(&tile[IM::addr(g)]);
 				*reinterpret_cast<float4*>(drow + c) = make_float4(from_key<NONNEG>(k.x), from_key<NONNEG>(k.y),
 				                                                   from_key<NONNEG>(k.z), from_key<NONNEG>(k.w));
@@ -264,6 +287,7 @@ __global__ __launch_bounds__(256) void median_net_time_kernel(FilterArgs a, RowM
 {
 	constexpr int T = znet::outputs_per_thread(W), mid = W / 2, NE = W + T - 1;
 	const int cols = a.cols;
+	const int pitch = a.pitch ? a.pitch : cols; // floats between rows (rows of which only the first cols are filtered)
 	const int c = (blockIdx.x * 256 + threadIdx.x) * VC;
 	if (c >= cols)
 		return;
@@ -277,7 +301,7 @@ __global__ __launch_bounds__(256) void median_net_time_kernel(FilterArgs a, RowM
 #pragma unroll
 	for (int q = 0; q < W - 1; ++q) { // taps r0-mid .. r0+mid-1
 		int k[VC];
-		load_keys<VC>(src + (long long)map_row(rm, r0 - mid + q) * cols, k);
+		load_keys<VC>(src + (long long)map_row(rm, r0 - mid + q) * pitch, k);
 #pragma unroll
 		for (int v = 0; v < VC; ++v)
 			e[v][q] = k[v];
@@ -286,7 +310,7 @@ __global__ __launch_bounds__(256) void median_net_time_kernel(FilterArgs a, RowM
 #pragma unroll
 		for (int i = 0; i < T; ++i) { // T new rows: rr+mid .. rr+mid+T-1
 			int k[VC];
-			load_keys<VC>(src + (long long)map_row(rm, rr + mid + i) * cols, k);
+			load_keys<VC>(src + (long long)map_row(rm, rr + mid + i) * pitch, k);
 #pragma unroll
 			for (int v = 0; v < VC; ++v)
 				e[v][W - 1 + i] = k[v];
@@ -302,7 +326,7 @@ __global__ __launch_bounds__(256) void median_net_time_kernel(FilterArgs a, RowM
 #pragma unroll
 				for (int v = 0; v < VC; ++v)
 					k[v] = out[v][g];
-				store_keys<VC>(dst + (long long)(rr + g) * cols, k);
+				store_keys<VC>(dst + (long long)(rr + g) * pitch, k);
 			}
 		}
 #pragma unroll
@@ -336,8 +360,10 @@ int launch_freq(const FilterArgs& a, const RowMap& rm, hipStream_t stream)
 	                   && ((reinterpret_cast<uintptr_t>(a.dst) & 15) == 0) && (a.src_stream_stride % 4 == 0)
 	                   && (a.dst_stream_stride % 4 == 0);
 	dim3 grid((unsigned)((long long)a.n_out_rows * segs), (unsigned)a.n_streams);
+	if (a.hermitian && !vec_ok)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "median: Hermitian rows need 16-byte aligned rows of a multiple of 4 columns");
 	if constexpr (W == 47) {
-		if (!g_opt_no_median47_neighbour) {
+		if (!g_opt_no_median47_neighbour && !a.hermitian) {
 			if (a.nonneg)
 				hipLaunchKernelGGL((median_net_freq_kernel<W, true, true>), grid, dim3(256), 0, stream, a, rm, segs, vec_ok);
 			else
@@ -369,11 +395,15 @@ __global__ __launch_bounds__(256) void median_tiny_freq_kernel(FilterArgs a, Row
 	const float* __restrict__ srow =
 	    a.src + (long long)blockIdx.y * a.src_stream_stride + (long long)map_row(rm, row) * cols;
 	float* __restrict__ drow = a.dst + (long long)blockIdx.y * a.dst_stream_stride + (long long)row * cols;
+	if (a.hermitian && c0 > (cols >> 1) && c0 + 4 <= cols - mid)
+		return; // Hermitian rows: only columns 0..cols/2 and the last `mid` ones are wanted
 	int k[4 + 2 * mid];
 #pragma unroll
 	for (int i = 0; i < 4 + 2 * mid; ++i) {
 		int c = c0 - mid + i;
 		c = c < 0 ? 0 : (c > cols - 1 ? cols - 1 : c); // replicate border (ippBorderRepl)
+		if (a.hermitian && c > (cols >> 1))
+			c = cols - c; // the stored half of a Hermitian row
 		k[i] = to_key<NONNEG>(srow[c]);
 	}
 #pragma unroll
@@ -466,6 +496,15 @@ int launch_median_net(const FilterArgs& a, hipStream_t stream, bool* handled)
 #undef X
 	default: *handled = false; return ZEN_HIP_OK;
 	}
+}
+
+// Hermitian rows (FilterArgs::hermitian): the sorting-network kernels of this file and median47_dpp_kernel
+// read the stored half and skip the unwanted outputs; the long-mask kernel does so for whole 4096-column segments
+bool filter_supports_hermitian(int len, int cols)
+{
+	if (cols % 4 != 0 || cols < 32)
+		return false;
+	return len >= 3 && len <= 63;
 }
 
 } // namespace zen_hip_impl

@@ -16,7 +16,8 @@ struct StftArgs {
 	const float2* tw;       // nfft/2
 	float2* S;              // ring: [n_streams][ring_rows][s_stride], bins 0..nfft/2 of each frame
 	long long s_stride;     // float2 per ring row (>= nfft/2 + 1)
-	float* mag;             // ring: [n_streams][ring_rows][nfft]
+	float* mag;             // ring: [n_streams][ring_rows][nfft]; bins 0..nfft/2 of every new row are written, the
+	int mag_full_from;      // mirrored upper half only for frames >= mag_full_from (0: every frame: full rows)
 	long long ring_rows;
 	long long row0;         // absolute row of the chunk's first frame
 	int n_frames;

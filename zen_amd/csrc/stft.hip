@@ -40,13 +40,19 @@ struct StftOut {
 	float2* S;  // n/2 + 1 bins are kept: the frame is real, so the spectrum is exactly Hermitian
 	            // (radix-2 DAG + a twiddle table with tw[n/2-j] == -conj(tw[j]) bit for bit) and the
 	            // synthesis kernel rebuilds S[n-k] = conj(S[k]).  Halves the spectrum traffic.
-	float* mag; // all n bins: the frequency median runs over the full spectrum
+	float* mag; // bins 0..n/2, and their mirror images n/2+1..n-1 where somebody reads whole rows (`full`):
+	            // |S[n-k]| == |S[k]| bit for bit, so the double-precision hypot is taken once per pair
 	int n;
+	bool full;
 	__device__ __forceinline__ void operator()(int idx, float2 X, bool lower, int) const
 	{
-		if (lower || idx == (n >> 1))
+		if (lower || idx == (n >> 1)) {
 			S[idx] = X;
-		mag[idx] = zfft::cabs_exact(X.x, X.y); // complex_abs_functor hps.h:82-89
+			const float m = zfft::cabs_exact(X.x, X.y); // complex_abs_functor hps.h:82-89
+			mag[idx] = m;
+			if (full && idx != 0 && idx != (n >> 1))
+				mag[n - idx] = m;
+		}
 	}
 };
 
@@ -86,6 +92,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void stft_kernel(StftArgs a)
 	out.S = a.S + row * a.s_stride;
 	out.mag = a.mag + row * PL::N;
 	out.n = PL::N;
+	out.full = f >= a.mag_full_from;
 	zfft::fft_frame<LOG2N, false, true, false>(tf, lds + slot * PL::LDS_FLOAT2, a.tw, in, out, active);
 }
 
