@@ -326,3 +326,51 @@ def test_oracle_agrees_with_independent_float64_model(hop):
                 assert np.sqrt(np.mean(err ** 2)) < 2e-6
             else:
                 assert np.sqrt(np.mean(err ** 2)) < 2e-4 and np.mean(np.abs(err) < 1e-4) > 0.95
+
+
+def test_hard_mask_without_divide_is_exact():
+    """zen_amd/csrc/masks.h hard_mask_exact: fl(x / d) >= beta (hard_mask_functor, hps.h:100-113) decided as
+    (double)x >= thr * (double)d, thr the rounding boundary below beta.  The same IEEE operations in numpy
+    (float32 division is correctly rounded, the float64 product of a 25-bit and a 24-bit number is exact),
+    on pairs placed a few ulps around the boundary, on random pairs, and on the special values."""
+    rng = np.random.default_rng(5)
+
+    def threshold(beta):
+        b = np.float32(beta)
+        u = b.view(np.uint32)
+        pred = np.uint32(u - 1).view(np.float32)
+        return (np.float64(pred) + np.float64(b)) * 0.5, (int(u) & 1) == 0
+
+    def exact(x, d, beta):
+        thr, incl = threshold(beta)
+        with np.errstate(invalid="ignore", over="ignore"):
+            t = thr * d.astype(np.float64)
+            t = t * 0.0 + t                       # fma(t, 0, t): inf -> nan, finite unchanged
+            xd = x.astype(np.float64)
+            return (xd >= t) if incl else (xd > t)
+
+    for beta in (2.0, np.float32(2.0) - np.float32(1.1920929e-07), 2.5, 1.0, 3.0, 0.1, 1.7, 1e-30, 3e38):
+        beta = np.float32(beta)
+        d = np.concatenate([rng.uniform(1e-7, 1e4, 200000), np.exp(rng.uniform(-80, 80, 200000))]).astype(np.float32)
+        with np.errstate(over="ignore", under="ignore"):
+            base = (beta * d).astype(np.float32)
+            # the boundary sits within a couple of ulps of beta * d: walk +-4 ulps around it
+            xs = [np.nextafter(base, np.float32(np.inf)) for _ in range(1)]
+            x = base.copy()
+            cases = [base]
+            up, dn = base.copy(), base.copy()
+            for _ in range(4):
+                up = np.nextafter(up, np.float32(np.inf))
+                dn = np.nextafter(dn, np.float32(-np.inf))
+                cases += [up.copy(), dn.copy()]
+            cases.append(rng.uniform(0, 1e4, d.size).astype(np.float32))
+            for x in cases:
+                ref = (x / d) >= beta
+                assert np.array_equal(ref, exact(x, d, beta)), float(beta)
+    # special values: the mask must be false for NaN anywhere and for d = inf, true for x = inf over finite d
+    beta = np.float32(2.0)
+    x = np.array([np.inf, np.inf, 1.0, np.nan, 1.0, 0.0, 3.0e38], np.float32)
+    d = np.array([np.inf, 1.0, np.inf, 1.0, np.nan, 1.0, 1.0e-3], np.float32)
+    with np.errstate(invalid="ignore", over="ignore"):
+        ref = (x / d) >= beta
+    assert np.array_equal(ref, exact(x, d, beta)) and list(ref) == [False, True, False, False, False, False, True]

@@ -20,6 +20,7 @@ opt_t g_opt_no_istft_multi{0};
 opt_t g_opt_no_median47_dpp{0};
 opt_t g_opt_median47_variant{0};
 opt_t g_opt_rt_fused_diag{0};
+opt_t g_opt_mask_divide{0};
 opt_t g_opt_no_half_rows{0};
 
 void set_error(const char* fmt, ...)
@@ -153,6 +154,7 @@ int zen_hip_set_option(const char* name, int value)
 	             {"no_median47_dpp", &g_opt_no_median47_dpp},
 	             {"median47_variant", &g_opt_median47_variant},
 	             {"rt_fused_diag", &g_opt_rt_fused_diag},
+	             {"mask_divide", &g_opt_mask_divide},
 	             {"no_half_rows", &g_opt_no_half_rows}};
 	for (const auto& t : table) {
 		if (name && !strcmp(name, t.name)) {

@@ -18,6 +18,7 @@
 #include "common.h"
 #include "filters.h"
 #include "hpr_engine.h"
+#include "masks.h"
 #include "rt_fused.h"
 #include "stft.h"
 
@@ -179,6 +180,7 @@ int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 	a.power = (int)e->beta;
 	a.out_h = e->out_h ? 1 : 0;
 	a.out_p = e->out_p ? 1 : 0;
+	a.thr = g_opt_mask_divide ? 0.0 : hard_mask_threshold(e->beta, &a.thr_inclusive);
 	a.diag = g_opt_rt_fused_diag;
 	a.stamps = e->dbg_stamps;
 	{

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <cstring>
 
 #pragma clang fp contract(off)
 
@@ -48,6 +49,21 @@ __device__ __forceinline__ float hmask_value(float h, float p, const MaskCfg& c)
 	return (float)((h / (p + EPS)) >= c.beta_h);
 }
 
+// hard_mask_functor (hps.h:100-113) without the division.  With IEEE round-to-nearest-even division,
+// fl(x / d) >= beta exactly when the real quotient x / d reaches the rounding boundary below beta: the
+// midpoint m of pred(beta) and beta if beta's significand is even (a tie rounds up to beta), else anything
+// above it.  m has 25 significant bits and d 24, so m * d is exact in double and the comparison
+// (double)x >= m * (double)d is exact too.  d = +inf gives fl(x / d) = 0 or NaN, never >= beta > 0:
+// fma(t, 0, t) turns t = inf into NaN (and leaves finite t alone), which no x reaches.  NaNs compare false on
+// both sides.  Valid for normal positive beta (hard_mask_threshold() returns 0 otherwise: divide).
+__device__ __forceinline__ float hard_mask_exact(float x, float d, double thr, bool inclusive)
+{
+	double t = thr * (double)d;
+	t = __builtin_fma(t, 0.0, t);
+	const double xd = (double)x;
+	return (inclusive ? xd >= t : xd > t) ? 1.0F : 0.0F;
+}
+
 // which: 0 percussive, 1 harmonic, 2 residual.  `which` and the cfg flags are wave-uniform, so only the
 // division(s) the requested output needs are executed.
 __device__ __forceinline__ float mask_value(int which, float h, float p, const MaskCfg& c)
@@ -59,6 +75,21 @@ __device__ __forceinline__ float mask_value(int which, float h, float p, const M
 	const float hm = c.out_h ? hmask_value(h, p, c) : 0.0f;
 	const float pm = c.out_p ? pmask_value(h, p, c) : 0.0f;
 	return 1 - (hm + pm); // residual_mask_functor hps.h:35-43
+}
+
+// host side of hard_mask_exact: the boundary and whether it belongs to the "true" side
+inline double hard_mask_threshold(float beta, int* inclusive)
+{
+	unsigned u;
+	memcpy(&u, &beta, sizeof(u));
+	const unsigned expo = (u >> 23) & 0xffu;
+	if ((u >> 31) || expo == 0 || expo == 0xffu) // negative, zero, subnormal, inf, NaN: keep the divide
+		return 0.0;
+	const unsigned up = u - 1; // pred(beta): the next float below (beta > FLT_MIN's pred is subnormal: still exact)
+	float pred;
+	memcpy(&pred, &up, sizeof(pred));
+	*inclusive = (u & 1u) == 0; // a tie rounds to the even significand
+	return ((double)pred + (double)beta) * 0.5;
 }
 
 } // namespace zen_hip_impl

@@ -32,6 +32,10 @@ struct RtFusedArgs {
 	int out_id[3];
 	float beta, beta_h, cola;
 	int soft, power, out_h, out_p;
+	// hard percussive mask without the divide (host: hard_mask_threshold): fl(p / d) >= beta  <=>  p >= thr * d
+	// (or > when !thr_inclusive) in exact arithmetic, thr the rounding boundary just below beta; 0: divide
+	double thr;
+	int thr_inclusive;
 	int diag;               // 0; 1 / 2: timing diagnostics of rt_fused_kernel (results are not valid)
 	unsigned long long* stamps; // diagnostic: 8 s_memrealtime stamps (100 MHz) of workgroup 0's phases, or null
 };

@@ -133,6 +133,8 @@ struct InvInLean {
 	const float* pc;
 	MaskCfg cfg;
 	int which;
+	double thr;     // != 0: hard percussive mask by exact comparison (masks.h hard_mask_exact)
+	bool thr_inclusive;
 	__device__ __forceinline__ float2 operator()(int idx, int slot) const
 	{
 		const int lo = slot * TF, hi = lo + TF - 1;
@@ -146,7 +148,9 @@ struct InvInLean {
 		const int g = idx + 24;
 		const float mag = __int_as_float(img[(g >> 4) * 20 + (g & 15)]);
 		const float2 z = r->S[slot];
-		const float m = mask_value(which, mag, pc[pi], cfg);
+		// thr is wave-uniform: one branch, no divide on the taken side
+		const float m = thr != 0.0 ? hard_mask_exact(pc[pi], mag + FLT_EPSILON, thr, thr_inclusive)
+		                           : mask_value(which, mag, pc[pi], cfg);
 		return make_float2(z.x * m, z.y * m); // apply_mask_functor hps.h:58-66
 	}
 };
@@ -343,6 +347,8 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		in.pc = Prow;
 		in.cfg = MaskCfg{a.beta, a.beta_h, a.soft, a.power, 0, a.out_h, a.out_p};
 		in.which = a.out_id[0];
+		in.thr = (in.which == 0 && !a.soft) ? a.thr : 0.0;
+		in.thr_inclusive = a.thr_inclusive != 0;
 		InvOut out;
 		out.Y = a.Y[in.which] + (long long)s * a.y_stream_stride + (long long)f * (2 * hop);
 		out.cola = a.cola;
