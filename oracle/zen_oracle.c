@@ -458,6 +458,9 @@ static inline float hard_mask(float x, float y, float beta) { return (float)((x 
  * glibc powf(x, 2.0f) agrees to within 1 ulp (tests/test_oracle.py checks). */
 static inline float powi(float x, int p)
 {
+#ifdef ZO_LITERAL_POWF /* tests/test_oracle.py builds this variant to measure what the substitution costs */
+	return powf(x, (float)p);
+#endif
 	if (p <= 0)
 		return 1.0F; /* powf(x, 0) = 1 */
 	float r = x;
@@ -475,6 +478,7 @@ static inline float soft_mask_f(float x, float y, int power)
 
 /* hps.h:132-140 sse_mask_functor */
 static inline float sse_mask_f(float x, float y) { return x * x / (x * x + y * y + ZO_EPS); }
+/* (hps.h:132-140 writes x*x itself; only complex_abs_squared_functor below calls powf) */
 
 /* mask the lag row, inverse FFT, overlap-add: hps.cu:517-528 (and :550-560, :569-579) */
 static void apply_ifft_ola(zo_hpr* h, const float* mask_row, float* out)
@@ -528,7 +532,11 @@ static void apply_sse_filter(zo_hpr* h) /* hps.cu:582-652 */
 	size_t r = W - (size_t)h->lag;
 	for (size_t i = 0; i < mat; ++i) { /* complex_abs_squared_functor hps.h:91-98 : powf(abs(z), 2) */
 		float a = zo_cabs(h->sliding_stft[2 * i], h->sliding_stft[2 * i + 1]);
+#ifdef ZO_LITERAL_POWF
+		h->s_mag[i] = powf(a, 2);
+#else
 		h->s_mag[i] = a * a;
+#endif
 	}
 	for (size_t i = 0; i < mat; ++i) /* reciprocal_functor(1.0F) hps.h:45-56 : (1/x)*factor */
 		h->reciprocal[i] = (1.0f / h->s_mag[i]) * 1.0F;
