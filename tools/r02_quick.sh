@@ -1,3 +1,7 @@
 #!/bin/bash
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
-for i in 1 2; do python3 bench.py --no-cpu-baseline --no-realtime | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); print(j['value'], j['kernel_ms_per_step'])"; done
+OUT=gpurun_out/r02_aa; mkdir -p $OUT
+g++ -O2 -std=c++17 -I include tools/rt_latency.cpp -o /tmp/rt_latency -L zen_amd -lzen_hip -Wl,-rpath,$PWD/zen_amd
+/tmp/rt_latency 3000 --stamps
+timeout 2700 python3 -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1; echo "rc=$?" >> $OUT/pytest_gpu.log
+tail -4 $OUT/pytest_gpu.log

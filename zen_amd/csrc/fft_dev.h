@@ -61,13 +61,47 @@ __device__ __forceinline__ float2 cmul(float2 w, float2 b)
 	return make_float2(w.x * b.x - w.y * b.y, w.x * b.y + w.y * b.x);
 }
 
+// Where a pass takes its twiddles from.  TwGlobal: the table in global memory, loaded where they are used (one
+// dependent L2 / HBM round trip per pass).  TwRegs: every twiddle a thread will need in any pass of a forward
+// or inverse transform of this size, loaded once up front (the single-hop kernel, where six such round trips are
+// a seventh of the call); slot = position of the load inside a pass: stage q, frequency group c < max(1, 2^(q-2)).
+struct TwGlobal {
+	const float2* __restrict__ p;
+	__device__ __forceinline__ float2 get(int, int, int, int idx) const { return p[idx]; }
+};
+
+template <int LOG2N>
+struct TwRegs {
+	using PL = Plan<LOG2N>;
+	static constexpr int NBMAX = 16 >> PL::BASE; // groups per thread in the pass with the fewest stages
+	float2 w[PL::P][NBMAX][8];
+	__device__ __forceinline__ float2 get(int pass, int i, int slot, int) const { return w[pass][i][slot]; }
+	template <int PASS = 0>
+	__device__ __forceinline__ void fill(int tf, const float2* __restrict__ p)
+	{
+		constexpr int rr = PL::r(PASS), R = 1 << rr, NB = 16 / R, sL = PL::s(PASS), log2J = LOG2N - sL - rr;
+#pragma unroll
+		for (int i = 0; i < NB; ++i) {
+			const int k = (tf + i * PL::TF) >> log2J;
+#pragma unroll
+			for (int q = 1; q <= rr; ++q) {
+				const int nload = q == 1 ? 1 : (1 << (q - 2));
+#pragma unroll
+				for (int c = 0; c < nload; ++c)
+					w[PASS][i][(q == 1 ? 0 : (1 << (q - 2))) + c] = p[(k << (LOG2N - sL - q)) + (c << (LOG2N - q))];
+			}
+		}
+		if constexpr (PASS + 1 < PL::P)
+			fill<PASS + 1>(tf, p);
+	}
+};
+
 // r = log2(R) radix-2 DIT stages on R values held by one thread.
 //   in : a[m] = Y_s[j + m*J][k], m < R            (J = N / (2^s * R))
 //   out: a[c] = Y_{s+r}[j][k + c*2^s], c < R
 // ZU: a[R/2..R) are known zeros (zero-padded analysis frame): the first stage is then a copy.
-template <int R, bool INV, bool ZU>
-__device__ __forceinline__ void butterfly(float2 (&a)[R], int k, int log2L, int log2N,
-                                          const float2* __restrict__ tw)
+template <int R, bool INV, bool ZU, class TW>
+__device__ __forceinline__ void butterfly(float2 (&a)[R], int k, int log2L, int log2N, const TW& tw, int pass, int grp)
 {
 	constexpr int r = Log2<R>::value;
 	float2 b[R];
@@ -84,7 +118,7 @@ __device__ __forceinline__ void butterfly(float2 (&a)[R], int k, int log2L, int 
 			}
 			else {
 				int idx = (k << (log2N - log2L - q)) + (c << (log2N - q));
-				float2 t = tw[idx];
+				float2 t = tw.get(pass, grp, (q == 1 ? 0 : (1 << (q - 2))) + c, idx);
 				w[c] = INV ? make_float2(t.x, -t.y) : t;
 			}
 		}
@@ -112,11 +146,11 @@ __device__ __forceinline__ void butterfly(float2 (&a)[R], int k, int log2L, int 
 
 // SYNC_FIRST: in() of the first pass reads LDS that the pass's own stores may overwrite (the fused kernel
 // keeps |S| and P inside the frame image): a barrier separates the two, as in every later pass.
-template <int LOG2N, int PASS, bool INV, bool ZU, bool HALF_OUT, class In, class Out, bool SYNC_FIRST = false>
+template <int LOG2N, int PASS, bool INV, bool ZU, bool HALF_OUT, class In, class Out, bool SYNC_FIRST = false,
+          class TW = TwGlobal>
 struct PassRunner {
 	using PL = Plan<LOG2N>;
-	static __device__ __forceinline__ void run(int tf, float2* __restrict__ lds,
-	                                           const float2* __restrict__ tw, In& in, Out& out, bool active)
+	static __device__ __forceinline__ void run(int tf, float2* __restrict__ lds, const TW& tw, In& in, Out& out, bool active)
 	{
 		constexpr int N = PL::N, TF = PL::TF;
 		constexpr int rr = PL::r(PASS), R = 1 << rr, NB = 16 / R;
@@ -149,7 +183,7 @@ struct PassRunner {
 		for (int i = 0; i < NB; ++i) {
 			const int b = tf + i * TF;
 			const int k = b >> log2J;
-			butterfly<R, INV, ZUP>(v[i], k, sL, LOG2N, tw);
+			butterfly<R, INV, ZUP>(v[i], k, sL, LOG2N, tw, PASS, i);
 #pragma unroll
 			for (int c = 0; c < R; ++c) {
 				const int idx = b + c * (N / R);
@@ -166,7 +200,7 @@ struct PassRunner {
 		}
 		if constexpr (!LAST) {
 			__syncthreads();
-			PassRunner<LOG2N, PASS + 1, INV, ZU, HALF_OUT, In, Out, SYNC_FIRST>::run(tf, lds, tw, in, out, active);
+			PassRunner<LOG2N, PASS + 1, INV, ZU, HALF_OUT, In, Out, SYNC_FIRST, TW>::run(tf, lds, tw, in, out, active);
 		}
 	}
 };
@@ -182,7 +216,15 @@ template <int LOG2N, bool INV, bool ZU, bool HALF_OUT, class In, class Out, bool
 __device__ __forceinline__ void fft_frame(int tf, float2* __restrict__ lds, const float2* __restrict__ tw,
                                           In& in, Out& out, bool active)
 {
-	PassRunner<LOG2N, 0, INV, ZU, HALF_OUT, In, Out, SYNC_FIRST>::run(tf, lds, tw, in, out, active);
+	const TwGlobal g{tw};
+	PassRunner<LOG2N, 0, INV, ZU, HALF_OUT, In, Out, SYNC_FIRST, TwGlobal>::run(tf, lds, g, in, out, active);
+}
+// the same with the twiddles already in registers (TwRegs::fill)
+template <int LOG2N, bool INV, bool ZU, bool HALF_OUT, class In, class Out, bool SYNC_FIRST = false>
+__device__ __forceinline__ void fft_frame(int tf, float2* __restrict__ lds, const TwRegs<LOG2N>& tw, In& in, Out& out,
+                                          bool active)
+{
+	PassRunner<LOG2N, 0, INV, ZU, HALF_OUT, In, Out, SYNC_FIRST, TwRegs<LOG2N>>::run(tf, lds, tw, in, out, active);
 }
 
 // |z| exactly as the oracle's zo_cabs: (float)sqrt((double)re*re + (double)im*im)

@@ -237,6 +237,12 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 	}
 
 	stamp(1);
+	// Single-hop launches (MINB == 1, registers to spare): every twiddle of both transforms is loaded here, next
+	// to the input samples, instead of in six dependent round trips later (fft_dev.h TwRegs).
+	constexpr bool TWC = (MINB == 1);
+	zfft::TwRegs<LOG2N> twr;
+	if constexpr (TWC)
+		twr.fill(tf, a.tw);
 	// ---- analysis: hps.cu:452-472, :492
 	Regs r;
 	{
@@ -258,7 +264,10 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		out.mid_al = MID_AL;
 		// the last pass overwrites the FFT image with the magnitude image: every thread has read its
 		// inputs of that pass before the barrier inside PassRunner, so the aliasing is safe
-		zfft::fft_frame<LOG2N, false, true, false>(tf, lds, a.tw, in, out, true);
+		if constexpr (TWC)
+			zfft::fft_frame<LOG2N, false, true, false>(tf, lds, twr, in, out, true);
+		else
+			zfft::fft_frame<LOG2N, false, true, false>(tf, lds, a.tw, in, out, true);
 	}
 	__syncthreads();
 	stamp(2);
@@ -355,7 +364,10 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		out.ready = (a.n_frames == 1 && a.ready[in.which]) ? a.ready[in.which] + (long long)s * hop : nullptr;
 		out.carry = a.carry[in.which] + (long long)s * hop;
 		out.hop = hop;
-		zfft::fft_frame<LOG2N, true, false, true, InvInLean<N, TF, mid>, InvOut, true>(tf, lds, a.tw, in, out, true);
+		if constexpr (TWC)
+			zfft::fft_frame<LOG2N, true, false, true, InvInLean<N, TF, mid>, InvOut, true>(tf, lds, twr, in, out, true);
+		else
+			zfft::fft_frame<LOG2N, true, false, true, InvInLean<N, TF, mid>, InvOut, true>(tf, lds, a.tw, in, out, true);
 		if (out.ready && a.publish_seq)
 			publish_ready(reinterpret_cast<unsigned*>(out.ready + hop), a.seq, tf);
 		return;
@@ -380,7 +392,10 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		out.ready = (a.n_frames == 1 && a.ready[which]) ? a.ready[which] + (long long)s * hop : nullptr;
 		out.carry = a.carry[which] + (long long)s * hop;
 		out.hop = hop;
-		zfft::fft_frame<LOG2N, true, false, true>(tf, lds, a.tw, in, out, true);
+		if constexpr (TWC)
+			zfft::fft_frame<LOG2N, true, false, true>(tf, lds, twr, in, out, true);
+		else
+			zfft::fft_frame<LOG2N, true, false, true>(tf, lds, a.tw, in, out, true);
 		if (out.ready && a.publish_seq)
 			publish_ready(reinterpret_cast<unsigned*>(out.ready + hop), a.seq, tf);
 	};
