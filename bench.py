@@ -376,6 +376,10 @@ def main():
     if args.workload == "offline_batch" and world == 1 and not args.no_cpu_baseline:
         cpu_all = cpu_baseline_offline_all_cores(4096, 256)      # forks: before anything loads or touches the GPU
     import torch
+    if os.environ.get("ZEN_ALLOW_GPU_SHARING") and torch.cuda.device_count() > 0:
+        # testing the N-rank path on a box with fewer GPUs than ranks (use --backend gloo: RCCL refuses two ranks
+        # on one device); never a measurement configuration
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     grp = zdist.Group(args.backend, torch.device("cuda", local_rank) if args.backend == "nccl" else None)
 

@@ -75,3 +75,30 @@ def test_spawn_ranks_reports_a_dead_rank_and_stops_the_others():
     rc = zdist.spawn_ranks([sys.executable, "-c", code], 3, timeout=50)
     assert rc == 7
     assert time.monotonic() - t0 < 30            # ranks 0 and 2 were terminated, not waited for
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_ranks_shard_clips_on_the_gpu_path():
+    """The real N-rank code path (engine per rank, clips sharded, counters reduced) on a 1-GPU box: two ranks
+    share the device (ZEN_ALLOW_GPU_SHARING) and talk over gloo; rank 0 reports the aggregate line."""
+    env = dict(os.environ, ZEN_ALLOW_GPU_SHARING="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    common = ["--workload", "offline_batch", "--clip-seconds", "2", "--steps", "2", "--warmup", "1", "--settle-ms", "0",
+              "--no-cpu-baseline"]
+
+    def line(extra):
+        r = subprocess.run([sys.executable, BENCH] + common + extra, cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        return json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][0])
+
+    two = line(["--gpus", "2", "--backend", "gloo", "--clips", "2"])
+    one = line(["--clips", "4"])
+    assert two["n_gpus"] == 2 and two["config"]["parallelism"].startswith("clips sharded x2")
+    assert two["config"]["clips_per_gpu"] == 2 and one["n_gpus"] == 1
+    # rank r owns clips r, r+2 (round robin); the checksum is over the first 4096 samples of each rank's FIRST clip
+    assert two["checksum"] > 0 and one["checksum"] > 0

@@ -149,3 +149,28 @@ def test_median_networks_on_the_host(tmp_path):
                            "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "passed" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
+def test_cli_batch_over_two_processes_matches_one(tmp_path):
+    """`zen batch --gpus 2` (SURVEY 8(e), configs[3]): the parent starts two copies of itself before anything has
+    touched a GPU, files are dealt round robin, every child separates its own.  Same PCM16 files as one process."""
+    rng = np.random.default_rng(3)
+    ind, out1, out2 = tmp_path / "in", tmp_path / "o1", tmp_path / "o2"
+    for d in (ind, out1, out2):
+        d.mkdir()
+    for i in range(5):
+        n = 30000 if i != 3 else 41000               # two (rate, length) groups
+        x = (0.4 * np.sin(2 * np.pi * 330 * np.arange(n) / 44100.0) + 0.3 * rng.uniform(-1, 1, n) * (np.arange(n) % 4000 < 100))
+        write_wav_pcm16(str(ind / ("clip%d.wav" % i)), np.round(x * 20000).astype(np.int16), 44100)
+    args = [ZEN, "batch", "-i", str(ind), "--hps", "1024", "2.0", "256", "2.0"]
+    r1 = subprocess.run(args + ["-o", str(out1)], capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0, r1.stdout + r1.stderr
+    env = dict(os.environ, ZEN_ALLOW_GPU_SHARING="1")  # one GPU here: both children use device 0
+    r2 = subprocess.run(args + ["-o", str(out2), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    assert "zen batch: 2 GPUs: 5 files" in r2.stdout and "[gpu 0]" in r2.stdout and "[gpu 1]" in r2.stdout
+    names = sorted(os.listdir(out1))
+    assert names == sorted(os.listdir(out2)) and len(names) == 10
+    for nme in names:
+        assert open(os.path.join(out1, nme), "rb").read() == open(os.path.join(out2, nme), "rb").read(), nme

@@ -138,9 +138,35 @@ int reset_state(zen_hip_hpr* e)
 	return ZEN_HIP_OK;
 }
 
+// Buffers only some paths touch are allocated when one of them first runs: the harmonic / percussive estimates
+// of the three-kernel path (the fused causal kernel keeps them on chip) and the synthesis rows of an output
+// that is not computed.  Y rows are zeroed once so that no kernel can see uninitialised memory.
+int ensure_estimates(zen_hip_hpr* e, bool need_h)
+{
+	const size_t bytes = sizeof(float) * e->n_streams * e->max_hops * e->nfft;
+	if (!e->d_P)
+		ZH_HIP(hipMalloc((void**)&e->d_P, bytes));
+	if (need_h && !e->d_H)
+		ZH_HIP(hipMalloc((void**)&e->d_H, bytes));
+	return ZEN_HIP_OK;
+}
+
+int ensure_rows(zen_hip_hpr* e, int o)
+{
+	if (e->d_Y[o])
+		return ZEN_HIP_OK;
+	const size_t bytes = sizeof(float) * e->n_streams * e->max_hops * e->nwin;
+	ZH_HIP(hipMalloc((void**)&e->d_Y[o], bytes));
+	ZH_HIP(hipMemsetAsync(e->d_Y[o], 0, bytes, e->stream));
+	return ZEN_HIP_OK;
+}
+
 // causal, median path: M hops of every stream in one launch, one workgroup per hop (rt_fused.hip)
 int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 {
+	for (int o = 0; o < 3; ++o)
+		if (output_computed(e, o))
+			ZH_TRY(ensure_rows(e, o));
 	RtFusedArgs a;
 	memset(&a, 0, sizeof(a));
 	a.in = in;
@@ -205,6 +231,10 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 	// kernel on the way does not know such rows.  The last W-1 frames of a chunk keep whole magnitude rows: a
 	// later use_sse_filter() (hps.h:289) reads them.
 	const bool time_identity = (e->causality == ZEN_HIP_TIME_CAUSAL || e->mt == 1);
+	ZH_TRY(ensure_estimates(e, e->use_sse || !time_identity));
+	for (int o = 0; o < 3; ++o)
+		if (output_computed(e, o))
+			ZH_TRY(ensure_rows(e, o));
 	const bool half = !e->use_sse && !g_opt_no_half_rows && !g_opt_median_general
 	                  && filter_supports_hermitian(e->mf, (int)N) && (time_identity || e->mt <= 63);
 	// ---- analysis
@@ -473,12 +503,10 @@ int zen_hip_hpr_create(float fs, size_t hop, float beta, unsigned output_flags, 
 	          && hipMalloc((void**)&e->d_tail[0], sizeof(float) * S * hop) == hipSuccess
 	          && hipMalloc((void**)&e->d_tail[1], sizeof(float) * S * hop) == hipSuccess
 	          && hipMalloc((void**)&e->d_S, sizeof(float2) * S * e->ring_rows * e->s_stride) == hipSuccess
-	          && hipMalloc((void**)&e->d_mag, sizeof(float) * S * e->ring_rows * nfft) == hipSuccess
-	          && hipMalloc((void**)&e->d_H, sizeof(float) * S * MH * nfft) == hipSuccess
-	          && hipMalloc((void**)&e->d_P, sizeof(float) * S * MH * nfft) == hipSuccess;
+	          && hipMalloc((void**)&e->d_mag, sizeof(float) * S * e->ring_rows * nfft) == hipSuccess;
+	// d_H, d_P and d_Y[] are allocated by the first call that needs them (ensure_estimates / ensure_rows)
 	for (int o = 0; o < 3 && ok; ++o)
-		ok = hipMalloc((void**)&e->d_Y[o], sizeof(float) * S * MH * nwin) == hipSuccess
-		     && hipMalloc((void**)&e->d_carry[o], sizeof(float) * S * hop) == hipSuccess;
+		ok = hipMalloc((void**)&e->d_carry[o], sizeof(float) * S * hop) == hipSuccess;
 	for (int o = 0; o < 3 && ok; ++o) {
 		if (S == 1) { // io.h:24-66 style: pinned, mapped; the kernel writes it over the host link
 			void* dev = nullptr;
@@ -505,8 +533,7 @@ int zen_hip_hpr_create(float fs, size_t hop, float beta, unsigned output_flags, 
 	// once, so that no kernel can ever see uninitialised memory; reset_buffers() clears only what is read
 	(void)hipMemsetAsync(e->d_S, 0, sizeof(float2) * S * e->ring_rows * e->s_stride, e->stream);
 	(void)hipMemsetAsync(e->d_mag, 0, sizeof(float) * S * e->ring_rows * nfft, e->stream);
-	for (int o = 0; o < 3; ++o)
-		(void)hipMemsetAsync(e->d_Y[o], 0, sizeof(float) * S * MH * nwin, e->stream);
+	(void)MH;
 	int rc = reset_state(e);
 	if (rc != ZEN_HIP_OK) {
 		free_all(e);
