@@ -192,7 +192,7 @@ def offline_rooflines(prof, steps, frames, nfft, hop, n_out1, copy_bw, freq_mask
     kernel as a stand-alone stage, half spectrum nfft/2+1 bins where the data is Hermitian):
       stft        : 4*hop in + 8*(nfft/2+1) spectrum + 4*(nfft/2+1) magnitude out
       freq_filter : 8 B per element (4 read + 4 written) of the frames x nfft matrix; where the engine filters
-                    half rows (masks <= 63 taps) of the frames x (nfft/2 + 1 + mask/2) it needs
+                    half rows of the frames x (nfft/2 + 1 + mask/2) it needs
       time_filter : 8 B per element of frames x nfft, or of frames x (nfft/2 + 1) with half rows
       istft       : per output 8*(nfft/2+1) spectrum + 8*(nfft/2+1) H and P in + 4*nwin out
       finalize    : per output 12*hop (two half frames in, one hop out)"""
@@ -201,7 +201,7 @@ def offline_rooflines(prof, steps, frames, nfft, hop, n_out1, copy_bw, freq_mask
         N, h, F = nfft[ps], hop[ps], frames[ps]
         nout = n_out1 if ps == "pass1" else 1
         mf = freq_mask[ps]
-        half = mf <= 63                                           # hpr.hip run_chunk: half rows on the median path
+        half = mf <= 63 or mf in (65, 85, 93, 129, 171, 187, 255)  # hpr.hip run_chunk: half rows on the median path
         per_frame = {"stft": 4 * h + 12 * (N // 2 + 1),
                      "freq_filter": 8 * (N // 2 + 1 + mf // 2) if half else 8 * N,
                      "time_filter": 8 * (N // 2 + 1) if half else 8 * N,

@@ -6,6 +6,7 @@
 #include "common.h"
 #include "filters.h"
 #include "median_big.h"
+#include "row_load.h"
 
 #pragma clang fp contract(off)
 
@@ -22,8 +23,11 @@ using znet::to_key;
 #ifndef ZEN_BIG_MINB
 #define ZEN_BIG_MINB 2
 #endif
+// nblk_main: the leading blocks of a row that are filtered (all of them; Hermitian rows: bins 0..cols/2 - 1, the
+// rest is median_big_tail_kernel's).
 template <int W, bool NONNEG>
-__global__ __launch_bounds__(256, ZEN_BIG_MINB) void median_big_kernel(FilterArgs a, int row_base, int ring, int segs_per_row)
+__global__ __launch_bounds__(256, ZEN_BIG_MINB) void median_big_kernel(FilterArgs a, int row_base, int ring, int segs_per_row,
+                                                                      int nblk_main)
 {
 	using G = zbig::Geo<W>;
 	// raw image: chunk c = block c - (a+2) of the segment; sorted image: entry s = block s - a
@@ -50,16 +54,8 @@ __global__ __launch_bounds__(256, ZEN_BIG_MINB) void median_big_kernel(FilterArg
 		for (int i = 0; i < NLD; ++i) {
 			const int vi = tid + 256 * i;
 			const int vc = c_lo + 4 * vi;
-			if (vi < NVEC) {
-				const int vcl = vc < 0 ? 0 : (vc > cols - 4 ? cols - 4 : vc);
-				const float4 x = *reinterpret_cast<const float4*>(srow + vcl);
-				int4 k = make_int4(to_key<NONNEG>(x.x), to_key<NONNEG>(x.y), to_key<NONNEG>(x.z), to_key<NONNEG>(x.w));
-				if (vc < 0)
-					k = make_int4(k.x, k.x, k.x, k.x);
-				else if (vc >= cols)
-					k = make_int4(k.w, k.w, k.w, k.w);
-				*reinterpret_cast<int4*>(&raw[(vi >> 2) * RSTR + 4 * (vi & 3)]) = k;
-			}
+			if (vi < NVEC)
+				*reinterpret_cast<int4*>(&raw[(vi >> 2) * RSTR + 4 * (vi & 3)]) = row_vec_keys<NONNEG>(srow, vc, cols, a.hermitian);
 		}
 	}
 	__syncthreads();
@@ -72,8 +68,12 @@ __global__ __launch_bounds__(256, ZEN_BIG_MINB) void median_big_kernel(FilterArg
 	}
 	__syncthreads();
 	// ---- 16 outputs per thread
+	const bool wanted = (col0 >> 4) + tid < nblk_main;
 	int out[16];
-	{
+#pragma unroll
+	for (int i = 0; i < 16; ++i)
+		out[i] = 0;
+	if (wanted) {
 		struct Loader {
 			const int* srt_t; // sorted block t-a
 			const int* raw_t; // raw block t-a-2
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256, ZEN_BIG_MINB) void median_big_kernel(FilterArg
 	for (int i = 0; i < 4; ++i) {
 		const int g = 4 * tid + 1024 * i;
 		const int c = col0 + g;
-		if (c < cols) {
+		if (c < cols && (c >> 4) < nblk_main) {
 			const int4 k = *reinterpret_cast<const int4*>(&raw[(g >> 4) * RSTR + (g & 15)]);
 			*reinterpret_cast<float4*>(drow + c) =
 			    make_float4(from_key<NONNEG>(k.x), from_key<NONNEG>(k.y), from_key<NONNEG>(k.z), from_key<NONNEG>(k.w));
@@ -98,17 +98,81 @@ __global__ __launch_bounds__(256, ZEN_BIG_MINB) void median_big_kernel(FilterArg
 	}
 }
 
+// Hermitian rows: what the main kernel leaves out -- the block that holds bin cols/2 and the last ceil(mid/16)
+// blocks (whose replicate border differs from the mirrored one) -- by ONE wavefront per row: lane 0
+// takes the middle block, lanes 1.. the tail blocks; both neighbourhoods are staged and sorted side by side.
+template <int W, bool NONNEG>
+__global__ __launch_bounds__(64) void median_big_tail_kernel(FilterArgs a, int row_base, int ring)
+{
+	using G = zbig::Geo<W>;
+	constexpr int NT = (G::m + 15) / 16;                // tail blocks
+	constexpr int HALO_L = G::a + 2, HALO_R = G::b + 1;  // raw blocks needed left / right of an output block
+	constexpr int NRAW_A = HALO_L + 1 + HALO_R, NRAW_B = HALO_L + NT + HALO_R;
+	constexpr int NSORT_A = 1 + G::NB - 1, NSORT_B = NT + G::NB - 1;
+	__shared__ __attribute__((aligned(16))) int raw[(NRAW_A + NRAW_B) * RSTR];
+	__shared__ __attribute__((aligned(16))) int srt[(NSORT_A + NSORT_B) * RSTR];
+	const int lane = threadIdx.x;
+	const int cols = a.cols, nblk = cols >> 4;
+	const int st = blockIdx.y, row = blockIdx.x;
+	const float* srow = a.src + (long long)st * a.src_stream_stride + (long long)((row_base + row) % ring) * cols;
+	float* drow = a.dst + (long long)st * a.dst_stream_stride + (long long)row * cols;
+	const int blkA = nblk >> 1, blkB = nblk - NT; // first output block of either piece
+	for (int vi = lane; vi < (NRAW_A + NRAW_B) * 4; vi += 64) {
+		const bool pb = vi >= NRAW_A * 4;
+		const int v = pb ? vi - NRAW_A * 4 : vi;
+		const int vc = 16 * ((pb ? blkB : blkA) - HALO_L) + 4 * v;
+		*reinterpret_cast<int4*>(&raw[(vi >> 2) * RSTR + 4 * (vi & 3)]) = row_vec_keys<NONNEG>(srow, vc, cols, 1);
+	}
+	__syncthreads();
+	for (int s = lane; s < NSORT_A + NSORT_B; s += 64) { // sorted entry s of a piece = raw chunk s + 2 of that piece
+		const bool pb = s >= NSORT_A;
+		const int chunk = pb ? NRAW_A + (s - NSORT_A) + 2 : s + 2;
+		int v[16];
+		znet::lds_load<16>(&raw[chunk * RSTR], v);
+		znet::sort_net<16>(v);
+		znet::lds_store<16>(&srt[s * RSTR], v);
+	}
+	__syncthreads();
+	if (lane > NT)
+		return;
+	const int loc = lane == 0 ? 0 : lane - 1; // block within the piece
+	struct Loader {
+		const int* srt_t;
+		const int* raw_t;
+		__device__ __forceinline__ void sorted(int i, int* v) const { znet::lds_load<16>(srt_t + i * RSTR, v); }
+		__device__ __forceinline__ void rawl(int j, int* v) const { znet::lds_load<16>(raw_t + j * RSTR, v); }
+		__device__ __forceinline__ void rawr(int j, int* v) const { znet::lds_load<16>(raw_t + (G::a + G::b + 2 + j) * RSTR, v); }
+	} ld{&srt[((lane == 0 ? 0 : NSORT_A) + loc) * RSTR], &raw[((lane == 0 ? 0 : NRAW_A) + loc) * RSTR]};
+	int out[16];
+	zbig::medians_big<W>(ld, out);
+	const int c = 16 * ((lane == 0 ? blkA : blkB) + loc);
+#pragma unroll
+	for (int v = 0; v < 4; ++v)
+		*reinterpret_cast<float4*>(drow + c + 4 * v) =
+		    make_float4(from_key<NONNEG>(out[4 * v]), from_key<NONNEG>(out[4 * v + 1]), from_key<NONNEG>(out[4 * v + 2]),
+		                from_key<NONNEG>(out[4 * v + 3]));
+}
+
 template <int W>
 int launch_w(const FilterArgs& a, hipStream_t stream)
 {
-	const int segs = (a.cols + OUTS - 1) / OUTS;
 	const int row_base = (int)(a.first_row % a.ring_rows);
+	const int nblk_main = a.hermitian ? a.cols >> 5 : (a.cols + 15) >> 4; // blocks 0 .. cols/32 - 1 hold bins 0 .. cols/2 - 1
+	const int segs = (nblk_main + 255) / 256;
 	dim3 grid((unsigned)((long long)a.n_out_rows * segs * a.n_streams));
 	if (a.nonneg)
-		hipLaunchKernelGGL((median_big_kernel<W, true>), grid, dim3(256), 0, stream, a, row_base, (int)a.ring_rows, segs);
+		hipLaunchKernelGGL((median_big_kernel<W, true>), grid, dim3(256), 0, stream, a, row_base, (int)a.ring_rows, segs, nblk_main);
 	else
-		hipLaunchKernelGGL((median_big_kernel<W, false>), grid, dim3(256), 0, stream, a, row_base, (int)a.ring_rows, segs);
+		hipLaunchKernelGGL((median_big_kernel<W, false>), grid, dim3(256), 0, stream, a, row_base, (int)a.ring_rows, segs, nblk_main);
 	ZH_HIP(hipGetLastError());
+	if (a.hermitian) {
+		dim3 tgrid((unsigned)a.n_out_rows, (unsigned)a.n_streams);
+		if (a.nonneg)
+			hipLaunchKernelGGL((median_big_tail_kernel<W, true>), tgrid, dim3(64), 0, stream, a, row_base, (int)a.ring_rows);
+		else
+			hipLaunchKernelGGL((median_big_tail_kernel<W, false>), tgrid, dim3(64), 0, stream, a, row_base, (int)a.ring_rows);
+		ZH_HIP(hipGetLastError());
+	}
 	return ZEN_HIP_OK;
 }
 
@@ -124,7 +188,11 @@ bool median_big_available(int len)
 int launch_median_big(const FilterArgs& a, hipStream_t stream, bool* handled)
 {
 	*handled = false;
-	if (a.direction != ZEN_HIP_FREQUENCY || !median_big_available(a.len) || a.hermitian)
+	if (a.direction != ZEN_HIP_FREQUENCY || !median_big_available(a.len))
+		return ZEN_HIP_OK;
+	// Hermitian rows: the main kernel takes whole 16-bin blocks below cols/2, the tail kernel one wavefront of
+	// blocks: rows of at least 64 blocks whose two pieces do not overlap
+	if (a.hermitian && (a.cols % 32 != 0 || (a.cols >> 5) < (a.len / 2 + 15) / 16 + 1 || a.n_streams > 65535))
 		return ZEN_HIP_OK;
 	const bool vec_ok = (a.cols % 4 == 0) && a.cols >= 4 && ((reinterpret_cast<uintptr_t>(a.src) & 15) == 0)
 	                    && ((reinterpret_cast<uintptr_t>(a.dst) & 15) == 0) && (a.src_stream_stride % 4 == 0)

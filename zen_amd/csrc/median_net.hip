@@ -18,6 +18,7 @@
 #include "common.h"
 #include "filters.h"
 #include "median_net.h"
+#include "row_load.h"
 
 #pragma clang fp contract(off)
 
@@ -61,32 +62,6 @@ struct RowImage {
 
 using znet::from_key;
 using znet::to_key;
-
-// Four consecutive logical columns vc..vc+3 (vc a multiple of 4, the row 16-byte aligned and a multiple of 4
-// long) of a source row as ordering keys: replicate border (ippBorderRepl) outside [0, cols); `herm`: only
-// columns 0..cols/2 are stored, column c > cols/2 is column cols - c (FilterArgs::hermitian).
-template <bool NONNEG>
-__device__ __forceinline__ int4 row_vec_keys(const float* __restrict__ srow, int vc, int cols, int herm)
-{
-	if (herm && vc >= (cols >> 1)) {
-		if (vc >= cols) { // beyond the row: column cols-1, which is column 1
-			const int b = to_key<NONNEG>(srow[1]);
-			return make_int4(b, b, b, b);
-		}
-		// columns cols-vc, cols-vc-1, cols-vc-2, cols-vc-3: one aligned vector and the scalar above it
-		const int mc = cols - vc;
-		const float4 v = *reinterpret_cast<const float4*>(srow + mc - 4);
-		return make_int4(to_key<NONNEG>(srow[mc]), to_key<NONNEG>(v.w), to_key<NONNEG>(v.z), to_key<NONNEG>(v.y));
-	}
-	const int vcl = vc < 0 ? 0 : (vc > cols - 4 ? cols - 4 : vc);
-	const float4 x = *reinterpret_cast<const float4*>(srow + vcl);
-	int4 k = make_int4(to_key<NONNEG>(x.x), to_key<NONNEG>(x.y), to_key<NONNEG>(x.z), to_key<NONNEG>(x.w));
-	if (vc < 0)
-		k = make_int4(k.x, k.x, k.x, k.x);
-	else if (vc >= cols)
-		k = make_int4(k.w, k.w, k.w, k.w);
-	return k;
-}
 
 // NEIGHBOUR (47 taps only): the 32 samples common to a thread's 16 windows are exactly two aligned
 // 16-sample blocks, its own and its right neighbour's own (mid + 1 = 24 = 8 mod 16).  Each thread sorts
@@ -504,7 +479,11 @@ bool filter_supports_hermitian(int len, int cols)
 {
 	if (cols % 4 != 0 || cols < 32)
 		return false;
-	return len >= 3 && len <= 63;
+	if (len >= 3 && len <= 63)
+		return true;
+	// the long masks of median_big.hip (hop 2048 / 4096): whole 16-bin blocks, the two pieces of the tail apart
+	const bool big = len == 65 || len == 85 || len == 93 || len == 129 || len == 171 || len == 187 || len == 255;
+	return big && cols % 32 == 0 && (cols >> 5) >= (len / 2 + 15) / 16 + 1;
 }
 
 } // namespace zen_hip_impl
