@@ -198,7 +198,9 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 	static_assert(IMG_WORDS * 4 <= PL::LDS_FLOAT2 * 8, "magnitude image must fit in the FFT image");
 	// 47 taps on 4096 bins (hop 1024 at 44.1 kHz, the headline configuration): the block scheme of
 	// median47_core.h on the half spectrum
-	constexpr bool BLOCK47 = (W == 47 && LOG2N == 12);
+	// (with several outputs the spectrum registers live through a loop of inverse transforms; the block scheme's
+	// pieces on top of them spill, 1.19 against 1.13 ms with the generic median stage: one output only)
+	constexpr bool BLOCK47 = (W == 47 && LOG2N == 12 && SINGLE);
 	static_assert(!LEAN || (BLOCK47 && SINGLE), "the lean layout is the one-output 47-tap kernel");
 	static_assert(!LEAN || (LEAN_EDGE_WORD + 256) * 4 <= PL::LDS_FLOAT2 * 8, "lean layout must fit in the frame image");
 
@@ -422,7 +424,7 @@ int launch_k(const RtFusedArgs& a, hipStream_t stream)
 {
 	using PL = Plan<LOG2N>;
 	const size_t lds = LEAN ? sizeof(float2) * PL::LDS_FLOAT2
-	                        : sizeof(float2) * PL::LDS_FLOAT2 + sizeof(float) * PL::N + (W == 47 && LOG2N == 12 ? 1024 : 0);
+	                        : sizeof(float2) * PL::LDS_FLOAT2 + sizeof(float) * PL::N + (W == 47 && LOG2N == 12 && SINGLE ? 1024 : 0);
 	auto kern = rt_fused_kernel<LOG2N, W, MINB, SINGLE, LEAN>;
 	if (lds > 64 * 1024)
 		ZH_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
