@@ -273,6 +273,31 @@ def test_hpr_realtime_api_mapped_memory(z):
     assert np.all(io.host_out == 0)
 
 
+def test_hpr_realtime_copy_into_interior_and_alternating_destinations(z):
+    """copy_* polls the engine's staging buffer and copies on the host when the destination is mapped host memory:
+    the host alias must be right for pointers INSIDE an allocation and for a destination that changes from hop to
+    hop; a device destination takes the asynchronous device copy instead."""
+    fs, hop, n_hops = 44100.0, 512, 12
+    x = music(hop * n_hops, 6)
+    _, ref = run_oracle(fs, hop, 2.0, o.OUTPUT_PERCUSSIVE, o.TIME_CAUSAL, x)
+    rt = z.HPRRealtime(fs, hop, 2.0, z.OUTPUT_PERCUSSIVE)
+    io = z.IOGPU(3 * hop)                            # three hop-sized slots in one mapped buffer
+    dev = z.DeviceBuffer(hop)
+    out = np.zeros_like(x)
+    io.host_out[:] = -7.0
+    for i in range(n_hops):
+        io.host_in[:hop] = x[i * hop:(i + 1) * hop]
+        rt.process_next_hop(io.device_in)
+        if i % 4 == 3:                               # a plain device destination
+            rt.copy_percussive(dev.ptr)
+            out[i * hop:(i + 1) * hop] = dev.download()
+            continue
+        slot = i % 3
+        rt.copy_percussive(io.device_out + 4 * hop * slot)
+        out[i * hop:(i + 1) * hop] = io.host_out[slot * hop:(slot + 1) * hop]
+    assert np.array_equal(out, ref["P"])
+
+
 def test_hpr_reset_gives_identical_rerun(z):
     fs, hop = 48000.0, 256                          # hps.test.cu:345-372
     x = noise(hop * 30, 2)

@@ -1,3 +1,3 @@
 #!/bin/bash
 cd "$(dirname "$0")/.." && export TMPDIR=/tmp
-for i in 1 2; do python3 bench.py --outputs HPR --no-cpu-baseline --no-realtime | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); print(j['value'], j['kernel_ms_per_step'])"; done
+timeout 900 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "realtime or mapped" 2>&1 | tail -6

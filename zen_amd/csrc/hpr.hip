@@ -637,10 +637,14 @@ static void* host_alias_of(zen_hip_hpr_t h, const void* out_dev)
 		return h->out_query_host;
 	hipPointerAttribute_t at;
 	void* host = nullptr;
-	if (hipPointerGetAttributes(&at, out_dev) == hipSuccess && at.type == hipMemoryTypeHost)
-		host = at.hostPointer;
-	else
+	if (hipPointerGetAttributes(&at, out_dev) == hipSuccess && at.type == hipMemoryTypeHost && at.hostPointer
+	    && at.devicePointer) {
+		// interior pointers: whatever the runtime reports for the pair, the two aliases differ by a constant
+		host = (char*)at.hostPointer + ((const char*)out_dev - (const char*)at.devicePointer);
+	}
+	else {
 		(void)hipGetLastError();
+	}
 	h->out_query_dev = out_dev;
 	h->out_query_host = host;
 	return host;
