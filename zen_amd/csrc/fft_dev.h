@@ -144,6 +144,23 @@ __device__ __forceinline__ void butterfly(float2 (&a)[R], int k, int log2L, int 
 	}
 }
 
+// Synchronisation between the LDS phases of a pass.  A frame is transformed by TF = N/16 threads; when those are
+// one wavefront or less (nfft <= 1024: several frames per workgroup, each in its own wavefront) nobody outside the
+// wavefront touches the frame's image: a wavefront executes its LDS instructions in order, so only the compiler has
+// to be kept from moving accesses across the phase boundary -- no s_barrier that would hold four independent
+// frames in lock step.
+template <int TF>
+__device__ __forceinline__ void frame_sync()
+{
+	if constexpr (TF <= 64) {
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+	}
+	else {
+		__syncthreads();
+	}
+}
+
 // SYNC_FIRST: in() of the first pass reads LDS that the pass's own stores may overwrite (the fused kernel
 // keeps |S| and P inside the frame image): a barrier separates the two, as in every later pass.
 template <int LOG2N, int PASS, bool INV, bool ZU, bool HALF_OUT, class In, class Out, bool SYNC_FIRST = false,
@@ -178,7 +195,7 @@ struct PassRunner {
 			}
 		}
 		if (!FIRST || SYNC_FIRST)
-			__syncthreads(); // every thread has its inputs in registers: LDS may be overwritten
+			frame_sync<TF>(); // every thread has its inputs in registers: LDS may be overwritten
 #pragma unroll
 		for (int i = 0; i < NB; ++i) {
 			const int b = tf + i * TF;
@@ -199,7 +216,7 @@ struct PassRunner {
 			}
 		}
 		if constexpr (!LAST) {
-			__syncthreads();
+			frame_sync<TF>();
 			PassRunner<LOG2N, PASS + 1, INV, ZU, HALF_OUT, In, Out, SYNC_FIRST, TW>::run(tf, lds, tw, in, out, active);
 		}
 	}
