@@ -350,6 +350,37 @@ def test_hpr_switch_to_sse_after_block_calls(z, hop, first, block):
     assert same(got_b, ref_b)
 
 
+@pytest.mark.parametrize("fs,hop,flags,streams", [(44100.0, 512, ALL, 1), (44100.0, 1024, o.OUTPUT_PERCUSSIVE, 1),
+                                                  (48000.0, 256, o.OUTPUT_HARMONIC | o.OUTPUT_PERCUSSIVE, 1),
+                                                  (44100.0, 128, ALL, 2), (22050.0, 512, o.OUTPUT_HARMONIC, 1)])
+def test_hpr_sse_hop_by_hop_single_launch(z, fs, hop, flags, streams):
+    """config 5 through the realtime API: every hop of the causal SSE path is ONE launch (rt_sse.hip), mixed with
+    block calls (four launches): same samples as the oracle either way, history handed over through the
+    magnitude ring in both directions."""
+    n_hops = 30
+    x = np.stack([music(hop * n_hops, 40 + s, fs) for s in range(streams)])
+    g = z.HPR(fs, hop, 2.0, flags, z.TIME_CAUSAL, True, streams)
+    g.use_sse_filter()
+    parts = [g.process_stream_host(x[:, :hop * 9] if streams > 1 else x[0, :hop * 9], block=1),     # single launches
+             g.process_stream_host(x[:, hop * 9:hop * 16] if streams > 1 else x[0, hop * 9:hop * 16], block=4),
+             g.process_stream_host(x[:, hop * 16:] if streams > 1 else x[0, hop * 16:], block=1)]
+    for s in range(streams):
+        _, ref = run_oracle(fs, hop, 2.0, flags, o.TIME_CAUSAL, x[s], sse=True)
+        for k in "PHR":
+            got = np.concatenate([(p[k][s] if streams > 1 else p[k]) for p in parts])
+            assert np.array_equal(got, ref[k]), (k, s)
+    z.set_option("no_rt_fused", 1)                    # the four-launch path hop by hop, for the same stream
+    try:
+        g2 = z.HPR(fs, hop, 2.0, flags, z.TIME_CAUSAL, True, streams)
+        g2.use_sse_filter()
+        alt = g2.process_stream_host(x if streams > 1 else x[0], block=1)
+    finally:
+        z.set_option("no_rt_fused", 0)
+    for s in range(streams):
+        _, ref = run_oracle(fs, hop, 2.0, flags, o.TIME_CAUSAL, x[s], sse=True)
+        assert all(np.array_equal(alt[k][s] if streams > 1 else alt[k], ref[k]) for k in "PHR")
+
+
 def test_hpr_multi_stream_matches_single(z):
     fs, hop, n_hops, S = 44100.0, 256, 40, 5
     x = np.stack([noise(hop * n_hops, 100 + s) for s in range(S)])

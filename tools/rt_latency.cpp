@@ -27,7 +27,10 @@ int main(int argc, char** argv)
 {
 	const int n_hops = argc > 1 ? std::atoi(argv[1]) : 2000;
 	CK(zen_hip_init(0));
-	for (int sse = 0; sse < 2; ++sse) {
+	if (const char* d = std::getenv("ZEN_RT_DIAG")) // timing diagnostics of the single-hop kernels (results not valid)
+		CK(zen_hip_set_option("rt_fused_diag", std::atoi(d)));
+	const bool only_sse = std::getenv("ZEN_RT_ONLY_SSE") != nullptr;
+	for (int sse = only_sse ? 1 : 0; sse < 2; ++sse) {
 		for (size_t hop : {256, 512, 1024, 2048, 4096}) {
 			if (sse && hop != 512 && hop != 2048)
 				continue;
@@ -57,6 +60,23 @@ int main(int argc, char** argv)
 					t_copy += t2 - t1;
 					t_all += t3 - t0;
 				}
+			}
+			if (argc > 2 && sse && hop <= 1024) { // the single-launch SSE kernel (rt_sse.hip)
+				unsigned long long* st = nullptr;
+				CK(zen_hip_hpr_debug_stamps(h, &st));
+				std::memcpy(hin, x.data(), hop * 4);
+				for (int rep = 0; rep < 3; ++rep) {
+					CK(zen_hip_hpr_process_next_hop(h, (const float*)din));
+					CK(zen_hip_hpr_copy_output(h, ZEN_HIP_OUTPUT_PERCUSSIVE, (float*)dout));
+				}
+				{ // the stamps are written after the flag the copy call waits for
+					const double t0 = now_us();
+					while (now_us() - t0 < 2000.0) {}
+				}
+				std::printf("{\"hop\": %zu, \"sse\": 1, \"phase_us\": {\"carry_history\": %.2f, \"forward_fft_abs\": %.2f, "
+				            "\"box_sums\": %.2f, \"mask_inverse_fft_store\": %.2f}, \"shader_clock_MHz\": %.0f}\n",
+				            hop, (st[1] - st[0]) / 100.0, (st[2] - st[1]) / 100.0, (st[3] - st[2]) / 100.0,
+				            (st[4] - st[3]) / 100.0, (double)st[5] / ((st[4] - st[0]) / 100.0));
 			}
 			if (argc > 2 && !sse && hop <= 1024) { // --stamps: phase times of the last single-hop launch
 				unsigned long long* st = nullptr;

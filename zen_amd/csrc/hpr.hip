@@ -162,7 +162,7 @@ int ensure_rows(zen_hip_hpr* e, int o)
 }
 
 // causal, median path: M hops of every stream in one launch, one workgroup per hop (rt_fused.hip)
-int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
+int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, bool sse = false)
 {
 	for (int o = 0; o < 3; ++o)
 		if (output_computed(e, o))
@@ -211,7 +211,10 @@ int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 	a.stamps = e->dbg_stamps;
 	{
 		ProfScope ps(e, zen_hip_hpr::K_FUSED);
-		ZH_TRY(launch_rt_fused(e->log2n, e->mf, a, e->stream));
+		if (sse) // single hop of the SSE path (rt_sse.hip); box lengths and factors as launch_box gets them below
+			ZH_TRY(launch_rt_sse(e->log2n, a, e->mt, e->mf, (float)e->l_harm + 1.0F, (float)e->l_perc + 1.0F, e->stream));
+		else
+			ZH_TRY(launch_rt_fused(e->log2n, e->mf, a, e->stream));
 	}
 	e->tail_sel ^= 1;
 	e->abs_frame += (long long)M;
@@ -225,6 +228,9 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 	if (e->causality == ZEN_HIP_TIME_CAUSAL && !e->use_sse && !g_opt_no_rt_fused && (M == 1 || !g_opt_no_block_fused)
 	    && rt_fused_available(e->log2n, e->mf))
 		return run_hop_fused(e, in, in_stride, M);
+	if (e->causality == ZEN_HIP_TIME_CAUSAL && e->use_sse && M == 1 && !g_opt_no_rt_fused
+	    && rt_sse_available(e->log2n, e->mt, e->mf))
+		return run_hop_fused(e, in, in_stride, 1, true);
 	// Half rows: |S| is exactly Hermitian, so the median path stores and filters bins 0..nfft/2 only (and the
 	// last mf/2 bins of P, whose replicate border differs): half the magnitude / H / P traffic, half the
 	// median work.  Not for the SSE box mean (its ascending summation is not mirror symmetric), nor where a

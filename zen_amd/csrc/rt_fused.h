@@ -43,4 +43,9 @@ struct RtFusedArgs {
 bool rt_fused_available(int log2n, int freq_len);
 int launch_rt_fused(int log2n, int freq_len, const RtFusedArgs& a, hipStream_t stream);
 
+// rt_sse.hip: the causal SSE path (apply_sse_filter, hps.cu:582-652) for ONE hop per stream in one launch.  len_t /
+// len_f: the odd box lengths (time, frequency), fac_h / fac_p: l_harm + 1, l_perc + 1 (hps.cu:599-604).
+bool rt_sse_available(int log2n, int len_t, int len_f);
+int launch_rt_sse(int log2n, const RtFusedArgs& a, int len_t, int len_f, float fac_h, float fac_p, hipStream_t stream);
+
 } // namespace zen_hip_impl
