@@ -49,16 +49,26 @@ struct IstftOut {
 	float* Y;
 	float cola;
 	float* ready;       // single-frame calls: the finished hop = carry + first half of this frame
-	const float* carry; // saved by the housekeeping block of the analysis kernel of the same call
-	int hop;
-	__device__ __forceinline__ void operator()(int idx, float2 x, bool, int) const
+	const float* cv;    // the thread's four carry samples (saved by the housekeeping block of the analysis kernel of
+	int hop;            // the same call), idx = tf + slot*TF, slot < 4: loaded before the transform -- a load here
+	                    // would queue behind the stores
+	__device__ __forceinline__ void operator()(int idx, float2 x, bool, int slot) const
 	{
 		const float y = x.x * cola; // the product of overlap_add_functor hps.h:68-80; the sum is in finalize ...
 		Y[idx] = y;
 		if (ready && idx < hop) // ... or here, when the call is a single hop (hps.cu:341-363 hands out [0, hop))
-			ready[idx] = carry[idx] + y;
+			ready[idx] = cv[slot & 3] + y;
 	}
 };
+
+// the four carry samples of thread tf (hop == 4*TF)
+template <int TF>
+__device__ __forceinline__ void load_carry(const float* carry, int tf, bool wanted, float (&cv)[4])
+{
+#pragma unroll
+	for (int i = 0; i < 4; ++i)
+		cv[i] = wanted ? carry[tf + i * TF] : 0.0f;
+}
 
 template <int LOG2N>
 __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void istft_kernel(IstftArgs a)
@@ -82,7 +92,9 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void istft_kernel(IstftArgs a
 	out.Y = a.Y[oi] + (long long)s * a.y_stream_stride + (long long)f * (PL::N / 2);
 	out.cola = a.cola;
 	out.ready = (a.n_frames == 1 && a.ready[oi]) ? a.ready[oi] + (long long)s * a.hop : nullptr;
-	out.carry = a.carry[oi] + (long long)s * a.hop;
+	float cv[4];
+	load_carry<PL::TF>(a.carry[oi] + (long long)s * a.hop, tf, out.ready != nullptr, cv);
+	out.cv = cv;
 	out.hop = a.hop;
 	zfft::fft_frame<LOG2N, true, false, true>(tf, lds + slot * PL::LDS_FLOAT2, a.tw, in, out, active);
 	if (a.n_frames == 1 && a.publish_seq && a.ready[oi]) { // see rt_fused.hip publish_ready (a.n_frames == 1: one frame per block)
@@ -153,7 +165,9 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void istft_hard_multi_kernel(
 		out.Y = a.Y[oi] + (long long)s * a.y_stream_stride + (long long)f * (PL::N / 2);
 		out.cola = a.cola;
 		out.ready = (a.n_frames == 1 && a.ready[oi]) ? a.ready[oi] + (long long)s * a.hop : nullptr;
-		out.carry = a.carry[oi] + (long long)s * a.hop;
+		float cv[4];
+		load_carry<PL::TF>(a.carry[oi] + (long long)s * a.hop, tf, out.ready != nullptr, cv);
+		out.cv = cv;
 		out.hop = a.hop;
 		// The thread index and the table pointer are made opaque per output: otherwise every LDS address and
 		// twiddle index of the transform (all functions of tf alone) is hoisted out of this loop and kept

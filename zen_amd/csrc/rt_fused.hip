@@ -51,15 +51,13 @@ struct FwdIn {
 	const float* prev;
 	const float* cur;
 	const float* window;
-	float* tail; // the call's last frame: receives its new hop (the next call's `prev`), else null
+	float* tail; // block calls, the call's last frame: receives its new hop (the next call's `prev`); else null
 	int hop;
 	__device__ __forceinline__ float2 operator()(int idx, int) const
 	{
 		const float x = idx < hop ? prev[idx] : cur[idx - hop];
-		// every sample of the new hop is loaded here exactly once: the input tail is stored from the same
-		// registers instead of being read again (over the host link, when `cur` is mapped host memory)
-		if (tail && idx >= hop)
-			tail[idx - hop] = x;
+		if (tail && idx >= hop) // (a store between two loads: the second waits for the first.  One workgroup of a
+			tail[idx - hop] = x; // block call can afford that; the single-hop call copies the tail below instead)
 		return make_float2(x * window[idx], 0.0f); // window_functor hps.h:24-33
 	}
 };
@@ -159,14 +157,14 @@ struct InvOut {
 	float* Y;
 	float cola;
 	float* ready;       // single-hop calls: the finished hop = carry + first half of this frame (hps.cu:526-528 + :341-363)
-	const float* carry; // second half of the previous frame, saved by this workgroup's housekeeping
-	int hop;
-	__device__ __forceinline__ void operator()(int idx, float2 x, bool, int) const
+	const float* cv;    // the thread's four carry samples (second half of the previous frame), idx = tf + slot*TF,
+	int hop;            // slot < 4: in registers since the housekeeping -- a load here would queue behind the stores
+	__device__ __forceinline__ void operator()(int idx, float2 x, bool, int slot) const
 	{
 		const float y = x.x * cola;
 		Y[idx] = y;
 		if (ready && idx < hop)
-			ready[idx] = carry[idx] + y;
+			ready[idx] = cv[slot & 3] + y;
 	}
 };
 
@@ -210,20 +208,71 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 
 	const int tf = threadIdx.x, hop = a.hop;
 	const int s = blockIdx.x / a.n_frames, f = blockIdx.x - s * a.n_frames; // consecutive blocks: consecutive hops
-	// diagnostic build hook (tools/rt_latency.cpp --stamps): phase times of a single-hop call.  The stamps go
-	// to a buffer nothing else reads.
+	// diagnostic hook (tools/rt_latency.cpp --stamps): phase times of a single-hop call (100 MHz), kept in scalar
+	// registers until the end -- a store to the host-mapped stamp buffer in front of a barrier would be waited for
+	// there -- and only in the single-hop build.
+	unsigned long long stamps[6] = {0, 0, 0, 0, 0, 0};
 	auto stamp = [&](int k) {
-		if (a.stamps && blockIdx.x == 0 && tf == 0)
-			a.stamps[k] = __builtin_amdgcn_s_memrealtime();
+		if constexpr (MINB == 1) {
+			if (a.stamps)
+				stamps[k] = __builtin_amdgcn_s_memrealtime();
+		}
+	};
+	auto flush_stamps = [&]() {
+		if constexpr (MINB == 1) {
+			if (a.stamps && blockIdx.x == 0 && tf == 0)
+				for (int k = 0; k < 6; ++k)
+					a.stamps[k] = stamps[k];
+		}
 	};
 	stamp(0);
 	const float* cur = a.in + (long long)s * a.in_stride + (long long)f * hop;
 
 	// ---- housekeeping (as the extra block of stft_kernel): overlap-add carries, input tail.  The carry is
 	// the second half of the previous call's last Y row; the workgroup that will overwrite that row (or, if
-	// this call is shorter, the last one) saves it first.
-	// (hop == 4*TF: four elements per thread, all loads in flight together, then the stores)
-	if (a.prev_frames > 0 && f == (a.prev_frames - 1 < a.n_frames - 1 ? a.prev_frames - 1 : a.n_frames - 1)) {
+	// this call is shorter, the last one) saves it first.  The tail is the call's last hop: the next call's `prev`.
+	// (hop == 4*TF: four elements per thread.)
+	const bool do_carry = a.prev_frames > 0 && f == (a.prev_frames - 1 < a.n_frames - 1 ? a.prev_frames - 1 : a.n_frames - 1);
+	float cv[3][4]; // single-hop calls: the carries of this hop, per output
+	if constexpr (MINB == 1) {
+		// Single-hop launches: all loads first, then the stores.  A store between two loads makes the second wait
+		// for the first (the compiler cannot know they do not alias): stored from inside the transform's input
+		// functor, the tail cost such a call eight dependent trips to memory.
+		float tv[4];
+#pragma unroll
+		for (int o = 0; o < 3; ++o) {
+			if (!a.carry[o])
+				continue;
+			// the carry comes from the previous call's Y row, or (first call, or this workgroup is not the saver)
+			// from the carry buffer
+			const float* y = do_carry ? a.Y[o] + (long long)s * a.y_stream_stride + (long long)(a.prev_frames - 1) * (2 * hop) + hop
+			                          : a.carry[o] + (long long)s * hop;
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+				cv[o][i] = y[tf + i * TF];
+		}
+		if (f == a.n_frames - 1) {
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+				tv[i] = cur[tf + i * TF];
+		}
+		if (do_carry) {
+#pragma unroll
+			for (int o = 0; o < 3; ++o) {
+				if (!a.carry[o])
+					continue;
+#pragma unroll
+				for (int i = 0; i < 4; ++i)
+					a.carry[o][(long long)s * hop + tf + i * TF] = cv[o][i];
+			}
+		}
+		if (f == a.n_frames - 1) {
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+				a.tail_next[(long long)s * hop + tf + i * TF] = tv[i];
+		}
+	}
+	else if (do_carry) {
 		for (int o = 0; o < 3; ++o) {
 			if (!a.carry[o])
 				continue;
@@ -238,6 +287,14 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		}
 	}
 
+	float cw[4] = {0.f, 0.f, 0.f, 0.f}; // the carries of the output being synthesised
+	auto pick_carry = [&](int which) {
+		if constexpr (MINB == 1) {
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+				cw[i] = which == 0 ? cv[0][i] : (which == 1 ? cv[1][i] : cv[2][i]);
+		}
+	};
 	stamp(1);
 	// Single-hop launches (MINB == 1, registers to spare): every twiddle of both transforms is loaded here, next
 	// to the input samples, instead of in six dependent round trips later (fft_dev.h TwRegs).
@@ -252,7 +309,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		in.prev = f > 0 ? cur - hop : a.tail_prev + (long long)s * hop;
 		in.cur = cur;
 		in.window = a.window;
-		in.tail = f == a.n_frames - 1 ? a.tail_next + (long long)s * hop : nullptr;
+		in.tail = (MINB > 1 && f == a.n_frames - 1) ? a.tail_next + (long long)s * hop : nullptr;
 		in.hop = hop;
 		const long long row = ((a.row0 + f) % a.ring_rows) + (long long)s * a.ring_rows;
 		FwdOut<T> out;
@@ -363,8 +420,9 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		InvOut out;
 		out.Y = a.Y[in.which] + (long long)s * a.y_stream_stride + (long long)f * (2 * hop);
 		out.cola = a.cola;
-		out.ready = (a.n_frames == 1 && a.ready[in.which]) ? a.ready[in.which] + (long long)s * hop : nullptr;
-		out.carry = a.carry[in.which] + (long long)s * hop;
+		out.ready = (MINB == 1 && a.n_frames == 1 && a.ready[in.which]) ? a.ready[in.which] + (long long)s * hop : nullptr;
+		pick_carry(in.which);
+		out.cv = cw;
 		out.hop = hop;
 		if constexpr (TWC)
 			zfft::fft_frame<LOG2N, true, false, true, InvInLean<N, TF, mid>, InvOut, true>(tf, lds, twr, in, out, true);
@@ -372,6 +430,9 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 			zfft::fft_frame<LOG2N, true, false, true, InvInLean<N, TF, mid>, InvOut, true>(tf, lds, a.tw, in, out, true);
 		if (out.ready && a.publish_seq)
 			publish_ready(reinterpret_cast<unsigned*>(out.ready + hop), a.seq, tf);
+		stamp(4);
+		stamp(5);
+		flush_stamps();
 		return;
 	}
 	// the thread's 16 magnitudes come back from the image (they were not held in registers across the
@@ -391,8 +452,9 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		InvOut out;
 		out.Y = a.Y[which] + (long long)s * a.y_stream_stride + (long long)f * (2 * hop);
 		out.cola = a.cola;
-		out.ready = (a.n_frames == 1 && a.ready[which]) ? a.ready[which] + (long long)s * hop : nullptr;
-		out.carry = a.carry[which] + (long long)s * hop;
+		out.ready = (MINB == 1 && a.n_frames == 1 && a.ready[which]) ? a.ready[which] + (long long)s * hop : nullptr;
+		pick_carry(which);
+		out.cv = cw;
 		out.hop = hop;
 		if constexpr (TWC)
 			zfft::fft_frame<LOG2N, true, false, true>(tf, lds, twr, in, out, true);
@@ -410,6 +472,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 	if constexpr (SINGLE) {
 		synth(a.out_id[0]);
 		stamp(5);
+		flush_stamps();
 	}
 	else {
 		for (int oi = 0; oi < a.n_out; ++oi) {

@@ -89,14 +89,14 @@ struct SseInvOut {
 	float* Y;
 	float cola;
 	float* ready;
-	const float* carry;
-	int hop;
-	__device__ __forceinline__ void operator()(int idx, float2 x, bool, int) const
+	const float* cv; // the thread's four carry samples, idx = tf + slot*TF, slot < 4 (hop == 4*TF): in registers since
+	int hop;         // before the transforms -- a load here would queue behind the stores of the previous outputs
+	__device__ __forceinline__ void operator()(int idx, float2 x, bool, int slot) const
 	{
 		const float y = x.x * cola;
 		Y[idx] = y;
 		if (idx < hop)
-			ready[idx] = carry[idx] + y; // hps.cu:526-528 + :341-363
+			ready[idx] = cv[slot & 3] + y; // hps.cu:526-528 + :341-363
 	}
 };
 
@@ -213,9 +213,21 @@ __global__ __launch_bounds__(SseGeo<LOG2N>::NT) void rt_sse_kernel(RtFusedArgs a
 	stamp(1);
 	SseRegs r;
 	zfft::TwRegs<LOG2N> twr;
+	float cv[3][4]; // the carries of this hop per output, as the synthesis will want them
 	if (fft_thread) {
 		// every twiddle of both transforms up front: one round trip instead of one per pass (fft_dev.h TwRegs)
 		twr.fill(t, a.tw);
+#pragma unroll
+		for (int o = 0; o < 3; ++o) {
+			if (!a.carry[o])
+				continue;
+			const float* y = a.prev_frames > 0
+			                     ? a.Y[o] + (long long)s * a.y_stream_stride + (long long)(a.prev_frames - 1) * (2 * hop) + hop
+			                     : a.carry[o] + (long long)s * hop;
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+				cv[o][i] = y[t + i * TF];
+		}
 		SseFwdIn in;
 		in.prev = a.tail_prev + (long long)s * hop;
 		in.cur = cur;
@@ -288,7 +300,11 @@ __global__ __launch_bounds__(SseGeo<LOG2N>::NT) void rt_sse_kernel(RtFusedArgs a
 			out.Y = a.Y[which] + (long long)s * a.y_stream_stride;
 			out.cola = a.cola;
 			out.ready = ready;
-			out.carry = a.carry[which] + (long long)s * hop;
+			float cw[4];
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+				cw[i] = which == 0 ? cv[0][i] : (which == 1 ? cv[1][i] : cv[2][i]);
+			out.cv = cw;
 			out.hop = hop;
 			zfft::fft_frame<LOG2N, true, false, true>(t, lds, twr, in, out, true);
 		}
