@@ -381,6 +381,40 @@ def test_hpr_sse_hop_by_hop_single_launch(z, fs, hop, flags, streams):
         assert all(np.array_equal(alt[k][s] if streams > 1 else alt[k], ref[k]) for k in "PHR")
 
 
+@pytest.mark.parametrize("fs,hop,flags,streams,soft", [
+    (44100.0, 2048, o.OUTPUT_PERCUSSIVE, 1, False), (44100.0, 4096, o.OUTPUT_PERCUSSIVE, 1, False),
+    (48000.0, 2048, ALL, 1, False), (48000.0, 4096, ALL, 1, False), (44100.0, 4096, o.OUTPUT_HARMONIC | o.OUTPUT_RESIDUAL, 1, True),
+    (44100.0, 2048, ALL, 3, False), (44100.0, 4096, o.OUTPUT_PERCUSSIVE | o.OUTPUT_HARMONIC, 2, True)])
+def test_hpr_long_hops_hop_by_hop_single_launch(z, fs, hop, flags, streams, soft):
+    """hop 2048 / 4096 through the realtime API: every hop of the causal median path is ONE launch whose frame is
+    spread over cooperating workgroups, the transforms cut in two steps (rt_wide.hip).  Same samples as the
+    oracle, mixed with block calls (general engine) in both directions, and equal to the four-launch path."""
+    n_hops = 14
+    x = np.stack([music(hop * n_hops, 60 + s, fs) for s in range(streams)])
+    xs = (lambda a, b: x[:, a * hop:b * hop]) if streams > 1 else (lambda a, b: x[0, a * hop:b * hop])
+
+    def engine():
+        g = z.HPR(fs, hop, 2.0, flags, z.TIME_CAUSAL, True, streams)
+        if soft:
+            g.use_soft_mask()
+        return g
+    g = engine()
+    parts = [g.process_stream_host(xs(0, 5), block=1), g.process_stream_host(xs(5, 9), block=4),
+             g.process_stream_host(xs(9, n_hops), block=1)]
+    refs = [run_oracle(fs, hop, 2.0, flags, o.TIME_CAUSAL, x[s], soft=soft)[1] for s in range(streams)]
+    for s in range(streams):
+        for k in "PHR":
+            got = np.concatenate([(p[k][s] if streams > 1 else p[k]) for p in parts])
+            assert np.array_equal(got, refs[s][k]), (k, s)
+    z.set_option("no_rt_fused", 1)                    # the four-launch path hop by hop
+    try:
+        alt = engine().process_stream_host(x if streams > 1 else x[0], block=1)
+    finally:
+        z.set_option("no_rt_fused", 0)
+    for s in range(streams):
+        assert all(np.array_equal(alt[k][s] if streams > 1 else alt[k], refs[s][k]) for k in "PHR")
+
+
 def test_hpr_multi_stream_matches_single(z):
     fs, hop, n_hops, S = 44100.0, 256, 40, 5
     x = np.stack([noise(hop * n_hops, 100 + s) for s in range(S)])

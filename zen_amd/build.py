@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libzen_hip.so")
 OBJDIR = os.path.join(HERE, "build")
-SOURCES = ["api.hip", "hpr.hip", "hpri.hip", "stft.hip", "istft.hip", "median.hip", "median_net.hip", "median47.hip", "median_big.hip", "rt_fused.hip", "rt_sse.hip", "box.hip"]
+SOURCES = ["api.hip", "hpr.hip", "hpri.hip", "stft.hip", "istft.hip", "median.hip", "median_net.hip", "median47.hip", "median_big.hip", "rt_fused.hip", "rt_sse.hip", "rt_wide.hip", "box.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 EXTRA = os.environ.get("ZEN_HIP_EXTRA_FLAGS", "").split()
 FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
@@ -25,7 +25,8 @@ FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-co
 # the 128-wide merge networks inside 256 VGPRs (187 taps: 56 spilled registers -> 4; 0.94 -> 0.73 ms).
 FILE_FLAGS = {"rt_fused.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
               "istft.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
-              "median_big.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-minreg"]}
+              "median_big.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-minreg"],
+              "rt_wide.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-minreg"]}
 FILE_FLAGS_ENV = os.environ.get("ZEN_HIP_FILE_FLAGS", "")   # A/B hook: "median_net.hip=-mllvm,-amdgpu-sched-strategy=max-ilp"
 for _item in filter(None, FILE_FLAGS_ENV.split(";")):
     _name, _, _fl = _item.partition("=")

@@ -94,6 +94,26 @@ struct TwRegs {
 		if constexpr (PASS + 1 < PL::P)
 			fill<PASS + 1>(tf, p);
 	}
+	// the same for a transform that is one step of a larger one (rt_wide.hip): f(stage, idx) maps the table index
+	// of this 2^LOG2N-point transform's stage (1-based) to the entry of the large transform's table
+	template <int PASS = 0, class F>
+	__device__ __forceinline__ void fill_with(int tf, const F& f)
+	{
+		constexpr int rr = PL::r(PASS), R = 1 << rr, NB = 16 / R, sL = PL::s(PASS), log2J = LOG2N - sL - rr;
+#pragma unroll
+		for (int i = 0; i < NB; ++i) {
+			const int k = (tf + i * PL::TF) >> log2J;
+#pragma unroll
+			for (int q = 1; q <= rr; ++q) {
+				const int nload = q == 1 ? 1 : (1 << (q - 2));
+#pragma unroll
+				for (int c = 0; c < nload; ++c)
+					w[PASS][i][(q == 1 ? 0 : (1 << (q - 2))) + c] = f(sL + q, (k << (LOG2N - sL - q)) + (c << (LOG2N - q)));
+			}
+		}
+		if constexpr (PASS + 1 < PL::P)
+			fill_with<PASS + 1>(tf, f);
+	}
 };
 
 // r = log2(R) radix-2 DIT stages on R values held by one thread.

@@ -106,6 +106,10 @@ void free_all(zen_hip_hpr* e)
 	}
 	if (e->dbg_stamps_host)
 		(void)hipHostFree(e->dbg_stamps_host);
+	if (e->d_wide_xch)
+		(void)hipFree(e->d_wide_xch);
+	if (e->d_wide_bar)
+		(void)hipFree(e->d_wide_bar);
 	for (auto& p : e->prof_pending) {
 		(void)hipEventDestroy(p.e0);
 		(void)hipEventDestroy(p.e1);
@@ -162,8 +166,11 @@ int ensure_rows(zen_hip_hpr* e, int o)
 }
 
 // causal, median path: M hops of every stream in one launch, one workgroup per hop (rt_fused.hip)
-int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, bool sse = false)
+enum HopKernel { HOP_FUSED = 0, HOP_SSE = 1, HOP_WIDE = 2 };
+
+int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, HopKernel kind = HOP_FUSED)
 {
+	const bool sse = kind == HOP_SSE;
 	for (int o = 0; o < 3; ++o)
 		if (output_computed(e, o))
 			ZH_TRY(ensure_rows(e, o));
@@ -209,9 +216,28 @@ int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, b
 	a.thr = g_opt_mask_divide ? 0.0 : hard_mask_threshold(e->beta, &a.thr_inclusive);
 	a.diag = g_opt_rt_fused_diag;
 	a.stamps = e->dbg_stamps;
+	if (kind == HOP_WIDE) {
+		ZH_TRY(ensure_estimates(e, false));
+		if (!e->d_wide_xch) {
+			ZH_HIP(hipMalloc((void**)&e->d_wide_xch, sizeof(float2) * e->n_streams * e->nfft));
+			ZH_HIP(hipMalloc((void**)&e->d_wide_bar, sizeof(unsigned) * 4 * e->n_streams));
+			ZH_HIP(hipMemsetAsync(e->d_wide_bar, 0, sizeof(unsigned) * 4 * e->n_streams, e->stream));
+			e->wide_arrivals = 0;
+			e->wide_calls = 0;
+		}
+		a.P = e->d_P;
+		a.p_stream_stride = (long long)(e->max_hops * e->nfft);
+		a.xch = e->d_wide_xch;
+		a.bar = e->d_wide_bar;
+		a.bar_base = e->wide_arrivals;
+		a.bar_parity = (int)(e->wide_calls++ & 1u);
+		e->wide_arrivals += rt_wide_arrivals(e->log2n, a.n_out);
+	}
 	{
 		ProfScope ps(e, zen_hip_hpr::K_FUSED);
-		if (sse) // single hop of the SSE path (rt_sse.hip); box lengths and factors as launch_box gets them below
+		if (kind == HOP_WIDE)
+			ZH_TRY(launch_rt_wide(e->log2n, e->mf, a, e->stream));
+		else if (sse) // single hop of the SSE path (rt_sse.hip); box lengths and factors as launch_box gets them below
 			ZH_TRY(launch_rt_sse(e->log2n, a, e->mt, e->mf, (float)e->l_harm + 1.0F, (float)e->l_perc + 1.0F, e->stream));
 		else
 			ZH_TRY(launch_rt_fused(e->log2n, e->mf, a, e->stream));
@@ -230,7 +256,10 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 		return run_hop_fused(e, in, in_stride, M);
 	if (e->causality == ZEN_HIP_TIME_CAUSAL && e->use_sse && M == 1 && !g_opt_no_rt_fused
 	    && rt_sse_available(e->log2n, e->mt, e->mf))
-		return run_hop_fused(e, in, in_stride, 1, true);
+		return run_hop_fused(e, in, in_stride, 1, HOP_SSE);
+	if (e->causality == ZEN_HIP_TIME_CAUSAL && !e->use_sse && M == 1 && !g_opt_no_rt_fused
+	    && rt_wide_available(e->log2n, e->mf))
+		return run_hop_fused(e, in, in_stride, 1, HOP_WIDE);
 	// Half rows: |S| is exactly Hermitian, so the median path stores and filters bins 0..nfft/2 only (and the
 	// last mf/2 bins of P, whose replicate border differs): half the magnitude / H / P traffic, half the
 	// median work.  Not for the SSE box mean (its ascending summation is not mirror symmetric), nor where a
@@ -728,10 +757,10 @@ int zen_hip_hpr_debug_stamps(zen_hip_hpr_t h, unsigned long long** host_stamps)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null argument");
 	if (!h->dbg_stamps_host) {
 		void* dev = nullptr;
-		ZH_HIP(hipHostMalloc((void**)&h->dbg_stamps_host, 8 * sizeof(unsigned long long), hipHostMallocMapped));
+		ZH_HIP(hipHostMalloc((void**)&h->dbg_stamps_host, 16 * sizeof(unsigned long long), hipHostMallocMapped));
 		ZH_HIP(hipHostGetDevicePointer(&dev, h->dbg_stamps_host, 0));
 		h->dbg_stamps = (unsigned long long*)dev;
-		memset(h->dbg_stamps_host, 0, 8 * sizeof(unsigned long long));
+		memset(h->dbg_stamps_host, 0, 16 * sizeof(unsigned long long));
 	}
 	*host_stamps = h->dbg_stamps_host;
 	return ZEN_HIP_OK;

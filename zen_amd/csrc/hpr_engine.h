@@ -41,6 +41,11 @@ struct zen_hip_hpr {
 	float* ready_dev[3] = {nullptr, nullptr, nullptr};  // device-visible address the kernels write to
 	float* ready_host[3] = {nullptr, nullptr, nullptr}; // host address of the same memory (single stream only)
 	bool ready_valid[3] = {false, false, false};
+	// rt_wide.hip (single hops at nfft 8192 / 16384): exchange buffer, grid-barrier words and their arrival count
+	float2* d_wide_xch = nullptr;
+	unsigned* d_wide_bar = nullptr;
+	unsigned wide_arrivals = 0;
+	unsigned wide_calls = 0;
 	unsigned hop_seq = 0; // number of the last single-hop call; the kernels publish it behind the finished hop
 	unsigned long long* dbg_stamps = nullptr;      // device alias of ...
 	unsigned long long* dbg_stamps_host = nullptr; // ... the mapped stamp buffer of zen_hip_hpr_debug_stamps

@@ -36,6 +36,14 @@ struct RtFusedArgs {
 	// (or > when !thr_inclusive) in exact arithmetic, thr the rounding boundary just below beta; 0: divide
 	double thr;
 	int thr_inclusive;
+	// rt_wide.hip only: the percussive estimate row, the exchange buffer of the two-step transforms ([n_streams][nfft])
+	// and the grid-barrier words ([n_streams][4]: arrivals, timeout flag, two vote words; bar_base = arrivals before this call)
+	float* P;
+	long long p_stream_stride;
+	float2* xch;
+	unsigned* bar;
+	unsigned bar_base;
+	int bar_parity;         // which of the two placement-vote words this call uses (alternates)
 	int diag;               // 0; 1 / 2: timing diagnostics of rt_fused_kernel (results are not valid)
 	unsigned long long* stamps; // diagnostic: 8 s_memrealtime stamps (100 MHz) of workgroup 0's phases, or null
 };
@@ -47,5 +55,11 @@ int launch_rt_fused(int log2n, int freq_len, const RtFusedArgs& a, hipStream_t s
 // len_f: the odd box lengths (time, frequency), fac_h / fac_p: l_harm + 1, l_perc + 1 (hps.cu:599-604).
 bool rt_sse_available(int log2n, int len_t, int len_f);
 int launch_rt_sse(int log2n, const RtFusedArgs& a, int len_t, int len_f, float fac_h, float fac_p, hipStream_t stream);
+
+// rt_wide.hip: ONE hop per stream of the causal median path at nfft 8192 / 16384 in one launch, the frame spread
+// over nfft/4096 cooperating workgroups.  rt_wide_arrivals: what a call adds to every stream's barrier word.
+bool rt_wide_available(int log2n, int freq_len);
+unsigned rt_wide_arrivals(int log2n, int n_out);
+int launch_rt_wide(int log2n, int freq_len, const RtFusedArgs& a, hipStream_t stream);
 
 } // namespace zen_hip_impl
