@@ -115,6 +115,10 @@ const char* zen_hip_version(void) { return "zen-mi355x 0.1 (gfx950)"; }
 
 int zen_hip_init(int device)
 {
+	// Kernel arguments in device memory instead of host memory (a ROCm runtime switch, read when the runtime
+	// starts: no effect if the process has used HIP before): the first instructions of a launch wait for them, and
+	// a single-hop call is short enough to notice (0.7-1 us of 17-21 us, tools/rt_latency.cpp).  Not overridden if set.
+	(void)setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
 	int n = 0;
 	ZH_HIP(hipGetDeviceCount(&n));
 	if (device < 0 || device >= n)

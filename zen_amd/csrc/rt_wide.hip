@@ -196,6 +196,8 @@ struct InvAIn { // (S * mask)[j + n*J] (IstftIn of istft.hip): the upper half of
 	const float* P;
 	MaskCfg cfg;
 	int which, n, p_mid, j;
+	double thr; // != 0: hard percussive mask by exact comparison instead of the division (masks.h hard_mask_exact)
+	bool thr_inclusive;
 	__device__ __forceinline__ float2 operator()(int nn, int) const
 	{
 		const int idx = j + (nn << LOG2J);
@@ -205,7 +207,7 @@ struct InvAIn { // (S * mask)[j + n*J] (IstftIn of istft.hip): the upper half of
 		if (mirror)
 			z.y = -z.y;
 		const int pi = (mirror && idx >= n - p_mid) ? idx : lo;
-		const float m = mask_value(which, H[lo], P[pi], cfg);
+		const float m = thr != 0.0 ? hard_mask_exact(P[pi], H[lo] + FLT_EPSILON, thr, thr_inclusive) : mask_value(which, H[lo], P[pi], cfg);
 		return make_float2(z.x * m, z.y * m); // apply_mask_functor hps.h:58-66
 	}
 };
@@ -279,17 +281,17 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 	const int tfA = (t & 63) / FWA, fA = (t >> 6) * FWA + (t & 63) % FWA, jA = g * GEO::FA + fA;
 	twA.fill_with(tfA, TwStrideMap<LOG2J>{a.tw});
 	twB.fill_with(u % PB::TF, TwTwistMap<LOG2M, LOG2J>{a.tw, u / PB::TF});
-	// ---- phase 1: carries and input tail (loads first, then stores); analysis step A
-	if (g == 0) {
-		constexpr int CP = N / 4 / WGT; // samples of a hop per thread
+	// ---- phase 1: carries and input tail, a share for every workgroup (loads first, then stores); analysis step A
+	{
+		constexpr int CP = N / 4 / (G * WGT); // samples of a hop per thread
 		const float* cur = a.in + (long long)s * a.in_stride;
 		float v[CP];
 #pragma unroll
 		for (int i = 0; i < CP; ++i)
-			v[i] = cur[t + i * WGT];
+			v[i] = cur[u + i * (G * WGT)];
 #pragma unroll
 		for (int i = 0; i < CP; ++i)
-			a.tail_next[(long long)s * hop + t + i * WGT] = v[i];
+			a.tail_next[(long long)s * hop + u + i * (G * WGT)] = v[i];
 		if (a.prev_frames > 0) {
 			for (int o = 0; o < 3; ++o) {
 				if (!a.carry[o])
@@ -297,10 +299,10 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 				const float* y = a.Y[o] + (long long)s * a.y_stream_stride + (long long)(a.prev_frames - 1) * (2 * hop) + hop;
 #pragma unroll
 				for (int i = 0; i < CP; ++i)
-					v[i] = y[t + i * WGT];
+					v[i] = y[u + i * (G * WGT)];
 #pragma unroll
 				for (int i = 0; i < CP; ++i)
-					a.carry[o][(long long)s * hop + t + i * WGT] = v[i];
+					a.carry[o][(long long)s * hop + u + i * (G * WGT)] = v[i];
 			}
 		}
 	}
@@ -378,7 +380,8 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 		const int which = a.out_id[oi];
 		{
 			const int j = jA, tf = tfA;
-			InvAIn<LOG2J> in{Srow, mrow, prow, MaskCfg{a.beta, a.beta_h, a.soft, a.power, 0, a.out_h, a.out_p}, which, N, GM::m, j};
+			InvAIn<LOG2J> in{Srow, mrow, prow, MaskCfg{a.beta, a.beta_h, a.soft, a.power, 0, a.out_h, a.out_p}, which, N, GM::m, j,
+			                  (which == 0 && !a.soft) ? a.thr : 0.0, a.thr_inclusive != 0};
 			XchOut<LOG2J> out{T, j};
 			zfft::PassRunner<LOG2M, 0, true, false, false, InvAIn<LOG2J>, XchOut<LOG2J>, false, zfft::TwRegs<LOG2M>>::run(
 			    tf, lds + fA * PA::LDS_FLOAT2, twA, in, out, true);
