@@ -23,6 +23,8 @@
 #include "median_net.h"
 #include "rt_fused.h"
 
+#include <type_traits>
+
 #pragma clang fp contract(off)
 
 namespace zen_hip_impl {
@@ -153,11 +155,25 @@ struct InvInLean {
 	}
 };
 
-struct InvOut {
+struct InvOut { // block builds
 	float* Y;
 	float cola;
 	float* ready;       // single-hop calls: the finished hop = carry + first half of this frame (hps.cu:526-528 + :341-363)
-	const float* cv;    // the thread's four carry samples (second half of the previous frame), idx = tf + slot*TF,
+	const float* carry; // second half of the previous frame, saved by this workgroup's housekeeping
+	int hop;
+	__device__ __forceinline__ void operator()(int idx, float2 x, bool, int) const
+	{
+		const float y = x.x * cola;
+		Y[idx] = y;
+		if (ready && idx < hop)
+			ready[idx] = carry[idx] + y;
+	}
+};
+struct InvOutReg { // the single-hop build
+	float* Y;
+	float cola;
+	float* ready;
+	float cv[4];        // the thread's four carry samples (second half of the previous frame), idx = tf + slot*TF,
 	int hop;            // slot < 4: in registers since the housekeeping -- a load here would queue behind the stores
 	__device__ __forceinline__ void operator()(int idx, float2 x, bool, int slot) const
 	{
@@ -211,18 +227,26 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 	// diagnostic hook (tools/rt_latency.cpp --stamps): phase times of a single-hop call (100 MHz), kept in scalar
 	// registers until the end -- a store to the host-mapped stamp buffer in front of a barrier would be waited for
 	// there -- and only in the single-hop build.
+	// (The block builds keep the direct store of round 1: their register allocation sits at the 168-VGPR limit and
+	// any change to their code moves the spill count -- 19 registers as committed, 69 with this hook compiled out.)
 	unsigned long long stamps[6] = {0, 0, 0, 0, 0, 0};
 	auto stamp = [&](int k) {
 		if constexpr (MINB == 1) {
 			if (a.stamps)
 				stamps[k] = __builtin_amdgcn_s_memrealtime();
 		}
+		else {
+			if (a.stamps && blockIdx.x == 0 && tf == 0)
+				a.stamps[k] = __builtin_amdgcn_s_memrealtime();
+		}
 	};
 	auto flush_stamps = [&]() {
 		if constexpr (MINB == 1) {
-			if (a.stamps && blockIdx.x == 0 && tf == 0)
+			if (a.stamps && blockIdx.x == 0 && tf == 0) {
+#pragma unroll
 				for (int k = 0; k < 6; ++k)
 					a.stamps[k] = stamps[k];
+			}
 		}
 	};
 	stamp(0);
@@ -232,24 +256,31 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 	// the second half of the previous call's last Y row; the workgroup that will overwrite that row (or, if
 	// this call is shorter, the last one) saves it first.  The tail is the call's last hop: the next call's `prev`.
 	// (hop == 4*TF: four elements per thread.)
-	const bool do_carry = a.prev_frames > 0 && f == (a.prev_frames - 1 < a.n_frames - 1 ? a.prev_frames - 1 : a.n_frames - 1);
-	float cv[3][4]; // single-hop calls: the carries of this hop, per output
+	float cv1[4] = {0.f, 0.f, 0.f, 0.f}; // single-hop calls with one output: the carries of this hop
 	if constexpr (MINB == 1) {
+		const bool do_carry = a.prev_frames > 0 && f == (a.prev_frames - 1 < a.n_frames - 1 ? a.prev_frames - 1 : a.n_frames - 1);
 		// Single-hop launches: all loads first, then the stores.  A store between two loads makes the second wait
 		// for the first (the compiler cannot know they do not alias): stored from inside the transform's input
 		// functor, the tail cost such a call eight dependent trips to memory.
-		float tv[4];
+		float tv[4], sv[3][4]; // (sv is only ever indexed by the unrolled loop counter: registers)
+		if (do_carry) {
 #pragma unroll
-		for (int o = 0; o < 3; ++o) {
-			if (!a.carry[o])
-				continue;
-			// the carry comes from the previous call's Y row, or (first call, or this workgroup is not the saver)
-			// from the carry buffer
-			const float* y = do_carry ? a.Y[o] + (long long)s * a.y_stream_stride + (long long)(a.prev_frames - 1) * (2 * hop) + hop
-			                          : a.carry[o] + (long long)s * hop;
+			for (int o = 0; o < 3; ++o) {
+				if (!a.carry[o])
+					continue;
+				const float* y = a.Y[o] + (long long)s * a.y_stream_stride + (long long)(a.prev_frames - 1) * (2 * hop) + hop;
+#pragma unroll
+				for (int i = 0; i < 4; ++i)
+					sv[o][i] = y[tf + i * TF];
+			}
+		}
+		if constexpr (SINGLE) { // the carries the synthesis will add: from the previous call's Y row or the carry buffer
+			const int w0 = a.out_id[0];
+			const float* y = do_carry ? a.Y[w0] + (long long)s * a.y_stream_stride + (long long)(a.prev_frames - 1) * (2 * hop) + hop
+			                          : a.carry[w0] + (long long)s * hop;
 #pragma unroll
 			for (int i = 0; i < 4; ++i)
-				cv[o][i] = y[tf + i * TF];
+				cv1[i] = y[tf + i * TF];
 		}
 		if (f == a.n_frames - 1) {
 #pragma unroll
@@ -263,7 +294,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 					continue;
 #pragma unroll
 				for (int i = 0; i < 4; ++i)
-					a.carry[o][(long long)s * hop + tf + i * TF] = cv[o][i];
+					a.carry[o][(long long)s * hop + tf + i * TF] = sv[o][i];
 			}
 		}
 		if (f == a.n_frames - 1) {
@@ -272,7 +303,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 				a.tail_next[(long long)s * hop + tf + i * TF] = tv[i];
 		}
 	}
-	else if (do_carry) {
+	else if (a.prev_frames > 0 && f == (a.prev_frames - 1 < a.n_frames - 1 ? a.prev_frames - 1 : a.n_frames - 1)) {
 		for (int o = 0; o < 3; ++o) {
 			if (!a.carry[o])
 				continue;
@@ -287,13 +318,13 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		}
 	}
 
-	float cw[4] = {0.f, 0.f, 0.f, 0.f}; // the carries of the output being synthesised
-	auto pick_carry = [&](int which) {
-		if constexpr (MINB == 1) {
+	using OutT = std::conditional_t<MINB == 1, InvOutReg, InvOut>;
+	// the carries of the output being synthesised: in registers since the housekeeping (one output), or read back
+	// from the carry buffer this thread wrote there, before the transform starts (several outputs)
+	auto pick_carry = [&](int which, float (&cw)[4]) {
 #pragma unroll
-			for (int i = 0; i < 4; ++i)
-				cw[i] = which == 0 ? cv[0][i] : (which == 1 ? cv[1][i] : cv[2][i]);
-		}
+		for (int i = 0; i < 4; ++i)
+			cw[i] = SINGLE ? cv1[i] : a.carry[which][(long long)s * hop + tf + i * TF];
 	};
 	stamp(1);
 	// Single-hop launches (MINB == 1, registers to spare): every twiddle of both transforms is loaded here, next
@@ -309,7 +340,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		in.prev = f > 0 ? cur - hop : a.tail_prev + (long long)s * hop;
 		in.cur = cur;
 		in.window = a.window;
-		in.tail = (MINB > 1 && f == a.n_frames - 1) ? a.tail_next + (long long)s * hop : nullptr;
+		in.tail = (MINB == 1 || f != a.n_frames - 1) ? nullptr : a.tail_next + (long long)s * hop;
 		in.hop = hop;
 		const long long row = ((a.row0 + f) % a.ring_rows) + (long long)s * a.ring_rows;
 		FwdOut<T> out;
@@ -417,22 +448,28 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		in.which = a.out_id[0];
 		in.thr = (in.which == 0 && !a.soft) ? a.thr : 0.0;
 		in.thr_inclusive = a.thr_inclusive != 0;
-		InvOut out;
+		OutT out;
 		out.Y = a.Y[in.which] + (long long)s * a.y_stream_stride + (long long)f * (2 * hop);
 		out.cola = a.cola;
-		out.ready = (MINB == 1 && a.n_frames == 1 && a.ready[in.which]) ? a.ready[in.which] + (long long)s * hop : nullptr;
-		pick_carry(in.which);
-		out.cv = cw;
+		out.ready = (a.n_frames == 1 && a.ready[in.which]) ? a.ready[in.which] + (long long)s * hop : nullptr;
+		if constexpr (MINB == 1) {
+			pick_carry(in.which, out.cv);
+		}
+		else {
+			out.carry = a.carry[in.which] + (long long)s * hop;
+		}
 		out.hop = hop;
 		if constexpr (TWC)
-			zfft::fft_frame<LOG2N, true, false, true, InvInLean<N, TF, mid>, InvOut, true>(tf, lds, twr, in, out, true);
+			zfft::fft_frame<LOG2N, true, false, true, InvInLean<N, TF, mid>, OutT, true>(tf, lds, twr, in, out, true);
 		else
-			zfft::fft_frame<LOG2N, true, false, true, InvInLean<N, TF, mid>, InvOut, true>(tf, lds, a.tw, in, out, true);
+			zfft::fft_frame<LOG2N, true, false, true, InvInLean<N, TF, mid>, OutT, true>(tf, lds, a.tw, in, out, true);
 		if (out.ready && a.publish_seq)
 			publish_ready(reinterpret_cast<unsigned*>(out.ready + hop), a.seq, tf);
-		stamp(4);
-		stamp(5);
-		flush_stamps();
+		if constexpr (MINB == 1) {
+			stamp(4);
+			stamp(5);
+			flush_stamps();
+		}
 		return;
 	}
 	// the thread's 16 magnitudes come back from the image (they were not held in registers across the
@@ -449,12 +486,16 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		in.P = Prow;
 		in.cfg = MaskCfg{a.beta, a.beta_h, a.soft, a.power, 0, a.out_h, a.out_p};
 		in.which = which;
-		InvOut out;
+		OutT out;
 		out.Y = a.Y[which] + (long long)s * a.y_stream_stride + (long long)f * (2 * hop);
 		out.cola = a.cola;
-		out.ready = (MINB == 1 && a.n_frames == 1 && a.ready[which]) ? a.ready[which] + (long long)s * hop : nullptr;
-		pick_carry(which);
-		out.cv = cw;
+		out.ready = (a.n_frames == 1 && a.ready[which]) ? a.ready[which] + (long long)s * hop : nullptr;
+		if constexpr (MINB == 1) {
+			pick_carry(which, out.cv);
+		}
+		else {
+			out.carry = a.carry[which] + (long long)s * hop;
+		}
 		out.hop = hop;
 		if constexpr (TWC)
 			zfft::fft_frame<LOG2N, true, false, true>(tf, lds, twr, in, out, true);

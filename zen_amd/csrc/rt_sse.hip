@@ -318,6 +318,7 @@ __global__ __launch_bounds__(SseGeo<LOG2N>::NT) void rt_sse_kernel(RtFusedArgs a
 	}
 	stamp(4);
 	if (a.stamps && blockIdx.x == 0 && t == 0) {
+#pragma unroll
 		for (int k = 0; k < 5; ++k)
 			a.stamps[k] = stamps[k];
 		a.stamps[5] = __builtin_amdgcn_s_memtime() - clk0; // shader clocks of the call (stamps 0..4: 100 MHz)

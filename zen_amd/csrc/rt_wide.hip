@@ -407,9 +407,11 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 		if (a.publish_seq && g == 0 && t == 0)
 			__hip_atomic_store(reinterpret_cast<unsigned*>(ready + hop), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
-	if (a.stamps && g == 0 && s == 0 && t == 0)
+	if (a.stamps && g == 0 && s == 0 && t == 0) {
+#pragma unroll
 		for (int k = 0; k < 12; ++k)
 			a.stamps[k] = stamps[k];
+	}
 	if (a.stamps && s == 0 && t == 0) // where the cooperating workgroups ran, and whether the barriers were light
 		a.stamps[12 + g] = xcc_id() | (light ? 16u : 0u);
 }
