@@ -37,7 +37,7 @@ def kernel(usage, src, prefix):
 def test_headline_block_kernel_keeps_its_register_allocation(usage):
     k = kernel(usage, "rt_fused.hip", "rt_fused_kernel<12, 47, 3, true, true>")
     assert k["vgprs"] <= 168 and k["occupancy"] >= 3
-    assert k["scratch"] <= 96, k                     # 76 bytes per lane (19 registers) as measured at 0.58 ms
+    assert k["scratch"] <= 32, k                     # 20 bytes per lane (5 registers) as measured at 0.566 ms
 
 
 def test_single_hop_kernels_do_not_spill(usage):
@@ -51,6 +51,8 @@ def test_single_hop_kernels_do_not_spill(usage):
 def test_median47_kernel_occupancy(usage):
     whole = [v for k, v in usage["median47.hip"].items() if "median47_dpp_kernel<true, 0, false>" in k]
     assert whole and whole[0]["vgprs"] <= 72 and whole[0]["scratch"] == 0   # 7 workgroups per CU
+    half = [v for k, v in usage["median47.hip"].items() if "median47_dpp_kernel<true, 0, true>" in k]
+    assert half and half[0]["vgprs"] <= 80 and half[0]["scratch"] == 0     # half rows (the engine's build): 6 per CU
 
 
 def test_every_kernel_fits_the_lds(usage):

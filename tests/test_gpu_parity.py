@@ -384,7 +384,9 @@ def test_hpr_sse_hop_by_hop_single_launch(z, fs, hop, flags, streams):
 @pytest.mark.parametrize("fs,hop,flags,streams,soft", [
     (44100.0, 2048, o.OUTPUT_PERCUSSIVE, 1, False), (44100.0, 4096, o.OUTPUT_PERCUSSIVE, 1, False),
     (48000.0, 2048, ALL, 1, False), (48000.0, 4096, ALL, 1, False), (44100.0, 4096, o.OUTPUT_HARMONIC | o.OUTPUT_RESIDUAL, 1, True),
-    (44100.0, 2048, ALL, 3, False), (44100.0, 4096, o.OUTPUT_PERCUSSIVE | o.OUTPUT_HARMONIC, 2, True)])
+    (44100.0, 2048, ALL, 3, False), (44100.0, 4096, o.OUTPUT_PERCUSSIVE | o.OUTPUT_HARMONIC, 2, True),
+    (22050.0, 2048, ALL, 1, False), (24000.0, 2048, o.OUTPUT_PERCUSSIVE, 1, False), (32000.0, 2048, ALL, 1, True),
+    (88200.0, 4096, ALL, 1, False), (96000.0, 4096, o.OUTPUT_PERCUSSIVE, 2, False), (64000.0, 4096, ALL, 1, False)])
 def test_hpr_long_hops_hop_by_hop_single_launch(z, fs, hop, flags, streams, soft):
     """hop 2048 / 4096 through the realtime API: every hop of the causal median path is ONE launch whose frame is
     spread over cooperating workgroups, the transforms cut in two steps (rt_wide.hip).  Same samples as the

@@ -434,11 +434,14 @@ int launch_wide_t(const RtFusedArgs& a, hipStream_t stream)
 
 } // namespace
 
-// hop 2048 and 4096 at 44.1 / 48 kHz (l_perc = 93 / 85 and 187 / 171 taps)
+// hop 2048 and 4096 at 44.1 / 48 kHz (l_perc = 93 / 85 and 187 / 171 taps), and the other sample rates whose masks
+// the block-merge median covers: hop 2048 at 22.05 / 24 / 32 kHz (187 / 171 / 129), hop 4096 at 88.2 / 96 / 64 kHz
+// (93 / 85 / 129)
 bool rt_wide_available(int log2n, int freq_len)
 {
 	switch (log2n * 1000 + freq_len) {
-	case 13085: case 13093: case 14171: case 14187: return true;
+	case 13085: case 13093: case 13129: case 13171: case 13187:
+	case 14085: case 14093: case 14129: case 14171: case 14187: return true;
 	default: return false;
 	}
 }
@@ -455,6 +458,12 @@ int launch_rt_wide(int log2n, int freq_len, const RtFusedArgs& a, hipStream_t st
 	switch (log2n * 1000 + freq_len) {
 	case 13085: return launch_wide_t<13, 85>(a, stream);
 	case 13093: return launch_wide_t<13, 93>(a, stream);
+	case 13129: return launch_wide_t<13, 129>(a, stream);
+	case 13171: return launch_wide_t<13, 171>(a, stream);
+	case 13187: return launch_wide_t<13, 187>(a, stream);
+	case 14085: return launch_wide_t<14, 85>(a, stream);
+	case 14093: return launch_wide_t<14, 93>(a, stream);
+	case 14129: return launch_wide_t<14, 129>(a, stream);
 	case 14171: return launch_wide_t<14, 171>(a, stream);
 	case 14187: return launch_wide_t<14, 187>(a, stream);
 	default: ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "no wide single-hop kernel for nfft 2^%d with a %d-tap mask", log2n, freq_len);
