@@ -44,6 +44,7 @@ for _item in filter(None, FILE_FLAGS_ENV.split(";")):
 def _deps():
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "zen_hip.h"))
+    hdrs.append(os.path.abspath(__file__))   # the flags live here
     return hdrs
 
 
