@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libzen_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 RESOURCES = os.path.join(HERE, "kernel_resources.json")   # per-kernel registers / scratch / LDS of the last build
-SOURCES = ["api.hip", "hpr.hip", "hpri.hip", "stft.hip", "istft.hip", "median.hip", "median_net.hip", "median47.hip", "median_big.hip", "rt_fused.hip", "rt_sse.hip", "rt_wide.hip", "box.hip"]
+SOURCES = ["api.hip", "hpr.hip", "hpri.hip", "stft.hip", "istft.hip", "median.hip", "median_net.hip", "median47.hip", "median_big.hip", "rt_fused.hip", "rt_fused_multi.hip", "rt_sse.hip", "rt_wide.hip", "box.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 EXTRA = os.environ.get("ZEN_HIP_EXTRA_FLAGS", "").split()
 FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
@@ -31,6 +31,7 @@ FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-co
 # 0.140 -> 0.115 ms); it makes istft.hip worse (nfft 16384: 3 -> 22 spilled registers, +20 %) and leaves the others
 # where they are (A/B of every file on the three bench workloads, round 2).
 FILE_FLAGS = {"rt_fused.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-amdgpu-use-amdgpu-trackers=1"],
+              "rt_fused_multi.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
               "median47.hip": ["-mllvm", "-amdgpu-use-amdgpu-trackers=1"],
               "istft.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
               "median_big.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-minreg"],
@@ -51,7 +52,8 @@ def _deps():
 def _compile(src):
     obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
     srcp = os.path.join(CSRC, src)
-    newest = max(os.path.getmtime(p) for p in [srcp] + _deps())
+    extra = [os.path.join(CSRC, "rt_fused.hip")] if src == "rt_fused_multi.hip" else []   # it includes that file
+    newest = max(os.path.getmtime(p) for p in [srcp] + extra + _deps())
     if os.path.exists(obj) and os.path.getmtime(obj) >= newest:
         return obj, False
     cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(src, []) + ["-Rpass-analysis=kernel-resource-usage", "-c", srcp, "-o", obj]

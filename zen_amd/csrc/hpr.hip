@@ -257,7 +257,9 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 	if (e->causality == ZEN_HIP_TIME_CAUSAL && e->use_sse && M == 1 && !g_opt_no_rt_fused
 	    && rt_sse_available(e->log2n, e->mt, e->mf))
 		return run_hop_fused(e, in, in_stride, 1, HOP_SSE);
-	if (e->causality == ZEN_HIP_TIME_CAUSAL && !e->use_sse && M == 1 && !g_opt_no_rt_fused
+	// (the cooperative kernel keeps its workgroups on one XCD -- 32 CUs: right for the latency of a few streams,
+	// wrong for the throughput of many, which the general engine spreads over the whole device)
+	if (e->causality == ZEN_HIP_TIME_CAUSAL && !e->use_sse && M == 1 && !g_opt_no_rt_fused && e->n_streams <= 8
 	    && rt_wide_available(e->log2n, e->mf))
 		return run_hop_fused(e, in, in_stride, 1, HOP_WIDE);
 	// Half rows: |S| is exactly Hermitian, so the median path stores and filters bins 0..nfft/2 only (and the

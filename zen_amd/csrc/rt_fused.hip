@@ -539,9 +539,24 @@ int launch_k(const RtFusedArgs& a, hipStream_t stream)
 
 // single hops are latency-bound (all the registers the compiler wants); blocks of hops are compiled for
 // BLOCK_MINB workgroups per CU
+// The kernels for several outputs are instantiated in a translation unit of their own (rt_fused_multi.hip, which
+// includes this file with ZEN_RT_FUSED_MULTI defined): the two sets want different scheduler flags (build.py).
+#ifdef ZEN_RT_FUSED_MULTI
+template <int LOG2N, int W>
+int launch_multi_t(const RtFusedArgs& a, hipStream_t stream)
+{
+	if (a.n_frames == 1 || g_opt_block_fused_minb == 1)
+		return launch_k<LOG2N, W, 1, false>(a, stream);
+	if (g_opt_block_fused_minb == 2)
+		return launch_k<LOG2N, W, 2, false>(a, stream);
+	return launch_k<LOG2N, W, 3, false>(a, stream);
+}
+#else
 template <int LOG2N, int W>
 int launch_t(const RtFusedArgs& a, hipStream_t stream)
 {
+	if (a.n_out != 1)
+		return launch_rt_fused_multi(LOG2N, W, a, stream);
 	if constexpr (LOG2N == 12 && W == 47) {
 		// the headline configuration with one output: the lean layout (34 KB of LDS, no |S| registers).  Built for
 		// three workgroups per CU: a fourth would fit in LDS but not in registers (128 VGPRs spill 60 of them:
@@ -555,22 +570,31 @@ int launch_t(const RtFusedArgs& a, hipStream_t stream)
 			return launch_k<LOG2N, W, 3, true, true>(a, stream);
 		}
 	}
-	if (a.n_out == 1) {
-		if (a.n_frames == 1 || g_opt_block_fused_minb == 1)
-			return launch_k<LOG2N, W, 1, true>(a, stream);
-		if (g_opt_block_fused_minb == 2)
-			return launch_k<LOG2N, W, 2, true>(a, stream);
-		return launch_k<LOG2N, W, 3, true>(a, stream);
-	}
 	if (a.n_frames == 1 || g_opt_block_fused_minb == 1)
-		return launch_k<LOG2N, W, 1, false>(a, stream);
+		return launch_k<LOG2N, W, 1, true>(a, stream);
 	if (g_opt_block_fused_minb == 2)
-		return launch_k<LOG2N, W, 2, false>(a, stream);
-	return launch_k<LOG2N, W, 3, false>(a, stream);
+		return launch_k<LOG2N, W, 2, true>(a, stream);
+	return launch_k<LOG2N, W, 3, true>(a, stream);
 }
+#endif
 
 } // namespace
 
+#ifdef ZEN_RT_FUSED_MULTI
+int launch_rt_fused_multi(int log2n, int freq_len, const RtFusedArgs& a, hipStream_t stream)
+{
+	switch (log2n * 100 + freq_len) {
+	case 907: return launch_multi_t<9, 7>(a, stream);
+	case 1011: return launch_multi_t<10, 11>(a, stream);
+	case 1013: return launch_multi_t<10, 13>(a, stream);
+	case 1121: return launch_multi_t<11, 21>(a, stream);
+	case 1123: return launch_multi_t<11, 23>(a, stream);
+	case 1243: return launch_multi_t<12, 43>(a, stream);
+	case 1247: return launch_multi_t<12, 47>(a, stream);
+	default: ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "no fused realtime kernel for nfft 2^%d, mask %d", log2n, freq_len);
+	}
+}
+#else
 opt_t g_opt_block_fused_minb{0}; // 0: default (three workgroups per CU)
 
 // (transform size, frequency mask) pairs with a fused kernel: hops 128..1024 at 44.1 and 48 kHz
@@ -595,5 +619,7 @@ int launch_rt_fused(int log2n, int freq_len, const RtFusedArgs& a, hipStream_t s
 	default: ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "no fused realtime kernel for nfft 2^%d, mask %d", log2n, freq_len);
 	}
 }
+
+#endif // ZEN_RT_FUSED_MULTI
 
 } // namespace zen_hip_impl

@@ -400,12 +400,29 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 		}
 		if (a.publish_seq)
 			__threadfence_system(); // the finished hop is host-mapped: visible there before the sequence word
-		if (oi == 0) // (the exchange buffer is free again, the hop complete)
-			sync(9);
-		else
-			sync(12);
-		if (a.publish_seq && g == 0 && t == 0)
-			__hip_atomic_store(reinterpret_cast<unsigned*>(ready + hop), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		if (oi + 1 < a.n_out) { // the exchange buffer is needed again: a full barrier
+			if (oi == 0)
+				sync(9);
+			else
+				sync(12);
+			if (a.publish_seq && g == 0 && t == 0)
+				__hip_atomic_store(reinterpret_cast<unsigned*>(ready + hop), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+		else { // the call's last barrier: nobody waits, whoever arrives last publishes the hop
+			stamp(oi == 0 ? 9 : 12);
+			arrivals += G;
+			if (light)
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			else
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+			__syncthreads();
+			if (t == 0) {
+				const unsigned before = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+				if (before + 1 == arrivals && a.publish_seq)
+					__hip_atomic_store(reinterpret_cast<unsigned*>(ready + hop), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+			}
+			stamp(oi == 0 ? 10 : 12);
+		}
 	}
 	if (a.stamps && g == 0 && s == 0 && t == 0) {
 #pragma unroll
