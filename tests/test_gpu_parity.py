@@ -417,6 +417,17 @@ def test_hpr_long_hops_hop_by_hop_single_launch(z, fs, hop, flags, streams, soft
         assert all(np.array_equal(alt[k][s] if streams > 1 else alt[k], refs[s][k]) for k in "PHR")
 
 
+def test_hpr_long_hops_many_streams_take_the_general_engine(z):
+    """More than 8 streams: single hops at hop 2048 go through the four-launch path (the cooperative kernel keeps its
+    workgroups on one XCD, which is wrong for many streams); same samples either way."""
+    fs, hop, n_hops, streams = 44100.0, 2048, 6, 10
+    x = np.stack([music(hop * n_hops, 80 + s, fs) for s in range(streams)])
+    got = z.HPR(fs, hop, 2.0, o.OUTPUT_PERCUSSIVE, z.TIME_CAUSAL, True, streams).process_stream_host(x, block=1)
+    for s in (0, 4, 9):
+        _, ref = run_oracle(fs, hop, 2.0, o.OUTPUT_PERCUSSIVE, o.TIME_CAUSAL, x[s])
+        assert np.array_equal(got["P"][s], ref["P"]), s
+
+
 def test_hpr_multi_stream_matches_single(z):
     fs, hop, n_hops, S = 44100.0, 256, 40, 5
     x = np.stack([noise(hop * n_hops, 100 + s) for s in range(S)])
