@@ -1,6 +1,9 @@
 // rt_latency.cpp -- per-hop latency of the realtime call path through the C-ABI, timed as zen/fakert.h:221-247
 // does (copy the hop into the mapped input buffer, process_next_hop, copy_percussive, copy the hop out),
 // without an interpreter in the loop.  Prints one JSON line per hop size.
+// Arguments: [hops per configuration, default 2000] [--stamps: also print the phase stamps of one single-hop kernel
+// of every kind].  Environment: ZEN_RT_ONLY_SSE=1 (only the SSE configurations), ZEN_RT_DIAG=<n> (sets the library's
+// "rt_fused_diag" option: timing diagnostics, results not valid; 4 = agent-scope grid barriers in rt_wide.hip).
 //   g++ -O2 -std=c++17 -I include tools/rt_latency.cpp -o /tmp/rt_latency -L zen_amd -lzen_hip -Wl,-rpath,$PWD/zen_amd
 #include <chrono>
 #include <cstdio>

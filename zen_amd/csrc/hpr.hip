@@ -713,8 +713,15 @@ static int copy_output_impl(zen_hip_hpr_t h, unsigned which, float* out_dev, boo
 				}
 				__builtin_ia32_pause();
 			}
-			if (!seen) // a fault or a hang: let the runtime report it
+			if (!seen) { // a fault or a hang: let the runtime report it
 				ZH_HIP(hipStreamSynchronize(h->stream));
+				if (h->d_wide_bar) { // rt_wide.hip: a grid barrier that gave up waiting leaves a mark (word 1 of a stream's four)
+					unsigned words[4] = {0, 0, 0, 0};
+					ZH_HIP(hipMemcpy(words, h->d_wide_bar, sizeof(words), hipMemcpyDeviceToHost));
+					if (words[1])
+						ZH_FAIL(ZEN_HIP_E_HIP, "hpr_copy_output: a workgroup of the cooperative single-hop kernel never reached its grid barrier");
+				}
+			}
 			memcpy(host, h->ready_host[o], bytes);
 			return ZEN_HIP_OK;
 		}
