@@ -417,6 +417,19 @@ def test_hpr_long_hops_hop_by_hop_single_launch(z, fs, hop, flags, streams, soft
         assert all(np.array_equal(alt[k][s] if streams > 1 else alt[k], refs[s][k]) for k in "PHR")
 
 
+@pytest.mark.parametrize("hop,n_hops", [(2048, 4000), (4096, 2500)])
+def test_hpr_long_hops_single_launch_stress(z, hop, n_hops):
+    """Thousands of cooperative single-hop launches in a row (five grid barriers each, released at workgroup scope
+    when the workgroups share an XCD) against the same stream in one block call of the general engine: a
+    visibility race between the workgroups would show up as a differing sample."""
+    fs = 44100.0
+    x = music(hop * n_hops, 7, fs)
+    ref = z.HPR(fs, hop, 2.0, o.OUTPUT_PERCUSSIVE, z.TIME_CAUSAL, True, 1, 256).process_stream_host(x, block=250)
+    got = z.HPR(fs, hop, 2.0, o.OUTPUT_PERCUSSIVE, z.TIME_CAUSAL).process_stream_host(x, block=1)
+    assert np.array_equal(got["P"], ref["P"])
+    assert np.any(got["P"] != 0)
+
+
 def test_hpr_long_hops_many_streams_take_the_general_engine(z):
     """More than 8 streams: single hops at hop 2048 go through the four-launch path (the cooperative kernel keeps its
     workgroups on one XCD, which is wrong for many streams); same samples either way."""

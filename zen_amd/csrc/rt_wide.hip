@@ -94,7 +94,14 @@ __device__ __forceinline__ unsigned xcc_id()
 {
 	unsigned v;
 	asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
-	return v & 7u;
+	return v & 15u;
+}
+// what a workgroup adds to the vote word: one vote in the nibble of its XCD -- or, should the register ever name an
+// XCD beyond the eight nibbles, a vote in two of them, which can only turn the light path off
+__device__ __forceinline__ unsigned xcc_vote()
+{
+	const unsigned x = xcc_id();
+	return x < 8 ? 1u << (4 * x) : 0x10000001u;
 }
 
 template <int G>
@@ -103,7 +110,7 @@ __device__ __forceinline__ bool placement_vote_result(const unsigned* vote)
 	__shared__ unsigned vote_seen;
 	if (threadIdx.x == 0) {
 		unsigned v = 0;
-		for (int spins = 0; spins < (1 << 22); ++spins) {
+		for (int spins = 0; spins < (1 << 16); ++spins) {
 			v = __hip_atomic_load(vote, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			unsigned sum = 0;
 			for (int x = 0; x < 8; ++x)
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 	};
 	unsigned* vote = bar + 2 + (a.bar_parity & 1);
 	if (t == 0) // the placement vote (grid_sync): counted long before the first barrier asks for it
-		__hip_atomic_fetch_add(vote, 1u << (4 * xcc_id()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__hip_atomic_fetch_add(vote, xcc_vote(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	bool light = false;
 	auto sync = [&](int k) { // stamps k (arrival) and k + 1 (release)
 		stamp(k);
