@@ -4,9 +4,9 @@
 //
 // A single frame of this size is too much for one compute unit: a 16384-point transform keeps the four SIMDs of a
 // CU busy for 15 us, the inverse for 20, and one thread's share of a 187-tap median is a 10 us dependent chain --
-// the four launches of the general engine add up to 57 us of kernel time per hop.  Here the frame is spread over
-// G = nfft/4096 workgroups that meet at grid barriers, and each transform is cut in two steps so that no step
-// needs data from another workgroup:
+// the four launches of the general engine add up to 57 us of kernel time per hop (65 us per call; this kernel:
+// 39 us, 48 per call).  Here the frame is spread over G = nfft/4096 workgroups that meet at grid barriers, and each
+// transform is cut in two steps so that no step needs data from another workgroup:
 //
 //   the radix-2 decimation-in-time DAG of fft_dev.h, N = M*J with M = 128:
 //     step A (stages 1..7):   J independent M-point transforms of the decimated sequences x[j + n*J], j < J.  They
@@ -18,18 +18,19 @@
 //   Both steps run through PassRunner of fft_dev.h with a twiddle source that does this index arithmetic, so
 //   every butterfly is the one the single-workgroup kernels (and the oracle's recursion) evaluate: same values.
 //
-//   phase 1  carries + input tail (workgroup 0); analysis step A -> exchange buffer              | grid barrier
+//   phase 1  carries + input tail (a share per workgroup); analysis step A -> exchange buffer   | grid barrier
 //   phase 2  analysis step B -> spectrum row (bins 0..N/2), whole magnitude row (hps.cu:492)     | grid barrier
 //   phase 3  frequency median (median_big.h): one 16-bin block per thread, bins 0..N/2+15 and the
 //            last blocks of the row (the rest is the mirror image: |S| is exactly Hermitian)     | grid barrier
 //   per output: mask * spectrum (hps.h:100-140, :58-66), synthesis step A                        | grid barrier
-//               synthesis step B, *COLA, overlap-add with the carry -> Y row + finished hop      | grid barrier
-//               workgroup 0 publishes the hop's sequence number
+//               synthesis step B, *COLA, overlap-add with the carry -> Y row + finished hop      | arrival count
+//               (a full barrier only if another output follows); whoever arrives last publishes the hop's
+//               sequence number
 //
 // XCD-aware launch: workgroups are dealt to the eight XCDs round-robin, each with its own L2.  The grid has 8*G
 // workgroups and only every eighth works (the others retire at once), so the G that cooperate share one L2: the
-// barrier word and the exchanged data stay there.  Correctness does not depend on the placement -- barriers and
-// exchanges use agent-scope release / acquire -- only the latency does.
+// barrier word and the exchanged data stay there.  Correctness does not depend on the placement: the workgroups
+// check where they run (grid_sync below) and release at agent scope unless they all share an XCD.
 #include "common.h"
 #include "fft_dev.h"
 #include "masks.h"
