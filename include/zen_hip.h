@@ -135,7 +135,8 @@ typedef struct {
  * ZEN_HIP_TIME_ANTICAUSAL (HPRIOffline passes, hps.cu:38-48).
  * n_streams >= 1 independent mono streams processed in lock step (1 for the reference API).
  * max_hops_per_chunk bounds device memory: longer calls are processed in chunks of that many hops
- * (0 = default: 2^26 / (n_streams * nfft) hops, clamped to 1..65536). */
+ * (0 = default: 2^30 / (n_streams * nfft) hops, clamped to 1..65536: 12 bytes of ring per element plus the rows of
+ * the outputs in use -- about 2.7 GB for one hop-1024 stream, 14 GB for 64 offline clips). */
 int zen_hip_hpr_create(float fs, size_t hop, float beta, unsigned output_flags, int causality,
                        int copy_bord, size_t n_streams, size_t max_hops_per_chunk, zen_hip_hpr_t* h);
 int zen_hip_hpr_destroy(zen_hip_hpr_t h);

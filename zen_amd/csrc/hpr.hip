@@ -517,7 +517,10 @@ int zen_hip_hpr_create(float fs, size_t hop, float beta, unsigned output_flags, 
 	e->soft = false;
 	e->n_streams = n_streams;
 	if (max_hops_per_chunk == 0) {
-		size_t m = ((size_t)1 << 26) / (n_streams * nfft);
+		// 2^30 ring elements per engine (S 8 B + |S| 4 B each, H / P / Y rows on demand: ~14 GB for 64 clips of the
+		// default offline configuration, 2 GB for one hop-1024 stream; the device has 288): whole clips go through
+		// in one or two chunks, every launch is large (offline batch +6 % against 2^26, measured)
+		size_t m = ((size_t)1 << 30) / (n_streams * nfft);
 		max_hops_per_chunk = m < 1 ? 1 : (m > 65536 ? 65536 : m);
 	}
 	e->max_hops = max_hops_per_chunk;
