@@ -81,7 +81,7 @@ int main(int argc, char** argv)
 				            hop, (st[1] - st[0]) / 100.0, (st[2] - st[1]) / 100.0, (st[3] - st[2]) / 100.0,
 				            (st[4] - st[3]) / 100.0, (double)st[5] / ((st[4] - st[0]) / 100.0));
 			}
-			if (argc > 2 && !sse && hop > 1024) { // the cooperative single-hop kernel (rt_wide.hip): phases and grid barriers
+			if (argc > 2 && hop > 1024) { // the cooperative single-hop kernel (rt_wide.hip): phases and grid barriers
 				unsigned long long* st = nullptr;
 				CK(zen_hip_hpr_debug_stamps(h, &st));
 				std::memcpy(hin, x.data(), hop * 4);
@@ -94,10 +94,10 @@ int main(int argc, char** argv)
 					while (now_us() - t0 < 2000.0) {}
 				}
 				auto d = [&](int i) { return (st[i + 1] - st[i]) / 100.0; };
-				std::printf("{\"hop\": %zu, \"phase_us\": {\"carries_analysis_a\": %.2f, \"barrier\": %.2f, \"analysis_b_abs\": %.2f, "
+				std::printf("{\"hop\": %zu, \"sse\": %d, \"phase_us\": {\"carries_analysis_a\": %.2f, \"barrier\": %.2f, \"analysis_b_abs\": %.2f, "
 				            "\"barrier2\": %.2f, \"median\": %.2f, \"barrier3\": %.2f, \"mask_synthesis_a\": %.2f, \"barrier4\": %.2f, "
 				            "\"synthesis_b_store\": %.2f, \"barrier5\": %.2f}, \"kernel_us\": %.2f, \"xcc_id_of_workgroups\": [%llu, %llu, %llu, %llu], \"light_barriers\": %llu}\n",
-				            hop, d(0), d(1), d(2), d(3), d(4), d(5), d(6), d(7), d(8), d(9), (st[10] - st[0]) / 100.0, st[12] & 15,
+				            hop, sse, d(0), d(1), d(2), d(3), d(4), d(5), d(6), d(7), d(8), d(9), (st[10] - st[0]) / 100.0, st[12] & 15,
 				            st[13] & 15, hop > 2048 ? st[14] & 15 : 99ull, hop > 2048 ? st[15] & 15 : 99ull, (st[12] >> 4) & 1);
 			}
 			if (argc > 2 && !sse && hop <= 1024) { // --stamps: phase times of the last single-hop launch
