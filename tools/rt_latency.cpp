@@ -81,7 +81,7 @@ int main(int argc, char** argv)
 				            hop, (st[1] - st[0]) / 100.0, (st[2] - st[1]) / 100.0, (st[3] - st[2]) / 100.0,
 				            (st[4] - st[3]) / 100.0, (double)st[5] / ((st[4] - st[0]) / 100.0));
 			}
-			if (argc > 2 && hop > 1024) { // the cooperative single-hop kernel (rt_wide.hip): phases and grid barriers
+			if (argc > 2 && !sse && hop > 1024) { // the cooperative single-hop kernel (rt_wide.hip): phases and grid barriers
 				unsigned long long* st = nullptr;
 				CK(zen_hip_hpr_debug_stamps(h, &st));
 				std::memcpy(hin, x.data(), hop * 4);
