@@ -66,12 +66,15 @@ __device__ __forceinline__ float2 cmul(float2 w, float2 b)
 // or inverse transform of this size, loaded once up front (the single-hop kernel, where six such round trips are
 // a seventh of the call); slot = position of the load inside a pass: stage q, frequency group c < max(1, 2^(q-2)).
 struct TwGlobal {
+	static constexpr bool PLAIN = true; // the table of the transform itself: entry 0 is 1 (see butterfly)
 	const float2* __restrict__ p;
 	__device__ __forceinline__ float2 get(int, int, int, int idx) const { return p[idx]; }
 };
 
-template <int LOG2N>
+// PLAIN = false: the registers hold something else than the transform's own table (rt_wide.hip's second step)
+template <int LOG2N, bool PLAIN_ = true>
 struct TwRegs {
+	static constexpr bool PLAIN = PLAIN_;
 	using PL = Plan<LOG2N>;
 	static constexpr int NBMAX = 16 >> PL::BASE; // groups per thread in the pass with the fewest stages
 	float2 w[PL::P][NBMAX][8];
@@ -120,7 +123,13 @@ struct TwRegs {
 //   in : a[m] = Y_s[j + m*J][k], m < R            (J = N / (2^s * R))
 //   out: a[c] = Y_{s+r}[j][k + c*2^s], c < R
 // ZU: a[R/2..R) are known zeros (zero-padded analysis frame): the first stage is then a copy.
-template <int R, bool INV, bool ZU, class TW>
+//
+// Trivial twiddles.  In the first pass of a transform (k == 0) frequency group c = 0 of every stage has the
+// twiddle tw[0] = 1 and, from the second stage on, group c = nc/2 has tw[N/4] = -i (the table has that symmetry
+// exactly): w * B is then B or (B.y, -B.x) -- what the general complex product evaluates to as well (x*1 = x,
+// x*0 = +-0, y +- 0 = y), except for the SIGN of an exact zero result (and 0 * inf).  The same kind of shortcut
+// as ZU; it removes 22 of the 32 complex products of a 16-value first pass.  TRIV: first pass, plain table.
+template <int R, bool INV, bool ZU, bool TRIV, class TW>
 __device__ __forceinline__ void butterfly(float2 (&a)[R], int k, int log2L, int log2N, const TW& tw, int pass, int grp)
 {
 	constexpr int r = Log2<R>::value;
@@ -136,6 +145,9 @@ __device__ __forceinline__ void butterfly(float2 (&a)[R], int k, int log2L, int 
 				float2 w0 = w[c - (nc >> 1)];
 				w[c] = INV ? make_float2(-w0.y, w0.x) : make_float2(w0.y, -w0.x);
 			}
+			else if (TRIV && c == 0) {
+				w[c] = make_float2(1.0f, 0.0f); // not loaded, not multiplied with (below)
+			}
 			else {
 				int idx = (k << (log2N - log2L - q)) + (c << (log2N - q));
 				float2 t = tw.get(pass, grp, (q == 1 ? 0 : (1 << (q - 2))) + c, idx);
@@ -150,6 +162,22 @@ __device__ __forceinline__ void butterfly(float2 (&a)[R], int k, int log2L, int 
 				if (ZU && q == 1) {
 					b[c * half + m] = A; // A + w*0, A - w*0
 					b[(c + nc) * half + m] = A;
+				}
+				else if (TRIV && c == 0) { // w = 1
+					const float2 B = a[c * 2 * half + m + half];
+					b[c * half + m] = make_float2(A.x + B.x, A.y + B.y);
+					b[(c + nc) * half + m] = make_float2(A.x - B.x, A.y - B.y);
+				}
+				else if (TRIV && q >= 2 && c == (nc >> 1)) { // w = -i (forward), +i (inverse): t = (B.y, -B.x) / (-B.y, B.x)
+					const float2 B = a[c * 2 * half + m + half];
+					if (INV) {
+						b[c * half + m] = make_float2(A.x - B.y, A.y + B.x);
+						b[(c + nc) * half + m] = make_float2(A.x + B.y, A.y - B.x);
+					}
+					else {
+						b[c * half + m] = make_float2(A.x + B.y, A.y - B.x);
+						b[(c + nc) * half + m] = make_float2(A.x - B.y, A.y + B.x);
+					}
 				}
 				else {
 					float2 t = cmul(w[c], a[c * 2 * half + m + half]);
@@ -220,7 +248,7 @@ struct PassRunner {
 		for (int i = 0; i < NB; ++i) {
 			const int b = tf + i * TF;
 			const int k = b >> log2J;
-			butterfly<R, INV, ZUP>(v[i], k, sL, LOG2N, tw, PASS, i);
+			butterfly<R, INV, ZUP, (FIRST && TW::PLAIN)>(v[i], k, sL, LOG2N, tw, PASS, i);
 #pragma unroll
 			for (int c = 0; c < R; ++c) {
 				const int idx = b + c * (N / R);

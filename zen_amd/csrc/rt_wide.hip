@@ -281,7 +281,7 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 	float2* T = a.xch + (long long)s * N;
 
 	zfft::TwRegs<LOG2M> twA;
-	zfft::TwRegs<LOG2J> twB;
+	zfft::TwRegs<LOG2J, false> twB; // (not the J-point transform's own table: no trivial twiddles)
 	// Lanes of step A: neighbouring lanes hold neighbouring sequences j (same position inside the sequence), so the
 	// strided elements x[j + n*J] they ask for are neighbours in memory; a frame still lives inside one wavefront.
 	// Step B: neighbouring lanes are neighbouring threads of one column, whose exchange-buffer entries are contiguous.
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 		const int kappa = u / PB::TF, tf = u % PB::TF;
 		XchIn<LOG2J> in{T, kappa};
 		FwdBOut<LOG2M> out{Srow, mrow, kappa, N};
-		zfft::PassRunner<LOG2J, 0, false, false, false, XchIn<LOG2J>, FwdBOut<LOG2M>, false, zfft::TwRegs<LOG2J>>::run(
+		zfft::PassRunner<LOG2J, 0, false, false, false, XchIn<LOG2J>, FwdBOut<LOG2M>, false, zfft::TwRegs<LOG2J, false>>::run(
 		    tf, lds + (t / PB::TF) * PB::LDS_FLOAT2, twB, in, out, true);
 	}
 	sync(3);
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 			const int kappa = u / PB::TF, tf = u % PB::TF;
 			XchIn<LOG2J> in{T, kappa};
 			InvBOut<LOG2M> out{a.Y[which] + (long long)s * a.y_stream_stride, a.cola, ready, a.carry[which] + (long long)s * hop, hop, kappa};
-			zfft::PassRunner<LOG2J, 0, true, false, true, XchIn<LOG2J>, InvBOut<LOG2M>, false, zfft::TwRegs<LOG2J>>::run(
+			zfft::PassRunner<LOG2J, 0, true, false, true, XchIn<LOG2J>, InvBOut<LOG2M>, false, zfft::TwRegs<LOG2J, false>>::run(
 			    tf, lds + (t / PB::TF) * PB::LDS_FLOAT2, twB, in, out, true);
 		}
 		if (a.publish_seq)
