@@ -15,6 +15,10 @@
 //
 // Twiddles come from the host table (exact octant symmetry): tw[i + N/4] == -i*tw[i] bit for bit, so
 // half of each stage's twiddles are formed by a swap/negate instead of a load.
+//
+// Two shortcuts skip arithmetic whose value is known: the first stage of a zero-padded frame (ZU: A +- w*0 = A)
+// and the products with the twiddles 1 and -i of a first pass (butterfly<..., TRIV>).  Every nonzero value is
+// still the oracle's; an exact zero may carry the other sign.
 #pragma once
 #include <hip/hip_runtime.h>
 
