@@ -99,53 +99,62 @@ __global__ __launch_bounds__(256, ZEN_BIG_MINB) void median_big_kernel(FilterArg
 }
 
 // Hermitian rows: what the main kernel leaves out -- the block that holds bin cols/2 and the last ceil(mid/16)
-// blocks (whose replicate border differs from the mirrored one) -- by ONE wavefront per row: lane 0
-// takes the middle block, lanes 1.. the tail blocks; both neighbourhoods are staged and sorted side by side.
+// blocks (whose replicate border differs from the mirrored one).  A wavefront takes TAIL_ROWS rows, 16
+// lanes each: lane 0 of a row's group takes the middle block, lanes 1.. the tail blocks (at most 8); both
+// neighbourhoods of every row are staged and sorted side by side.  (One row per wavefront left 57 of 64 lanes idle
+// through the selection: 0.33 ms of the 12 ms offline batch step.)
+constexpr int TAIL_ROWS = 4;
 template <int W, bool NONNEG>
 __global__ __launch_bounds__(64) void median_big_tail_kernel(FilterArgs a, int row_base, int ring)
 {
 	using G = zbig::Geo<W>;
 	constexpr int NT = (G::m + 15) / 16;                // tail blocks
+	static_assert(NT + 1 <= 16, "a row's blocks fit its 16 lanes");
 	constexpr int HALO_L = G::a + 2, HALO_R = G::b + 1;  // raw blocks needed left / right of an output block
-	constexpr int NRAW_A = HALO_L + 1 + HALO_R, NRAW_B = HALO_L + NT + HALO_R;
-	constexpr int NSORT_A = 1 + G::NB - 1, NSORT_B = NT + G::NB - 1;
-	__shared__ __attribute__((aligned(16))) int raw[(NRAW_A + NRAW_B) * RSTR];
-	__shared__ __attribute__((aligned(16))) int srt[(NSORT_A + NSORT_B) * RSTR];
+	constexpr int NRAW_A = HALO_L + 1 + HALO_R, NRAW_B = HALO_L + NT + HALO_R, NRAW = NRAW_A + NRAW_B;
+	constexpr int NSORT_A = 1 + G::NB - 1, NSORT_B = NT + G::NB - 1, NSORT = NSORT_A + NSORT_B;
+	__shared__ __attribute__((aligned(16))) int raw[TAIL_ROWS * NRAW * RSTR];
+	__shared__ __attribute__((aligned(16))) int srt[TAIL_ROWS * NSORT * RSTR];
 	const int lane = threadIdx.x;
 	const int cols = a.cols, nblk = cols >> 4;
-	const int st = blockIdx.y, row = blockIdx.x;
-	const float* srow = a.src + (long long)st * a.src_stream_stride + (long long)((row_base + row) % ring) * cols;
-	float* drow = a.dst + (long long)st * a.dst_stream_stride + (long long)row * cols;
+	const int st = blockIdx.y, row0 = blockIdx.x * TAIL_ROWS;
+	const int rows_here = a.n_out_rows - row0 < TAIL_ROWS ? a.n_out_rows - row0 : TAIL_ROWS;
+	const float* src_s = a.src + (long long)st * a.src_stream_stride;
 	const int blkA = nblk >> 1, blkB = nblk - NT; // first output block of either piece
-	for (int vi = lane; vi < (NRAW_A + NRAW_B) * 4; vi += 64) {
+	for (int wi = lane; wi < rows_here * NRAW * 4; wi += 64) {
+		const int rr = wi / (NRAW * 4), vi = wi - rr * (NRAW * 4);
+		const float* srow = src_s + (long long)((row_base + row0 + rr) % ring) * cols;
 		const bool pb = vi >= NRAW_A * 4;
 		const int v = pb ? vi - NRAW_A * 4 : vi;
 		const int vc = 16 * ((pb ? blkB : blkA) - HALO_L) + 4 * v;
-		*reinterpret_cast<int4*>(&raw[(vi >> 2) * RSTR + 4 * (vi & 3)]) = row_vec_keys<NONNEG>(srow, vc, cols, 1);
+		*reinterpret_cast<int4*>(&raw[(rr * NRAW + (vi >> 2)) * RSTR + 4 * (vi & 3)]) = row_vec_keys<NONNEG>(srow, vc, cols, 1);
 	}
 	__syncthreads();
-	for (int s = lane; s < NSORT_A + NSORT_B; s += 64) { // sorted entry s of a piece = raw chunk s + 2 of that piece
+	for (int ws = lane; ws < rows_here * NSORT; ws += 64) { // sorted entry s of a piece = raw chunk s + 2 of that piece
+		const int rr = ws / NSORT, s = ws - rr * NSORT;
 		const bool pb = s >= NSORT_A;
 		const int chunk = pb ? NRAW_A + (s - NSORT_A) + 2 : s + 2;
 		int v[16];
-		znet::lds_load<16>(&raw[chunk * RSTR], v);
+		znet::lds_load<16>(&raw[(rr * NRAW + chunk) * RSTR], v);
 		znet::sort_net<16>(v);
-		znet::lds_store<16>(&srt[s * RSTR], v);
+		znet::lds_store<16>(&srt[(rr * NSORT + s) * RSTR], v);
 	}
 	__syncthreads();
-	if (lane > NT)
+	const int rr = lane >> 4, l = lane & 15;
+	if (rr >= rows_here || l > NT)
 		return;
-	const int loc = lane == 0 ? 0 : lane - 1; // block within the piece
+	const int loc = l == 0 ? 0 : l - 1; // block within the piece
 	struct Loader {
 		const int* srt_t;
 		const int* raw_t;
 		__device__ __forceinline__ void sorted(int i, int* v) const { znet::lds_load<16>(srt_t + i * RSTR, v); }
 		__device__ __forceinline__ void rawl(int j, int* v) const { znet::lds_load<16>(raw_t + j * RSTR, v); }
 		__device__ __forceinline__ void rawr(int j, int* v) const { znet::lds_load<16>(raw_t + (G::a + G::b + 2 + j) * RSTR, v); }
-	} ld{&srt[((lane == 0 ? 0 : NSORT_A) + loc) * RSTR], &raw[((lane == 0 ? 0 : NRAW_A) + loc) * RSTR]};
+	} ld{&srt[(rr * NSORT + (l == 0 ? 0 : NSORT_A) + loc) * RSTR], &raw[(rr * NRAW + (l == 0 ? 0 : NRAW_A) + loc) * RSTR]};
 	int out[16];
 	zbig::medians_big<W>(ld, out);
-	const int c = 16 * ((lane == 0 ? blkA : blkB) + loc);
+	float* drow = a.dst + (long long)st * a.dst_stream_stride + (long long)(row0 + rr) * cols;
+	const int c = 16 * ((l == 0 ? blkA : blkB) + loc);
 #pragma unroll
 	for (int v = 0; v < 4; ++v)
 		*reinterpret_cast<float4*>(drow + c + 4 * v) =
@@ -166,7 +175,7 @@ int launch_w(const FilterArgs& a, hipStream_t stream)
 		hipLaunchKernelGGL((median_big_kernel<W, false>), grid, dim3(256), 0, stream, a, row_base, (int)a.ring_rows, segs, nblk_main);
 	ZH_HIP(hipGetLastError());
 	if (a.hermitian) {
-		dim3 tgrid((unsigned)a.n_out_rows, (unsigned)a.n_streams);
+		dim3 tgrid((unsigned)((a.n_out_rows + TAIL_ROWS - 1) / TAIL_ROWS), (unsigned)a.n_streams);
 		if (a.nonneg)
 			hipLaunchKernelGGL((median_big_tail_kernel<W, true>), tgrid, dim3(64), 0, stream, a, row_base, (int)a.ring_rows);
 		else
