@@ -41,13 +41,24 @@ int chunk_padder(size_t audio_size, size_t hop, size_t lag, size_t* padded)
 	return n;
 }
 
+// The three streaming helpers below move four samples per thread: one 16-byte access where the four come from one
+// aligned run (VEC: the caller's rows are 16-byte aligned; the engine's own buffers always are), sample by sample
+// at the seams and the ends.
+template <bool VEC>
 __global__ __launch_bounds__(256) void pad_clips_kernel(const float* __restrict__ in, long long in_stride,
                                                         size_t n, float* __restrict__ out, size_t padded)
 {
 	const float* src = in + (long long)blockIdx.y * in_stride;
-	float* dst = out + (size_t)blockIdx.y * padded;
-	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < padded; i += (size_t)gridDim.x * blockDim.x)
-		dst[i] = i < n ? src[i] : 0.0F; // audio.resize(size + pad, 0.0F)  hps.cu:123
+	float* dst = out + (size_t)blockIdx.y * padded; // (padded is a multiple of the hop: rows stay aligned)
+	for (size_t i = 4 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x); i < padded; i += 4 * (size_t)gridDim.x * blockDim.x) {
+		if (VEC && i + 4 <= n) {
+			*reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(src + i);
+		}
+		else {
+			for (size_t k = i; k < i + 4 && k < padded; ++k)
+				dst[k] = k < n ? src[k] : 0.0F; // audio.resize(size + pad, 0.0F)  hps.cu:123
+		}
+	}
 }
 
 // hps.cu:153-160 (xp1 + xr1), :171-176 (shift left by lag_h*hop_h in place; the tail keeps its old
@@ -59,28 +70,56 @@ __global__ __launch_bounds__(256) void intermediate_kernel(const float* __restri
 	const float* p = P1 + (size_t)blockIdx.y * padded1;
 	const float* r = R1 + (size_t)blockIdx.y * padded1;
 	float* dst = in2 + (size_t)blockIdx.y * padded2;
-	for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < padded2; j += (size_t)gridDim.x * blockDim.x) {
-		float v = 0.0F; // beyond the reference's allocation (undefined there)
-		if (j < padded1) {
-			const size_t q = (j < padded1 - sh1) ? j + sh1 : j;
-			v = p[q] + r[q]; // sum_vectors_functor hps.h:142-150
+	for (size_t j = 4 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x); j < padded2; j += 4 * (size_t)gridDim.x * blockDim.x) {
+		if (j + 4 <= padded1 - sh1 && j + 4 <= padded2) { // (padded1, padded2 and sh1 are multiples of a hop: aligned)
+			const float4 x = *reinterpret_cast<const float4*>(p + j + sh1), y = *reinterpret_cast<const float4*>(r + j + sh1);
+			*reinterpret_cast<float4*>(dst + j) = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w); // sum_vectors_functor hps.h:142-150
 		}
-		dst[j] = v;
+		else {
+			for (size_t k = j; k < j + 4 && k < padded2; ++k) {
+				float v = 0.0F; // beyond the reference's allocation (undefined there)
+				if (k < padded1) {
+					const size_t q = (k < padded1 - sh1) ? k + sh1 : k;
+					v = p[q] + r[q];
+				}
+				dst[k] = v;
+			}
+		}
 	}
 }
 
 // hps.cu:171-178, :209-217 : drop the lag*hop delay, truncate to the clip length
+template <bool VEC>
 __global__ __launch_bounds__(256) void unshift_kernel(const float* __restrict__ full, size_t padded, size_t sh,
                                                       float* __restrict__ out, long long out_stride, size_t n)
 {
 	const float* src = full + (size_t)blockIdx.y * padded;
 	float* dst = out + (long long)blockIdx.y * out_stride;
-	for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
-		float v = 0.0F;
-		if (j < padded)
-			v = (j < padded - sh) ? src[j + sh] : src[j];
-		dst[j] = v;
+	for (size_t j = 4 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x); j < n; j += 4 * (size_t)gridDim.x * blockDim.x) {
+		if (VEC && j + 4 <= n && j + 4 <= padded - sh) {
+			*reinterpret_cast<float4*>(dst + j) = *reinterpret_cast<const float4*>(src + j + sh);
+		}
+		else {
+			for (size_t k = j; k < j + 4 && k < n; ++k) {
+				float v = 0.0F;
+				if (k < padded)
+					v = (k < padded - sh) ? src[k + sh] : src[k];
+				dst[k] = v;
+			}
+		}
 	}
+}
+
+// rows of a caller's buffer on which 16-byte accesses are allowed
+bool rows_aligned(const void* base, long long stride_floats, size_t rows)
+{
+	return (reinterpret_cast<uintptr_t>(base) & 15) == 0 && (rows <= 1 || stride_floats % 4 == 0);
+}
+
+unsigned grid_for4(size_t n) // four samples per thread
+{
+	size_t b = (n + 1023) / 1024;
+	return (unsigned)(b > 4096 ? 4096 : (b ? b : 1));
 }
 
 unsigned grid_for(size_t n)
@@ -217,26 +256,38 @@ int zen_hip_hpri_process_device(zen_hip_hpri_t h, const float* audio_dev, size_t
 	ZH_TRY(zen_hip_hpr_reset_buffers(h->eh)); // each process() call is a fresh pair of HPR objects' state
 	ZH_TRY(zen_hip_hpr_reset_buffers(h->ep));
 
-	hipLaunchKernelGGL(pad_clips_kernel, dim3(grid_for(padded1), (unsigned)C), dim3(256), 0, h->stream, audio_dev,
-	                   (long long)stride, n, h->a1, padded1);
+	if (rows_aligned(audio_dev, (long long)stride, C))
+		hipLaunchKernelGGL(pad_clips_kernel<true>, dim3(grid_for4(padded1), (unsigned)C), dim3(256), 0, h->stream, audio_dev,
+		                   (long long)stride, n, h->a1, padded1);
+	else
+		hipLaunchKernelGGL(pad_clips_kernel<false>, dim3(grid_for4(padded1), (unsigned)C), dim3(256), 0, h->stream, audio_dev,
+		                   (long long)stride, n, h->a1, padded1);
 	ZH_HIP(hipGetLastError());
 	// pass 1: large hop, harmonic + percussive + residual (hps.cu:142-167)
 	ZH_TRY(zen_hip_hpr_process(h->eh, h->a1, (size_t)n1, padded1, h->H1, h->P1, h->R1, padded1));
 	const size_t sh1 = (size_t)h->eh->lag * h->hop_h;
-	hipLaunchKernelGGL(intermediate_kernel, dim3(grid_for(padded2), (unsigned)C), dim3(256), 0, h->stream, h->P1,
+	hipLaunchKernelGGL(intermediate_kernel, dim3(grid_for4(padded2), (unsigned)C), dim3(256), 0, h->stream, h->P1,
 	                   h->R1, padded1, sh1, h->in2, padded2);
 	ZH_HIP(hipGetLastError());
 	// pass 2: small hop on xp1 + xr1, percussive only (hps.cu:185-205)
 	ZH_TRY(zen_hip_hpr_process(h->ep, h->in2, (size_t)n2, padded2, nullptr, h->P2, nullptr, padded2));
 	const size_t sh2 = (size_t)h->ep->lag * h->hop_p;
 	if (harm_dev) {
-		hipLaunchKernelGGL(unshift_kernel, dim3(grid_for(n), (unsigned)C), dim3(256), 0, h->stream, h->H1, padded1,
-		                   sh1, harm_dev, (long long)out_stride, n);
+		if (rows_aligned(harm_dev, (long long)out_stride, C))
+			hipLaunchKernelGGL(unshift_kernel<true>, dim3(grid_for4(n), (unsigned)C), dim3(256), 0, h->stream, h->H1, padded1,
+			                   sh1, harm_dev, (long long)out_stride, n);
+		else
+			hipLaunchKernelGGL(unshift_kernel<false>, dim3(grid_for4(n), (unsigned)C), dim3(256), 0, h->stream, h->H1, padded1,
+			                   sh1, harm_dev, (long long)out_stride, n);
 		ZH_HIP(hipGetLastError());
 	}
 	if (perc_dev) {
-		hipLaunchKernelGGL(unshift_kernel, dim3(grid_for(n), (unsigned)C), dim3(256), 0, h->stream, h->P2, padded2,
-		                   sh2, perc_dev, (long long)out_stride, n);
+		if (rows_aligned(perc_dev, (long long)out_stride, C))
+			hipLaunchKernelGGL(unshift_kernel<true>, dim3(grid_for4(n), (unsigned)C), dim3(256), 0, h->stream, h->P2, padded2,
+			                   sh2, perc_dev, (long long)out_stride, n);
+		else
+			hipLaunchKernelGGL(unshift_kernel<false>, dim3(grid_for4(n), (unsigned)C), dim3(256), 0, h->stream, h->P2, padded2,
+			                   sh2, perc_dev, (long long)out_stride, n);
 		ZH_HIP(hipGetLastError());
 	}
 	if (resid_dev) // pass 2's residual_out is never written: zeros (hps.cu:45-48, :200-204)
