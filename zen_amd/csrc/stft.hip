@@ -97,19 +97,31 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void stft_kernel(StftArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// VEC: four consecutive samples of a hop per thread, 16-byte accesses (hop is a multiple of 4 and the engine's rows
+// are aligned; the caller's `out` rows must be too: launch_finalize checks)
+template <bool VEC>
 __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a)
 {
 	const int s = blockIdx.y, hop = a.hop;
 	const float* Y = a.Y + (long long)s * a.y_stream_stride;
 	const float* carry = a.carry + (long long)s * hop;
 	float* out = a.out + (long long)s * a.out_stride;
-	const long long n = (long long)a.n_frames * hop;
+	constexpr int V = VEC ? 4 : 1;
+	const long long n = (long long)a.n_frames * hop / V;
+	const int per_hop = hop / V;
 	for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n;
 	     e += (long long)gridDim.x * blockDim.x) {
-		const long long i = e / hop;
-		const int k = (int)(e - i * hop);
-		const float prev = (i == 0) ? carry[k] : Y[(i - 1) * 2 * hop + hop + k];
-		out[e] = prev + Y[i * 2 * hop + k];
+		const long long i = e / per_hop;
+		const int k = (int)(e - i * per_hop) * V;
+		const float* prev = (i == 0) ? carry + k : Y + (i - 1) * 2 * hop + hop + k;
+		const float* cur = Y + i * 2 * hop + k;
+		if constexpr (VEC) {
+			const float4 p = *reinterpret_cast<const float4*>(prev), c = *reinterpret_cast<const float4*>(cur);
+			*reinterpret_cast<float4*>(out + i * hop + k) = make_float4(p.x + c.x, p.y + c.y, p.z + c.z, p.w + c.w);
+		}
+		else {
+			out[i * hop + k] = prev[0] + cur[0];
+		}
 	}
 }
 
@@ -192,11 +204,15 @@ int launch_finalize(const FinalizeArgs& a, hipStream_t stream)
 {
 	if (a.n_frames <= 0)
 		return ZEN_HIP_OK;
-	const long long n = (long long)a.n_frames * a.hop;
+	const bool vec = a.hop % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 && (a.n_streams <= 1 || a.out_stride % 4 == 0);
+	const long long n = (long long)a.n_frames * a.hop / (vec ? 4 : 1);
 	long long blocks = (n + 255) / 256;
 	if (blocks > 4096)
 		blocks = 4096;
-	hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)blocks, (unsigned)a.n_streams), dim3(256), 0, stream, a);
+	if (vec)
+		hipLaunchKernelGGL(finalize_kernel<true>, dim3((unsigned)blocks, (unsigned)a.n_streams), dim3(256), 0, stream, a);
+	else
+		hipLaunchKernelGGL(finalize_kernel<false>, dim3((unsigned)blocks, (unsigned)a.n_streams), dim3(256), 0, stream, a);
 	ZH_HIP(hipGetLastError());
 	return ZEN_HIP_OK;
 }
