@@ -302,6 +302,7 @@ int zen_hip_hpri_process_device(zen_hip_hpri_t h, const float* audio_dev, size_t
 // 2W+2 hops early from zero state reaches exactly the serial state before its first kept sample.  The
 // shard therefore needs only a halo of input: (2W_p+2)*hop_p + lag_p*hop_p for pass 2 on top of
 // (2W_h+2)*hop_h + lag_h*hop_h for pass 1; ranks exchange nothing.
+extern "C++" {
 namespace {
 
 struct RangePlan {
@@ -352,47 +353,79 @@ int plan_range(zen_hip_hpri* h, size_t n, size_t begin, size_t end, RangePlan* p
 }
 
 // a1[i] = audio[off + i] (zero beyond n), i < count
+// (the three range kernels move four samples per thread like the whole-clip helpers above; VEC: the launcher found
+// source and destination 16-byte aligned for every group of four)
+template <bool VEC>
 __global__ __launch_bounds__(256) void range_input_kernel(const float* __restrict__ audio, size_t n, size_t off,
                                                           float* __restrict__ dst, size_t count)
 {
-	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x)
-		dst[i] = (off + i < n) ? audio[off + i] : 0.0F;
+	for (size_t i = 4 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x); i < count; i += 4 * (size_t)gridDim.x * blockDim.x) {
+		if (VEC && i + 4 <= count && off + i + 4 <= n) {
+			*reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(audio + off + i);
+		}
+		else {
+			for (size_t k = i; k < i + 4 && k < count; ++k)
+				dst[k] = (off + k < n) ? audio[off + k] : 0.0F;
+		}
+	}
 }
 
 // pass-2 input positions j in [j0, j0+count): intermediate'[j] as intermediate_kernel defines it;
 // P1/R1 hold pass-1 output positions [base1, ...)
+template <bool VEC>
 __global__ __launch_bounds__(256) void range_intermediate_kernel(const float* __restrict__ P1, const float* __restrict__ R1,
                                                                  size_t base1, size_t padded1, size_t sh1, size_t j0,
                                                                  float* __restrict__ dst, size_t count)
 {
-	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+	for (size_t i = 4 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x); i < count; i += 4 * (size_t)gridDim.x * blockDim.x) {
 		const size_t j = j0 + i;
-		float v = 0.0F;
-		if (j < padded1) {
-			const size_t q = (j < padded1 - sh1) ? j + sh1 : j;
-			v = P1[q - base1] + R1[q - base1];
+		if (VEC && i + 4 <= count && j + 4 <= padded1 - sh1) {
+			const float4 x = *reinterpret_cast<const float4*>(P1 + (j + sh1 - base1)), y = *reinterpret_cast<const float4*>(R1 + (j + sh1 - base1));
+			*reinterpret_cast<float4*>(dst + i) = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
 		}
-		dst[i] = v;
+		else {
+			for (size_t k = i; k < i + 4 && k < count; ++k) {
+				const size_t jk = j0 + k;
+				float v = 0.0F;
+				if (jk < padded1) {
+					const size_t q = (jk < padded1 - sh1) ? jk + sh1 : jk;
+					v = P1[q - base1] + R1[q - base1];
+				}
+				dst[k] = v;
+			}
+		}
 	}
 }
 
 // out[i] = full'[begin + i] where full' is `full` with the lag*hop delay removed (unshift_kernel);
 // `full` holds positions [base, ...)
+template <bool VEC>
 __global__ __launch_bounds__(256) void range_unshift_kernel(const float* __restrict__ full, size_t base, size_t padded,
                                                             size_t sh, size_t begin, float* __restrict__ out, size_t count)
 {
-	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+	for (size_t i = 4 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x); i < count; i += 4 * (size_t)gridDim.x * blockDim.x) {
 		const size_t j = begin + i;
-		float v = 0.0F;
-		if (j < padded) {
-			const size_t q = (j < padded - sh) ? j + sh : j;
-			v = full[q - base];
+		if (VEC && i + 4 <= count && j + 4 <= padded - sh) {
+			*reinterpret_cast<float4*>(out + i) = *reinterpret_cast<const float4*>(full + (j + sh - base));
 		}
-		out[i] = v;
+		else {
+			for (size_t k = i; k < i + 4 && k < count; ++k) {
+				const size_t jk = begin + k;
+				float v = 0.0F;
+				if (jk < padded) {
+					const size_t q = (jk < padded - sh) ? jk + sh : jk;
+					v = full[q - base];
+				}
+				out[k] = v;
+			}
+		}
 	}
 }
 
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 } // namespace
+} // extern "C++"
 
 int zen_hip_hpri_range_halo(zen_hip_hpri_t h, size_t n, size_t begin, size_t end, size_t* in_begin, size_t* in_end)
 {
@@ -433,24 +466,39 @@ int zen_hip_hpri_process_range(zen_hip_hpri_t h, const float* audio_dev, size_t 
 	ZH_TRY(zen_hip_hpr_reset_buffers(h->eh));
 	ZH_TRY(zen_hip_hpr_reset_buffers(h->ep));
 	const size_t base1 = p.q1 * hop_h, base2 = p.q2 * hop_p;
-	hipLaunchKernelGGL(range_input_kernel, dim3(grid_for(c1)), dim3(256), 0, h->stream, audio_dev, n, base1, h->a1, c1);
+	if (aligned16(audio_dev + base1))
+		hipLaunchKernelGGL(range_input_kernel<true>, dim3(grid_for4(c1)), dim3(256), 0, h->stream, audio_dev, n, base1, h->a1, c1);
+	else
+		hipLaunchKernelGGL(range_input_kernel<false>, dim3(grid_for4(c1)), dim3(256), 0, h->stream, audio_dev, n, base1, h->a1, c1);
 	ZH_HIP(hipGetLastError());
 	ZH_TRY(zen_hip_hpr_process(h->eh, h->a1, p.k1 - p.q1, c1, h->H1, h->P1, h->R1, c1));
 	if (c2) {
-		hipLaunchKernelGGL(range_intermediate_kernel, dim3(grid_for(c2)), dim3(256), 0, h->stream, h->P1, h->R1, base1,
-		                   p.padded1, p.sh1, base2, h->in2, c2);
+		if ((base2 + p.sh1 - base1) % 4 == 0)
+			hipLaunchKernelGGL(range_intermediate_kernel<true>, dim3(grid_for4(c2)), dim3(256), 0, h->stream, h->P1, h->R1, base1,
+			                   p.padded1, p.sh1, base2, h->in2, c2);
+		else
+			hipLaunchKernelGGL(range_intermediate_kernel<false>, dim3(grid_for4(c2)), dim3(256), 0, h->stream, h->P1, h->R1, base1,
+			                   p.padded1, p.sh1, base2, h->in2, c2);
 		ZH_HIP(hipGetLastError());
 		ZH_TRY(zen_hip_hpr_process(h->ep, h->in2, p.m1 - p.q2, c2, nullptr, h->P2, nullptr, c2));
 	}
 	const size_t cnt = end - begin;
 	if (harm_dev) {
-		hipLaunchKernelGGL(range_unshift_kernel, dim3(grid_for(cnt)), dim3(256), 0, h->stream, h->H1, base1, p.padded1,
-		                   p.sh1, begin, harm_dev, cnt);
+		if (aligned16(harm_dev) && (begin + p.sh1 - base1) % 4 == 0)
+			hipLaunchKernelGGL(range_unshift_kernel<true>, dim3(grid_for4(cnt)), dim3(256), 0, h->stream, h->H1, base1, p.padded1,
+			                   p.sh1, begin, harm_dev, cnt);
+		else
+			hipLaunchKernelGGL(range_unshift_kernel<false>, dim3(grid_for4(cnt)), dim3(256), 0, h->stream, h->H1, base1, p.padded1,
+			                   p.sh1, begin, harm_dev, cnt);
 		ZH_HIP(hipGetLastError());
 	}
 	if (perc_dev) {
-		hipLaunchKernelGGL(range_unshift_kernel, dim3(grid_for(cnt)), dim3(256), 0, h->stream, h->P2, base2, p.padded2,
-		                   p.sh2, begin, perc_dev, cnt);
+		if (aligned16(perc_dev) && (begin + p.sh2 - base2) % 4 == 0)
+			hipLaunchKernelGGL(range_unshift_kernel<true>, dim3(grid_for4(cnt)), dim3(256), 0, h->stream, h->P2, base2, p.padded2,
+			                   p.sh2, begin, perc_dev, cnt);
+		else
+			hipLaunchKernelGGL(range_unshift_kernel<false>, dim3(grid_for4(cnt)), dim3(256), 0, h->stream, h->P2, base2, p.padded2,
+			                   p.sh2, begin, perc_dev, cnt);
 		ZH_HIP(hipGetLastError());
 	}
 	return ZEN_HIP_OK;
