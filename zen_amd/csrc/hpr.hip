@@ -214,6 +214,7 @@ int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, H
 	a.out_h = e->out_h ? 1 : 0;
 	a.out_p = e->out_p ? 1 : 0;
 	a.thr = g_opt_mask_divide ? 0.0 : hard_mask_threshold(e->beta, &a.thr_inclusive);
+	a.thr_h = g_opt_mask_divide ? 0.0 : hard_mask_threshold(a.beta_h, &a.thr_h_inclusive);
 	a.diag = g_opt_rt_fused_diag;
 	a.stamps = e->dbg_stamps;
 	if (kind == HOP_WIDE) {
@@ -411,6 +412,13 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 	ia.out_h = e->out_h ? 1 : 0;
 	ia.out_p = e->out_p ? 1 : 0;
 	ia.cola = e->cola;
+	{
+		const HardThr t = hard_mask_thresholds(ia.beta, ia.beta_h, g_opt_mask_divide != 0);
+		ia.thr_p = t.p;
+		ia.thr_h = t.h;
+		ia.thr_p_inc = t.p_inc;
+		ia.thr_h_inc = t.h_inc;
+	}
 	{
 		ProfScope ps(e, zen_hip_hpr::K_ISTFT);
 		ZH_TRY(launch_istft(e->log2n, ia, e->stream));

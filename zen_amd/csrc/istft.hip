@@ -29,6 +29,7 @@ struct IstftIn {
 	const float* H;
 	const float* P;
 	MaskCfg cfg;
+	HardThr thr;
 	int which;
 	int n;
 	int p_mid;
@@ -40,7 +41,7 @@ struct IstftIn {
 		if (mirror)
 			z.y = -z.y;
 		const int pi = (mirror && idx >= n - p_mid) ? idx : lo;
-		const float m = mask_value(which, H[lo], P[pi], cfg);
+		const float m = mask_value_thr(which, H[lo], P[pi], cfg, thr);
 		return make_float2(z.x * m, z.y * m); // apply_mask_functor hps.h:58-66
 	}
 };
@@ -86,6 +87,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void istft_kernel(IstftArgs a
 	in.H = a.h_is_ring ? a.H + ring_row * PL::N : a.H + (long long)s * a.h_stream_stride + (long long)f * PL::N;
 	in.P = a.P + (long long)s * a.p_stream_stride + (long long)f * PL::N;
 	in.cfg = MaskCfg{a.beta, a.beta_h, a.soft, a.power, a.sse, a.out_h, a.out_p};
+	in.thr = HardThr{a.thr_p, a.thr_h, a.thr_p_inc, a.thr_h_inc};
 	in.which = a.out_id[oi];
 	in.p_mid = a.p_mid;
 	IstftOut out;
@@ -115,6 +117,7 @@ struct IstftHardIn {
 	const float* H;
 	const float* P;
 	MaskCfg cfg;
+	HardThr thr;
 	unsigned* bits; // bit 2*slot: percussive mask, bit 2*slot + 1: harmonic mask
 	int which;
 	int first;
@@ -129,8 +132,8 @@ struct IstftHardIn {
 			z.y = -z.y;
 		if (first) {
 			const float h = H[lo], p = P[(mirror && idx >= n - p_mid) ? idx : lo]; // see IstftIn
-			const unsigned pm = cfg.out_p || which == 0 ? (unsigned)(pmask_value(h, p, cfg) != 0.0f) : 0u;
-			const unsigned hm = cfg.out_h || which == 1 ? (unsigned)(hmask_value(h, p, cfg) != 0.0f) : 0u;
+			const unsigned pm = cfg.out_p || which == 0 ? (unsigned)(pmask_thr(h, p, cfg, thr) != 0.0f) : 0u;
+			const unsigned hm = cfg.out_h || which == 1 ? (unsigned)(hmask_thr(h, p, cfg, thr) != 0.0f) : 0u;
 			*bits |= (pm | (hm << 1)) << (2 * slot);
 		}
 		const float pm = (float)((*bits >> (2 * slot)) & 1u), hm = (float)((*bits >> (2 * slot + 1)) & 1u);
@@ -156,6 +159,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void istft_hard_multi_kernel(
 	in.H = a.h_is_ring ? a.H + ring_row * PL::N : a.H + (long long)s * a.h_stream_stride + (long long)f * PL::N;
 	in.P = a.P + (long long)s * a.p_stream_stride + (long long)f * PL::N;
 	in.cfg = MaskCfg{a.beta, a.beta_h, 0, a.power, 0, a.out_h, a.out_p};
+	in.thr = HardThr{a.thr_p, a.thr_h, a.thr_p_inc, a.thr_h_inc};
 	in.bits = &bits;
 	in.p_mid = a.p_mid;
 	for (int oi = 0; oi < a.n_out; ++oi) {

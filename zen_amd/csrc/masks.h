@@ -77,6 +77,37 @@ __device__ __forceinline__ float mask_value(int which, float h, float p, const M
 	return 1 - (hm + pm); // residual_mask_functor hps.h:35-43
 }
 
+// Both hard masks by exact comparison (hard_mask_exact): thr_p for (P / (H + Eps)) >= beta, thr_h for
+// (H / (P + Eps)) >= beta - Eps (hps.cu:501-505, :535-540).  A zero threshold keeps the division.
+struct HardThr {
+	double p, h;
+	int p_inc, h_inc;
+};
+
+__device__ __forceinline__ float pmask_thr(float h, float p, const MaskCfg& c, const HardThr& t)
+{
+	if (!c.sse && !c.soft && t.p != 0.0)
+		return hard_mask_exact(p, h + FLT_EPSILON, t.p, t.p_inc != 0);
+	return pmask_value(h, p, c);
+}
+__device__ __forceinline__ float hmask_thr(float h, float p, const MaskCfg& c, const HardThr& t)
+{
+	if (!c.sse && !c.soft && t.h != 0.0)
+		return hard_mask_exact(h, p + FLT_EPSILON, t.h, t.h_inc != 0);
+	return hmask_value(h, p, c);
+}
+// mask_value with the divisions of the hard masks replaced where the thresholds allow
+__device__ __forceinline__ float mask_value_thr(int which, float h, float p, const MaskCfg& c, const HardThr& t)
+{
+	if (which == 0)
+		return pmask_thr(h, p, c, t);
+	if (which == 1)
+		return hmask_thr(h, p, c, t);
+	const float hm = c.out_h ? hmask_thr(h, p, c, t) : 0.0f;
+	const float pm = c.out_p ? pmask_thr(h, p, c, t) : 0.0f;
+	return 1 - (hm + pm); // residual_mask_functor hps.h:35-43
+}
+
 // host side of hard_mask_exact: the boundary and whether it belongs to the "true" side
 inline double hard_mask_threshold(float beta, int* inclusive)
 {
@@ -90,6 +121,16 @@ inline double hard_mask_threshold(float beta, int* inclusive)
 	memcpy(&pred, &up, sizeof(pred));
 	*inclusive = (u & 1u) == 0; // a tie rounds to the even significand
 	return ((double)pred + (double)beta) * 0.5;
+}
+// both thresholds of an engine (beta for the percussive mask, beta - Eps for the harmonic one)
+inline HardThr hard_mask_thresholds(float beta, float beta_h, bool divide)
+{
+	HardThr t{0.0, 0.0, 0, 0};
+	if (!divide) {
+		t.p = hard_mask_threshold(beta, &t.p_inc);
+		t.h = hard_mask_threshold(beta_h, &t.h_inc);
+	}
+	return t;
 }
 
 } // namespace zen_hip_impl

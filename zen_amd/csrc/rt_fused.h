@@ -36,6 +36,8 @@ struct RtFusedArgs {
 	// (or > when !thr_inclusive) in exact arithmetic, thr the rounding boundary just below beta; 0: divide
 	double thr;
 	int thr_inclusive;
+	double thr_h;           // the same for the hard harmonic mask: fl(h / (p + Eps)) >= beta - Eps
+	int thr_h_inclusive;
 	// rt_wide.hip only: the percussive estimate row, the exchange buffer of the two-step transforms ([n_streams][nfft])
 	// and the grid-barrier words ([n_streams][4]: arrivals, timeout flag, two vote words; bar_base = arrivals before this call)
 	float* P;

@@ -204,8 +204,7 @@ struct InvAIn { // (S * mask)[j + n*J] (IstftIn of istft.hip): the upper half of
 	const float* P;
 	MaskCfg cfg;
 	int which, n, p_mid, j;
-	double thr; // != 0: hard percussive mask by exact comparison instead of the division (masks.h hard_mask_exact)
-	bool thr_inclusive;
+	HardThr thr; // hard masks by exact comparison instead of the division (masks.h)
 	__device__ __forceinline__ float2 operator()(int nn, int) const
 	{
 		const int idx = j + (nn << LOG2J);
@@ -215,7 +214,7 @@ struct InvAIn { // (S * mask)[j + n*J] (IstftIn of istft.hip): the upper half of
 		if (mirror)
 			z.y = -z.y;
 		const int pi = (mirror && idx >= n - p_mid) ? idx : lo;
-		const float m = thr != 0.0 ? hard_mask_exact(P[pi], H[lo] + FLT_EPSILON, thr, thr_inclusive) : mask_value(which, H[lo], P[pi], cfg);
+		const float m = mask_value_thr(which, H[lo], P[pi], cfg, thr);
 		return make_float2(z.x * m, z.y * m); // apply_mask_functor hps.h:58-66
 	}
 };
@@ -389,7 +388,7 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 		{
 			const int j = jA, tf = tfA;
 			InvAIn<LOG2J> in{Srow, mrow, prow, MaskCfg{a.beta, a.beta_h, a.soft, a.power, 0, a.out_h, a.out_p}, which, N, GM::m, j,
-			                  (which == 0 && !a.soft) ? a.thr : 0.0, a.thr_inclusive != 0};
+			                  HardThr{a.thr, a.thr_h, a.thr_inclusive, a.thr_h_inclusive}};
 			XchOut<LOG2J> out{T, j};
 			zfft::PassRunner<LOG2M, 0, true, false, false, InvAIn<LOG2J>, XchOut<LOG2J>, false, zfft::TwRegs<LOG2M>>::run(
 			    tf, lds + fA * PA::LDS_FLOAT2, twA, in, out, true);

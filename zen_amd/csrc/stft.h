@@ -62,6 +62,9 @@ struct IstftArgs {
 	int soft, power, sse;
 	int out_h, out_p;       // which masks exist for the residual (hps.cu:562-567)
 	float cola;
+	// hard masks by exact comparison instead of the division (masks.h HardThr; zeros: divide)
+	double thr_p, thr_h;
+	int thr_p_inc, thr_h_inc;
 };
 
 // overlap-add of consecutive frames (hps.cu:435-449 + :526-528) and copy-out (hps.cu:341-363):
