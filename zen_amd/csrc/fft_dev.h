@@ -59,10 +59,48 @@ struct Plan {
 // (an unpadded XOR-swizzled image, 5 instead of 4 workgroups per CU, measured no faster)
 __device__ __forceinline__ int lds_pad(int i) { return i + (i >> 4); }
 
+// PK: two-lane float arithmetic, which the backend maps to the packed instructions (v_pk_mul_f32 / v_pk_add_f32: two
+// results per lane and cycle); every lane's product and sum is rounded separately, as in the scalar form.  The
+// throughput kernels use it (TwGlobal: fused launch 0.544 -> 0.532 ms, nfft-16384 transforms -1..3 %); the single-hop
+// kernels (TwRegs: all registers in use, one wavefront per SIMD) do not -- the aligned register pairs the packed
+// operands need made them spill 30 to 40 registers and cost 2 us per hop.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <bool PK>
 __device__ __forceinline__ float2 cmul(float2 w, float2 b)
 {
 	// oracle: tr = wr*br - wi*bi ; ti = wr*bi + wi*br   (each product and sum rounded separately)
-	return make_float2(w.x * b.x - w.y * b.y, w.x * b.y + w.y * b.x);
+	if constexpr (PK) {
+		const v2f t1 = (v2f){w.x, w.x} * (v2f){b.x, b.y};
+		const v2f t2 = (v2f){w.y, w.y} * (v2f){b.y, b.x};
+		const v2f r = t1 + (v2f){-t2.x, t2.y}; // a - b == a + (-b) exactly
+		return make_float2(r.x, r.y);
+	}
+	else {
+		return make_float2(w.x * b.x - w.y * b.y, w.x * b.y + w.y * b.x);
+	}
+}
+template <bool PK>
+__device__ __forceinline__ float2 cadd(float2 a, float2 b)
+{
+	if constexpr (PK) {
+		const v2f r = (v2f){a.x, a.y} + (v2f){b.x, b.y};
+		return make_float2(r.x, r.y);
+	}
+	else {
+		return make_float2(a.x + b.x, a.y + b.y);
+	}
+}
+template <bool PK>
+__device__ __forceinline__ float2 csub(float2 a, float2 b)
+{
+	if constexpr (PK) {
+		const v2f r = (v2f){a.x, a.y} - (v2f){b.x, b.y};
+		return make_float2(r.x, r.y);
+	}
+	else {
+		return make_float2(a.x - b.x, a.y - b.y);
+	}
 }
 
 // Where a pass takes its twiddles from.  TwGlobal: the table in global memory, loaded where they are used (one
@@ -71,6 +109,7 @@ __device__ __forceinline__ float2 cmul(float2 w, float2 b)
 // a seventh of the call); slot = position of the load inside a pass: stage q, frequency group c < max(1, 2^(q-2)).
 struct TwGlobal {
 	static constexpr bool PLAIN = true; // the table of the transform itself: entry 0 is 1 (see butterfly)
+	static constexpr bool PACKED = true; // throughput kernels: packed butterflies (cmul)
 	const float2* __restrict__ p;
 	__device__ __forceinline__ float2 get(int, int, int, int idx) const { return p[idx]; }
 };
@@ -79,6 +118,7 @@ struct TwGlobal {
 template <int LOG2N, bool PLAIN_ = true>
 struct TwRegs {
 	static constexpr bool PLAIN = PLAIN_;
+	static constexpr bool PACKED = false; // single-hop kernels: scalar butterflies (cmul)
 	using PL = Plan<LOG2N>;
 	static constexpr int NBMAX = 16 >> PL::BASE; // groups per thread in the pass with the fewest stages
 	float2 w[PL::P][NBMAX][8];
@@ -169,8 +209,8 @@ __device__ __forceinline__ void butterfly(float2 (&a)[R], int k, int log2L, int 
 				}
 				else if (TRIV && c == 0) { // w = 1
 					const float2 B = a[c * 2 * half + m + half];
-					b[c * half + m] = make_float2(A.x + B.x, A.y + B.y);
-					b[(c + nc) * half + m] = make_float2(A.x - B.x, A.y - B.y);
+					b[c * half + m] = cadd<TW::PACKED>(A, B);
+					b[(c + nc) * half + m] = csub<TW::PACKED>(A, B);
 				}
 				else if (TRIV && q >= 2 && c == (nc >> 1)) { // w = -i (forward), +i (inverse): t = (B.y, -B.x) / (-B.y, B.x)
 					const float2 B = a[c * 2 * half + m + half];
@@ -184,9 +224,9 @@ __device__ __forceinline__ void butterfly(float2 (&a)[R], int k, int log2L, int 
 					}
 				}
 				else {
-					float2 t = cmul(w[c], a[c * 2 * half + m + half]);
-					b[c * half + m] = make_float2(A.x + t.x, A.y + t.y);
-					b[(c + nc) * half + m] = make_float2(A.x - t.x, A.y - t.y);
+					float2 t = cmul<TW::PACKED>(w[c], a[c * 2 * half + m + half]);
+					b[c * half + m] = cadd<TW::PACKED>(A, t);
+					b[(c + nc) * half + m] = csub<TW::PACKED>(A, t);
 				}
 			}
 		}
