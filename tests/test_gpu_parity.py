@@ -2,6 +2,8 @@
 BIT-EXACTLY with the CPU oracle on the same seeded inputs (float waveforms included: the engine
 reproduces the oracle's float32 dataflow operation for operation, so the north-star tolerance of
 1e-5 relative RMS is met with margin 0)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -439,6 +441,23 @@ def test_hpr_long_hops_many_streams_take_the_general_engine(z):
     for s in (0, 4, 9):
         _, ref = run_oracle(fs, hop, 2.0, o.OUTPUT_PERCUSSIVE, o.TIME_CAUSAL, x[s])
         assert np.array_equal(got["P"][s], ref["P"]), s
+
+
+def test_unscaled_double_sqrt_is_sqrt(z, tmp_path):
+    """|S| = (float)sqrt((double)re^2 + (double)im^2): the kernels take that square root with the compiler's own
+    correctly rounded sequence minus its range scaling (fft_dev.h cabs_exact).  tools/check_sqrt.hip compares the two
+    on the device for 3e10 pairs of floats of every kind the path can produce."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "check_sqrt")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-I", os.path.join(root, "zen_amd", "csrc"),
+                    os.path.join(root, "tools", "check_sqrt.hip"), "-o", exe], check=True, stdout=subprocess.PIPE,
+                   stderr=subprocess.PIPE, timeout=600)
+    r = subprocess.run([exe], stdout=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()
+    assert '"mismatches": 0' in r.stdout.decode()
 
 
 def test_hpr_multi_stream_matches_single(z):

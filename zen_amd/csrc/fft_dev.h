@@ -336,11 +336,31 @@ __device__ __forceinline__ void fft_frame(int tf, float2* __restrict__ lds, cons
 	PassRunner<LOG2N, 0, INV, ZU, HALF_OUT, In, Out, SYNC_FIRST, TwRegs<LOG2N>>::run(tf, lds, tw, in, out, active);
 }
 
-// |z| exactly as the oracle's zo_cabs: (float)sqrt((double)re*re + (double)im*im)
+// |z| exactly as the oracle's zo_cabs: (float)sqrt((double)re*re + (double)im*im).
+// The square root is the sequence the compiler emits for a correctly rounded double sqrt (rsq, one Goldschmidt
+// step on g ~ sqrt and h ~ 1/(2 sqrt), two residual corrections) WITHOUT its range scaling: the sum of two squared
+// floats is 0 or lies in [2^-298, 2^257), far from the doubles (< 2^-767) the scaling is for; that is a compare, a
+// select and two ldexp less per value, all at the half rate of double precision (tools/check_sqrt.hip compares it
+// with sqrt() on 3e10 pairs of every kind the path can produce).
+__device__ __forceinline__ double sqrt_of_sum_of_squares(double x)
+{
+	const double y = __builtin_amdgcn_rsq(x);
+	double g = x * y;
+	double h = 0.5 * y;
+	const double r = __builtin_fma(-h, g, 0.5);
+	g = __builtin_fma(g, r, g);
+	h = __builtin_fma(h, r, h);
+	double d = __builtin_fma(-g, g, x);
+	g = __builtin_fma(d, h, g);
+	d = __builtin_fma(-g, g, x);
+	g = __builtin_fma(d, h, g);
+	return (x == 0.0 || x == __builtin_inf()) ? x : g; // rsq(0) = inf, rsq(inf) = 0: the products above are NaN there
+}
+
 __device__ __forceinline__ float cabs_exact(float re, float im)
 {
 	double r = (double)re, i = (double)im;
-	return (float)sqrt(r * r + i * i);
+	return (float)sqrt_of_sum_of_squares(r * r + i * i);
 }
 
 } // namespace zfft
