@@ -545,7 +545,8 @@ def test_waveforms_with_literal_powf_stay_within_the_north_star_tolerance(tmp_pa
 
 def test_hard_mask_without_divide_is_exact():
     """zen_amd/csrc/masks.h hard_mask_exact: fl(x / d) >= beta (hard_mask_functor, hps.h:100-113) decided as
-    (double)x >= thr * (double)d, thr the rounding boundary below beta.  The same IEEE operations in numpy
+    (double)x > thr * (double)d, thr the rounding boundary below beta (times 1 - 2^-50 where the boundary itself
+    counts: even beta).  The same IEEE operations in numpy
     (float32 division is correctly rounded, the float64 product of a 25-bit and a 24-bit number is exact),
     on pairs placed a few ulps around the boundary, on random pairs, and on the special values."""
     rng = np.random.default_rng(5)
@@ -554,15 +555,15 @@ def test_hard_mask_without_divide_is_exact():
         b = np.float32(beta)
         u = b.view(np.uint32)
         pred = np.uint32(u - 1).view(np.float32)
-        return (np.float64(pred) + np.float64(b)) * 0.5, (int(u) & 1) == 0
+        m = (np.float64(pred) + np.float64(b)) * 0.5
+        return m * (1.0 - 2.0 ** -50) if (int(u) & 1) == 0 else m     # masks.h hard_mask_threshold
 
     def exact(x, d, beta):
-        thr, incl = threshold(beta)
+        thr = threshold(beta)
         with np.errstate(invalid="ignore", over="ignore"):
             t = thr * d.astype(np.float64)
             t = t * 0.0 + t                       # fma(t, 0, t): inf -> nan, finite unchanged
-            xd = x.astype(np.float64)
-            return (xd >= t) if incl else (xd > t)
+            return x.astype(np.float64) > t
 
     for beta in (2.0, np.float32(2.0) - np.float32(1.1920929e-07), 2.5, 1.0, 3.0, 0.1, 1.7, 1e-30, 3e38):
         beta = np.float32(beta)

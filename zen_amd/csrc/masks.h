@@ -52,16 +52,17 @@ __device__ __forceinline__ float hmask_value(float h, float p, const MaskCfg& c)
 // hard_mask_functor (hps.h:100-113) without the division.  With IEEE round-to-nearest-even division,
 // fl(x / d) >= beta exactly when the real quotient x / d reaches the rounding boundary below beta: the
 // midpoint m of pred(beta) and beta if beta's significand is even (a tie rounds up to beta), else anything
-// above it.  m has 25 significant bits and d 24, so m * d is exact in double and the comparison
-// (double)x >= m * (double)d is exact too.  d = +inf gives fl(x / d) = 0 or NaN, never >= beta > 0:
-// fma(t, 0, t) turns t = inf into NaN (and leaves finite t alone), which no x reaches.  NaNs compare false on
-// both sides.  Valid for normal positive beta (hard_mask_threshold() returns 0 otherwise: divide).
-__device__ __forceinline__ float hard_mask_exact(float x, float d, double thr, bool inclusive)
+// above it.  m has 25 significant bits and d 24, so m * d is exact in double (49 bits) and (double)x >= m * (double)d
+// resp. > is an exact test.  The inclusive case is folded into the threshold on the host (hard_mask_threshold):
+// x and m*d are both multiples of the last of those 49 bits wherever they are close, so x >= m*d  <=>
+// x > m*d*(1 - 2^-50), and the device compares strictly in both cases.  d = +inf gives fl(x / d) = 0 or NaN, never
+// >= beta > 0: fma(t, 0, t) turns t = inf into NaN (and leaves finite t alone), which no x exceeds.  NaNs compare
+// false on both sides.  Valid for normal positive beta (hard_mask_threshold() returns 0 otherwise: divide).
+__device__ __forceinline__ float hard_mask_exact(float x, float d, double thr, bool /*unused*/ = false)
 {
 	double t = thr * (double)d;
 	t = __builtin_fma(t, 0.0, t);
-	const double xd = (double)x;
-	return (inclusive ? xd >= t : xd > t) ? 1.0F : 0.0F;
+	return (double)x > t ? 1.0F : 0.0F;
 }
 
 // which: 0 percussive, 1 harmonic, 2 residual.  `which` and the cfg flags are wave-uniform, so only the
@@ -119,8 +120,11 @@ inline double hard_mask_threshold(float beta, int* inclusive)
 	const unsigned up = u - 1; // pred(beta): the next float below (beta > FLT_MIN's pred is subnormal: still exact)
 	float pred;
 	memcpy(&pred, &up, sizeof(pred));
-	*inclusive = (u & 1u) == 0; // a tie rounds to the even significand
-	return ((double)pred + (double)beta) * 0.5;
+	*inclusive = 0; // (kept for the callers' structs: the inclusive case is folded into the value below)
+	const double m = ((double)pred + (double)beta) * 0.5;
+	// a tie rounds to the even significand: beta even -> the boundary itself counts -> compare against a threshold
+	// a quarter of the 49-bit product's last place lower (see hard_mask_exact)
+	return (u & 1u) == 0 ? m * (1.0 - 0x1p-50) : m;
 }
 // both thresholds of an engine (beta for the percussive mask, beta - Eps for the harmonic one)
 inline HardThr hard_mask_thresholds(float beta, float beta_h, bool divide)
