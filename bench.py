@@ -3,38 +3,38 @@
 
 Metric (BASELINE.json): "hops/sec (1024-hop HPR, 44.1 kHz mono) + median-filter HBM GB/s vs roofline".
 
-Default workload (BASELINE configs[1], the one `value` is quoted on): HPRRealtime<GPU> semantics -- hop
-1024 (nwin 2048, transform size 4096), beta 2.0, OUTPUT_PERCUSSIVE, hard mask, causal -- on a synthetic
-44.1 kHz mono stream (S-music of BASELINE.md) already resident in HBM.  One "step" pushes the next
-`--hops` hops (default 25 840 = 10 minutes of audio) of the stream through zen_hip_hpr_process with the
-percussive output written (STFT -> 47-tap frequency median -> hard mask -> iSTFT -> overlap-add).  State
-carries over between steps exactly as consecutive process_next_hop calls leave it, and the samples are
-bit-identical to per-hop calls (tests/test_gpu_parity.py::test_hpr_blocking_is_invisible,
-::test_block_fused_matches_three_kernel_path).
+`value` (BASELINE configs[1]): HPRRealtime<GPU> semantics -- hop 1024 (nwin 2048, transform size 4096), beta 2.0,
+OUTPUT_PERCUSSIVE, hard mask, causal -- on a synthetic 44.1 kHz mono stream (S-music of BASELINE.md) already
+resident in HBM.  One "step" pushes the next `--hops` hops (default 25 840 = 10 minutes of audio) of the stream
+through zen_hip_hpr_process (the BLOCK form of the reference's process_next_hop: an MI355X extension of the API;
+the per-hop reference API is timed in `realtime`) with the percussive output written.  State carries over between
+steps exactly as consecutive process_next_hop calls leave it, and the samples are bit-identical to per-hop calls and
+to the oracle (tests/test_gpu_round3.py::test_headline_block_windows_vs_oracle checks this very block).
 
-N > 1: a realtime stream is a sequential recurrence and does not shard ("replicas only"):
-every rank runs its own independent stream of the same size (weak scaling), no data-path collective;
-torch.distributed (RCCL) carries the barrier and the max-over-ranks time only.
-
-Also in the JSON line:
+Everything else in the JSON line is measured OUTSIDE the timed region of `value`, each leg between its own
+synchronisation points:
   roofline        -- the dominant kernel of the timed region, timed with HIP events on the engine's stream
-                     (zen_hip_hpr_profile).  Default path: rt_fused_kernel (one workgroup per hop), priced
-                     with SURVEY 8(d)'s per-frame minimum 24*(nfft/2+1) + 8*hop bytes per hop.  With
-                     --no-block-fused: the 47-tap frequency median kernel, 8 B/element.
-  roofline_median -- BASELINE's second metric: the stand-alone frequency-direction median kernel (47 taps
-                     over the 25 840 x 4096 magnitude matrix, 8 B/element: 4 read + 4 written), timed
-                     with HIP events in a second leg that sends the same stream through the STFT /
-                     median / iSTFT kernels (outside the timed region of `value`).
-  cpu_baseline    -- the CPU oracle (restatement of the reference's CPU/IPP path, kind "port") timed on
-                     this box's host, one thread, on a bounded prefix of the same stream; rank 0, N = 1.
-  realtime        -- the single-stream per-hop call path (process_next_hop + copy_percussive through
-                     mapped host memory, timed like zen/fakert.h:221-247), outside the timed region.
+                     (zen_hip_hpr_profile): rt_fused_kernel (one workgroup per hop), priced with SURVEY 8(d)'s
+                     per-frame minimum 24*(nfft/2+1) + 8*hop bytes per hop.
+  roofline_median -- BASELINE's second metric: the stand-alone frequency-direction median kernel (47 taps over
+                     whole rows of the 25 840 x 4096 magnitude matrix, 8 B/element).  `burst`: 10 launches inside
+                     the three-kernel path (input freshly written: Infinity-Cache help); `sustained`: >= 1 s of
+                     back-to-back launches; `cold`: a 512 MiB write between launches.  frac = sustained.
+  all_outputs     -- the same stream with H + P + R written (the second case SURVEY 8(d) names for config 2)
+  s_noise         -- the headline configuration on the S-noise seed
+  offline_batch   -- BASELINE configs[3] per GPU: 64 x 30 s clips, HPRIOffline<GPU> 4096/256, hard masks
+  offline_long    -- BASELINE configs[2]: the 10-minute stereo clip, soft mask p = 2
+  sse_block       -- BASELINE configs[4]: SSE path, hop 512, nocopybord, blocks of hops
+  cpu_baseline    -- the CPU oracle (kind "port") on this box's host, one thread, bounded prefix; rank 0, N = 1
+  realtime        -- the reference API: process_next_hop + copy_percussive per hop through mapped host memory,
+                     timed like zen/fakert.h:221-247
 
-Other workloads (not the headline; `--workload`):
-  offline_batch -- BASELINE configs[3]: independent 30 s mono clips, HPRIOffline<GPU> 4096/256 hard mask,
-                   clips sharded over the ranks (64 per GPU by default), two passes resident in HBM.
-  offline_long  -- BASELINE configs[2]: one 10-minute stereo clip, soft mask; with N ranks each channel is
-                   cut into N time ranges computed independently (strong scaling).
+N > 1 (`--gpus N`, one process per GPU): a realtime stream is a sequential recurrence and does not shard
+("replicas only"): `value` is N independent streams (weak scaling).  The path north_star scales --
+the batched offline HPR-I, clips sharded over the ranks with no data-path collective -- is timed in the same run
+and reported as `offline_batch_sharded` next to it; `ranks_reported` is an all-reduce of ones.
+
+`--workload offline_batch | offline_long` run those as the main workload with the full step count.
 """
 import argparse
 import json
@@ -52,8 +52,11 @@ FS = 44100.0
 HOP = 1024
 BETA = 2.0
 # HBM bytes per launch measured with rocprofv3 --pmc (tools/pmc_cmd.sh); re-collected whenever a kernel changes
-FUSED_TRAFFIC_FILE = "r02_fused_hbm_traffic.json"
-MEDIAN_TRAFFIC_FILE = "r02_median47_hbm_traffic.json"
+TRAFFIC_FILE = "r03_hbm_traffic.json"   # {demangled kernel name: {elements, rows, cols, hbm_bytes_per_launch, ...}}
+K_FUSED_P = "rt_fused_kernel<12, 47, 3, true, true>"
+K_FUSED_HPR = "rt_fused_kernel<12, 47, 3, false, false>"
+K_MEDIAN_WHOLE = "median47_dpp_kernel<true, 0, false>"
+K_MEDIAN_HALF = "median47_dpp_kernel<true, 0, true>"
 
 
 def s_music(n, seed=0, fs=FS):
@@ -67,6 +70,11 @@ def s_music(n, seed=0, fs=FS):
         m = min(env.size, n - s)
         x[s:s + m] += 0.9 * env[:m] * rng.uniform(-1, 1, m)
     return (x + 0.01 * rng.uniform(-1, 1, n)).astype(np.float32)
+
+
+def s_noise(n, seed=0):
+    """BASELINE.md S-noise: i.i.d. uniform(-1, 1), the reference tests' distribution (hps.test.cu:24-36)."""
+    return np.random.default_rng(seed).uniform(-1, 1, n).astype(np.float32)
 
 
 def usable_cores():
@@ -219,7 +227,7 @@ def offline_rooflines(prof, steps, frames, nfft, hop, n_out1, copy_bw, freq_mask
     roof = {"bound": "hbm", "achieved": d["achieved"], "peak": 8000.0, "unit": "GB/s", "frac": d["frac"],
             "traffic": None, "kernel": dom, "avg_launch_ms": d["ms_per_step"] / max(d["launches_per_step"], 1),
             "algorithmic_bytes_per_frame": d["algorithmic_bytes_per_frame"], "frames_per_step": d["frames_per_step"],
-            "device_copy_GBps": copy_bw, "frac_of_device_copy": d["achieved"] / copy_bw,
+            "device_copy_GBps": copy_bw, "frac_of_device_copy": d["achieved"] / copy_bw if copy_bw else None,
             "share_of_kernel_time": d["ms_per_step"] / sum(v["ms_per_step"] for v in out.values()),
             "note": "dominant kernel of the step by HIP-event time; every kernel's line is in `kernels`"}
     return roof, out
@@ -298,6 +306,336 @@ def realtime_leg(zen_amd, x, n_hops=400):
     return res
 
 
+class _Solo:
+    """A world of one: what the legs that only rank 0 runs hand to the helpers in place of the process group."""
+
+    def max(self, v):
+        return float(v)
+
+    def sum(self, vs):
+        return [float(v) for v in vs]
+
+    def barrier(self):
+        pass
+
+
+def traffic_record(kernel, elems):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 cannot run inside this process).
+    The record is keyed by the demangled kernel name the counters were collected under and carries the elements
+    that launch processed: a record for another kernel or another shape is REFUSED (null + the reason), never quoted."""
+    path = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
+    try:
+        tj = json.load(open(path))
+    except (OSError, ValueError):
+        return None, "no profiles/%s" % TRAFFIC_FILE
+    rec = tj.get("kernels", {}).get(kernel)
+    if rec is None:
+        return None, "profiles/%s holds no record for %s" % (TRAFFIC_FILE, kernel)
+    if int(rec.get("elements", -1)) != int(elems):
+        return None, "profiles/%s: the record of %s is for %s elements per launch, this launch has %d" % (
+            TRAFFIC_FILE, kernel, rec.get("elements"), elems)
+    return rec["hbm_bytes_per_launch"], ("profiles/%s (rocprofv3 --pmc, FETCH_SIZE and WRITE_SIZE in passes of their own, "
+                                         "FETCH doubled per the gfx950 correction; build %s)" % (TRAFFIC_FILE, tj.get("build", "?")))
+
+
+def fused_bytes_per_hop(nfft, hop, n_out):
+    """SURVEY 8(d) per-frame minimum of the batched pipeline: 4*hop in, spectrum written + read 2*8*(nfft/2+1),
+    magnitude written + read 2*4*(nfft/2+1), 4*hop out -- 24*(nfft/2+1) + 8*hop for one output; every further
+    output reads the spectrum again and writes its hop."""
+    return 24 * (nfft // 2 + 1) + 4 * hop + n_out * 4 * hop + (n_out - 1) * 8 * (nfft // 2 + 1)
+
+
+def block_run(zen_amd, grp, x2d, flags, M, steps, warmup, settle_ms, barrier, hop=HOP, sse=False, copy_bord=True):
+    """`steps` timed zen_hip_hpr_process calls of M hops per stream between two barriers; returns the engine too."""
+    S, n = x2d.shape
+    d_in = zen_amd.DeviceBuffer.from_host(x2d)
+    want = {"P": bool(flags & zen_amd.OUTPUT_PERCUSSIVE), "H": bool(flags & zen_amd.OUTPUT_HARMONIC),
+            "R": bool(flags & zen_amd.OUTPUT_RESIDUAL) and not sse}
+    bufs = {k: (zen_amd.DeviceBuffer(S * n) if w else None) for k, w in want.items()}
+    eng = zen_amd.HPR(FS, hop, BETA, flags, zen_amd.TIME_CAUSAL, copy_bord, S, M)
+    if sse:
+        eng.use_sse_filter()
+    ptr = {k: (b.ptr if b else None) for k, b in bufs.items()}
+
+    def step():
+        eng.process(d_in.ptr, M, n, ptr["H"], ptr["P"], ptr["R"], n)
+
+    t_end = time.perf_counter() + settle_ms / 1e3
+    while time.perf_counter() < t_end:
+        for _ in range(5):
+            step()
+        zen_amd.synchronize()
+    for _ in range(warmup):
+        step()
+    barrier()
+    eng.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    dt = grp.max(time.perf_counter() - t0)
+    med = eng.profile_get()
+    breakdown = eng.profile_get_all()
+    eng.profile(False)
+    first = next(b for b in (bufs["P"], bufs["H"], bufs["R"]) if b is not None)
+    chk = float(np.abs(first.download(4096)).sum())            # liveness only; bytes, not data path
+    return {"dt": dt, "breakdown": breakdown, "median": med, "checksum": chk, "eng": eng, "step": step,
+            "bufs": [d_in] + [b for b in bufs.values() if b is not None]}
+
+
+def free_run(run):
+    run["eng"] = None
+    run["step"] = None
+    for b in run["bufs"]:
+        b.free()
+    run["bufs"] = []
+
+
+def fused_roofline(run, S, M, steps, n_out, kernel, copy_bw):
+    nfft = 4 * HOP
+    fl = run["breakdown"]["rt_fused"]
+    t_f = 1e-3 * fl["ms"] / fl["launches"]
+    bph = fused_bytes_per_hop(nfft, HOP, n_out)
+    ach = bph * S * M / t_f / 1e9
+    moved = 4 * HOP + n_out * 8 * HOP
+    tr, src = traffic_record(kernel, S * M * nfft)
+    return {
+        "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+        "limiter": "valu-issue", "device_copy_GBps": copy_bw, "frac_of_device_copy": ach / copy_bw if copy_bw else None,
+        "traffic": tr, "traffic_source": src,
+        "kernel": kernel + " (one workgroup per hop: STFT, |S|, 47-tap median, hard mask%s, iSTFT%s)"
+                  % ("s" if n_out > 1 else "", " x%d" % n_out if n_out > 1 else ""),
+        "hops_per_launch": S * M, "algorithmic_bytes_per_hop": bph,
+        "algorithmic_bytes_formula": "24*(nfft/2+1) + 4*hop + n_out*4*hop + (n_out-1)*8*(nfft/2+1) (SURVEY 8(d): per-frame "
+                                     "minimum of the batched pipeline; 24*(nfft/2+1) + 8*hop for one output)",
+        "hbm_bytes_moved_per_hop_by_design": moved, "moved_GBps": moved * S * M / t_f / 1e9,
+        "avg_launch_ms": 1e3 * t_f, "launches": fl["launches"],
+        "share_of_step": (fl["ms"] / 1e3) / run["dt"] if run["dt"] > 0 else None,
+        "note": "`achieved`/`frac` price the launch with SURVEY 8(d)'s ALGORITHMIC bytes as the bench contract asks; the "
+                "kernel does not move them: spectrum, |S| and P stay in registers / LDS, its own HBM traffic is 4*hop read "
+                "+ 8*hop written per hop and output (`moved_GBps`, `traffic`).  Its limiter is VALU issue: DESIGN.md section 5"}
+
+
+def median_rooflines(zen_amd, run, S, M, copy_bw):
+    """BASELINE's second metric.  burst: the kernel inside the three-kernel path of the engine (whole rows), 10 launches;
+    sustained: >= 1 s of back-to-back launches of the same kernel build through the drop-in wrapper on a magnitude
+    matrix (option "mfilt_nonneg"); cold: a 512 MiB write between launches, each launch timed on its own."""
+    eng, step = run["eng"], run["step"]
+    zen_amd.set_option("no_block_fused", 1)
+
+    def leg():
+        for _ in range(3):
+            step()
+        zen_amd.synchronize()
+        eng.profile(True)
+        t1 = time.perf_counter()
+        for _ in range(10):
+            step()
+        zen_amd.synchronize()
+        dt3 = (time.perf_counter() - t1) / 10
+        r = eng.profile_get()
+        kern = {k: v["ms"] / 10 for k, v in eng.profile_get_all().items() if v["launches"]}
+        eng.profile(False)
+        return dt3, r, kern
+
+    dt3, (h_ms, h_launches, h_elems), kern3 = leg()      # as the engine runs it: half rows
+    three = {"ms_per_step": 1e3 * dt3, "hops_per_s": S * M / dt3, "kernel_ms_per_step": kern3,
+             "rows": "half (bins 0..2048 and 4073..4095 filtered)", "median_kernel": K_MEDIAN_HALF,
+             "median_elements_per_launch": h_elems // max(h_launches, 1)}
+    tr_h, src_h = traffic_record(K_MEDIAN_HALF, h_elems // max(h_launches, 1))
+    three["median_traffic"], three["median_traffic_source"] = tr_h, src_h
+    zen_amd.set_option("no_half_rows", 1)                # BASELINE's metric: the kernel over whole rows
+    dt3f, (med_ms, med_launches, med_elems), kern3f = leg()
+    three["whole_rows"] = {"ms_per_step": 1e3 * dt3f, "hops_per_s": S * M / dt3f, "kernel_ms_per_step": kern3f}
+    zen_amd.set_option("no_half_rows", 0)
+    zen_amd.set_option("no_block_fused", 0)
+    t_b = 1e-3 * med_ms / max(med_launches, 1)
+    el = med_elems // max(med_launches, 1)
+    burst = 8.0 * el / t_b / 1e9 if t_b > 0 else 0.0
+
+    # ---- sustained and cold, through the drop-in wrapper on the same shape
+    rows, cols = S * M, 4 * HOP
+    rng = np.random.default_rng(3)
+    mat = rng.random((rows, cols), dtype=np.float32)       # magnitudes: >= +0
+    src, dst = zen_amd.DeviceBuffer.from_host(mat), zen_amd.DeviceBuffer(rows * cols)
+    del mat
+    zen_amd.set_option("mfilt_nonneg", 1)
+    f = zen_amd.MedianFilterGPU(rows, cols, 47, zen_amd.FREQUENCY)
+    for _ in range(5):
+        f.filter(src, dst)
+    zen_amd.synchronize()
+    e0, e1 = zen_amd.Event(), zen_amd.Event()
+    n_l, t_host = 0, time.perf_counter()
+    e0.record()
+    while time.perf_counter() - t_host < 1.2:
+        for _ in range(200):
+            f.filter(src, dst)
+        n_l += 200
+        zen_amd.synchronize()                             # (bounds the queue; 200 launches = ~30 ms of device work)
+    e1.record()
+    ms_sus = e0.elapsed_ms(e1) / n_l
+    evs = [(zen_amd.Event(), zen_amd.Event()) for _ in range(60)]   # 60 consecutive launches, each timed on its own
+    for a, b in evs:
+        a.record()
+        f.filter(src, dst)
+        b.record()
+    each = sorted(a.elapsed_ms(b) for a, b in evs)
+    flush = zen_amd.DeviceBuffer(128 << 20)               # 512 MiB
+    cold = []
+    for _ in range(12):
+        flush.zero()
+        a, b = zen_amd.Event(), zen_amd.Event()
+        a.record()
+        f.filter(src, dst)
+        b.record()
+        cold.append(a.elapsed_ms(b))
+    zen_amd.set_option("mfilt_nonneg", 0)
+    for bfr in (src, dst, flush):
+        bfr.free()
+    cold.sort()
+    sus = 8.0 * rows * cols / (1e-3 * ms_sus) / 1e9
+    cold_med = cold[len(cold) // 2]
+    tr, tsrc = traffic_record(K_MEDIAN_WHOLE, el)
+    roof = {
+        "bound": "hbm", "achieved": sus, "peak": 8000.0, "unit": "GB/s", "frac": sus / 8000.0,
+        "frac_is": "sustained (the conservative figure); burst and cold-cache beside it",
+        "sustained": {"avg_launch_ms": ms_sus, "launches": n_l, "seconds": 1e-3 * ms_sus * n_l, "GBps": sus, "frac": sus / 8000.0,
+                      "each_of_60_ms": {"min": each[0], "median": each[30], "max": each[-1]}},
+        "burst": {"avg_launch_ms": 1e3 * t_b, "launches": med_launches, "GBps": burst, "frac": burst / 8000.0,
+                  "note": "inside the engine's three-kernel path: the STFT kernel has just written the matrix"},
+        "cold": {"median_launch_ms": cold_med, "min": cold[0], "max": cold[-1], "launches": len(cold),
+                 "GBps": 8.0 * rows * cols / (1e-3 * cold_med) / 1e9, "frac": 8.0 * rows * cols / (1e-3 * cold_med) / 1e9 / 8000.0,
+                 "note": "512 MiB written elsewhere before every launch: nothing of the input is left in the Infinity Cache"},
+        "device_copy_GBps": copy_bw, "frac_of_device_copy": sus / copy_bw if copy_bw else None,
+        "traffic": tr, "traffic_source": tsrc,
+        "kernel": K_MEDIAN_WHOLE + " (frequency direction, 47 taps, whole 4096-bin rows, non-negative keys)",
+        "elements_per_launch": el, "rows": rows, "cols": cols, "algorithmic_bytes_per_element": 8}
+    return roof, three
+
+
+def sse_rooflines(prof, steps, frames, nfft, hop):
+    """Per-kernel lines of the SSE block path (BASELINE configs[4]); whole rows: the box mean is not mirror symmetric."""
+    per_frame = {"stft": 4 * hop + 8 * (nfft // 2 + 1) + 4 * nfft, "freq_filter": 8 * nfft, "time_filter": 8 * nfft,
+                 "istft": 8 * (nfft // 2 + 1) + 8 * nfft + 8 * hop, "finalize": 12 * hop}
+    out = {}
+    for k, v in prof.items():
+        if v["launches"] and k in per_frame:
+            ms = v["ms"] / steps
+            ach = per_frame[k] * frames / (ms * 1e-3) / 1e9
+            out[k] = {"ms_per_step": ms, "algorithmic_bytes_per_frame": per_frame[k], "achieved": ach, "frac": ach / 8000.0}
+    dom = max(out, key=lambda k: out[k]["ms_per_step"])
+    return {"bound": "hbm", "achieved": out[dom]["achieved"], "peak": 8000.0, "unit": "GB/s", "frac": out[dom]["frac"],
+            "traffic": None, "kernel": dom, "note": "dominant kernel of the step by HIP-event time"}, out
+
+
+def offline_batch_run(zen_amd, zdist, grp, rank, world, C, clip_seconds, steps, warmup, settle_ms, barrier, rooflines=True):
+    """BASELINE configs[3]: C clips per GPU, clips sharded over the ranks, both passes resident in HBM."""
+    n = int(clip_seconds * FS)
+    hop_h, hop_p = 4096, 256
+    ids = zdist.shard_units(C * world, world, rank)          # clip ids of this rank (C each)
+    x = np.stack([s_music(n, seed=7000 + i) for i in ids])
+    d_in = zen_amd.DeviceBuffer.from_host(x)
+    d_h, d_p = zen_amd.DeviceBuffer(C * n), zen_amd.DeviceBuffer(C * n)
+    eng = zen_amd.HPRIOffline(FS, hop_h, hop_p, BETA, BETA, False, C)
+    n1, n2 = eng.hop_counts(n)
+
+    def step():
+        eng.process_device(d_in.ptr, n, n, d_h.ptr, d_p.ptr, None, n)
+
+    t_end = time.perf_counter() + settle_ms / 1e3
+    step()
+    zen_amd.synchronize()
+    while time.perf_counter() < t_end:
+        step()
+        zen_amd.synchronize()
+    for _ in range(warmup):
+        step()
+    barrier()
+    eng.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    dt = grp.max(time.perf_counter() - t0)
+    prof = eng.profile_get_all()
+    eng.profile(False)
+    chk, ranks = grp.sum([float(np.abs(d_p.download(4096)).sum()), 1.0])
+    res = {"metric": "hops/sec (HPR-I offline, hops of both passes)", "unit": "hops/s",
+           "value": world * C * (n1 + n2) * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
+           "x_realtime": world * C * clip_seconds * steps / dt, "ranks_reported": int(round(ranks)),
+           "config": {"workload": "HPRIOffline<GPU> 4096/256 beta 2.0 hard mask, %d x %.0f s mono S-music clips per GPU "
+                                  "resident in HBM, both passes + harmonic/percussive outputs" % (C, clip_seconds),
+                      "clips_per_gpu": C, "clips_total": C * world, "clip_samples": n, "hops_pass1": n1, "hops_pass2": n2,
+                      "parallelism": "clips sharded x%d, no data-path collective" % world},
+           "checksum": chk}
+    if rooflines and rank == 0:
+        roof, kern = offline_rooflines(prof, steps, {"pass1": C * n1, "pass2": C * n2},
+                                       {"pass1": 4 * hop_h, "pass2": 4 * hop_p}, {"pass1": hop_h, "pass2": hop_p},
+                                       3, None, {"pass1": 187, "pass2": 13})
+        res.update({"roofline": roof, "kernels": kern})
+    first_clip = x[0].copy()
+    eng = None
+    for b in (d_in, d_h, d_p):
+        b.free()
+    return res, first_clip, (n1, n2)
+
+
+def offline_long_run(zen_amd, zdist, grp, rank, world, steps, warmup, settle_ms, barrier):
+    """BASELINE configs[2]: one 10-minute stereo clip = 2 mono channels, HPR-I 4096/256, soft mask p = 2.  N > 1: every
+    channel is cut into N time ranges, rank r computes range r of both channels from its own halo of
+    input; strong scaling, no exchange."""
+    n = int(600 * FS)
+    hop_h, hop_p = 4096, 256
+    b, e = zdist.time_shards(n, world, hop_h)[rank]
+    chans = [s_music(n, seed=9000 + c) for c in range(2)]
+    d_in = [zen_amd.DeviceBuffer.from_host(c) for c in chans]
+    d_h, d_p = zen_amd.DeviceBuffer(max(e - b, 1)), zen_amd.DeviceBuffer(max(e - b, 1))
+    eng = zen_amd.HPRIOffline(FS, hop_h, hop_p, 2.5, 2.5, False, 1)
+    eng.use_soft_mask()
+    n1, n2 = eng.hop_counts(n)
+
+    def step():
+        for c in range(2):
+            if e > b:
+                eng.process_range(d_in[c].ptr, n, b, e, d_h.ptr, d_p.ptr)
+
+    step()
+    zen_amd.synchronize()
+    t_end = time.perf_counter() + settle_ms / 1e3
+    while time.perf_counter() < t_end:
+        step()
+        zen_amd.synchronize()
+    for _ in range(warmup):
+        step()
+    barrier()
+    eng.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    dt = grp.max(time.perf_counter() - t0)
+    prof = eng.profile_get_all()
+    eng.profile(False)
+    chk, ranks = grp.sum([float(np.abs(d_p.download(min(4096, max(e - b, 1)))).sum()), 1.0])
+    res = {"metric": "hops/sec (HPR-I offline, hops of both passes)", "unit": "hops/s", "scaling": "strong",
+           "value": 2 * (n1 + n2) * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
+           "x_realtime": 600.0 * steps / dt, "ranks_reported": int(round(ranks)),
+           "config": {"workload": "HPRIOffline<GPU> 4096/256 beta 2.5 soft mask (p = 2), one 10-minute stereo clip (2 mono "
+                                  "channels of 26 460 000 samples) resident in HBM, zen_hip_hpri_process_range",
+                      "hops_pass1": n1, "hops_pass2": n2,
+                      "parallelism": "each channel time-sharded x%d with warm-up halos, no exchange" % world},
+           "checksum": chk}
+    if rank == 0 and world == 1:
+        roof, kern = offline_rooflines(prof, steps, {"pass1": 2 * n1, "pass2": 2 * n2}, {"pass1": 4 * hop_h, "pass2": 4 * hop_p},
+                                       {"pass1": hop_h, "pass2": hop_p}, 2, None, {"pass1": 187, "pass2": 13})
+        res.update({"roofline": roof, "kernels": kern})
+    ch0 = chans[0]
+    eng = None
+    for bfr in d_in + [d_h, d_p]:
+        bfr.free()
+    return res, ch0, (n1, n2)
+
+
 def dry_main(args, zdist):
     """The N-rank plumbing without a GPU: rendezvous, sharding of the workload's units, empty timed steps
     between barriers, max-over-ranks time, summed counters, one JSON line from rank 0.  What tests/ run on
@@ -321,14 +659,22 @@ def dry_main(args, zdist):
     grp.barrier()
     dt = grp.max(time.perf_counter() - t0)
     tot_units, ranks = grp.sum([units, 1])
+    line = {"metric": "dry run (launch / sharding plumbing only)", "dry": True, "value": None,
+            "unit": "hops/s", "n_gpus": world, "ranks_reported": int(ranks), "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1),
+            "higher_is_better": True, "scaling": "strong" if args.workload == "offline_long" else "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "none",
+            "config": {"workload": args.workload, "units_all_ranks": int(tot_units),
+                       "units_rank0": units, "parallelism": par, "backend": "gloo"}}
+    if args.workload == "realtime_block" and world > 1 and not args.no_legs:
+        # the sharded offline-batch leg of the N > 1 line: every rank owns --leg-clips clips of the global batch
+        mine = zdist.shard_units(args.leg_clips * world, world, rank)
+        grp.barrier()
+        tot_clips, ranks2 = grp.sum([len(mine), 1])
+        line["offline_batch_sharded"] = {"dry": True, "clips_total": int(tot_clips), "clips_rank0": len(mine),
+                                         "ranks_reported": int(ranks2)}
     if rank == 0:
-        print(json.dumps({"metric": "dry run (launch / sharding plumbing only)", "dry": True, "value": None,
-                          "unit": "hops/s", "n_gpus": world, "ranks_reported": int(ranks), "steps": args.steps,
-                          "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1),
-                          "higher_is_better": True, "scaling": "strong" if args.workload == "offline_long" else "weak",
-                          "vs_baseline": None, "dtype": "f32", "data": "none",
-                          "config": {"workload": args.workload, "units_all_ranks": int(tot_units),
-                                     "units_rank0": units, "parallelism": par, "backend": "gloo"}}))
+        print(json.dumps(line))
     grp.close()
     return 0
 
@@ -345,8 +691,14 @@ def main():
     ap.add_argument("--clip-seconds", type=float, default=30.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-realtime", action="store_true")
+    ap.add_argument("--no-legs", action="store_true",
+                    help="realtime_block: only `value` and its roofline -- none of the legs outside the timed region "
+                         "(roofline_median, all_outputs, s_noise, sse_block, offline_batch, offline_long)")
+    ap.add_argument("--leg-steps", type=int, default=6, help="timed steps of each leg (2 warm-up steps before them)")
+    ap.add_argument("--leg-clips", type=int, default=64, help="clips per GPU of the offline_batch leg")
     ap.add_argument("--outputs", default="P", choices=["P", "HPR"],
                     help="realtime_block: percussive only (the headline config) or all three outputs")
+    ap.add_argument("--seed-kind", default="music", choices=["music", "noise"], help="realtime_block input: S-music or S-noise")
     ap.add_argument("--no-block-fused", action="store_true",
                     help="realtime_block: STFT / median / iSTFT kernels instead of the fused per-hop kernel")
     ap.add_argument("--fused-minb", type=int, default=0, help="tuning: occupancy the fused kernel is built for")
@@ -372,8 +724,10 @@ def main():
     if args.dry:
         return dry_main(args, zdist)
 
+    legs = args.workload == "realtime_block" and not args.no_legs and not args.no_block_fused and args.outputs == "P" \
+        and args.seed_kind == "music" and args.streams == 1
     cpu_all = None
-    if args.workload == "offline_batch" and world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and (args.workload == "offline_batch" or legs):
         cpu_all = cpu_baseline_offline_all_cores(4096, 256)      # forks: before anything loads or touches the GPU
     import torch
     if os.environ.get("ZEN_ALLOW_GPU_SHARING") and torch.cuda.device_count() > 0:
@@ -392,15 +746,9 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
+        zen_amd.synchronize()
         grp.barrier()
         torch.cuda.synchronize()
-
-    def settle(step_fn, ms):
-        t_end = time.perf_counter() + ms / 1e3
-        while time.perf_counter() < t_end:
-            for _ in range(5):
-                step_fn()
-            zen_amd.synchronize()
 
     out = {"metric": "hops/sec (1024-hop HPR, 44.1 kHz mono)", "unit": "hops/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
@@ -409,247 +757,122 @@ def main():
     if args.workload == "realtime_block":
         M, S = args.hops, args.streams
         n = M * HOP
-        x = np.stack([s_music(n, seed=1000 * rank + s) for s in range(S)])
-        d_in = zen_amd.DeviceBuffer.from_host(x)
-        d_out = zen_amd.DeviceBuffer(S * n)
+        gen = s_music if args.seed_kind == "music" else s_noise
+        x = np.stack([gen(n, seed=1000 * rank + s) for s in range(S)])
         all_out = args.outputs == "HPR"
         flags = (zen_amd.OUTPUT_PERCUSSIVE | zen_amd.OUTPUT_HARMONIC | zen_amd.OUTPUT_RESIDUAL) if all_out \
             else zen_amd.OUTPUT_PERCUSSIVE
-        d_h = zen_amd.DeviceBuffer(S * n) if all_out else None
-        d_r = zen_amd.DeviceBuffer(S * n) if all_out else None
-        eng = zen_amd.HPR(FS, HOP, BETA, flags, zen_amd.TIME_CAUSAL, True, S, M)
-
-        def step():
-            eng.process(d_in.ptr, M, n, d_h.ptr if all_out else None, d_out.ptr, d_r.ptr if all_out else None, n)
-
-        settle(step, args.settle_ms)
-        for _ in range(args.warmup):
-            step()
-        barrier()
-        eng.profile(True)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        barrier()
-        dt = grp.max(time.perf_counter() - t0)
-        med_ms, med_launches, med_elems = eng.profile_get()
-        breakdown = eng.profile_get_all()
-        eng.profile(False)
-        chk = grp.sum([float(np.abs(d_out.download(4096)).sum())])[0]   # liveness only; bytes, not data path
+        run = block_run(zen_amd, grp, x, flags, M, args.steps, args.warmup, args.settle_ms, barrier)
+        dt, breakdown = run["dt"], run["breakdown"]
+        chk, ranks = grp.sum([run["checksum"], 1.0])
         fused = breakdown["rt_fused"]["launches"] > 0
-        three = None
-        if fused and rank == 0:
-            # second leg, outside the timed region: the same stream through the general engine (STFT / median /
-            # iSTFT kernels) for the stand-alone median kernel's roofline, BASELINE's second metric
-            zen_amd.set_option("no_block_fused", 1)
-
-            def leg():
-                for _ in range(3):
-                    step()
-                zen_amd.synchronize()
-                eng.profile(True)
-                t1 = time.perf_counter()
-                for _ in range(10):
-                    step()
-                zen_amd.synchronize()
-                dt3 = (time.perf_counter() - t1) / 10
-                r = eng.profile_get()
-                kern = {k: v["ms"] / 10 for k, v in eng.profile_get_all().items() if v["launches"]}
-                eng.profile(False)
-                return dt3, r, kern
-
-            # the path as the engine runs it (half rows: bins 0..nfft/2 and the last 23 of every magnitude / P row)
-            dt3, _, kern3 = leg()
-            three = {"ms_per_step": 1e3 * dt3, "hops_per_s": S * M / dt3, "kernel_ms_per_step": kern3,
-                     "rows": "half (bins 0..2048 and 4073..4095 filtered)"}
-            # BASELINE's median metric is the kernel over the whole 25 840 x 4096 matrix: whole rows
-            zen_amd.set_option("no_half_rows", 1)
-            dt3f, (med_ms, med_launches, med_elems), kern3f = leg()
-            three["whole_rows"] = {"ms_per_step": 1e3 * dt3f, "hops_per_s": S * M / dt3f, "kernel_ms_per_step": kern3f}
-            zen_amd.set_option("no_half_rows", 0)
-            zen_amd.set_option("no_block_fused", 0)
         if rank == 0:
-            total_hops = world * S * M * args.steps
-            value = total_hops / dt
-            nfft = 4 * HOP
-
-            def traffic_of(fname, kernel, elems):
-                """HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this
-                process); only quoted for the shape it was measured on."""
-                try:
-                    tj = json.load(open(os.path.join(ROOT, "profiles", fname)))
-                    if tj["shape"]["elements"] == elems:
-                        return tj["kernels"][kernel]["hbm_bytes_per_launch"]
-                except (OSError, KeyError, ValueError):
-                    pass
-                return None
-
             copy_bw = device_copy_bandwidth(zen_amd)
-            t_med = 1e-3 * med_ms / max(med_launches, 1)
-            el_med = med_elems // max(med_launches, 1)
-            ach_med = 8.0 * el_med / t_med / 1e9 if t_med > 0 else 0.0
-            tr_med = traffic_of(MEDIAN_TRAFFIC_FILE, "median47_dpp_kernel<nonneg>", el_med)
-            roof_median = {
-                "bound": "hbm", "achieved": ach_med, "peak": 8000.0, "unit": "GB/s", "frac": ach_med / 8000.0,
-                "device_copy_GBps": copy_bw, "frac_of_device_copy": ach_med / copy_bw,
-                "traffic": tr_med,
-                "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in passes of their own, FETCH "
-                                  "doubled per the gfx950 correction)" % MEDIAN_TRAFFIC_FILE if tr_med else None,
-                "kernel": "median47_dpp_kernel<nonneg> (frequency direction, 47 taps, whole 4096-bin rows)",
-                "elements_per_launch": el_med, "algorithmic_bytes_per_element": 8, "avg_launch_ms": 1e3 * t_med,
-                "launches": med_launches,
-                "note": "stand-alone kernel of the three-kernel path (second leg, outside the timed region of `value`); "
-                        "its data movement alone (same loads, LDS image, transposed stores, no sorting) takes 0.145 ms, "
-                        "the nontemporal copy of the same bytes 0.139 ms (profiles/r02_median47_variants.txt, "
-                        "profiles/r02_ubench_copy.txt)"}
+            value = world * S * M * args.steps / dt
             if fused:
-                fl = breakdown["rt_fused"]
-                t_f = 1e-3 * fl["ms"] / fl["launches"]
-                bytes_per_hop = 24 * (nfft // 2 + 1) + 8 * HOP       # SURVEY 8(d): per-frame minimum, P-only hard mask
-                ach = bytes_per_hop * S * M / t_f / 1e9
-                tr = traffic_of(FUSED_TRAFFIC_FILE, "rt_fused_kernel<12,47>", S * M * nfft)
-                moved = 4 * HOP + 8 * HOP                              # what the kernel itself must move per hop
-                roof = {
-                    "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-                    "limiter": "valu-issue",
-                    "device_copy_GBps": copy_bw, "frac_of_device_copy": ach / copy_bw,
-                    "traffic": tr,
-                    "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in passes of their own, "
-                                      "FETCH doubled per the gfx950 correction)" % FUSED_TRAFFIC_FILE if tr else None,
-                    "kernel": "rt_fused_kernel<12, 47> (one workgroup per hop: STFT, |S|, 47-tap median, hard mask, iSTFT)",
-                    "hops_per_launch": S * M, "algorithmic_bytes_per_hop": bytes_per_hop,
-                    "algorithmic_bytes_formula": "24*(nfft/2+1) + 8*hop (SURVEY 8(d): per-frame minimum of the batched "
-                                                 "pipeline, percussive-only hard mask)",
-                    "hbm_bytes_moved_per_hop_by_design": moved,
-                    "moved_GBps": moved * S * M / t_f / 1e9,
-                    "avg_launch_ms": 1e3 * t_f, "launches": fl["launches"],
-                    "share_of_step": (fl["ms"] / 1e3) / dt if dt > 0 else None,
-                    "note": "`achieved`/`frac` price the launch with SURVEY 8(d)'s ALGORITHMIC bytes as the bench contract "
-                            "asks; the kernel does not move them: the spectrum, |S| and P stay in registers/LDS, its own HBM "
-                            "traffic is 4*hop read + 8*hop written per hop (`moved_GBps`, `traffic`), far from the HBM roof. "
-                            "Its limiter is VALU issue (FFT butterflies at full rate; median min/max, DPP moves, double-"
-                            "precision |z| at half rate): see DESIGN.md section 5 and profiles/r02_*fused*"}
+                roof = fused_roofline(run, S, M, args.steps, 3 if all_out else 1, K_FUSED_HPR if all_out else K_FUSED_P, copy_bw)
             else:
-                roof = dict(roof_median, share_of_step=(med_ms / 1e3) / dt if dt > 0 else None)
+                med_ms, med_launches, med_elems = run["median"]
+                t_med = 1e-3 * med_ms / max(med_launches, 1)
+                el_med = med_elems // max(med_launches, 1)
+                ach_med = 8.0 * el_med / t_med / 1e9 if t_med > 0 else 0.0
+                tr, src = traffic_record(K_MEDIAN_HALF, el_med)
+                roof = {"bound": "hbm", "achieved": ach_med, "peak": 8000.0, "unit": "GB/s", "frac": ach_med / 8000.0,
+                        "traffic": tr, "traffic_source": src, "kernel": K_MEDIAN_HALF, "elements_per_launch": el_med,
+                        "avg_launch_ms": 1e3 * t_med, "share_of_step": (med_ms / 1e3) / dt if dt > 0 else None}
             out.update({
-                "value": value, "ms_per_step": 1e3 * dt / args.steps,
+                "value": value, "ms_per_step": 1e3 * dt / args.steps, "ranks_reported": int(round(ranks)),
                 "config": {
                     "workload": "HPRRealtime<GPU> semantics: hop 1024, nwin 2048, transform 4096, beta 2.0, "
-                                "%s, hard mask, causal; S-music 44.1 kHz mono stream resident "
+                                "%s, hard mask, causal; S-%s 44.1 kHz mono stream resident "
                                 "in HBM; block mode (zen_hip_hpr_process), %d hops/step/stream"
-                                % ("OUTPUT_HARMONIC|PERCUSSIVE|RESIDUAL" if all_out else "OUTPUT_PERCUSSIVE", M),
+                                % ("OUTPUT_HARMONIC|PERCUSSIVE|RESIDUAL" if all_out else "OUTPUT_PERCUSSIVE", args.seed_kind, M),
                     "hops_per_step": M, "streams_per_gpu": S, "fs": FS, "hop": HOP,
                     "time_mask": 3, "freq_mask": 47, "parallelism": "replicas x%d" % world,
+                    "api": "zen_hip_hpr_process: the block form of process_next_hop (an MI355X extension; the reference's "
+                           "per-hop API is timed in `realtime`)",
                     "path": "fused per-hop kernel + overlap-add" if fused else "STFT / median / iSTFT kernels + overlap-add"},
                 "x_realtime": value * HOP / FS,
                 "checksum": chk,
                 "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in breakdown.items() if v["launches"]},
                 "roofline": roof})
-            if fused:
-                out["roofline_median"] = roof_median
-                out["three_kernel_path"] = three
+            if legs and fused and world == 1:
+                out["roofline_median"], out["three_kernel_path"] = median_rooflines(zen_amd, run, S, M, copy_bw)
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_realtime(x[0])
                 out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
             if world == 1 and not args.no_realtime:
                 out["realtime"] = realtime_leg(zen_amd, x[0])
-    elif args.workload == "offline_batch":
-        C = args.clips
-        n = int(args.clip_seconds * FS)
-        hop_h, hop_p = 4096, 256
-        ids = zdist.shard_units(C * world, world, rank)          # clip ids of this rank (C each)
-        x = np.stack([s_music(n, seed=7000 + i) for i in ids])
-        d_in = zen_amd.DeviceBuffer.from_host(x)
-        d_h, d_p = zen_amd.DeviceBuffer(C * n), zen_amd.DeviceBuffer(C * n)
-        eng = zen_amd.HPRIOffline(FS, hop_h, hop_p, BETA, BETA, False, C)
-        n1, n2 = eng.hop_counts(n)
+        free_run(run)
+        if legs:
+            ls, lw = args.leg_steps, 2
 
-        def step():
-            eng.process_device(d_in.ptr, n, n, d_h.ptr, d_p.ptr, None, n)
+            def sync_only():
+                zen_amd.synchronize()
 
-        settle(step, args.settle_ms)
-        for _ in range(args.warmup):
-            step()
-        barrier()
-        eng.profile(True)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        barrier()
-        dt = grp.max(time.perf_counter() - t0)
-        prof = eng.profile_get_all()
-        eng.profile(False)
-        chk = grp.sum([float(np.abs(d_p.download(4096)).sum())])[0]
-        if rank == 0:
-            total_hops = world * C * (n1 + n2) * args.steps
-            value = total_hops / dt
-            roof, kern = offline_rooflines(prof, args.steps, {"pass1": C * n1, "pass2": C * n2},
-                                           {"pass1": 4 * hop_h, "pass2": 4 * hop_p}, {"pass1": hop_h, "pass2": hop_p},
-                                           3, device_copy_bandwidth(zen_amd), {"pass1": 187, "pass2": 13})
-            out.update({"roofline": roof, "kernels": kern})
-            out.update({
-                "metric": "hops/sec (HPR-I offline, hops of both passes)", "value": value,
-                "ms_per_step": 1e3 * dt / args.steps,
-                "config": {
-                    "workload": "HPRIOffline<GPU> 4096/256 beta 2.0 hard mask, %d x %.0f s mono S-music clips per "
-                                "GPU resident in HBM, both passes + harmonic/percussive outputs" % (C, args.clip_seconds),
-                    "clips_per_gpu": C, "clip_samples": n, "hops_pass1": n1, "hops_pass2": n2,
-                    "parallelism": "clips sharded x%d, no data-path collective" % world},
-                "x_realtime": world * C * args.clip_seconds * args.steps / dt,
-                "checksum": chk})
-            if world == 1 and not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline_offline(x[0], hop_h, hop_p, n1 + n2)
-                out["cpu_baseline_all_cores"] = cpu_all
-    if args.workload == "offline_long":
-        # BASELINE configs[2]: one 10-minute stereo clip = 2 mono channels, HPR-I 4096/256, soft mask p = 2.
-        # N > 1: every channel is cut into N time ranges (SURVEY 8(f)-2), rank r computes range r of both
-        # channels from its own halo of input; strong scaling, no exchange.
-        n = int(600 * FS)
-        hop_h, hop_p = 4096, 256
-        b, e = zdist.time_shards(n, world, hop_h)[rank]
-        chans = [s_music(n, seed=9000 + c) for c in range(2)]
-        d_in = [zen_amd.DeviceBuffer.from_host(c) for c in chans]
-        d_h, d_p = zen_amd.DeviceBuffer(max(e - b, 1)), zen_amd.DeviceBuffer(max(e - b, 1))
-        eng = zen_amd.HPRIOffline(FS, hop_h, hop_p, 2.5, 2.5, False, 1)
-        eng.use_soft_mask()
-        n1, n2 = eng.hop_counts(n)
-
-        def step():
-            for c in range(2):
-                if e > b:
-                    eng.process_range(d_in[c].ptr, n, b, e, d_h.ptr, d_p.ptr)
-
-        settle(step, args.settle_ms)
-        for _ in range(args.warmup):
-            step()
-        barrier()
-        eng.profile(True)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        barrier()
-        dt = grp.max(time.perf_counter() - t0)
-        prof = eng.profile_get_all()
-        eng.profile(False)
-        chk = grp.sum([float(np.abs(d_p.download(min(4096, max(e - b, 1)))).sum())])[0]
-        if rank == 0:
-            if world == 1:
-                roof, kern = offline_rooflines(prof, args.steps, {"pass1": 2 * n1, "pass2": 2 * n2},
-                                               {"pass1": 4 * hop_h, "pass2": 4 * hop_p},
-                                               {"pass1": hop_h, "pass2": hop_p}, 2, device_copy_bandwidth(zen_amd),
-                                               {"pass1": 187, "pass2": 13})
-                out.update({"roofline": roof, "kernels": kern})
+            solo = _Solo()
+            if rank == 0 and world == 1:
+                # -- H + P + R on the same stream (second case)
+                flags3 = zen_amd.OUTPUT_PERCUSSIVE | zen_amd.OUTPUT_HARMONIC | zen_amd.OUTPUT_RESIDUAL
+                r3 = block_run(zen_amd, solo, x, flags3, M, 20, 5, 100.0, sync_only)
+                v3 = S * M * 20 / r3["dt"]
+                out["all_outputs"] = {"value": v3, "unit": "hops/s", "ms_per_step": 1e3 * r3["dt"] / 20, "steps": 20,
+                                      "x_realtime": v3 * HOP / FS, "outputs": "H+P+R", "checksum": r3["checksum"],
+                                      "kernel_ms_per_step": {k: v["ms"] / 20 for k, v in r3["breakdown"].items() if v["launches"]},
+                                      "roofline": fused_roofline(r3, S, M, 20, 3, K_FUSED_HPR, copy_bw)}
+                free_run(r3)
+                # -- the headline configuration on the S-noise seed
+                xn = s_noise(n, seed=1)[None, :]
+                rn = block_run(zen_amd, solo, xn, zen_amd.OUTPUT_PERCUSSIVE, M, 20, 5, 100.0, sync_only)
+                vn = S * M * 20 / rn["dt"]
+                out["s_noise"] = {"value": vn, "unit": "hops/s", "ms_per_step": 1e3 * rn["dt"] / 20, "steps": 20,
+                                  "x_realtime": vn * HOP / FS, "checksum": rn["checksum"],
+                                  "roofline": fused_roofline(rn, S, M, 20, 1, K_FUSED_P, copy_bw)}
+                free_run(rn)
+                del xn
+                # -- BASELINE configs[4]: SSE path, hop 512 (nwin 1024, transform 2048, boxes 7 / 23), nocopybord
+                hop5, M5 = 512, 2 * M
+                x5 = x[:, :M5 * hop5]
+                r5 = block_run(zen_amd, solo, x5, zen_amd.OUTPUT_PERCUSSIVE, M5, 10, 3, 100.0, sync_only, hop=hop5, sse=True,
+                               copy_bord=False)
+                v5 = M5 * 10 / r5["dt"]
+                roof5, kern5 = sse_rooflines(r5["breakdown"], 10, M5, 4 * hop5, hop5)
+                out["sse_block"] = {"value": v5, "unit": "hops/s", "ms_per_step": 1e3 * r5["dt"] / 10, "steps": 10,
+                                    "x_realtime": v5 * hop5 / FS, "checksum": r5["checksum"], "roofline": roof5, "kernels": kern5,
+                                    "config": {"workload": "HPRRealtime<GPU>(44100, 512, 2.0, P, nocopybord).use_sse_filter() "
+                                                           "semantics, block mode, %d hops/step" % M5}}
+                free_run(r5)
+                # -- the offline workloads, short
+                ob, clip0, (n1, n2) = offline_batch_run(zen_amd, zdist, solo, 0, 1, args.leg_clips, args.clip_seconds, ls, lw,
+                                                       100.0, sync_only)
                 if not args.no_cpu_baseline:
-                    out["cpu_baseline"] = cpu_baseline_offline(chans[0], hop_h, hop_p, n1 + n2, seconds=4.0, beta=2.5,
-                                                               soft=True)
-            out.update({
-                "metric": "hops/sec (HPR-I offline, hops of both passes)", "scaling": "strong",
-                "value": 2 * (n1 + n2) * args.steps / dt, "ms_per_step": 1e3 * dt / args.steps,
-                "config": {"workload": "HPRIOffline<GPU> 4096/256 beta 2.5 soft mask (p = 2), one 10-minute stereo "
-                                       "clip (2 mono channels of 26 460 000 samples) resident in HBM",
-                           "hops_pass1": n1, "hops_pass2": n2,
-                           "parallelism": "each channel time-sharded x%d with warm-up halos, no exchange" % world},
-                "x_realtime": 600.0 * args.steps / dt, "checksum": chk})
+                    ob["cpu_baseline"] = cpu_baseline_offline(clip0, 4096, 256, n1 + n2)
+                    ob["cpu_baseline_all_cores"] = cpu_all
+                out["offline_batch"] = ob
+                ol, ch0, (m1, m2) = offline_long_run(zen_amd, zdist, solo, 0, 1, ls, lw, 100.0, sync_only)
+                if not args.no_cpu_baseline:
+                    ol["cpu_baseline"] = cpu_baseline_offline(ch0, 4096, 256, m1 + m2, seconds=4.0, beta=2.5, soft=True)
+                out["offline_long"] = ol
+            elif world > 1:
+                # -- the path that shards: the offline batch, clips dealt to the ranks, no data-path collective
+                ob, _, _ = offline_batch_run(zen_amd, zdist, grp, rank, world, args.leg_clips, args.clip_seconds, ls, lw, 100.0,
+                                             barrier, rooflines=False)
+                if rank == 0:
+                    out["offline_batch_sharded"] = ob
+    elif args.workload == "offline_batch":
+        res, clip0, (n1, n2) = offline_batch_run(zen_amd, zdist, grp, rank, world, args.clips, args.clip_seconds, args.steps,
+                                                 args.warmup, args.settle_ms, barrier)
+        if rank == 0:
+            out.update(res)
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline_offline(clip0, 4096, 256, n1 + n2)
+                out["cpu_baseline_all_cores"] = cpu_all
+    elif args.workload == "offline_long":
+        res, ch0, (n1, n2) = offline_long_run(zen_amd, zdist, grp, rank, world, args.steps, args.warmup, args.settle_ms, barrier)
+        if rank == 0:
+            out.update(res)
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline_offline(ch0, 4096, 256, n1 + n2, seconds=4.0, beta=2.5, soft=True)
     if rank == 0:
         print(json.dumps(out))
     grp.close()

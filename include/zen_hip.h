@@ -35,7 +35,7 @@ enum {
 	ZEN_HIP_E_BAD_ARG = 2,
 	ZEN_HIP_E_HOPS_NOT_DIVISIBLE = 3, /* [ZgException] hps.cu:33-36 */
 	ZEN_HIP_E_HIP = 4,                /* a HIP runtime call failed (reference: std::exit, io.h:37-66) */
-	ZEN_HIP_E_UNSUPPORTED = 5         /* size outside what the gfx950 kernels cover (nfft 32..16384) */
+	ZEN_HIP_E_UNSUPPORTED = 5         /* size outside what the gfx950 kernels cover (engine: nfft 32..16384; FFT wrapper: ..32768) */
 };
 
 /* libzen/mfilt.h:27-31  enum MedianFilterDirection */
@@ -58,6 +58,16 @@ const char* zen_hip_last_error(void);  /* thread-local text of the last failure 
 const char* zen_hip_version(void);
 int zen_hip_device_name(char* buf, size_t n);
 int zen_hip_synchronize(void* stream); /* hipStreamSynchronize; synchronises */
+/* a hipStream_t for the `stream` arguments and *_set_stream (a host without HIP headers: one stream per host thread,
+ * the reference's intended --default-stream-per-thread, CMakeLists.txt:43); non-blocking with respect to the null stream */
+int zen_hip_stream_create(void** stream);
+int zen_hip_stream_destroy(void* stream);
+/* hipEvent_t timing on a stream (the harness's clock for a single launch: bench.py, tools/bench_median.py; the
+ * reference times with std::chrono around synchronising thrust calls).  elapsed_ms synchronises on `stop`. */
+int zen_hip_event_create(void** event);
+int zen_hip_event_record(void* event, void* stream);
+int zen_hip_event_elapsed_ms(void* start, void* stop, float* ms);
+int zen_hip_event_destroy(void* event);
 /* process-wide tuning/debug switches (no reference counterpart; atomics, may be set from any thread).
  * "median_general" = 1 forces the general wave-cooperative median kernel even where the sorting-network
  * fast paths apply; "no_rt_fused" = 1 sends causal calls through the three-kernel path instead of the fused
@@ -67,7 +77,9 @@ int zen_hip_synchronize(void* stream); /* hipStreamSynchronize; synchronises */
  * 47-tap frequency masks on 4096-bin rows through the generic sorting-network kernel instead of
  * median47_dpp_kernel, "no_median47_neighbour" = 1 additionally switches off that kernel's DPP exchange of
  * sorted blocks; "no_half_rows" = 1 makes the three-kernel path store and filter whole magnitude rows instead of the
- * non-redundant half (bins 0..nfft/2); "median47_variant" = 1 lets median47_dpp_kernel store results without the LDS transpose (2, 3: timing
+ * non-redundant half (bins 0..nfft/2); "mfilt_nonneg" = 1: the caller promises that every sample handed to
+ * zen_hip_mfilt_run is >= +0 (a magnitude matrix), so the filter orders by the raw bits as the engine's own launches do
+ * (the kernel build BASELINE's median metric is quoted on); "median47_variant" = 1 lets median47_dpp_kernel store results without the LDS transpose (2, 3: timing
  * diagnostics whose outputs are not medians). */
 int zen_hip_set_option(const char* name, int value);
 
@@ -150,9 +162,13 @@ int zen_hip_hpr_reset_buffers(zen_hip_hpr_t h);  /* hps.h:296-321 */
  * host memory; n_streams == 1).  Asynchronous. */
 int zen_hip_hpr_process_next_hop(zen_hip_hpr_t h, const float* in_dev);
 /* HPRRealtime<GPU>::copy_{harmonic,percussive,residual} (hps.cu:341-363): writes the first `hop`
- * floats of the accumulator for the hop(s) of the LAST process call to out_dev, then synchronises the
- * stream so that a mapped host_out is readable on return (the reference relies on thrust's implicit
- * sync, SURVEY 8(b) "Threading").  After a block call it writes n_hops*hop floats per stream
+ * floats of the accumulator for the hop(s) of the LAST process call to out_dev and returns when they are
+ * readable there (the reference relies on thrust's implicit sync, SURVEY 8(b) "Threading"): by
+ * synchronising the stream, or -- single stream, single hop, mapped host destination -- by polling the
+ * sequence word the kernel publishes behind the finished hop (no stream synchronise: other work the caller
+ * queued on the stream is NOT waited for, except earlier zen_hip_hpr_copy_output_async calls of this
+ * engine).  A hop of the cooperative long-hop kernel whose grid barrier timed out is reported as
+ * ZEN_HIP_E_HIP by every synchronous copy until zen_hip_hpr_reset_buffers.  After a block call it writes n_hops*hop floats per stream
  * (valid only if that call fitted in one chunk).  `which` is one ZEN_HIP_OUTPUT_* flag. */
 int zen_hip_hpr_copy_output(zen_hip_hpr_t h, unsigned which, float* out_dev);
 int zen_hip_hpr_copy_output_async(zen_hip_hpr_t h, unsigned which, float* out_dev);

@@ -41,6 +41,9 @@ def test_plain_launch_time_shards_and_replicas():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 3 and j["ranks_reported"] == 3 and j["config"]["units_all_ranks"] == 300
     assert j["config"]["parallelism"] == "replicas x3"
+    # the default N > 1 line also carries the path that shards: the offline batch, clips dealt to the ranks
+    sh = j["offline_batch_sharded"]
+    assert sh["ranks_reported"] == 3 and sh["clips_total"] == 3 * 64 and sh["clips_rank0"] == 64
 
 
 def test_torchrun_launch_is_not_respawned():
@@ -102,3 +105,22 @@ def test_two_ranks_shard_clips_on_the_gpu_path():
     assert two["config"]["clips_per_gpu"] == 2 and one["n_gpus"] == 1
     # rank r owns clips r, r+2 (round robin); the checksum is over the first 4096 samples of each rank's FIRST clip
     assert two["checksum"] > 0 and one["checksum"] > 0
+
+
+@pytest.mark.gpu
+def test_default_line_at_two_ranks_carries_the_sharded_offline_batch():
+    """`bench.py --gpus N` (what the driver runs for the scaling curve): `value` is N replicas of the realtime stream,
+    and the same line carries the sharded offline batch -- the path north_star scales -- with ranks_reported."""
+    env = dict(os.environ, ZEN_ALLOW_GPU_SHARING="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--hops", "300", "--steps", "2", "--warmup", "1",
+                        "--settle-ms", "0", "--leg-clips", "2", "--clip-seconds", "2", "--leg-steps", "2"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    j = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][0])
+    assert j["n_gpus"] == 2 and j["ranks_reported"] == 2 and j["config"]["parallelism"] == "replicas x2"
+    assert j["value"] > 0 and j["roofline"]["frac"] > 0
+    sh = j["offline_batch_sharded"]
+    assert sh["ranks_reported"] == 2 and sh["config"]["clips_total"] == 4 and sh["value"] > 0 and sh["x_realtime"] > 0
+    assert "cpu_baseline" not in j and "realtime" not in j          # rank 0 at N = 1 only

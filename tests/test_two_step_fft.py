@@ -42,7 +42,7 @@ def dit_stages(xr, xi, tw_index, twr, twi, first_stage, n_stages, inverse):
     return rec(xr, xi, n)
 
 
-@pytest.mark.parametrize("log2n", [13, 14])
+@pytest.mark.parametrize("log2n", [13, 14, 15])   # 15: fft_big.hip (nfft 32768, two kernels)
 @pytest.mark.parametrize("inverse", [False, True])
 def test_two_step_transform_is_the_one_piece_transform(log2n, inverse):
     n, log2m = 1 << log2n, 7

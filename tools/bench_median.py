@@ -44,8 +44,13 @@ if __name__ == "__main__":
     ap.add_argument("--cols", type=int, default=4096)
     ap.add_argument("--len", type=int, default=47)
     ap.add_argument("--dir", default="frequency")
+    ap.add_argument("--nonneg", action="store_true",
+                    help="option mfilt_nonneg: the input is a magnitude matrix (>= +0), ordering keys are the raw bits -- the "
+                         "kernel build the engine launches and BASELINE's median metric is quoted on")
     args = ap.parse_args()
     zen_amd.init(0)
+    if args.nonneg:
+        zen_amd.set_option("mfilt_nonneg", 1)
     for opt in ("median47_blocks", "median47_shared"):
         if os.environ.get("ZEN_" + opt.upper()):
             zen_amd.set_option(opt, int(os.environ["ZEN_" + opt.upper()]))

@@ -29,6 +29,9 @@ static double now_us()
 int main(int argc, char** argv)
 {
 	const int n_hops = argc > 1 ? std::atoi(argv[1]) : 2000;
+	// the two latency switches a realtime host opts into before its first HIP call; not overridden if set
+	setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
+	setenv("ZEN_HIP_SCHEDULE", "spin", 0);
 	CK(zen_hip_init(0));
 	if (const char* d = std::getenv("ZEN_RT_DIAG")) // timing diagnostics of the single-hop kernels (results not valid)
 		CK(zen_hip_set_option("rt_fused_diag", std::atoi(d)));

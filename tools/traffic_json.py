@@ -1,31 +1,43 @@
 #!/usr/bin/env python3
-"""Turns the per-dispatch counter means of tools/pmc_cmd.sh into the HBM-traffic record bench.py quotes.
+"""Merges the per-kernel counter means of tools/pmc_cmd.sh into the HBM-traffic record bench.py quotes
+(profiles/r03_hbm_traffic.json), keyed by the EXACT kernel name the counters were collected under.
 
-usage: traffic_json.py <pmc.json> <kernel label> <rows> <cols> <build rev>
+usage: traffic_json.py <record.json> <build rev> <pmc.json> "<exact kernel name>" <elements per launch> <rows> <cols> [note]
+
 FETCH_SIZE / WRITE_SIZE are KiB per dispatch, collected in passes of their own; on gfx950 FETCH_SIZE counts
-128-byte requests of 16-byte-per-lane streaming loads as 64 bytes and is doubled (MI355X_MICROARCH.md, HBM)."""
+128-byte requests of 16-byte-per-lane streaming loads as 64 bytes and is doubled (MI355X_MICROARCH.md, HBM).
+bench.py refuses a record whose kernel name or element count is not the timed launch's."""
 import json
+import os
 import sys
 
-pmc = json.load(open(sys.argv[1]))["per_dispatch_mean"]
-label, rows, cols, rev = sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+path, rev, pmc_path, name, elements, rows, cols = sys.argv[1:8]
+note = sys.argv[8] if len(sys.argv) > 8 else None
+elements, rows, cols = int(elements), int(rows), int(cols)
+pmc_all = json.load(open(pmc_path))["kernels"]
+if name not in pmc_all:
+    sys.exit("traffic_json.py: %s has no kernel %r (it has: %s)" % (pmc_path, name, ", ".join(sorted(pmc_all)) or "none"))
+pmc = pmc_all[name]
+rec = json.load(open(path)) if os.path.exists(path) else {
+    "source": "tools/pmc_cmd.sh (rocprofv3 --pmc, one pass per counter group, no trace domains) on MI355X",
+    "units": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch; reads doubled per the gfx950 correction",
+    "kernels": {}}
+rec["build"] = rev
 fetch_raw = 1024.0 * pmc.get("FETCH_SIZE", 0.0)
 write = 1024.0 * pmc.get("WRITE_SIZE", 0.0)
-rec = {
-    "source": "tools/pmc_cmd.sh (rocprofv3 --pmc, one pass per counter group) on MI355X; build " + rev,
-    "units": "FETCH_SIZE / WRITE_SIZE in KiB per dispatch; reads doubled per the gfx950 correction",
-    "shape": {"rows": rows, "cols": cols, "elements": rows * cols},
-    "kernels": {label: {
-        "FETCH_SIZE_KiB": pmc.get("FETCH_SIZE"), "WRITE_SIZE_KiB": pmc.get("WRITE_SIZE"),
-        "hbm_read_bytes": 2.0 * fetch_raw, "hbm_write_bytes": write,
-        "hbm_bytes_per_launch": 2.0 * fetch_raw + write,
-        "hbm_bytes_per_element": (2.0 * fetch_raw + write) / (rows * cols),
-        "hbm_bytes_per_row": (2.0 * fetch_raw + write) / rows}},
-    "sq_counters_per_launch": {k: v for k, v in pmc.items() if k.startswith("SQ_") or k.startswith("GRBM")},
-}
-c = rec["sq_counters_per_launch"]
+k = {"elements": elements, "rows": rows, "cols": cols, "dispatches_averaged": pmc.get("dispatches"),
+     "FETCH_SIZE_KiB": pmc.get("FETCH_SIZE"), "WRITE_SIZE_KiB": pmc.get("WRITE_SIZE"),
+     "hbm_read_bytes": 2.0 * fetch_raw, "hbm_write_bytes": write, "hbm_bytes_per_launch": 2.0 * fetch_raw + write,
+     "hbm_bytes_per_element": (2.0 * fetch_raw + write) / elements, "hbm_bytes_per_row": (2.0 * fetch_raw + write) / rows,
+     "sq_counters_per_launch": {c: v for c, v in pmc.items() if c.startswith("SQ_") or c.startswith("GRBM")}}
+c = k["sq_counters_per_launch"]
 if c.get("SQ_LDS_IDX_ACTIVE"):
-    rec["lds_conflict_cycle_share"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]
+    k["lds_conflict_cycle_share"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]
 if c.get("SQ_WAVES") and c.get("SQ_INSTS_VALU"):
-    rec["valu_instructions_per_wave"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
-print(json.dumps(rec, indent=1))
+    k["valu_instructions_per_wave"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
+if note:
+    k["note"] = note
+rec["kernels"][name] = k
+json.dump(rec, open(path, "w"), indent=1)
+print("%s: %s  %.1f MB read + %.1f MB written per launch = %.2f B/element" % (
+    path, name, 2e-6 * fetch_raw, 1e-6 * write, k["hbm_bytes_per_element"]))

@@ -22,6 +22,8 @@ opt_t g_opt_median47_variant{0};
 opt_t g_opt_rt_fused_diag{0};
 opt_t g_opt_mask_divide{0};
 opt_t g_opt_no_half_rows{0};
+opt_t g_opt_mfilt_nonneg{0};
+std::atomic<unsigned> g_host_free_gen{0};
 
 void set_error(const char* fmt, ...)
 {
@@ -101,6 +103,8 @@ struct zen_hip_fft {
 	size_t nfft;
 	int log2n;
 	float2* tw;
+	float2* xch = nullptr; // nfft 32768 only: exchange buffer of the two-step transform (fft_big.hip), grown on demand
+	size_t xch_batch = 0;
 };
 
 struct zen_hip_filter {
@@ -115,21 +119,22 @@ const char* zen_hip_version(void) { return "zen-mi355x 0.1 (gfx950)"; }
 
 int zen_hip_init(int device)
 {
-	// Kernel arguments in device memory instead of host memory (a ROCm runtime switch, read when the runtime
-	// starts: no effect if the process has used HIP before): the first instructions of a launch wait for them, and
-	// a single-hop call is short enough to notice (0.7-1 us of 17-21 us, tools/rt_latency.cpp).  Not overridden if set.
-	(void)setenv("HIP_FORCE_DEV_KERNARG", "1", 0);
+	// No process-wide side effects by default.  Two latency switches a realtime host may opt into, both BEFORE its first
+	// HIP call (documented in INTEGRATION.md; tools/rt_latency.cpp and the bench's per-hop leg do):
+	//   HIP_FORCE_DEV_KERNARG=1 in the environment (a ROCm runtime switch, read when the runtime starts): kernel
+	//     arguments in device memory instead of host memory; the first instructions of a launch wait for them, and a
+	//     single-hop call is short enough to notice (0.7-1 us of 17-21 us).
+	//   ZEN_HIP_SCHEDULE=spin: hipDeviceScheduleSpin for this device -- every synchronising HIP call of the process
+	//     then polls (one busy core per synchronising thread) instead of sleeping on an interrupt.  The mapped-memory
+	//     copy_* path polls its own sequence word and does not need it; the other copy_* paths gain the wake-up time.
 	int n = 0;
 	ZH_HIP(hipGetDeviceCount(&n));
 	if (device < 0 || device >= n)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "zen_hip_init: device %d of %d", device, n);
 	// core.cu:4-6 sets cudaDeviceMapHost before a context exists; on ROCm mapped host memory needs
 	// no device flag, the call is kept for symmetry and its "already active" status is ignored.
-	// hipDeviceScheduleSpin: a synchronising call polls instead of sleeping on an interrupt; the realtime path
-	// synchronises once per hop and the wake-up would cost more than the hop's kernel (ZEN_HIP_SCHEDULE=auto
-	// in the environment keeps the runtime's default).
 	const char* sched = getenv("ZEN_HIP_SCHEDULE");
-	const unsigned spin = (sched && !strcmp(sched, "auto")) ? 0u : (unsigned)hipDeviceScheduleSpin;
+	const unsigned spin = (sched && !strcmp(sched, "spin")) ? (unsigned)hipDeviceScheduleSpin : 0u;
 	ZH_HIP(hipSetDevice(device));
 	(void)hipSetDeviceFlags(hipDeviceMapHost | spin);
 	(void)hipGetLastError();
@@ -159,7 +164,8 @@ int zen_hip_set_option(const char* name, int value)
 	             {"median47_variant", &g_opt_median47_variant},
 	             {"rt_fused_diag", &g_opt_rt_fused_diag},
 	             {"mask_divide", &g_opt_mask_divide},
-	             {"no_half_rows", &g_opt_no_half_rows}};
+	             {"no_half_rows", &g_opt_no_half_rows},
+	             {"mfilt_nonneg", &g_opt_mfilt_nonneg}};
 	for (const auto& t : table) {
 		if (name && !strcmp(name, t.name)) {
 			t.var->store(value, std::memory_order_relaxed);
@@ -182,6 +188,53 @@ int zen_hip_device_name(char* buf, size_t n)
 int zen_hip_synchronize(void* stream)
 {
 	ZH_HIP(hipStreamSynchronize((hipStream_t)stream));
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_stream_create(void** stream)
+{
+	if (!stream)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "stream_create: null argument");
+	hipStream_t st = nullptr;
+	ZH_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+	*stream = (void*)st;
+	return ZEN_HIP_OK;
+}
+int zen_hip_stream_destroy(void* stream)
+{
+	if (stream)
+		ZH_HIP(hipStreamDestroy((hipStream_t)stream));
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_event_create(void** event)
+{
+	if (!event)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "event_create: null argument");
+	hipEvent_t e = nullptr;
+	ZH_HIP(hipEventCreate(&e));
+	*event = (void*)e;
+	return ZEN_HIP_OK;
+}
+int zen_hip_event_record(void* event, void* stream)
+{
+	if (!event)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "event_record: null event");
+	ZH_HIP(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+	return ZEN_HIP_OK;
+}
+int zen_hip_event_elapsed_ms(void* start, void* stop, float* ms)
+{
+	if (!start || !stop || !ms)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "event_elapsed_ms: null argument");
+	ZH_HIP(hipEventSynchronize((hipEvent_t)stop));
+	ZH_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+	return ZEN_HIP_OK;
+}
+int zen_hip_event_destroy(void* event)
+{
+	if (event)
+		ZH_HIP(hipEventDestroy((hipEvent_t)event));
 	return ZEN_HIP_OK;
 }
 
@@ -259,6 +312,7 @@ int zen_hip_host_free(void* host)
 {
 	if (!host)
 		return ZEN_HIP_OK;
+	g_host_free_gen.fetch_add(1, std::memory_order_relaxed); // engines drop what they remember about host buffers (hpr.hip host_alias_of)
 	{
 		std::lock_guard<std::mutex> lk(g_bar_mu);
 		for (size_t i = 0; i < g_bar_bufs.size(); ++i) {
@@ -280,8 +334,8 @@ int zen_hip_fft_create(size_t nfft, zen_hip_fft_t* h)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "fft_create: null handle");
 	if (!is_pow2(nfft))
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "fft_create: nfft %zu is not a power of two", nfft);
-	if (nfft < 32 || nfft > 16384)
-		ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "fft_create: nfft %zu outside 32..16384", nfft);
+	if (nfft < 32 || nfft > 32768) // (fftw.bench.cu:231-252 sweeps 256..32768; the engine itself stops at 16384)
+		ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "fft_create: nfft %zu outside 32..32768", nfft);
 	zen_hip_fft* f = new zen_hip_fft;
 	f->nfft = nfft;
 	f->log2n = ilog2(nfft);
@@ -303,6 +357,17 @@ int zen_hip_fft_exec_batched(zen_hip_fft_t h, float* inout_dev, size_t batch, in
 {
 	if (!h || !inout_dev)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "fft_exec: null argument");
+	if (h->log2n > 14) { // one frame does not fit a workgroup's LDS: two steps through a scratch buffer
+		if (batch > h->xch_batch) {
+			ZH_HIP(hipStreamSynchronize((hipStream_t)stream));
+			(void)hipFree(h->xch);
+			h->xch = nullptr;
+			h->xch_batch = 0;
+			ZH_HIP(hipMalloc((void**)&h->xch, sizeof(float2) * h->nfft * batch));
+			h->xch_batch = batch;
+		}
+		return launch_fft_big(h->log2n, (float2*)inout_dev, h->xch, h->tw, batch, inverse, (hipStream_t)stream);
+	}
 	return launch_fft(h->log2n, (float2*)inout_dev, h->tw, batch, inverse, (hipStream_t)stream);
 }
 
@@ -315,6 +380,7 @@ int zen_hip_fft_destroy(zen_hip_fft_t h)
 {
 	if (h) {
 		(void)hipFree(h->tw);
+		(void)hipFree(h->xch);
 		delete h;
 	}
 	return ZEN_HIP_OK;
@@ -357,6 +423,7 @@ static int filter_run(zen_hip_filter* h, const float* src, float* dst, void* str
 	a.clamp_hi = h->time - 1;
 	a.len = h->len;
 	a.direction = h->direction;
+	a.nonneg = (!h->is_box && g_opt_mfilt_nonneg) ? 1 : 0; // "mfilt_nonneg": the caller's promise (magnitudes)
 	return h->is_box ? launch_box(a, (hipStream_t)stream) : launch_median(a, (hipStream_t)stream);
 }
 

@@ -23,9 +23,12 @@ extern opt_t g_opt_no_median47_neighbour; // "no_median47_neighbour": generic 47
 extern opt_t g_opt_median_general;       // "median_general": force the general wave kernel
 extern opt_t g_opt_no_median47_dpp;      // "no_median47_dpp": 4096-bin rows / 47 taps through the generic kernel
 extern opt_t g_opt_no_half_rows;         // "no_half_rows": the three-kernel path stores and filters whole magnitude rows
+extern opt_t g_opt_mfilt_nonneg;        // "mfilt_nonneg": zen_hip_mfilt_run's input is promised to be >= +0 (raw-bit ordering keys)
 extern opt_t g_opt_mask_divide;          // "mask_divide": the lean fused kernel forms its hard mask with the IEEE divide
 extern opt_t g_opt_rt_fused_diag;         // "rt_fused_diag": 1 = fused kernel without its median stage, 2 = without synthesis (timing only)
 extern opt_t g_opt_median47_variant;    // "median47_variant": median47_dpp_kernel build (0 default, 1 direct stores, 2/3 diagnostics)
+
+extern std::atomic<unsigned> g_host_free_gen; // bumped by zen_hip_host_free: cached host/device alias lookups are stale
 
 // Evaluate a HIP call; on failure record file:line + hipGetErrorString and return ZEN_HIP_E_HIP.
 #define ZH_HIP(call)                                                                                  \

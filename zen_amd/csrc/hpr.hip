@@ -110,6 +110,8 @@ void free_all(zen_hip_hpr* e)
 		(void)hipFree(e->d_wide_xch);
 	if (e->d_wide_bar)
 		(void)hipFree(e->d_wide_bar);
+	if (e->wide_fail_host)
+		(void)hipHostFree(e->wide_fail_host);
 	for (auto& p : e->prof_pending) {
 		(void)hipEventDestroy(p.e0);
 		(void)hipEventDestroy(p.e1);
@@ -137,8 +139,13 @@ int reset_state(zen_hip_hpr* e)
 	e->tail_sel = 0;
 	e->abs_frame = (long long)e->W - 1; // rows 0..W-2 are the all-zero history of a fresh stream
 	e->last_frames = 0;
-	e->drain[0] = e->drain[1] = e->drain[2] = false;
+	e->drain[0] = e->drain[1] = e->drain[2] = 0;
 	e->ready_valid[0] = e->ready_valid[1] = e->ready_valid[2] = false;
+	if (e->d_wide_bar) { // a time-out mark of rt_wide.hip must not outlive the stream it happened in
+		ZH_HIP(hipStreamSynchronize(e->stream));
+		ZH_HIP(hipMemset2DAsync(e->d_wide_bar + 1, sizeof(unsigned) * 4, 0, sizeof(unsigned), S, e->stream));
+		*e->wide_fail_host = 0;
+	}
 	return ZEN_HIP_OK;
 }
 
@@ -148,10 +155,14 @@ int reset_state(zen_hip_hpr* e)
 int ensure_estimates(zen_hip_hpr* e, bool need_h)
 {
 	const size_t bytes = sizeof(float) * e->n_streams * e->max_hops * e->nfft;
-	if (!e->d_P)
+	if (!e->d_P) { // zeroed like the Y rows: the half-row filters leave the bins nobody reads untouched
 		ZH_HIP(hipMalloc((void**)&e->d_P, bytes));
-	if (need_h && !e->d_H)
+		ZH_HIP(hipMemsetAsync(e->d_P, 0, bytes, e->stream));
+	}
+	if (need_h && !e->d_H) {
 		ZH_HIP(hipMalloc((void**)&e->d_H, bytes));
+		ZH_HIP(hipMemsetAsync(e->d_H, 0, bytes, e->stream));
+	}
 	return ZEN_HIP_OK;
 }
 
@@ -225,7 +236,13 @@ int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, H
 			ZH_HIP(hipMemsetAsync(e->d_wide_bar, 0, sizeof(unsigned) * 4 * e->n_streams, e->stream));
 			e->wide_arrivals = 0;
 			e->wide_calls = 0;
+			void* dev = nullptr;
+			ZH_HIP(hipHostMalloc((void**)&e->wide_fail_host, 64, hipHostMallocMapped | hipHostMallocPortable));
+			*e->wide_fail_host = 0;
+			ZH_HIP(hipHostGetDevicePointer(&dev, e->wide_fail_host, 0));
+			e->wide_fail_dev = (unsigned*)dev;
 		}
+		a.wide_fail = e->wide_fail_dev;
 		a.P = e->d_P;
 		a.p_stream_stride = (long long)(e->max_hops * e->nfft);
 		a.xch = e->d_wide_xch;
@@ -249,9 +266,30 @@ int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, H
 	return ZEN_HIP_OK;
 }
 
+// An output switched off in mid-stream (see zen_hip_hpr::drain): the reference rotates its accumulator once per hop
+// all the same (hps.cu:435-449), so the call after the switch hands out the second half of the last frame that was
+// still added to it, and the call after that zeros.
+int advance_drain(zen_hip_hpr* e)
+{
+	for (int o = 0; o < 3; ++o) {
+		if (e->drain[o] == 2) {
+			e->drain[o] = 0;
+		}
+		else if (e->drain[o] == 1) {
+			const float* y = e->d_Y[o] + (e->last_frames - 1) * e->nwin + e->hop;
+			ZH_HIP(hipMemcpy2DAsync(e->d_carry[o], sizeof(float) * e->hop, y, sizeof(float) * e->max_hops * e->nwin,
+			                        sizeof(float) * e->hop, e->n_streams, hipMemcpyDeviceToDevice, e->stream));
+			e->drain[o] = 2;
+		}
+	}
+	return ZEN_HIP_OK;
+}
+
 int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 {
 	const size_t S = e->n_streams, N = e->nfft;
+	if (e->drain[0] | e->drain[1] | e->drain[2])
+		ZH_TRY(advance_drain(e));
 	if (e->causality == ZEN_HIP_TIME_CAUSAL && !e->use_sse && !g_opt_no_rt_fused && (M == 1 || !g_opt_no_block_fused)
 	    && rt_fused_available(e->log2n, e->mf))
 		return run_hop_fused(e, in, in_stride, M);
@@ -429,35 +467,31 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 	return ZEN_HIP_OK;
 }
 
-// Called when use_sse_filter / use_soft_mask switch an output off in mid-stream: park the second half of its
-// last frame in the carry buffer, from where the next copy-out drains it.
+// Called when use_sse_filter / use_soft_mask switch an output off in mid-stream.  Nothing moves yet: until the next
+// hop is processed copy_* keeps handing out the hop(s) finished before the switch (the Y rows and the carry are
+// untouched); advance_drain() takes it from there.
 int park_dropped_outputs(zen_hip_hpr* e, const bool (&before)[3])
 {
 	for (int o = 0; o < 3; ++o) {
 		if (!before[o] || output_computed(e, o))
 			continue;
-		if (e->last_frames > 0) {
-			const float* y = e->d_Y[o] + (e->last_frames - 1) * e->nwin + e->hop;
-			ZH_HIP(hipMemcpy2DAsync(e->d_carry[o], sizeof(float) * e->hop, y, sizeof(float) * e->max_hops * e->nwin,
-			                        sizeof(float) * e->hop, e->n_streams, hipMemcpyDeviceToDevice, e->stream));
-		}
-		e->drain[o] = true;
+		e->drain[o] = (e->last_frames > 0 && e->d_Y[o]) ? 1 : 0;
 	}
 	return ZEN_HIP_OK;
 }
 
+// copy_* of output o hands out what the kernels of the last call left for it
+bool output_served(const zen_hip_hpr* e, int o) { return output_computed(e, o) || e->drain[o] == 1; }
+
 int finalize_output(zen_hip_hpr* e, int o, float* out, size_t out_stride, size_t M)
 {
-	if (!output_computed(e, o)) {
+	if (!output_served(e, o)) {
 		// the reference's accumulator for a disabled output stays all zero (hps.test.cu:321-343) ...
 		ZH_HIP(hipMemset2DAsync(out, sizeof(float) * out_stride, 0, sizeof(float) * M * e->hop, e->n_streams,
 		                        e->stream));
-		if (e->drain[o]) { // ... except for the tail of the last frame computed before it was switched off
+		if (e->drain[o] == 2) // ... except, in the call after it was switched off, for the tail of its last frame
 			ZH_HIP(hipMemcpy2DAsync(out, sizeof(float) * out_stride, e->d_carry[o], sizeof(float) * e->hop,
 			                        sizeof(float) * e->hop, e->n_streams, hipMemcpyDeviceToDevice, e->stream));
-			ZH_HIP(hipMemsetAsync(e->d_carry[o], 0, sizeof(float) * e->n_streams * e->hop, e->stream));
-			e->drain[o] = false;
-		}
 		return ZEN_HIP_OK;
 	}
 	FinalizeArgs fa;
@@ -471,6 +505,65 @@ int finalize_output(zen_hip_hpr* e, int o, float* out, size_t out_stride, size_t
 	fa.n_streams = (int)e->n_streams;
 	ProfScope ps(e, zen_hip_hpr::K_FINALIZE);
 	return launch_finalize(fa, e->stream);
+}
+
+// A default-sized engine (max_hops_per_chunk == 0 at create) grows to the block calls it is given.  What has to
+// survive: the stft_width-1 history rows of the two rings (they move to their positions in the longer ring) and the
+// Y rows of the last call (the next call's carry, and what copy_* hands out).  H and P are scratch.
+int grow_buffers(zen_hip_hpr* e, size_t new_hops)
+{
+	const size_t S = e->n_streams, N = e->nfft, old_hops = e->max_hops;
+	const long long old_rows = e->ring_rows, new_rows = (long long)(new_hops + e->W - 1);
+	const size_t srow = sizeof(float2) * e->s_stride, mrow = sizeof(float) * N;
+	ZH_HIP(hipStreamSynchronize(e->stream));
+	float2* nS = nullptr;
+	float* nmag = nullptr;
+	float* nY[3] = {nullptr, nullptr, nullptr};
+	bool ok = hipMalloc((void**)&nS, srow * S * new_rows) == hipSuccess && hipMalloc((void**)&nmag, mrow * S * new_rows) == hipSuccess;
+	for (int o = 0; o < 3 && ok; ++o)
+		if (e->d_Y[o])
+			ok = hipMalloc((void**)&nY[o], sizeof(float) * S * new_hops * e->nwin) == hipSuccess;
+	if (!ok) {
+		(void)hipFree(nS);
+		(void)hipFree(nmag);
+		for (int o = 0; o < 3; ++o)
+			(void)hipFree(nY[o]);
+		(void)hipGetLastError();
+		ZH_FAIL(ZEN_HIP_E_HIP, "hpr_process: growing the engine to %zu hops per chunk failed (nfft %zu, streams %zu)", new_hops, N, S);
+	}
+	ZH_HIP(hipMemsetAsync(nS, 0, srow * S * new_rows, e->stream));
+	ZH_HIP(hipMemsetAsync(nmag, 0, mrow * S * new_rows, e->stream));
+	for (long long r = e->abs_frame - ((long long)e->W - 1); r < e->abs_frame; ++r) {
+		ZH_HIP(hipMemcpy2DAsync(nS + (r % new_rows) * e->s_stride, srow * new_rows, e->d_S + (r % old_rows) * e->s_stride,
+		                        srow * old_rows, srow, S, hipMemcpyDeviceToDevice, e->stream));
+		ZH_HIP(hipMemcpy2DAsync(nmag + (r % new_rows) * N, mrow * new_rows, e->d_mag + (r % old_rows) * N, mrow * old_rows, mrow, S,
+		                        hipMemcpyDeviceToDevice, e->stream));
+	}
+	for (int o = 0; o < 3; ++o) {
+		if (!e->d_Y[o])
+			continue;
+		ZH_HIP(hipMemsetAsync(nY[o], 0, sizeof(float) * S * new_hops * e->nwin, e->stream));
+		if (e->last_frames > 0)
+			ZH_HIP(hipMemcpy2DAsync(nY[o], sizeof(float) * new_hops * e->nwin, e->d_Y[o], sizeof(float) * old_hops * e->nwin,
+			                        sizeof(float) * e->last_frames * e->nwin, S, hipMemcpyDeviceToDevice, e->stream));
+	}
+	ZH_HIP(hipStreamSynchronize(e->stream));
+	(void)hipFree(e->d_S);
+	(void)hipFree(e->d_mag);
+	(void)hipFree(e->d_H);
+	(void)hipFree(e->d_P);
+	e->d_S = nS;
+	e->d_mag = nmag;
+	e->d_H = e->d_P = nullptr; // ensure_estimates
+	for (int o = 0; o < 3; ++o) {
+		if (e->d_Y[o]) {
+			(void)hipFree(e->d_Y[o]);
+			e->d_Y[o] = nY[o];
+		}
+	}
+	e->max_hops = new_hops;
+	e->ring_rows = new_rows;
+	return ZEN_HIP_OK;
 }
 
 } // namespace
@@ -525,11 +618,18 @@ int zen_hip_hpr_create(float fs, size_t hop, float beta, unsigned output_flags, 
 	e->soft = false;
 	e->n_streams = n_streams;
 	if (max_hops_per_chunk == 0) {
-		// 2^30 ring elements per engine (S 8 B + |S| 4 B each, H / P / Y rows on demand: ~14 GB for 64 clips of the
-		// default offline configuration, 2 GB for one hop-1024 stream; the device has 288): whole clips go through
-		// in one or two chunks, every launch is large (offline batch +6 % against 2^26, measured)
+		// At most 2^30 ring elements per engine (S 8 B + |S| 4 B each = 13 GB, plus 4 B per element for each of H / P
+		// and 2 B for each output's Y rows as they come into use: up to ~25 GB for the three-output pass of 64 offline
+		// clips; the device has 288): whole clips go through in one or two chunks, every launch is large (offline batch
+		// +6 % against 2^26, measured).  That is a CAP: the buffers start at one hop (a per-hop realtime engine never
+		// needs more: its rings stay at stft_width rows) and grow to the size of the block calls that come
+		// (grow_buffers), so a three-second clip does not cost what a ten-minute one does.
 		size_t m = ((size_t)1 << 30) / (n_streams * nfft);
-		max_hops_per_chunk = m < 1 ? 1 : (m > 65536 ? 65536 : m);
+		e->max_hops_cap = m < 1 ? 1 : (m > 65536 ? 65536 : m);
+		max_hops_per_chunk = 1;
+	}
+	else {
+		e->max_hops_cap = max_hops_per_chunk; // the caller's bound on device memory: allocated as asked, never grown
 	}
 	e->max_hops = max_hops_per_chunk;
 	e->ring_rows = (long long)(e->max_hops + W - 1);
@@ -617,7 +717,7 @@ int zen_hip_hpr_get_params(zen_hip_hpr_t h, zen_hip_hpr_params* p)
 	p->freq_len = h->mf;
 	p->cola_factor = h->cola;
 	p->n_streams = h->n_streams;
-	p->max_hops_per_chunk = h->max_hops;
+	p->max_hops_per_chunk = h->max_hops_cap;
 	return ZEN_HIP_OK;
 }
 
@@ -661,6 +761,8 @@ int zen_hip_hpr_process(zen_hip_hpr_t h, const float* in_dev, size_t n_hops, siz
 	if (!h || !in_dev)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpr_process: null argument");
 	float* outs[3] = {out_perc_dev, out_harm_dev, out_resid_dev};
+	if (n_hops > h->max_hops && h->max_hops < h->max_hops_cap)
+		ZH_TRY(grow_buffers(h, n_hops < h->max_hops_cap ? n_hops : h->max_hops_cap));
 	for (size_t off = 0; off < n_hops; off += h->max_hops) {
 		const size_t M = (n_hops - off < h->max_hops) ? n_hops - off : h->max_hops;
 		ZH_TRY(run_chunk(h, in_dev + off * h->hop, in_stride, M));
@@ -681,7 +783,8 @@ int zen_hip_hpr_process_next_hop(zen_hip_hpr_t h, const float* in_dev)
 // host address of a copy_* destination if it is (mapped) host memory, else null; one lookup per distinct pointer
 static void* host_alias_of(zen_hip_hpr_t h, const void* out_dev)
 {
-	if (h->out_query_dev == out_dev)
+	const unsigned gen = g_host_free_gen.load(std::memory_order_relaxed);
+	if (h->out_query_dev == out_dev && h->out_query_gen == gen)
 		return h->out_query_host;
 	hipPointerAttribute_t at;
 	void* host = nullptr;
@@ -695,7 +798,19 @@ static void* host_alias_of(zen_hip_hpr_t h, const void* out_dev)
 	}
 	h->out_query_dev = out_dev;
 	h->out_query_host = host;
+	h->out_query_gen = gen;
 	return host;
+}
+
+// rt_wide.hip: a grid barrier that gave up waiting (a cooperating workgroup never arrived) marks a host-mapped word
+// before the kernel goes on with incomplete data; the sequence word is still published.  Every synchronous copy_*
+// looks at the mark (the asynchronous one cannot: the next synchronous call, or reset_buffers, reports / clears it).
+static int check_wide_fail(zen_hip_hpr_t h)
+{
+	if (h->wide_fail_host && __atomic_load_n(h->wide_fail_host, __ATOMIC_ACQUIRE))
+		ZH_FAIL(ZEN_HIP_E_HIP, "hpr_copy_output: a workgroup of the cooperative single-hop kernel never reached its grid "
+		                       "barrier; the hop is invalid (zen_hip_hpr_reset_buffers clears the mark)");
+	return ZEN_HIP_OK;
 }
 
 static int copy_output_impl(zen_hip_hpr_t h, unsigned which, float* out_dev, bool sync)
@@ -708,7 +823,7 @@ static int copy_output_impl(zen_hip_hpr_t h, unsigned which, float* out_dev, boo
 	if (h->last_frames == 0) { // before any hop: the zero accumulator
 		ZH_HIP(hipMemsetAsync(out_dev, 0, sizeof(float) * h->hop * h->n_streams, h->stream));
 	}
-	else if (h->last_frames == 1 && h->ready_valid[o] && output_computed(h, o)) {
+	else if (h->last_frames == 1 && h->ready_valid[o] && output_served(h, o)) {
 		// the hop was finished by the synthesis kernel itself (InvOut / IstftOut): no launch here
 		const size_t bytes = sizeof(float) * h->hop * h->n_streams;
 		void* host = (sync && h->ready_host[o]) ? host_alias_of(h, out_dev) : nullptr;
@@ -724,15 +839,11 @@ static int copy_output_impl(zen_hip_hpr_t h, unsigned which, float* out_dev, boo
 				}
 				__builtin_ia32_pause();
 			}
-			if (!seen) { // a fault or a hang: let the runtime report it
+			if (!seen || h->async_pending) { // a fault or a hang: let the runtime report it; or earlier asynchronous copies
 				ZH_HIP(hipStreamSynchronize(h->stream));
-				if (h->d_wide_bar) { // rt_wide.hip: a grid barrier that gave up waiting leaves a mark (word 1 of a stream's four)
-					unsigned words[4] = {0, 0, 0, 0};
-					ZH_HIP(hipMemcpy(words, h->d_wide_bar, sizeof(words), hipMemcpyDeviceToHost));
-					if (words[1])
-						ZH_FAIL(ZEN_HIP_E_HIP, "hpr_copy_output: a workgroup of the cooperative single-hop kernel never reached its grid barrier");
-				}
+				h->async_pending = false;
 			}
+			ZH_TRY(check_wide_fail(h));
 			memcpy(host, h->ready_host[o], bytes);
 			return ZEN_HIP_OK;
 		}
@@ -742,8 +853,14 @@ static int copy_output_impl(zen_hip_hpr_t h, unsigned which, float* out_dev, boo
 		const size_t M = h->last_frames;
 		ZH_TRY(finalize_output(h, o, out_dev, M * h->hop, M));
 	}
-	if (sync)
+	if (sync) {
 		ZH_HIP(hipStreamSynchronize(h->stream));
+		h->async_pending = false;
+		ZH_TRY(check_wide_fail(h));
+	}
+	else {
+		h->async_pending = true;
+	}
 	return ZEN_HIP_OK;
 }
 

@@ -15,7 +15,8 @@ struct zen_hip_hpr {
 	int causality, log2n, mt, mf;
 	float cola;
 	bool out_h, out_p, out_r, use_sse, soft;
-	size_t n_streams, max_hops;
+	size_t n_streams, max_hops; // max_hops: hops per chunk the buffers are allocated for right now ...
+	size_t max_hops_cap;        // ... and the most they may grow to (zen_hip_hpr_process grows them to the call's size)
 	long long ring_rows;
 	size_t s_stride; // float2 per spectrum-ring row: nfft/2 + 1 bins, padded to a 64-byte multiple
 	hipStream_t stream;
@@ -34,7 +35,11 @@ struct zen_hip_hpr {
 	size_t last_frames = 0;
 	// An output that stops being computed (residual after use_soft_mask / use_sse_filter, hps.cu:562, :582-652)
 	// still owes the second half of its last frame: the reference's accumulator is shifted, not cleared.
-	bool drain[3] = {false, false, false};
+	// 0: nothing owed.  1: switched off, no hop processed since: copy_* still hands out the last finished hop(s), as
+	// the reference's untouched accumulator does.  2: one call processed since: the first hop of that call's copy_* is
+	// the parked tail, the rest zeros (hps.cu:435-449 rotates the accumulator of every ENABLED output each hop, whether
+	// or not something is added to it).  Back to 0 with the call after that.
+	int drain[3] = {0, 0, 0};
 	// Single-hop calls (the realtime API): the synthesis kernel itself adds the two overlapping halves and
 	// leaves the finished hop in `ready` -- host-mapped staging memory for a single stream, so that copy_*
 	// is a fence plus a 4*hop-byte host copy instead of a second launch; device memory otherwise.
@@ -46,11 +51,16 @@ struct zen_hip_hpr {
 	unsigned* d_wide_bar = nullptr;
 	unsigned wide_arrivals = 0;
 	unsigned wide_calls = 0;
+	unsigned* wide_fail_host = nullptr; // pinned, mapped: a grid barrier of rt_wide.hip that gave up waiting sets it;
+	unsigned* wide_fail_dev = nullptr;  // every copy_* looks at it (a hop computed past a timed-out barrier is garbage)
 	unsigned hop_seq = 0; // number of the last single-hop call; the kernels publish it behind the finished hop
 	unsigned long long* dbg_stamps = nullptr;      // device alias of ...
 	unsigned long long* dbg_stamps_host = nullptr; // ... the mapped stamp buffer of zen_hip_hpr_debug_stamps
 	const void* out_query_dev = nullptr; // last copy_* destination looked up with hipPointerGetAttributes ...
 	void* out_query_host = nullptr;      // ... and its host address (null: not host memory)
+	bool async_pending = false;          // a copy_output_async since the last stream synchronise: the polling fast path of
+	                                     // the synchronous copy_* synchronises first, so that "everything before is done" holds
+	unsigned out_query_gen = 0;          // zen_hip_host_free count at the time of the lookup (a freed buffer's address may be reused)
 
 	// profiling hook (bench.py): HIP events around every launch, per kernel class
 	enum { K_STFT = 0, K_FREQ = 1, K_TIME = 2, K_ISTFT = 3, K_FINALIZE = 4, K_FUSED = 5, K_COUNT = 6 };

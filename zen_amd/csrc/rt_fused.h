@@ -46,6 +46,7 @@ struct RtFusedArgs {
 	unsigned* bar;
 	unsigned bar_base;
 	int bar_parity;         // which of the two placement-vote words this call uses (alternates)
+	unsigned* wide_fail;    // host-mapped word: set (and never cleared by the device) when a grid barrier gave up waiting
 	int diag;               // 0; 1 / 2: timing diagnostics of rt_fused_kernel (results are not valid)
 	unsigned long long* stamps; // diagnostic: 8 s_memrealtime stamps (100 MHz) of workgroup 0's phases, or null
 };

@@ -130,12 +130,21 @@ __device__ __forceinline__ bool placement_vote_result(const unsigned* vote)
 	return one;
 }
 
-__device__ __forceinline__ void grid_sync(unsigned* bar, unsigned target, bool light)
+// What every wave does before it arrives at a barrier.  Light: the stores only have to be IN the shared L2, which
+// they are once the memory counter has drained -- a workgroup-scope release fence compiles to nothing on gfx950 (no
+// s_waitcnt at all: the arrival atomic could overtake stores still in flight), so the wait is written out.
+// Agent scope: the fence emits buffer_wbl2 + s_waitcnt vmcnt(0).
+__device__ __forceinline__ void release_stores(bool light)
 {
 	if (light)
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	else
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+}
+
+__device__ __forceinline__ void grid_sync(unsigned* bar, unsigned target, bool light, unsigned* fail)
+{
+	release_stores(light);
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		// the last to arrive (the one everybody waits for) knows it from the value the add returns: no polling trip
@@ -146,6 +155,10 @@ __device__ __forceinline__ void grid_sync(unsigned* bar, unsigned target, bool l
 			__builtin_amdgcn_s_sleep(1);
 			if (++spins > (1 << 22)) {
 				__hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (fail) { // host-mapped: every later copy_* of the engine reports the hop as failed (hpr.hip)
+					__hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					__threadfence_system();
+				}
 				break;
 			}
 		}
@@ -268,7 +281,7 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 			if (g == 0 && t == 0)
 				__hip_atomic_store(bar + 2 + ((a.bar_parity & 1) ^ 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
-		grid_sync(bar, arrivals, light);
+		grid_sync(bar, arrivals, light, a.wide_fail);
 		stamp(k + 1);
 	};
 	stamp(0);
@@ -418,10 +431,7 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 		else { // the call's last barrier: nobody waits, whoever arrives last publishes the hop
 			stamp(oi == 0 ? 9 : 12);
 			arrivals += G;
-			if (light)
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			else
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+			release_stores(light);
 			__syncthreads();
 			if (t == 0) {
 				const unsigned before = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);

@@ -83,5 +83,7 @@ int launch_istft(int log2n, const IstftArgs& a, hipStream_t stream);
 int launch_finalize(const FinalizeArgs& a, hipStream_t stream);
 // FFTC2CWrapperGPU::forward/backward (fftw.h:35-43), `batch` consecutive transforms in place
 int launch_fft(int log2n, float2* data, const float2* tw, size_t batch, int inverse, hipStream_t stream);
+// the same for nfft = 32768 (fft_big.hip: two steps through `xch`, batch * nfft float2 of scratch)
+int launch_fft_big(int log2n, float2* data, float2* xch, const float2* tw, size_t batch, int inverse, hipStream_t stream);
 
 } // namespace zen_hip_impl

@@ -45,6 +45,12 @@ SYMBOLS = [
     ("zen_hip_version", C.c_char_p, []),
     ("zen_hip_device_name", _i, [C.c_char_p, _sz]),
     ("zen_hip_synchronize", _i, [_vp]),
+    ("zen_hip_stream_create", _i, [_pvp]),
+    ("zen_hip_stream_destroy", _i, [_vp]),
+    ("zen_hip_event_create", _i, [_pvp]),
+    ("zen_hip_event_record", _i, [_vp, _vp]),
+    ("zen_hip_event_elapsed_ms", _i, [_vp, _vp, C.POINTER(C.c_float)]),
+    ("zen_hip_event_destroy", _i, [_vp]),
     ("zen_hip_set_option", _i, [C.c_char_p, _i]),
     ("zen_hip_malloc", _i, [_pvp, _sz]),
     ("zen_hip_free", _i, [_vp]),
@@ -126,6 +132,28 @@ def init(device=0):
     for item in filter(None, os.environ.get("ZEN_HIP_OPTIONS", "").split(",")):
         name, _, val = item.partition("=")
         set_option(name.strip(), int(val or 1))
+
+
+class Event:
+    """hipEvent_t on a stream (zen_hip_event_*): the harness's clock around a launch."""
+
+    def __init__(self):
+        e = C.c_void_p()
+        _ck(load().zen_hip_event_create(C.byref(e)))
+        self._e = e.value
+
+    def record(self, stream=None):
+        _ck(load().zen_hip_event_record(self._e, stream))
+
+    def elapsed_ms(self, stop):
+        ms = C.c_float()
+        _ck(load().zen_hip_event_elapsed_ms(self._e, stop._e, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        if getattr(self, "_e", None):
+            load().zen_hip_event_destroy(self._e)
+            self._e = None
 
 
 def synchronize(stream=None):
