@@ -128,10 +128,12 @@ def cpu_baseline_realtime(x, budget_s=12.0):
         h.process_next_hop(x[i * HOP:(i + 1) * HOP])
         _ = h.percussive_out            # copy_percussive
     dt = time.perf_counter() - t0
+    from oracle import ipp_probe                      # "if the box has ipp.h / libipp*, say so"
     return {"value": n / dt, "unit": "hops/s", "cores": 1, "kind": "port",
             "sample": "first %d hops (%.1f s of audio) of the same S-music stream, oracle/zen_oracle.c "
                       "HPR<CPU> hop 1024 P-only causal, 1 thread" % (n, n * HOP / FS),
-            "ms_per_hop": 1e3 * dt / n, "host_cpu": host_cpu_name(), "host_cores_available": os.cpu_count()}
+            "ms_per_hop": 1e3 * dt / n, "host_cpu": host_cpu_name(), "host_cores_available": os.cpu_count(),
+            "ipp": ipp_probe.check()}
 
 
 def cpu_baseline_offline(x, hop_h, hop_p, total_hops_per_clip, seconds=6.0, beta=BETA, soft=False):

@@ -124,10 +124,10 @@ def test_full_size_offline_long_config3_properties(z):
     m = int(4 * FS)
     rh, rp, _ = oo.process(x[:int(6 * FS)])
     assert np.array_equal(H[:m], rh[:m]) and np.array_equal(P[:m], rp[:m])
-    # a 2 s range in the middle from the oracle: zero state 8 pass-1 hops (and > 2W+2 pass-2 hops) before it is the
+    # a 2 s range in the middle from the oracle: zero state 12 pass-1 hops (and > 2W+2 pass-2 hops) before it is the
     # same warm-up the sharded engine uses (hpri.hip plan_range)
     b0 = (n // 2 // hop_h) * hop_h
-    lead, m2 = 8 * hop_h, int(2 * FS)
+    lead, m2 = 12 * hop_h, int(2 * FS)
     oo2 = o.HPRIOffline(FS, hop_h, hop_p, 2.5, 2.5)
     oo2.use_soft_mask()
     rh2, rp2, _ = oo2.process(x[b0 - lead:b0 + m2 + 8 * hop_h])
@@ -144,7 +144,7 @@ def test_dropped_output_drains_like_the_reference(z, switch, caus, hop):
     the second half of the last frame after that hop (on every copy), zeros from the hop after.  Sequence:
     hops, copy, switch, copy, copy, hop, copy, copy, hop, copy -- through the per-hop API and the oracle."""
     from tests.test_gpu_parity import music
-    n_pre = 9
+    n_pre = 16                                        # (anticausal hop 256: the first lag = 11 output hops are the zero state)
     x = music(hop * (n_pre + 3), 33)
     ref = o.HPR(FS, hop, 2.0, ALL, caus)
     g = z.HPR(FS, hop, 2.0, ALL, caus, True, 1, 1)

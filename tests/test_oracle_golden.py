@@ -148,3 +148,20 @@ def test_box_reference_column_vectors(x, y, f):
     with np.errstate(divide="ignore"):
         back = (np.float32(f + 1.0) / res).astype(np.float32)
     assert np.array_equal(back, exp)
+
+
+def test_ipp_probe_reports_what_it_found():
+    """BASELINE.md section 3 / SURVEY 8(d): a configure-time probe for ipp.h + libipp*; where IPP exists the literal
+    calls of the reference are run next to the restatement (oracle/ipp_check.c).  This pool has no IPP: the probe must
+    say so, name where it looked, and leave the port as the baseline."""
+    from oracle import ipp_probe
+    p = ipp_probe.check()
+    assert isinstance(p["found"], bool) and len(p["searched"]) >= 3
+    if p["found"]:
+        assert "report" in p or "error" in p
+        if "report" in p:                      # the median is an order statistic: IPP and the restatement must agree exactly
+            for c in p["report"]["cases"]:
+                if c["case"].startswith("median"):
+                    assert c["differing"] == 0, c
+    else:
+        assert "report" not in p
