@@ -26,7 +26,7 @@ timeout 1300 tools/pmc_cmd.sh median47_dpp_kernel $B --no-block-fused > $OUT/pmc
 timeout 1300 tools/pmc_cmd.sh median47_dpp_kernel python3 tools/bench_median.py --suite one --rows 25840 --cols 4096 --len 47 --iters 6 --nonneg > $OUT/pmc_median47_whole.json 2>> $OUT/pmc.err
 T=$OUT/hbm_traffic.json; rm -f $T
 python3 tools/traffic_json.py $T "$REV" $OUT/pmc_fused_p.json "rt_fused_kernel<12, 47, 3, true, true>" $((25840*4096)) 25840 4096 "one workgroup per hop, percussive output" >> $OUT/pmc.err 2>&1
-python3 tools/traffic_json.py $T "$REV" $OUT/pmc_fused_hpr.json "rt_fused_kernel<12, 47, 3, false, false>" $((25840*4096)) 25840 4096 "one workgroup per hop, three outputs" >> $OUT/pmc.err 2>&1
+python3 tools/traffic_json.py $T "$REV" $OUT/pmc_fused_hpr.json "rt_fused_kernel<12, 47, 3, false, true>" $((25840*4096)) 25840 4096 "one workgroup per hop, three outputs" >> $OUT/pmc.err 2>&1
 python3 tools/traffic_json.py $T "$REV" $OUT/pmc_fused_p_minb2.json "rt_fused_kernel<12, 47, 2, true, true>" $((25840*4096)) 25840 4096 "the two-workgroups-per-CU build: no scratch -- what the write traffic is without spills" >> $OUT/pmc.err 2>&1
 python3 tools/traffic_json.py $T "$REV" $OUT/pmc_median47_half.json "median47_dpp_kernel<true, 0, true>" $((25840*2072)) 25840 4096 "engine launch: bins 0..2048 and 4073..4095 of every row" >> $OUT/pmc.err 2>&1
 python3 tools/traffic_json.py $T "$REV" $OUT/pmc_median47_whole.json "median47_dpp_kernel<true, 0, false>" $((25840*4096)) 25840 4096 "whole rows (BASELINE's median metric)" >> $OUT/pmc.err 2>&1

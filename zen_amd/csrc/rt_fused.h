@@ -54,6 +54,7 @@ struct RtFusedArgs {
 bool rt_fused_available(int log2n, int freq_len);
 int launch_rt_fused(int log2n, int freq_len, const RtFusedArgs& a, hipStream_t stream);
 int launch_rt_fused_multi(int log2n, int freq_len, const RtFusedArgs& a, hipStream_t stream); // n_out > 1 (rt_fused_multi.hip)
+int launch_rt_fused_multi_lean(const RtFusedArgs& a, hipStream_t stream); // nfft 4096, 47 taps, n_out > 1, hard masks, blocks (rt_fused_multi_lean.hip)
 
 // rt_sse.hip: the causal SSE path (apply_sse_filter, hps.cu:582-652) for ONE hop per stream in one launch.  len_t /
 // len_f: the odd box lengths (time, frequency), fac_h / fac_p: l_harm + 1, l_perc + 1 (hps.cu:599-604).

@@ -155,6 +155,46 @@ struct InvInLean {
 	}
 };
 
+// LEAN build with several outputs (hard masks): the two binary masks of the thread's 16 bins are compared ONCE, between
+// the median stage and the first inverse transform, and kept as two bits per bin (as istft_hard_multi_kernel keeps
+// them); every output's transform then reads nothing but the spectrum registers.  Same values as mask_value().
+template <int N, int TF, int MID>
+__device__ __forceinline__ unsigned lean_mask_bits(const int* img, const float* pc, int tf, const MaskCfg& cfg, double thr_p,
+                                                   double thr_h)
+{
+	unsigned bits = 0;
+#pragma unroll
+	for (int slot = 0; slot < 16; ++slot) {
+		const int idx = tf + slot * TF, lo = slot * TF, hi = lo + TF - 1;
+		int pi; // where P of bin idx lives in the compact half row (InvInLean)
+		if (hi <= N / 2)
+			pi = idx;
+		else if (lo > N / 2 && hi < N - MID)
+			pi = N - idx;
+		else
+			pi = (idx > N / 2 && idx < N - MID) ? N - idx : (idx > N / 2 ? idx - (N - 512) + LEAN_PC_TAIL : idx);
+		const int g = idx + 24;
+		const float h = __int_as_float(img[(g >> 4) * 20 + (g & 15)]), p = pc[pi]; // H = |S|: causal, SURVEY Q1
+		const HardThr t{thr_p, thr_h, 0, 0};
+		const unsigned pm = cfg.out_p ? (unsigned)(pmask_thr(h, p, cfg, t) != 0.0f) : 0u;
+		const unsigned hm = cfg.out_h ? (unsigned)(hmask_thr(h, p, cfg, t) != 0.0f) : 0u;
+		bits |= (pm | (hm << 1)) << (2 * slot);
+	}
+	return bits;
+}
+struct InvInBits {
+	const Regs* r;
+	unsigned bits;
+	int which;
+	__device__ __forceinline__ float2 operator()(int, int slot) const
+	{
+		const float pm = (float)((bits >> (2 * slot)) & 1u), hm = (float)((bits >> (2 * slot + 1)) & 1u);
+		const float m = which == 0 ? pm : (which == 1 ? hm : 1 - (hm + pm)); // residual_mask_functor hps.h:35-43
+		const float2 z = r->S[slot];
+		return make_float2(z.x * m, z.y * m); // apply_mask_functor hps.h:58-66
+	}
+};
+
 struct InvOut { // block builds
 	float* Y;
 	float cola;
@@ -214,8 +254,8 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 	// median47_core.h on the half spectrum
 	// (with several outputs the spectrum registers live through a loop of inverse transforms; the block scheme's
 	// pieces on top of them spill, 1.19 against 1.13 ms with the generic median stage: one output only)
-	constexpr bool BLOCK47 = (W == 47 && LOG2N == 12 && SINGLE);
-	static_assert(!LEAN || (BLOCK47 && SINGLE), "the lean layout is the one-output 47-tap kernel");
+	constexpr bool BLOCK47 = (W == 47 && LOG2N == 12 && (SINGLE || LEAN));
+	static_assert(!LEAN || BLOCK47, "the lean layout is the 47-tap kernel (one output, or several with hard masks)");
 	static_assert(!LEAN || (LEAN_EDGE_WORD + 256) * 4 <= PL::LDS_FLOAT2 * 8, "lean layout must fit in the frame image");
 
 	extern __shared__ float2 lds[];       // [FFT image | P row]; the magnitude image aliases the FFT image
@@ -223,7 +263,14 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 	float* Prow = LEAN ? reinterpret_cast<float*>(img + LEAN_PC_WORD) : reinterpret_cast<float*>(lds + PL::LDS_FLOAT2);
 
 	const int tf = threadIdx.x, hop = a.hop;
-	const int s = blockIdx.x / a.n_frames, f = blockIdx.x - s * a.n_frames; // consecutive blocks: consecutive hops
+	// XCD-aware order.  Workgroups are dealt to the eight XCDs round-robin (workgroup b runs on XCD b % 8), each with its
+	// own L2; consecutive hops share an input hop (frame f = hops f-1, f).  Workgroup b therefore takes item
+	// (b % 8) * (total / 8) + b / 8 of the launch: the workgroups of one XCD walk through consecutive hops, and the
+	// shared hop is an L2 hit instead of a second fetch from memory by another XCD (measured before the change: 220 MB
+	// read per 25 840-hop launch for 106 MB of input).  Any other placement is only slower, not wrong.
+	const int total = a.n_streams * a.n_frames, xq = total >> 3, xr = total & 7, xcd = blockIdx.x & 7;
+	const int item = xcd * xq + (xcd < xr ? xcd : xr) + (blockIdx.x >> 3);
+	const int s = item / a.n_frames, f = item - s * a.n_frames;
 	// diagnostic hook (tools/rt_latency.cpp --stamps): phase times of a single-hop call (100 MHz), kept in scalar
 	// registers until the end -- a store to the host-mapped stamp buffer in front of a barrier would be waited for
 	// there -- and only in the single-hop build.
@@ -437,7 +484,43 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 	}
 	__syncthreads(); // P row complete
 	stamp(3);
-	if constexpr (LEAN) { // |S| and P are read inside the first inverse pass, which then meets at a barrier
+	if constexpr (LEAN && !SINGLE) { // several outputs, hard masks: two bits per bin, then one transform per output
+		if (a.diag == 2)
+			return;
+		const MaskCfg cfg{a.beta, a.beta_h, 0, a.power, 0, a.out_h, a.out_p};
+		const unsigned bits = lean_mask_bits<N, TF, mid>(img, Prow, tf, cfg, a.thr, a.thr_h);
+		__syncthreads(); // the magnitude image and the P row are dead: the transforms overwrite them
+		for (int oi = 0; oi < a.n_out; ++oi) {
+			const int which = a.out_id[oi];
+			InvInBits in{&r, bits, which};
+			OutT out;
+			out.Y = a.Y[which] + (long long)s * a.y_stream_stride + (long long)f * (2 * hop);
+			out.cola = a.cola;
+			out.ready = (a.n_frames == 1 && a.ready[which]) ? a.ready[which] + (long long)s * hop : nullptr;
+			if constexpr (MINB == 1) {
+				pick_carry(which, out.cv);
+			}
+			else {
+				out.carry = a.carry[which] + (long long)s * hop;
+			}
+			out.hop = hop;
+			// opaque per output (see istft_hard_multi_kernel): otherwise every LDS address and twiddle index of the
+			// transform, all functions of tf alone, is hoisted out of this loop and kept in registers
+			int tf_o = tf;
+			const float2* tw_o = a.tw;
+			asm volatile("" : "+v"(tf_o));
+			asm volatile("" : "+s"(tw_o));
+			if constexpr (TWC)
+				zfft::fft_frame<LOG2N, true, false, true>(tf_o, lds, twr, in, out, true);
+			else
+				zfft::fft_frame<LOG2N, true, false, true>(tf_o, lds, tw_o, in, out, true);
+			if (out.ready && a.publish_seq)
+				publish_ready(reinterpret_cast<unsigned*>(out.ready + hop), a.seq, tf);
+			__syncthreads(); // the frame image is reused by the next output
+		}
+		return;
+	}
+	else if constexpr (LEAN) { // |S| and P are read inside the first inverse pass, which then meets at a barrier
 		if (a.diag == 2)
 			return;
 		InvInLean<N, TF, mid> in;
@@ -541,10 +624,22 @@ int launch_k(const RtFusedArgs& a, hipStream_t stream)
 // BLOCK_MINB workgroups per CU
 // The kernels for several outputs are instantiated in a translation unit of their own (rt_fused_multi.hip, which
 // includes this file with ZEN_RT_FUSED_MULTI defined): the two sets want different scheduler flags (build.py).
-#ifdef ZEN_RT_FUSED_MULTI
+#if defined(ZEN_RT_FUSED_MULTI_LEAN)
+// (rt_fused_multi_lean.hip: the several-output lean kernel alone, compiled with the default scheduler -- no scratch
+// there, 12 bytes per lane under the max-ILP strategy the other several-output builds want)
+#elif defined(ZEN_RT_FUSED_MULTI)
 template <int LOG2N, int W>
 int launch_multi_t(const RtFusedArgs& a, hipStream_t stream)
 {
+	if constexpr (LOG2N == 12 && W == 47) {
+		// hard masks, blocks of hops: the lean layout with the masks kept as two bits per bin ("block_fused_minb" = 5:
+		// the roomy layout below, 6: this translation unit's build of the lean kernel, for comparison)
+		if (a.n_frames > 1 && !a.soft && g_opt_block_fused_minb != 5 && g_opt_block_fused_minb != 1 && g_opt_block_fused_minb != 2) {
+			if (g_opt_block_fused_minb == 6)
+				return launch_k<LOG2N, W, 3, false, true>(a, stream);
+			return launch_rt_fused_multi_lean(a, stream);
+		}
+	}
 	if (a.n_frames == 1 || g_opt_block_fused_minb == 1)
 		return launch_k<LOG2N, W, 1, false>(a, stream);
 	if (g_opt_block_fused_minb == 2)
@@ -563,7 +658,7 @@ int launch_t(const RtFusedArgs& a, hipStream_t stream)
 		// 0.74 ms against 0.60 ms per 25 840 hops, measured); "block_fused_minb" = 4 selects that build, 5 the
 		// roomy layout below, for comparison.
 		if (a.n_out == 1 && g_opt_block_fused_minb != 5) {
-			if (a.n_frames == 1)
+			if (a.n_frames == 1 || g_opt_block_fused_minb == 1) // (1 on a block: the register-rich build, no scratch -- a diagnostic)
 				return launch_k<LOG2N, W, 1, true, true>(a, stream);
 			if (g_opt_block_fused_minb == 4)
 				return launch_k<LOG2N, W, 4, true, true>(a, stream);
@@ -580,7 +675,9 @@ int launch_t(const RtFusedArgs& a, hipStream_t stream)
 
 } // namespace
 
-#ifdef ZEN_RT_FUSED_MULTI
+#if defined(ZEN_RT_FUSED_MULTI_LEAN)
+int launch_rt_fused_multi_lean(const RtFusedArgs& a, hipStream_t stream) { return launch_k<12, 47, 3, false, true>(a, stream); }
+#elif defined(ZEN_RT_FUSED_MULTI)
 int launch_rt_fused_multi(int log2n, int freq_len, const RtFusedArgs& a, hipStream_t stream)
 {
 	switch (log2n * 100 + freq_len) {
