@@ -77,9 +77,8 @@ int zen_hip_event_destroy(void* event);
  * 47-tap frequency masks on 4096-bin rows through the generic sorting-network kernel instead of
  * median47_dpp_kernel, "no_median47_neighbour" = 1 additionally switches off that kernel's DPP exchange of
  * sorted blocks; "no_half_rows" = 1 makes the three-kernel path store and filter whole magnitude rows instead of the
- * non-redundant half (bins 0..nfft/2); "two_step" = 0 sends blocks of frames at nfft 8192 / 16384 through the one-piece
- * transform kernels (one frame per CU) instead of the two-step ones, "two_step_frames" = n sizes their sub-batches;
- * "mfilt_nonneg" = 1: the caller promises that every sample handed to
+ * non-redundant half (bins 0..nfft/2); "no_persist" = 1 sends blocks of frames at nfft 8192 / 16384 through the
+ * one-frame-per-workgroup transform kernels instead of the persistent ones; "mfilt_nonneg" = 1: the caller promises that every sample handed to
  * zen_hip_mfilt_run is >= +0 (a magnitude matrix), so the filter orders by the raw bits as the engine's own launches do
  * (the kernel build BASELINE's median metric is quoted on); "median47_variant" = 1 lets median47_dpp_kernel store results without the LDS transpose (2, 3: timing
  * diagnostics whose outputs are not medians). */

@@ -326,45 +326,42 @@ def test_long_hop_single_launch_under_contention(z, hop):
     assert np.array_equal(out, ref)
 
 
-# ---------------------------------------------------------------------------- two-step block transforms (nfft 8192 / 16384)
-@pytest.mark.parametrize("fs,hop,caus,soft,streams", [(44100.0, 4096, o.TIME_ANTICAUSAL, False, 1), (44100.0, 4096, o.TIME_CAUSAL, True, 1),
-                                                       (44100.0, 2048, o.TIME_ANTICAUSAL, False, 2), (48000.0, 4096, o.TIME_ANTICAUSAL, True, 1),
-                                                       (44100.0, 2048, o.TIME_CAUSAL, False, 1)])
-@pytest.mark.parametrize("two_step,sub", [(1, 0), (1, 7), (0, 0)])
-def test_long_transforms_in_blocks_two_step_and_one_piece(z, fs, hop, caus, soft, streams, two_step, sub):
-    """Blocks of frames at nfft 8192 / 16384 (pass 1 of the default offline configuration) go through the two-step
-    kernels of stft_two_step.hip (many small workgroups, exchange through a scratch buffer, sub-batches of frames) or
-    the one-piece kernels (one frame per CU): both must give the oracle's samples, with any sub-batch size, across
-    calls (the input tail and the overlap-add carry change hands between the two kinds of kernels)."""
+# ---------------------------------------------------------------------------- persistent transform kernels (nfft 8192 / 16384)
+@pytest.mark.parametrize("hop,n_hops,soft", [(2048, 1100, False), (4096, 600, False), (4096, 600, True), (2048, 1100, True)])
+def test_long_transforms_persistent_kernels(z, hop, n_hops, soft):
+    """Blocks of >= 512 / 1024 frames at nfft 16384 / 8192 go through persistent workgroups (a run of consecutive frames
+    each, the next frame's spectrum loaded during the current frame's last pass: stft.hip / istft.hip *_persist_kernel).
+    Same samples as one workgroup per frame ("no_persist"), and as the oracle on a prefix and -- through the state the
+    engine carries from call to call -- on a second call."""
     from tests.test_gpu_parity import music, same
-    n_hops = 70
-    x = np.stack([music(hop * n_hops, 50 + s, fs) for s in range(streams)])
-    refs = []
-    for s in range(streams):
-        h = o.HPR(fs, hop, 2.0, ALL, caus)
-        if soft:
-            h.use_soft_mask()
-        refs.append(h.process_stream(x[s]))
-    ref = {k: np.stack([r[k] for r in refs]) for k in "PHR"}
-    z.set_option("no_block_fused", 1)            # (the causal cases: the general engine, not the fused per-hop kernel)
-    z.set_option("two_step", two_step)
-    z.set_option("two_step_frames", sub)
-    try:
-        g = z.HPR(fs, hop, 2.0, ALL, caus, True, streams)
-        if soft:
-            g.use_soft_mask()
-        got = g.process_stream_host(x if streams > 1 else x[0], block=40)      # 40 + 30 hops: two calls, a carry between them
-        z.set_option("two_step", 1 - two_step)                                   # and the other kind takes over in mid-stream
-        g2 = z.HPR(fs, hop, 2.0, ALL, caus, True, streams)
-        if soft:
-            g2.use_soft_mask()
-        a = g2.process_stream_host((x if streams > 1 else x[0])[..., :hop * 35])
-        z.set_option("two_step", two_step)
-        b = g2.process_stream_host((x if streams > 1 else x[0])[..., hop * 35:])
-    finally:
-        z.set_option("two_step", 1)
-        z.set_option("two_step_frames", 0)
-        z.set_option("no_block_fused", 0)
-    want = ref if streams > 1 else {k: v[0] for k, v in ref.items()}
-    assert same(got, want)
-    assert same({k: np.concatenate([a[k], b[k]], axis=-1) for k in "PHR"}, want)
+    x = music(hop * n_hops, 60 + hop)
+
+    def run(no_persist):
+        z.set_option("no_persist", no_persist)
+        try:
+            g = z.HPR(FS, hop, 2.0, ALL, z.TIME_ANTICAUSAL)
+            if soft:
+                g.use_soft_mask()
+            a = g.process_stream_host(x[:hop * (n_hops - 30)])      # persistent (when allowed)
+            b = g.process_stream_host(x[hop * (n_hops - 30):])      # 30 hops: one workgroup per frame either way
+        finally:
+            z.set_option("no_persist", 0)
+        return {k: np.concatenate([a[k], b[k]]) for k in "PHR"}
+
+    got, plain = run(0), run(1)
+    assert same(got, plain)
+    m = 36
+    ho = o.HPR(FS, hop, 2.0, ALL, o.TIME_ANTICAUSAL)
+    if soft:
+        ho.use_soft_mask()
+    ref = ho.process_stream(x[:hop * m])
+    for k in "PHR":
+        assert np.array_equal(got[k][:hop * m], ref[k]), k
+    # the tail of the stream against an oracle that starts a few hops earlier (state = the last stft_width + 1 hops)
+    j = n_hops - 44
+    ho2 = o.HPR(FS, hop, 2.0, ALL, o.TIME_ANTICAUSAL)
+    if soft:
+        ho2.use_soft_mask()
+    ref2 = ho2.process_stream(x[hop * j:])
+    for k in "PHR":
+        assert np.array_equal(got[k][hop * (j + 8):], ref2[k][hop * 8:]), k

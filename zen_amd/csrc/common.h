@@ -23,8 +23,7 @@ extern opt_t g_opt_no_median47_neighbour; // "no_median47_neighbour": generic 47
 extern opt_t g_opt_median_general;       // "median_general": force the general wave kernel
 extern opt_t g_opt_no_median47_dpp;      // "no_median47_dpp": 4096-bin rows / 47 taps through the generic kernel
 extern opt_t g_opt_no_half_rows;         // "no_half_rows": the three-kernel path stores and filters whole magnitude rows
-extern opt_t g_opt_two_step;            // "two_step": blocks of frames at nfft 8192 / 16384 through stft_two_step.hip (1, default) or the one-piece kernels (0)
-extern opt_t g_opt_two_step_frames;     // "two_step_frames": frames per sub-batch of those kernels (0: 128 MB of exchange scratch)
+extern opt_t g_opt_no_persist;          // "no_persist": blocks of frames at nfft 8192 / 16384 through the one-frame-per-workgroup kernels
 extern opt_t g_opt_mfilt_nonneg;        // "mfilt_nonneg": zen_hip_mfilt_run's input is promised to be >= +0 (raw-bit ordering keys)
 extern opt_t g_opt_mask_divide;          // "mask_divide": the lean fused kernel forms its hard mask with the IEEE divide
 extern opt_t g_opt_rt_fused_diag;         // "rt_fused_diag": 1 = fused kernel without its median stage, 2 = without synthesis (timing only)

@@ -96,7 +96,6 @@ void free_all(zen_hip_hpr* e)
 	(void)hipFree(e->d_mag);
 	(void)hipFree(e->d_H);
 	(void)hipFree(e->d_P);
-	(void)hipFree(e->d_xch2);
 	for (int o = 0; o < 3; ++o) {
 		(void)hipFree(e->d_Y[o]);
 		(void)hipFree(e->d_carry[o]);
@@ -338,31 +337,9 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 		sa.Y[o] = e->d_Y[o];
 	}
 	sa.y_stream_stride = (long long)(e->max_hops * e->nwin);
-	// long transforms, blocks of frames: two-step kernels with many small workgroups instead of one frame per CU
-	const bool two_step = M > 1 && S * M >= 32 && g_opt_two_step && stft_two_step_available(e->log2n);
-	if (two_step) {
-		int want = g_opt_two_step_frames;
-		if (want <= 0)
-			want = (int)(((size_t)128 << 20) / (sizeof(float2) * N));
-		if ((size_t)want > S * M)
-			want = (int)(S * M);
-		if (want > e->xch2_frames) {
-			ZH_HIP(hipStreamSynchronize(e->stream));
-			(void)hipFree(e->d_xch2);
-			e->d_xch2 = nullptr;
-			e->xch2_frames = 0;
-			ZH_HIP(hipMalloc((void**)&e->d_xch2, sizeof(float2) * N * (size_t)want));
-			e->xch2_frames = want;
-		}
-		sa.xch = e->d_xch2;
-		sa.xch_frames = want;
-	}
 	{
 		ProfScope ps(e, zen_hip_hpr::K_STFT);
-		if (two_step)
-			ZH_TRY(launch_stft_two_step(e->log2n, sa, e->stream));
-		else
-			ZH_TRY(launch_stft(e->log2n, sa, e->stream));
+		ZH_TRY(launch_stft(e->log2n, sa, e->stream));
 	}
 	e->tail_sel ^= 1;
 
@@ -482,14 +459,7 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 	}
 	{
 		ProfScope ps(e, zen_hip_hpr::K_ISTFT);
-		if (two_step) {
-			ia.xch = sa.xch;
-			ia.xch_frames = sa.xch_frames;
-			ZH_TRY(launch_istft_two_step(e->log2n, ia, e->stream));
-		}
-		else {
-			ZH_TRY(launch_istft(e->log2n, ia, e->stream));
-		}
+		ZH_TRY(launch_istft(e->log2n, ia, e->stream));
 	}
 
 	e->abs_frame += (long long)M;

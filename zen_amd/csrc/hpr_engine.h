@@ -27,8 +27,6 @@ struct zen_hip_hpr {
 	int tail_sel = 0;
 	float2* d_S = nullptr;
 	float* d_mag = nullptr;
-	float2* d_xch2 = nullptr;  // stft_two_step.hip: exchange scratch of the two-step block transforms (nfft 8192 / 16384)
-	int xch2_frames = 0;
 	float* d_H = nullptr;
 	float* d_P = nullptr;
 	float* d_Y[3] = {nullptr, nullptr, nullptr};     // 0 percussive, 1 harmonic, 2 residual

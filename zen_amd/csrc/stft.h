@@ -28,10 +28,6 @@ struct StftArgs {
 	float* carry[3];        // [n_streams][hop]
 	const float* Y[3];      // [n_streams][max_frames][nwin]
 	long long y_stream_stride;
-	// two-step kernels only (stft_two_step.hip): scratch for the values the two steps of a transform exchange,
-	// xch_frames * nfft float2; the frames of a call go through it xch_frames at a time
-	float2* xch;
-	int xch_frames;
 };
 
 // Synthesis: masks (hps.h:100-140), apply (hps.h:58-66), inverse FFT, *COLA (hps.h:68-80) for the
@@ -69,8 +65,6 @@ struct IstftArgs {
 	// hard masks by exact comparison instead of the division (masks.h HardThr; zeros: divide)
 	double thr_p, thr_h;
 	int thr_p_inc, thr_h_inc;
-	float2* xch;            // two-step kernels only: see StftArgs
-	int xch_frames;
 };
 
 // overlap-add of consecutive frames (hps.cu:435-449 + :526-528) and copy-out (hps.cu:341-363):
@@ -87,11 +81,6 @@ struct FinalizeArgs {
 int launch_stft(int log2n, const StftArgs& a, hipStream_t stream);
 int launch_istft(int log2n, const IstftArgs& a, hipStream_t stream);
 int launch_finalize(const FinalizeArgs& a, hipStream_t stream);
-// Blocks of frames at nfft 8192 / 16384 as two-step transforms with many small workgroups (stft_two_step.hip): the
-// same rows, bit for bit, as launch_stft / launch_istft; single-frame calls (`ready`, `seq`) are not served.
-bool stft_two_step_available(int log2n);
-int launch_stft_two_step(int log2n, const StftArgs& a, hipStream_t stream);
-int launch_istft_two_step(int log2n, const IstftArgs& a, hipStream_t stream);
 // FFTC2CWrapperGPU::forward/backward (fftw.h:35-43), `batch` consecutive transforms in place
 int launch_fft(int log2n, float2* data, const float2* tw, size_t batch, int inverse, hipStream_t stream);
 // the same for nfft = 32768 (fft_big.hip: two steps through `xch`, batch * nfft float2 of scratch)
