@@ -22,8 +22,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include <type_traits>
-
 #pragma clang fp contract(off)
 
 namespace zfft {
@@ -255,14 +253,6 @@ __device__ __forceinline__ void frame_sync()
 	}
 }
 
-// An input functor may carry a hook `void last_pass_loads()` (and say so with `static constexpr bool PREFETCH`): it is
-// called in the LAST pass, once every thread holds that pass's inputs in registers -- the moment a persistent kernel
-// issues the loads of its NEXT frame, so that they travel while this frame's last butterflies and stores run.
-template <class T, class = void>
-struct has_prefetch : std::false_type {};
-template <class T>
-struct has_prefetch<T, std::void_t<decltype(T::PREFETCH)>> : std::true_type {};
-
 // SYNC_FIRST: in() of the first pass reads LDS that the pass's own stores may overwrite (the fused kernel
 // keeps |S| and P inside the frame image): a barrier separates the two, as in every later pass.
 template <int LOG2N, int PASS, bool INV, bool ZU, bool HALF_OUT, class In, class Out, bool SYNC_FIRST = false,
@@ -298,8 +288,6 @@ struct PassRunner {
 		}
 		if (!FIRST || SYNC_FIRST)
 			frame_sync<TF>(); // every thread has its inputs in registers: LDS may be overwritten
-		if constexpr (LAST && !FIRST && has_prefetch<In>::value)
-			in.last_pass_loads();
 #pragma unroll
 		for (int i = 0; i < NB; ++i) {
 			const int b = tf + i * TF;

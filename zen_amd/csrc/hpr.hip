@@ -285,7 +285,7 @@ int advance_drain(zen_hip_hpr* e)
 	return ZEN_HIP_OK;
 }
 
-int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
+int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long long in_valid = LLONG_MAX)
 {
 	const size_t S = e->n_streams, N = e->nfft;
 	if (e->drain[0] | e->drain[1] | e->drain[2])
@@ -318,6 +318,7 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M)
 	memset(&sa, 0, sizeof(sa));
 	sa.in = in;
 	sa.in_stride = (long long)in_stride;
+	sa.in_valid = in_valid;
 	sa.tail_prev = e->d_tail[e->tail_sel];
 	sa.tail_next = e->d_tail[e->tail_sel ^ 1];
 	sa.window = e->d_window;
@@ -566,7 +567,65 @@ int grow_buffers(zen_hip_hpr* e, size_t new_hops)
 	return ZEN_HIP_OK;
 }
 
+// finished hops of output o of the last chunk, delivered as the spec says
+int finalize_spec(zen_hip_hpr* e, int o, const HprOutSpec& sp, size_t M, long long pos0)
+{
+	if (!output_served(e, o))
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpr_process_spec: output %d is not computed by this engine", o);
+	FinalizeArgs fa;
+	memset(&fa, 0, sizeof(fa));
+	fa.Y = e->d_Y[o];
+	fa.carry = e->d_carry[o];
+	fa.out = sp.dst;
+	fa.y_stream_stride = (long long)(e->max_hops * e->nwin);
+	fa.out_stride = sp.stride;
+	fa.n_frames = (int)M;
+	fa.hop = (int)e->hop;
+	fa.n_streams = (int)e->n_streams;
+	if (sp.add >= 0) {
+		if (output_served(e, sp.add)) {
+			fa.Y2 = e->d_Y[sp.add];
+			fa.carry2 = e->d_carry[sp.add];
+		}
+		else {
+			fa.add_zero = 1; // (soft masks, SSE: no residual -- the reference adds the all-zero accumulator)
+		}
+	}
+	fa.pos0 = pos0;
+	fa.shift = sp.shift;
+	fa.len = sp.len;
+	fa.dup_from = sp.dup_from;
+	fa.dup_shift = sp.dup_shift;
+	fa.dup_len = sp.dup_len;
+	ProfScope ps(e, zen_hip_hpr::K_FINALIZE);
+	return launch_finalize_spec(fa, e->stream);
+}
+
 } // namespace
+
+namespace zen_hip_impl {
+
+int hpr_process_spec(zen_hip_hpr* h, const float* in_dev, size_t n_hops, size_t in_stride, long long in_valid,
+                     const HprOutSpec (&spec)[3])
+{
+	if (!h || !in_dev)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpr_process_spec: null argument");
+	if (h->causality != ZEN_HIP_TIME_ANTICAUSAL)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpr_process_spec: anticausal engines only");
+	if (n_hops > h->max_hops && h->max_hops < h->max_hops_cap)
+		ZH_TRY(grow_buffers(h, n_hops < h->max_hops_cap ? n_hops : h->max_hops_cap));
+	for (size_t off = 0; off < n_hops; off += h->max_hops) {
+		const size_t M = (n_hops - off < h->max_hops) ? n_hops - off : h->max_hops;
+		const long long pos0 = (long long)(off * h->hop);
+		ZH_TRY(run_chunk(h, in_dev + off * h->hop, in_stride, M, in_valid - pos0));
+		for (int o = 0; o < 3; ++o)
+			if (spec[o].dst)
+				ZH_TRY(finalize_spec(h, o, spec[o], M, pos0));
+	}
+	return ZEN_HIP_OK;
+}
+
+} // namespace zen_hip_impl
 
 extern "C" {
 

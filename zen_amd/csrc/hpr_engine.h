@@ -6,6 +6,19 @@
 #include <utility>
 #include <vector>
 
+#include <climits>
+
+// Where the finished hops of one output of a block call go (zen_hip_impl::hpr_process_spec, used by hpri.hip): the
+// offline driver's "add P and R", "drop the lag*hop delay" and "truncate to the clip" folded into the overlap-add.
+struct HprOutSpec {
+	float* dst = nullptr;   // null: the output is not wanted
+	long long stride = 0;   // floats between the streams' rows of dst
+	long long shift = 0;    // the sample at stream position p (0 = first sample of the call) goes to dst[p - shift] ...
+	long long len = 0;      // ... if 0 <= p - shift < len
+	int add = -1;           // >= 0: id of an output whose finished hops are added first (P + R: hps.cu:153-160)
+	long long dup_from = LLONG_MAX, dup_shift = 0, dup_len = 0; // positions >= dup_from also go to dst[p - dup_shift]
+};
+
 struct zen_hip_hpr {
 	float fs;
 	size_t hop, nwin, nfft;
@@ -75,3 +88,11 @@ struct zen_hip_hpr {
 	std::vector<Pending> prof_pending;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
 };
+
+namespace zen_hip_impl {
+// zen_hip_hpr_process with (a) an input of which only the first in_valid samples of every row exist -- the rest reads
+// as zero, no padded copy -- and (b) the outputs delivered as the specs say (indexed by output id: 0 percussive,
+// 1 harmonic, 2 residual).  The engine must be an anticausal one (the two passes of HPRIOffline).
+int hpr_process_spec(zen_hip_hpr* h, const float* in_dev, size_t n_hops, size_t in_stride, long long in_valid,
+                     const HprOutSpec (&spec)[3]);
+} // namespace zen_hip_impl

@@ -23,9 +23,9 @@ struct zen_hip_hpri {
 	zen_hip_hpr* ep = nullptr; // p_impl_p : hop_p, P only, anticausal (hps.cu:45-48)
 	size_t hop_h, hop_p, n_clips;
 	hipStream_t stream = nullptr;
-	// scratch, grown on demand
-	size_t cap1 = 0, cap2 = 0;
-	float *a1 = nullptr, *H1 = nullptr, *P1 = nullptr, *R1 = nullptr, *in2 = nullptr, *P2 = nullptr;
+	// scratch, grown on demand: pass 2's input (the only intermediate that has to exist in memory)
+	size_t cap2 = 0;
+	float* in2 = nullptr;
 	float *stage_in = nullptr, *stage_out[3] = {nullptr, nullptr, nullptr};
 	size_t stage_cap = 0;
 };
@@ -41,103 +41,11 @@ int chunk_padder(size_t audio_size, size_t hop, size_t lag, size_t* padded)
 	return n;
 }
 
-// The three streaming helpers below move four samples per thread: one 16-byte access where the four come from one
-// aligned run (VEC: the caller's rows are 16-byte aligned; the engine's own buffers always are), sample by sample
-// at the seams and the ends.
-template <bool VEC>
-__global__ __launch_bounds__(256) void pad_clips_kernel(const float* __restrict__ in, long long in_stride,
-                                                        size_t n, float* __restrict__ out, size_t padded)
-{
-	const float* src = in + (long long)blockIdx.y * in_stride;
-	float* dst = out + (size_t)blockIdx.y * padded; // (padded is a multiple of the hop: rows stay aligned)
-	for (size_t i = 4 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x); i < padded; i += 4 * (size_t)gridDim.x * blockDim.x) {
-		if (VEC && i + 4 <= n) {
-			*reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(src + i);
-		}
-		else {
-			for (size_t k = i; k < i + 4 && k < padded; ++k)
-				dst[k] = k < n ? src[k] : 0.0F; // audio.resize(size + pad, 0.0F)  hps.cu:123
-		}
-	}
-}
-
-// hps.cu:153-160 (xp1 + xr1), :171-176 (shift left by lag_h*hop_h in place; the tail keeps its old
-// contents) and :186-190 (pass 2 reads `intermediate` up to n2*hop_p, past size() -- SURVEY Q9).
-__global__ __launch_bounds__(256) void intermediate_kernel(const float* __restrict__ P1, const float* __restrict__ R1,
-                                                           size_t padded1, size_t sh1, float* __restrict__ in2,
-                                                           size_t padded2)
-{
-	const float* p = P1 + (size_t)blockIdx.y * padded1;
-	const float* r = R1 + (size_t)blockIdx.y * padded1;
-	float* dst = in2 + (size_t)blockIdx.y * padded2;
-	for (size_t j = 4 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x); j < padded2; j += 4 * (size_t)gridDim.x * blockDim.x) {
-		if (j + 4 <= padded1 - sh1 && j + 4 <= padded2) { // (padded1, padded2 and sh1 are multiples of a hop: aligned)
-			const float4 x = *reinterpret_cast<const float4*>(p + j + sh1), y = *reinterpret_cast<const float4*>(r + j + sh1);
-			*reinterpret_cast<float4*>(dst + j) = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w); // sum_vectors_functor hps.h:142-150
-		}
-		else {
-			for (size_t k = j; k < j + 4 && k < padded2; ++k) {
-				float v = 0.0F; // beyond the reference's allocation (undefined there)
-				if (k < padded1) {
-					const size_t q = (k < padded1 - sh1) ? k + sh1 : k;
-					v = p[q] + r[q];
-				}
-				dst[k] = v;
-			}
-		}
-	}
-}
-
-// hps.cu:171-178, :209-217 : drop the lag*hop delay, truncate to the clip length
-template <bool VEC>
-__global__ __launch_bounds__(256) void unshift_kernel(const float* __restrict__ full, size_t padded, size_t sh,
-                                                      float* __restrict__ out, long long out_stride, size_t n)
-{
-	const float* src = full + (size_t)blockIdx.y * padded;
-	float* dst = out + (long long)blockIdx.y * out_stride;
-	for (size_t j = 4 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x); j < n; j += 4 * (size_t)gridDim.x * blockDim.x) {
-		if (VEC && j + 4 <= n && j + 4 <= padded - sh) {
-			*reinterpret_cast<float4*>(dst + j) = *reinterpret_cast<const float4*>(src + j + sh);
-		}
-		else {
-			for (size_t k = j; k < j + 4 && k < n; ++k) {
-				float v = 0.0F;
-				if (k < padded)
-					v = (k < padded - sh) ? src[k + sh] : src[k];
-				dst[k] = v;
-			}
-		}
-	}
-}
-
-// rows of a caller's buffer on which 16-byte accesses are allowed
-bool rows_aligned(const void* base, long long stride_floats, size_t rows)
-{
-	return (reinterpret_cast<uintptr_t>(base) & 15) == 0 && (rows <= 1 || stride_floats % 4 == 0);
-}
-
-unsigned grid_for4(size_t n) // four samples per thread
-{
-	size_t b = (n + 1023) / 1024;
-	return (unsigned)(b > 4096 ? 4096 : (b ? b : 1));
-}
-
-unsigned grid_for(size_t n)
-{
-	size_t b = (n + 255) / 256;
-	return (unsigned)(b > 4096 ? 4096 : (b ? b : 1));
-}
-
 void hpri_free_scratch(zen_hip_hpri* o)
 {
-	(void)hipFree(o->a1);
-	(void)hipFree(o->H1);
-	(void)hipFree(o->P1);
-	(void)hipFree(o->R1);
 	(void)hipFree(o->in2);
-	(void)hipFree(o->P2);
-	o->a1 = o->H1 = o->P1 = o->R1 = o->in2 = o->P2 = nullptr;
-	o->cap1 = o->cap2 = 0;
+	o->in2 = nullptr;
+	o->cap2 = 0;
 }
 
 } // namespace
@@ -241,55 +149,52 @@ int zen_hip_hpri_process_device(zen_hip_hpri_t h, const float* audio_dev, size_t
 	const int n2 = chunk_padder(n, h->hop_p, (size_t)h->ep->lag, &padded2); // hps.cu:180-181
 	if (n1 <= 0 || n2 <= 0)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_process: clip too short");
-	if (padded1 > h->cap1 || padded2 > h->cap2) {
+	// One scratch buffer: pass 2's input.  The reference pads the clip (hps.cu:116-123), collects three padded outputs
+	// of pass 1, adds two of them, shifts the sum and the harmonic output left by lag_h*hop_h in place and truncates
+	// (hps.cu:153-178), and does the same after pass 2 (hps.cu:209-217).  Here the analysis kernel reads the clip
+	// itself (samples beyond n are zero) and the overlap-add kernel writes every finished sample where it ends up
+	// (hpr_process_spec): no padded copy, no P1 / R1 / H1 / P2 buffers, no sum / shift / truncate passes.
+	if (padded2 > h->cap2) {
 		ZH_HIP(hipStreamSynchronize(h->stream));
 		hpri_free_scratch(h);
-		ZH_HIP(hipMalloc((void**)&h->a1, sizeof(float) * C * padded1));
-		ZH_HIP(hipMalloc((void**)&h->H1, sizeof(float) * C * padded1));
-		ZH_HIP(hipMalloc((void**)&h->P1, sizeof(float) * C * padded1));
-		ZH_HIP(hipMalloc((void**)&h->R1, sizeof(float) * C * padded1));
 		ZH_HIP(hipMalloc((void**)&h->in2, sizeof(float) * C * padded2));
-		ZH_HIP(hipMalloc((void**)&h->P2, sizeof(float) * C * padded2));
-		h->cap1 = padded1;
 		h->cap2 = padded2;
 	}
 	ZH_TRY(zen_hip_hpr_reset_buffers(h->eh)); // each process() call is a fresh pair of HPR objects' state
 	ZH_TRY(zen_hip_hpr_reset_buffers(h->ep));
+	const size_t sh1 = (size_t)h->eh->lag * h->hop_h, sh2 = (size_t)h->ep->lag * h->hop_p;
 
-	if (rows_aligned(audio_dev, (long long)stride, C))
-		hipLaunchKernelGGL(pad_clips_kernel<true>, dim3(grid_for4(padded1), (unsigned)C), dim3(256), 0, h->stream, audio_dev,
-		                   (long long)stride, n, h->a1, padded1);
-	else
-		hipLaunchKernelGGL(pad_clips_kernel<false>, dim3(grid_for4(padded1), (unsigned)C), dim3(256), 0, h->stream, audio_dev,
-		                   (long long)stride, n, h->a1, padded1);
-	ZH_HIP(hipGetLastError());
 	// pass 1: large hop, harmonic + percussive + residual (hps.cu:142-167)
-	ZH_TRY(zen_hip_hpr_process(h->eh, h->a1, (size_t)n1, padded1, h->H1, h->P1, h->R1, padded1));
-	const size_t sh1 = (size_t)h->eh->lag * h->hop_h;
-	hipLaunchKernelGGL(intermediate_kernel, dim3(grid_for4(padded2), (unsigned)C), dim3(256), 0, h->stream, h->P1,
-	                   h->R1, padded1, sh1, h->in2, padded2);
-	ZH_HIP(hipGetLastError());
-	// pass 2: small hop on xp1 + xr1, percussive only (hps.cu:185-205)
-	ZH_TRY(zen_hip_hpr_process(h->ep, h->in2, (size_t)n2, padded2, nullptr, h->P2, nullptr, padded2));
-	const size_t sh2 = (size_t)h->ep->lag * h->hop_p;
-	if (harm_dev) {
-		if (rows_aligned(harm_dev, (long long)out_stride, C))
-			hipLaunchKernelGGL(unshift_kernel<true>, dim3(grid_for4(n), (unsigned)C), dim3(256), 0, h->stream, h->H1, padded1,
-			                   sh1, harm_dev, (long long)out_stride, n);
-		else
-			hipLaunchKernelGGL(unshift_kernel<false>, dim3(grid_for4(n), (unsigned)C), dim3(256), 0, h->stream, h->H1, padded1,
-			                   sh1, harm_dev, (long long)out_stride, n);
-		ZH_HIP(hipGetLastError());
+	HprOutSpec s1[3];
+	if (harm_dev) { // harm[j] = H1[j + sh1], j < n (hps.cu:171-178; n <= padded1 - sh1 always)
+		s1[1].dst = harm_dev;
+		s1[1].stride = (long long)out_stride;
+		s1[1].shift = (long long)sh1;
+		s1[1].len = (long long)n;
 	}
+	// intermediate[j] = (P1 + R1)[j + sh1] for j < padded1 - sh1; the in-place shift leaves (P1 + R1)[j] in
+	// [padded1 - sh1, padded1), which pass 2 reads past size() (hps.cu:186-190); beyond padded1: the
+	// reference's allocation ends (zeros here)
+	s1[0].dst = h->in2;
+	s1[0].stride = (long long)padded2;
+	s1[0].shift = (long long)sh1;
+	s1[0].len = (long long)padded2;
+	s1[0].add = 2;
+	s1[0].dup_from = (long long)(padded1 - sh1);
+	s1[0].dup_shift = 0;
+	s1[0].dup_len = (long long)padded2;
+	if (padded2 > padded1)
+		ZH_HIP(hipMemset2DAsync(h->in2 + padded1, sizeof(float) * padded2, 0, sizeof(float) * (padded2 - padded1), C, h->stream));
+	ZH_TRY(hpr_process_spec(h->eh, audio_dev, (size_t)n1, stride, (long long)n, s1));
+	// pass 2: small hop on xp1 + xr1, percussive only (hps.cu:185-205); perc[j] = P2[j + sh2], j < n (hps.cu:209-217)
+	HprOutSpec s2[3];
 	if (perc_dev) {
-		if (rows_aligned(perc_dev, (long long)out_stride, C))
-			hipLaunchKernelGGL(unshift_kernel<true>, dim3(grid_for4(n), (unsigned)C), dim3(256), 0, h->stream, h->P2, padded2,
-			                   sh2, perc_dev, (long long)out_stride, n);
-		else
-			hipLaunchKernelGGL(unshift_kernel<false>, dim3(grid_for4(n), (unsigned)C), dim3(256), 0, h->stream, h->P2, padded2,
-			                   sh2, perc_dev, (long long)out_stride, n);
-		ZH_HIP(hipGetLastError());
+		s2[0].dst = perc_dev;
+		s2[0].stride = (long long)out_stride;
+		s2[0].shift = (long long)sh2;
+		s2[0].len = (long long)n;
 	}
+	ZH_TRY(hpr_process_spec(h->ep, h->in2, (size_t)n2, padded2, (long long)padded2, s2));
 	if (resid_dev) // pass 2's residual_out is never written: zeros (hps.cu:45-48, :200-204)
 		ZH_HIP(hipMemset2DAsync(resid_dev, sizeof(float) * out_stride, 0, sizeof(float) * n, C, h->stream));
 	return ZEN_HIP_OK;
@@ -352,78 +257,6 @@ int plan_range(zen_hip_hpri* h, size_t n, size_t begin, size_t end, RangePlan* p
 	return ZEN_HIP_OK;
 }
 
-// a1[i] = audio[off + i] (zero beyond n), i < count
-// (the three range kernels move four samples per thread like the whole-clip helpers above; VEC: the launcher found
-// source and destination 16-byte aligned for every group of four)
-template <bool VEC>
-__global__ __launch_bounds__(256) void range_input_kernel(const float* __restrict__ audio, size_t n, size_t off,
-                                                          float* __restrict__ dst, size_t count)
-{
-	for (size_t i = 4 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x); i < count; i += 4 * (size_t)gridDim.x * blockDim.x) {
-		if (VEC && i + 4 <= count && off + i + 4 <= n) {
-			*reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(audio + off + i);
-		}
-		else {
-			for (size_t k = i; k < i + 4 && k < count; ++k)
-				dst[k] = (off + k < n) ? audio[off + k] : 0.0F;
-		}
-	}
-}
-
-// pass-2 input positions j in [j0, j0+count): intermediate'[j] as intermediate_kernel defines it;
-// P1/R1 hold pass-1 output positions [base1, ...)
-template <bool VEC>
-__global__ __launch_bounds__(256) void range_intermediate_kernel(const float* __restrict__ P1, const float* __restrict__ R1,
-                                                                 size_t base1, size_t padded1, size_t sh1, size_t j0,
-                                                                 float* __restrict__ dst, size_t count)
-{
-	for (size_t i = 4 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x); i < count; i += 4 * (size_t)gridDim.x * blockDim.x) {
-		const size_t j = j0 + i;
-		if (VEC && i + 4 <= count && j + 4 <= padded1 - sh1) {
-			const float4 x = *reinterpret_cast<const float4*>(P1 + (j + sh1 - base1)), y = *reinterpret_cast<const float4*>(R1 + (j + sh1 - base1));
-			*reinterpret_cast<float4*>(dst + i) = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
-		}
-		else {
-			for (size_t k = i; k < i + 4 && k < count; ++k) {
-				const size_t jk = j0 + k;
-				float v = 0.0F;
-				if (jk < padded1) {
-					const size_t q = (jk < padded1 - sh1) ? jk + sh1 : jk;
-					v = P1[q - base1] + R1[q - base1];
-				}
-				dst[k] = v;
-			}
-		}
-	}
-}
-
-// out[i] = full'[begin + i] where full' is `full` with the lag*hop delay removed (unshift_kernel);
-// `full` holds positions [base, ...)
-template <bool VEC>
-__global__ __launch_bounds__(256) void range_unshift_kernel(const float* __restrict__ full, size_t base, size_t padded,
-                                                            size_t sh, size_t begin, float* __restrict__ out, size_t count)
-{
-	for (size_t i = 4 * ((size_t)blockIdx.x * blockDim.x + threadIdx.x); i < count; i += 4 * (size_t)gridDim.x * blockDim.x) {
-		const size_t j = begin + i;
-		if (VEC && i + 4 <= count && j + 4 <= padded - sh) {
-			*reinterpret_cast<float4*>(out + i) = *reinterpret_cast<const float4*>(full + (j + sh - base));
-		}
-		else {
-			for (size_t k = i; k < i + 4 && k < count; ++k) {
-				const size_t jk = begin + k;
-				float v = 0.0F;
-				if (jk < padded) {
-					const size_t q = (jk < padded - sh) ? jk + sh : jk;
-					v = full[q - base];
-				}
-				out[k] = v;
-			}
-		}
-	}
-}
-
-bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-
 } // namespace
 } // extern "C++"
 
@@ -450,56 +283,50 @@ int zen_hip_hpri_process_range(zen_hip_hpri_t h, const float* audio_dev, size_t 
 	RangePlan p;
 	ZH_TRY(plan_range(h, n, begin, end, &p));
 	const size_t hop_h = h->hop_h, hop_p = h->hop_p;
-	const size_t c1 = (p.k1 - p.q1) * hop_h, c2 = (p.m1 - p.q2) * hop_p;
-	if (c1 > h->cap1 || c2 > h->cap2) {
+	const size_t c2 = (p.m1 - p.q2) * hop_p;
+	if (c2 > h->cap2) {
 		ZH_HIP(hipStreamSynchronize(h->stream));
 		hpri_free_scratch(h);
-		ZH_HIP(hipMalloc((void**)&h->a1, sizeof(float) * c1));
-		ZH_HIP(hipMalloc((void**)&h->H1, sizeof(float) * c1));
-		ZH_HIP(hipMalloc((void**)&h->P1, sizeof(float) * c1));
-		ZH_HIP(hipMalloc((void**)&h->R1, sizeof(float) * c1));
 		ZH_HIP(hipMalloc((void**)&h->in2, sizeof(float) * (c2 ? c2 : 1)));
-		ZH_HIP(hipMalloc((void**)&h->P2, sizeof(float) * (c2 ? c2 : 1)));
-		h->cap1 = c1;
 		h->cap2 = c2;
 	}
 	ZH_TRY(zen_hip_hpr_reset_buffers(h->eh));
 	ZH_TRY(zen_hip_hpr_reset_buffers(h->ep));
-	const size_t base1 = p.q1 * hop_h, base2 = p.q2 * hop_p;
-	if (aligned16(audio_dev + base1))
-		hipLaunchKernelGGL(range_input_kernel<true>, dim3(grid_for4(c1)), dim3(256), 0, h->stream, audio_dev, n, base1, h->a1, c1);
-	else
-		hipLaunchKernelGGL(range_input_kernel<false>, dim3(grid_for4(c1)), dim3(256), 0, h->stream, audio_dev, n, base1, h->a1, c1);
-	ZH_HIP(hipGetLastError());
-	ZH_TRY(zen_hip_hpr_process(h->eh, h->a1, p.k1 - p.q1, c1, h->H1, h->P1, h->R1, c1));
+	// Positions below are relative to the first sample each pass is run on: base1 = q1*hop_h of the clip for pass 1,
+	// base2 = q2*hop_p for pass 2.  Same destinations as zen_hip_hpri_process_device, offset by the range.
+	const long long base1 = (long long)(p.q1 * hop_h), base2 = (long long)(p.q2 * hop_p);
+	const long long sh1 = (long long)p.sh1, sh2 = (long long)p.sh2, cnt = (long long)(end - begin);
+	HprOutSpec s1[3];
+	if (harm_dev) { // harm[begin + i] = H1[begin + i + sh1]
+		s1[1].dst = harm_dev;
+		s1[1].shift = sh1 + (long long)begin - base1;
+		s1[1].len = cnt;
+	}
+	if (c2) { // pass-2 input positions base2 + i, i < c2: (P1 + R1)[base2 + i + sh1], or the unshifted leftovers near the end (Q9)
+		s1[0].dst = h->in2;
+		s1[0].shift = sh1 + base2 - base1;
+		s1[0].len = (long long)c2;
+		s1[0].add = 2;
+		s1[0].dup_from = (long long)p.padded1 - sh1 - base1;
+		s1[0].dup_shift = base2 - base1;
+		s1[0].dup_len = (long long)c2;
+		if (base2 + (long long)c2 > (long long)p.padded1) { // beyond the reference's allocation: zeros
+			const long long z0 = (long long)p.padded1 > base2 ? (long long)p.padded1 - base2 : 0;
+			ZH_HIP(hipMemsetAsync(h->in2 + z0, 0, sizeof(float) * ((long long)c2 - z0), h->stream));
+		}
+	}
+	ZH_TRY(hpr_process_spec(h->eh, audio_dev + base1, p.k1 - p.q1, (p.k1 - p.q1) * hop_h, (long long)n - base1, s1));
 	if (c2) {
-		if ((base2 + p.sh1 - base1) % 4 == 0)
-			hipLaunchKernelGGL(range_intermediate_kernel<true>, dim3(grid_for4(c2)), dim3(256), 0, h->stream, h->P1, h->R1, base1,
-			                   p.padded1, p.sh1, base2, h->in2, c2);
-		else
-			hipLaunchKernelGGL(range_intermediate_kernel<false>, dim3(grid_for4(c2)), dim3(256), 0, h->stream, h->P1, h->R1, base1,
-			                   p.padded1, p.sh1, base2, h->in2, c2);
-		ZH_HIP(hipGetLastError());
-		ZH_TRY(zen_hip_hpr_process(h->ep, h->in2, p.m1 - p.q2, c2, nullptr, h->P2, nullptr, c2));
+		HprOutSpec s2[3];
+		if (perc_dev) { // perc[begin + i] = P2[begin + i + sh2]
+			s2[0].dst = perc_dev;
+			s2[0].shift = sh2 + (long long)begin - base2;
+			s2[0].len = cnt;
+		}
+		ZH_TRY(hpr_process_spec(h->ep, h->in2, p.m1 - p.q2, c2, (long long)c2, s2));
 	}
-	const size_t cnt = end - begin;
-	if (harm_dev) {
-		if (aligned16(harm_dev) && (begin + p.sh1 - base1) % 4 == 0)
-			hipLaunchKernelGGL(range_unshift_kernel<true>, dim3(grid_for4(cnt)), dim3(256), 0, h->stream, h->H1, base1, p.padded1,
-			                   p.sh1, begin, harm_dev, cnt);
-		else
-			hipLaunchKernelGGL(range_unshift_kernel<false>, dim3(grid_for4(cnt)), dim3(256), 0, h->stream, h->H1, base1, p.padded1,
-			                   p.sh1, begin, harm_dev, cnt);
-		ZH_HIP(hipGetLastError());
-	}
-	if (perc_dev) {
-		if (aligned16(perc_dev) && (begin + p.sh2 - base2) % 4 == 0)
-			hipLaunchKernelGGL(range_unshift_kernel<true>, dim3(grid_for4(cnt)), dim3(256), 0, h->stream, h->P2, base2, p.padded2,
-			                   p.sh2, begin, perc_dev, cnt);
-		else
-			hipLaunchKernelGGL(range_unshift_kernel<false>, dim3(grid_for4(cnt)), dim3(256), 0, h->stream, h->P2, base2, p.padded2,
-			                   p.sh2, begin, perc_dev, cnt);
-		ZH_HIP(hipGetLastError());
+	else if (perc_dev) {
+		ZH_HIP(hipMemsetAsync(perc_dev, 0, sizeof(float) * (end - begin), h->stream));
 	}
 	return ZEN_HIP_OK;
 }

@@ -108,104 +108,6 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void istft_kernel(IstftArgs a
 	}
 }
 
-// ------------------------------------------------------------------------------------------------
-// Blocks of frames at nfft 8192 / 16384 (pass 1 of the default offline configuration).  A CU holds one or two frames
-// (70 / 139 KB of LDS each), so with one workgroup per frame the 128 KB of inputs of a transform arrive at the CU's
-// share of the HBM bandwidth (5-6 us) before the first butterfly, all CUs in lock step, and nothing overlaps: 16 us
-// per transform for 10 us of arithmetic.  Here a persistent workgroup walks through a run of consecutive frames of
-// one output, and in the LAST pass of a frame -- once its inputs are in registers -- it issues the spectrum loads of
-// the NEXT frame (half of a transform's input bytes; fft_dev.h last_pass_loads), which travel while the last
-// butterflies and the stores of the current frame run.  Same arithmetic, same order: bit-identical rows.
-struct IstftInPf {
-	static constexpr bool PREFETCH = true;
-	float2 sv[16];          // S[lo(slot)] of the current frame (not yet conjugated), slot order: idx = tf + slot*TF
-	float2 nx[16];          // the same of the next frame, in flight since the current frame's last pass
-	const float2* S_next;   // next frame's spectrum row, or null
-	const float* H;
-	const float* P;
-	MaskCfg cfg;
-	HardThr thr;
-	int which, n, p_mid, tf, tf_stride;
-	__device__ __forceinline__ int lo_of(int idx) const { return idx > (n >> 1) ? n - idx : idx; }
-	__device__ __forceinline__ void load_first(const float2* S)
-	{
-#pragma unroll
-		for (int slot = 0; slot < 16; ++slot)
-			sv[slot] = S[lo_of(tf + slot * tf_stride)];
-	}
-	__device__ __forceinline__ void last_pass_loads()
-	{
-		if (S_next) {
-#pragma unroll
-			for (int slot = 0; slot < 16; ++slot)
-				nx[slot] = S_next[lo_of(tf + slot * tf_stride)];
-		}
-	}
-	__device__ __forceinline__ void advance()
-	{
-#pragma unroll
-		for (int slot = 0; slot < 16; ++slot)
-			sv[slot] = nx[slot];
-	}
-	__device__ __forceinline__ float2 operator()(int idx, int slot) const
-	{
-		const bool mirror = idx > (n >> 1); // upper half: S[n-k] = conj(S[k])
-		const int lo = mirror ? n - idx : idx;
-		float2 z = sv[slot];
-		if (mirror)
-			z.y = -z.y;
-		const int pi = (mirror && idx >= n - p_mid) ? idx : lo;
-		const float m = mask_value_thr(which, H[lo], P[pi], cfg, thr);
-		return make_float2(z.x * m, z.y * m); // apply_mask_functor hps.h:58-66
-	}
-};
-
-struct IstftOutPlain {
-	float* Y;
-	float cola;
-	__device__ __forceinline__ void operator()(int idx, float2 x, bool, int) const { Y[idx] = x.x * cola; }
-};
-
-template <int LOG2N>
-__global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) void istft_persist_kernel(IstftArgs a, int per_wg)
-{
-	using PL = Plan<LOG2N>;
-	static_assert(PL::FRAMES_PER_BLOCK == 1, "one frame per workgroup at these sizes");
-	extern __shared__ float2 lds[];
-	const int tf = threadIdx.x, oi = blockIdx.y;
-	const int total = a.n_streams * a.n_frames;
-	const int first = blockIdx.x * per_wg, last = first + per_wg < total ? first + per_wg : total;
-	IstftInPf in;
-	in.cfg = MaskCfg{a.beta, a.beta_h, a.soft, a.power, a.sse, a.out_h, a.out_p};
-	in.thr = HardThr{a.thr_p, a.thr_h, a.thr_p_inc, a.thr_h_inc};
-	in.which = a.out_id[oi];
-	in.n = PL::N;
-	in.p_mid = a.p_mid;
-	in.tf = tf;
-	in.tf_stride = PL::TF;
-	auto s_row = [&](int item) {
-		const int s = item / a.n_frames, f = item - s * a.n_frames;
-		return a.S + (((a.crow0 + f) % a.ring_rows) + (long long)s * a.ring_rows) * a.s_stride;
-	};
-	if (first < last)
-		in.load_first(s_row(first));
-	for (int item = first; item < last; ++item) {
-		const int s = item / a.n_frames, f = item - s * a.n_frames;
-		const long long ring_row = ((a.crow0 + f) % a.ring_rows) + (long long)s * a.ring_rows;
-		in.H = a.h_is_ring ? a.H + ring_row * PL::N : a.H + (long long)s * a.h_stream_stride + (long long)f * PL::N;
-		in.P = a.P + (long long)s * a.p_stream_stride + (long long)f * PL::N;
-		in.S_next = item + 1 < last ? s_row(item + 1) : nullptr;
-		IstftOutPlain out{a.Y[oi] + (long long)s * a.y_stream_stride + (long long)f * (PL::N / 2), a.cola};
-		int tf_o = tf; // opaque per frame: see stft_persist_kernel
-		const float2* tw_o = a.tw;
-		asm volatile("" : "+v"(tf_o));
-		asm volatile("" : "+s"(tw_o));
-		in.tf = tf_o;
-		zfft::fft_frame<LOG2N, true, false, true>(tf_o, lds, tw_o, in, out, true);
-		in.advance();
-	}
-}
-
 // Hard masks with more than one output (HPRIOffline pass 1: H, P and R of every frame): one workgroup
 // synthesises all outputs of its frame.  The two binary masks of a bin are compared once, while the first
 // output loads S, H and P, and kept as two bits per bin in one register; the other outputs re-read only S
@@ -303,19 +205,6 @@ int launch_istft_t(const IstftArgs& a, hipStream_t stream)
 		hipLaunchKernelGGL(kern, grid, dim3(PL::THREADS), lds_bytes<LOG2N>(), stream, a);
 		ZH_HIP(hipGetLastError());
 		return ZEN_HIP_OK;
-	}
-	if constexpr (LOG2N >= 13) {
-		const int total = a.n_streams * a.n_frames, slots = persistent_workgroups(LOG2N);
-		if (a.n_frames > 1 && total * a.n_out >= 2 * slots && !g_opt_no_persist) {
-			auto pk = istft_persist_kernel<LOG2N>;
-			ZH_TRY(set_lds(pk, lds_bytes<LOG2N>()));
-			// the outputs run side by side: `slots` workgroups in all, each a run of consecutive frames of one output
-			const int per_out = slots / a.n_out > 0 ? slots / a.n_out : 1;
-			const int per_wg = (total + per_out - 1) / per_out, nwg = (total + per_wg - 1) / per_wg;
-			hipLaunchKernelGGL(pk, dim3((unsigned)nwg, (unsigned)a.n_out), dim3(PL::THREADS), lds_bytes<LOG2N>(), stream, a, per_wg);
-			ZH_HIP(hipGetLastError());
-			return ZEN_HIP_OK;
-		}
 	}
 	auto kern = istft_kernel<LOG2N>;
 	ZH_TRY(set_lds(kern, lds_bytes<LOG2N>()));

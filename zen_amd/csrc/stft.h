@@ -10,6 +10,8 @@ namespace zen_hip_impl {
 struct StftArgs {
 	const float* in;        // stream s, hop i: in[s*in_stride + i*hop ...]
 	long long in_stride;
+	long long in_valid;     // samples of every stream's row that exist: sample i >= in_valid reads as zero (the zero
+	                        // padding of hps.cu:116-123 without a padded copy of the clip); >= n_frames*hop: all of them
 	const float* tail_prev; // [n_streams][hop] : the hop before this chunk (zeros at stream start)
 	float* tail_next;       // [n_streams][hop] : receives the last hop of this chunk
 	const float* window;    // nwin
@@ -76,11 +78,22 @@ struct FinalizeArgs {
 	long long y_stream_stride;
 	long long out_stride;
 	int n_frames, hop, n_streams;
+	// launch_finalize_spec only.  A second output whose finished hops are added (hps.cu:153-160: xp1 + xr1; null Y2
+	// with add_zero: the reference adds its all-zero accumulator), and where the samples go: the sample at stream
+	// position p = pos0 + i*hop + k is written to out[p - shift] if 0 <= p - shift < len (the reference's "drop the
+	// lag*hop delay, truncate to the clip length", hps.cu:171-178, folded into the overlap-add), and positions
+	// p >= dup_from ALSO to out[p - dup_shift] if that is in [0, dup_len) (the leftovers the in-place shift of
+	// hps.cu:171-176 leaves behind, which pass 2 reads: SURVEY Q9).
+	const float* Y2;
+	const float* carry2;
+	int add_zero;
+	long long pos0, shift, len, dup_from, dup_shift, dup_len;
 };
 
 int launch_stft(int log2n, const StftArgs& a, hipStream_t stream);
 int launch_istft(int log2n, const IstftArgs& a, hipStream_t stream);
 int launch_finalize(const FinalizeArgs& a, hipStream_t stream);
+int launch_finalize_spec(const FinalizeArgs& a, hipStream_t stream);
 // FFTC2CWrapperGPU::forward/backward (fftw.h:35-43), `batch` consecutive transforms in place
 int launch_fft(int log2n, float2* data, const float2* tw, size_t batch, int inverse, hipStream_t stream);
 // the same for nfft = 32768 (fft_big.hip: two steps through `xch`, batch * nfft float2 of scratch)

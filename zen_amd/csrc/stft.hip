@@ -29,12 +29,20 @@ struct StftIn {
 	const float* cur;  // hop samples
 	const float* window;
 	int hop;
+	int nv_prev, nv_cur; // samples of `prev` / `cur` that exist (StftArgs::in_valid); the rest of the hop reads as zero
 	__device__ __forceinline__ float2 operator()(int idx, int) const
 	{
-		const float x = idx < hop ? prev[idx] : cur[idx - hop];
+		const float x = idx < hop ? (idx < nv_prev ? prev[idx] : 0.0f) : (idx - hop < nv_cur ? cur[idx - hop] : 0.0f);
 		return make_float2(x * window[idx], 0.0f); // window_functor hps.h:24-33
 	}
 };
+
+// samples of hop i of a row that exist when the row holds in_valid samples
+__device__ __forceinline__ int valid_in_hop(long long in_valid, int i, int hop)
+{
+	const long long v = in_valid - (long long)i * hop;
+	return v <= 0 ? 0 : (v >= hop ? hop : (int)v);
+}
 
 struct StftOut {
 	float2* S;  // n/2 + 1 bins are kept: the frame is real, so the spectrum is exactly Hermitian
@@ -64,8 +72,9 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void stft_kernel(StftArgs a)
 	const int tid = threadIdx.x, s = blockIdx.y, hop = a.hop;
 	if (blockIdx.x == gridDim.x - 1) { // housekeeping block
 		const float* last = a.in + (long long)s * a.in_stride + (long long)(a.n_frames - 1) * hop;
+		const int nv = valid_in_hop(a.in_valid, a.n_frames - 1, hop);
 		for (int i = tid; i < hop; i += PL::THREADS)
-			a.tail_next[(long long)s * hop + i] = last[i];
+			a.tail_next[(long long)s * hop + i] = i < nv ? last[i] : 0.0f;
 		if (a.prev_frames > 0) {
 			for (int o = 0; o < 3; ++o) {
 				if (!a.carry[o])
@@ -87,6 +96,8 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void stft_kernel(StftArgs a)
 	in.cur = in_s + (long long)f * hop;
 	in.window = a.window;
 	in.hop = hop;
+	in.nv_prev = f == 0 ? hop : valid_in_hop(a.in_valid, f - 1, hop);
+	in.nv_cur = valid_in_hop(a.in_valid, f, hop);
 	const long long row = ((a.row0 + f) % a.ring_rows) + (long long)s * a.ring_rows;
 	StftOut out;
 	out.S = a.S + row * a.s_stride;
@@ -109,10 +120,11 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) void stft_persist_kernel(S
 	extern __shared__ float2 lds[];
 	const int tid = threadIdx.x, hop = a.hop;
 	if (blockIdx.x == gridDim.x - 1) { // housekeeping block
+		const int nv = valid_in_hop(a.in_valid, a.n_frames - 1, hop);
 		for (int s = 0; s < a.n_streams; ++s) {
 			const float* last = a.in + (long long)s * a.in_stride + (long long)(a.n_frames - 1) * hop;
 			for (int i = tid; i < hop; i += PL::THREADS)
-				a.tail_next[(long long)s * hop + i] = last[i];
+				a.tail_next[(long long)s * hop + i] = i < nv ? last[i] : 0.0f;
 			if (a.prev_frames > 0) {
 				for (int o = 0; o < 3; ++o) {
 					if (!a.carry[o])
@@ -135,6 +147,8 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) void stft_persist_kernel(S
 		in.cur = in_s + (long long)f * hop;
 		in.window = a.window;
 		in.hop = hop;
+		in.nv_prev = f == 0 ? hop : valid_in_hop(a.in_valid, f - 1, hop);
+		in.nv_cur = valid_in_hop(a.in_valid, f, hop);
 		const long long row = ((a.row0 + f) % a.ring_rows) + (long long)s * a.ring_rows;
 		StftOut out;
 		out.S = a.S + row * a.s_stride;
@@ -179,6 +193,73 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a)
 		}
 		else {
 			out[i * hop + k] = prev[0] + cur[0];
+		}
+	}
+}
+
+// The overlap-add with the destination arithmetic of the offline driver folded in (FinalizeArgs, second part): one
+// pass over the Y rows instead of overlap-add, sum, shift and truncate as four (hpri.hip).
+template <bool VEC>
+__global__ __launch_bounds__(256) void finalize_spec_kernel(FinalizeArgs a)
+{
+	const int s = blockIdx.y, hop = a.hop;
+	const float* Y = a.Y + (long long)s * a.y_stream_stride;
+	const float* carry = a.carry + (long long)s * hop;
+	const float* Y2 = a.Y2 ? a.Y2 + (long long)s * a.y_stream_stride : nullptr;
+	const float* carry2 = a.Y2 ? a.carry2 + (long long)s * hop : nullptr;
+	float* out = a.out + (long long)s * a.out_stride;
+	constexpr int V = VEC ? 4 : 1;
+	const long long n = (long long)a.n_frames * hop / V;
+	const int per_hop = hop / V;
+	for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+		const long long i = e / per_hop;
+		const int k = (int)(e - i * per_hop) * V;
+		float v[V];
+		{
+			const float* prev = (i == 0) ? carry + k : Y + (i - 1) * 2 * hop + hop + k;
+			const float* cur = Y + i * 2 * hop + k;
+			if constexpr (VEC) {
+				const float4 p = *reinterpret_cast<const float4*>(prev), c = *reinterpret_cast<const float4*>(cur);
+				v[0] = p.x + c.x, v[1] = p.y + c.y, v[2] = p.z + c.z, v[3] = p.w + c.w;
+			}
+			else {
+				v[0] = prev[0] + cur[0];
+			}
+		}
+		if (Y2) { // sum_vectors_functor hps.h:142-150 on the two finished hops
+			const float* prev = (i == 0) ? carry2 + k : Y2 + (i - 1) * 2 * hop + hop + k;
+			const float* cur = Y2 + i * 2 * hop + k;
+			if constexpr (VEC) {
+				const float4 p = *reinterpret_cast<const float4*>(prev), c = *reinterpret_cast<const float4*>(cur);
+				v[0] = v[0] + (p.x + c.x), v[1] = v[1] + (p.y + c.y), v[2] = v[2] + (p.z + c.z), v[3] = v[3] + (p.w + c.w);
+			}
+			else {
+				v[0] = v[0] + (prev[0] + cur[0]);
+			}
+		}
+		else if (a.add_zero) { // the partner is not computed: the reference adds its all-zero accumulator
+#pragma unroll
+			for (int q = 0; q < V; ++q)
+				v[q] = v[q] + 0.0f;
+		}
+		const long long p0 = a.pos0 + i * hop + k;
+		const long long j = p0 - a.shift;
+		if (VEC && j >= 0 && j + 4 <= a.len) {
+			*reinterpret_cast<float4*>(out + j) = make_float4(v[0], v[1], v[2], v[3]);
+		}
+		else {
+#pragma unroll
+			for (int q = 0; q < V; ++q)
+				if (j + q >= 0 && j + q < a.len)
+					out[j + q] = v[q];
+		}
+		if (p0 + V > a.dup_from) {
+#pragma unroll
+			for (int q = 0; q < V; ++q) {
+				const long long j2 = p0 + q - a.dup_shift;
+				if (p0 + q >= a.dup_from && j2 >= 0 && j2 < a.dup_len)
+					out[j2] = v[q];
+			}
 		}
 	}
 }
@@ -282,6 +363,24 @@ int launch_finalize(const FinalizeArgs& a, hipStream_t stream)
 		hipLaunchKernelGGL(finalize_kernel<true>, dim3((unsigned)blocks, (unsigned)a.n_streams), dim3(256), 0, stream, a);
 	else
 		hipLaunchKernelGGL(finalize_kernel<false>, dim3((unsigned)blocks, (unsigned)a.n_streams), dim3(256), 0, stream, a);
+	ZH_HIP(hipGetLastError());
+	return ZEN_HIP_OK;
+}
+
+int launch_finalize_spec(const FinalizeArgs& a, hipStream_t stream)
+{
+	if (a.n_frames <= 0)
+		return ZEN_HIP_OK;
+	const bool vec = a.hop % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 && (a.n_streams <= 1 || a.out_stride % 4 == 0)
+	                 && a.shift % 4 == 0 && a.pos0 % 4 == 0;
+	const long long n = (long long)a.n_frames * a.hop / (vec ? 4 : 1);
+	long long blocks = (n + 255) / 256;
+	if (blocks > 4096)
+		blocks = 4096;
+	if (vec)
+		hipLaunchKernelGGL(finalize_spec_kernel<true>, dim3((unsigned)blocks, (unsigned)a.n_streams), dim3(256), 0, stream, a);
+	else
+		hipLaunchKernelGGL(finalize_spec_kernel<false>, dim3((unsigned)blocks, (unsigned)a.n_streams), dim3(256), 0, stream, a);
 	ZH_HIP(hipGetLastError());
 	return ZEN_HIP_OK;
 }
