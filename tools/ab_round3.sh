@@ -1,10 +1,10 @@
 cd $GRAFT_REPO_ROOT
-export ZEN_HIP_OPTIONS="no_persist=1"
-tools/pmc_cmd.sh stft_kernel python3 bench.py --workload offline_batch --steps 2 --warmup 1 --settle-ms 0 --no-cpu-baseline > gpurun_out/pmc_ob_stft.json 2>/dev/null
-python3 - <<'PY'
-import json
-j=json.load(open('gpurun_out/pmc_ob_stft.json'))
-for k,v in j['kernels'].items():
-    print(k)
-    for c in sorted(v): print('   %-24s %.4g' % (c, v[c]))
-PY
+python -m pytest tests -x -q -m gpu -k "offline or sharded or config or golden or persistent or fuzz or differential or libzen or cpp or cli" 2>&1 | tail -8
+for opt in ""; do
+  echo "== offline_batch $opt"; ZEN_HIP_OPTIONS="$opt" python bench.py --workload offline_batch --steps 10 --warmup 3 --no-cpu-baseline | python -c "
+import json,sys
+j=json.loads(sys.stdin.readline()); print(j['ms_per_step'], j['x_realtime'], {k: round(v['ms_per_step'],3) for k,v in j['kernels'].items()})"
+  echo "== offline_long $opt"; ZEN_HIP_OPTIONS="$opt" python bench.py --workload offline_long --steps 10 --warmup 3 --no-cpu-baseline | python -c "
+import json,sys
+j=json.loads(sys.stdin.readline()); print(j['ms_per_step'], j['x_realtime'], {k: round(v['ms_per_step'],3) for k,v in j['kernels'].items()})"
+done

@@ -73,7 +73,12 @@ __device__ __forceinline__ float2 cmul(float2 w, float2 b)
 	if constexpr (PK) {
 		const v2f t1 = (v2f){w.x, w.x} * (v2f){b.x, b.y};
 		const v2f t2 = (v2f){w.y, w.y} * (v2f){b.y, b.x};
-		const v2f r = t1 + (v2f){-t2.x, t2.y}; // a - b == a + (-b) exactly
+		// r = (t1.x - t2.x, t1.y + t2.y): one packed add with the first lane's second operand negated (a - b == a + (-b)
+		// exactly).  Written as t1 + (v2f){-t2.x, t2.y} the backend negates BOTH lanes with an extra packed add and moves
+		// the second one back (two more instructions per complex product: a fifth of a transform's VALU work); the
+		// half-negation is a source modifier of the instruction, spelled out here.
+		v2f r;
+		asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(r) : "v"(t1), "v"(t2));
 		return make_float2(r.x, r.y);
 	}
 	else {
@@ -214,7 +219,15 @@ __device__ __forceinline__ void butterfly(float2 (&a)[R], int k, int log2L, int 
 				}
 				else if (TRIV && q >= 2 && c == (nc >> 1)) { // w = -i (forward), +i (inverse): t = (B.y, -B.x) / (-B.y, B.x)
 					const float2 B = a[c * 2 * half + m + half];
-					if (INV) {
+					if constexpr (TW::PACKED) { // A + / - (B.y, -B.x) as one packed add each: lanes of B swapped, one negated
+						const v2f Av = (v2f){A.x, A.y}, Bv = (v2f){B.x, B.y};
+						v2f p, n; // p = (A.x + B.y, A.y - B.x), n = (A.x - B.y, A.y + B.x)
+						asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(p) : "v"(Av), "v"(Bv));
+						asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(n) : "v"(Av), "v"(Bv));
+						b[c * half + m] = INV ? make_float2(n.x, n.y) : make_float2(p.x, p.y);
+						b[(c + nc) * half + m] = INV ? make_float2(p.x, p.y) : make_float2(n.x, n.y);
+					}
+					else if (INV) {
 						b[c * half + m] = make_float2(A.x - B.y, A.y + B.x);
 						b[(c + nc) * half + m] = make_float2(A.x + B.y, A.y - B.x);
 					}
