@@ -561,8 +561,7 @@ def test_hard_mask_without_divide_is_exact():
     def exact(x, d, beta):
         thr = threshold(beta)
         with np.errstate(invalid="ignore", over="ignore"):
-            t = thr * d.astype(np.float64)
-            t = t * 0.0 + t                       # fma(t, 0, t): inf -> nan, finite unchanged
+            t = thr * d.astype(np.float64)      # (+inf for d = inf: nothing exceeds it under the strict comparison)
             return x.astype(np.float64) > t
 
     for beta in (2.0, np.float32(2.0) - np.float32(1.1920929e-07), 2.5, 1.0, 3.0, 0.1, 1.7, 1e-30, 3e38):

@@ -56,12 +56,12 @@ __device__ __forceinline__ float hmask_value(float h, float p, const MaskCfg& c)
 // resp. > is an exact test.  The inclusive case is folded into the threshold on the host (hard_mask_threshold):
 // x and m*d are both multiples of the last of those 49 bits wherever they are close, so x >= m*d  <=>
 // x > m*d*(1 - 2^-50), and the device compares strictly in both cases.  d = +inf gives fl(x / d) = 0 or NaN, never
-// >= beta > 0: fma(t, 0, t) turns t = inf into NaN (and leaves finite t alone), which no x exceeds.  NaNs compare
-// false on both sides.  Valid for normal positive beta (hard_mask_threshold() returns 0 otherwise: divide).
+// >= beta > 0: the threshold is +inf then, which no x exceeds under a STRICT comparison (while the comparison was
+// inclusive an extra fma(t, 0, t) turned it into a NaN; gone with it: one double-precision instruction per mask).
+// NaNs compare false on both sides.  Valid for normal positive beta (hard_mask_threshold() returns 0 otherwise: divide).
 __device__ __forceinline__ float hard_mask_exact(float x, float d, double thr, bool /*unused*/ = false)
 {
-	double t = thr * (double)d;
-	t = __builtin_fma(t, 0.0, t);
+	const double t = thr * (double)d;
 	return (double)x > t ? 1.0F : 0.0F;
 }
 
