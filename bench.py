@@ -53,8 +53,8 @@ HOP = 1024
 BETA = 2.0
 # HBM bytes per launch measured with rocprofv3 --pmc (tools/pmc_cmd.sh); re-collected whenever a kernel changes
 TRAFFIC_FILE = "r03_hbm_traffic.json"   # {demangled kernel name: {elements, rows, cols, hbm_bytes_per_launch, ...}}
-K_FUSED_P = "rt_fused_kernel<12, 47, 3, true, true>"
-K_FUSED_HPR = "rt_fused_kernel<12, 47, 3, false, true>"
+K_FUSED_P = "rt_fused_kernel<12, 47, 3, true, true, true>"
+K_FUSED_HPR = "rt_fused_kernel<12, 47, 3, false, true, true>"
 K_MEDIAN_WHOLE = "median47_dpp_kernel<true, 0, false>"
 K_MEDIAN_HALF = "median47_dpp_kernel<true, 0, true>"
 

@@ -35,7 +35,7 @@ def kernel(usage, src, prefix):
 
 
 def test_headline_block_kernel_keeps_its_register_allocation(usage):
-    k = kernel(usage, "rt_fused.hip", "rt_fused_kernel<12, 47, 3, true, true>")
+    k = kernel(usage, "rt_fused.hip", "rt_fused_kernel<12, 47, 3, true, true, true>")
     assert k["vgprs"] <= 168 and k["occupancy"] >= 3
     assert k["scratch"] <= 48, k                     # 36 bytes per lane (9 registers) as measured at 0.532 ms
 

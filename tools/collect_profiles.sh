@@ -21,13 +21,13 @@ rm -rf $OUT/kt
 B="python3 bench.py --no-legs --steps 3 --warmup 1 --settle-ms 0 --no-cpu-baseline --no-realtime"
 timeout 1300 tools/pmc_cmd.sh rt_fused_kernel $B > $OUT/pmc_fused_p.json 2> $OUT/pmc.err
 timeout 1300 tools/pmc_cmd.sh rt_fused_kernel $B --outputs HPR > $OUT/pmc_fused_hpr.json 2>> $OUT/pmc.err
-timeout 1300 tools/pmc_cmd.sh rt_fused_kernel $B --fused-minb 2 > $OUT/pmc_fused_p_minb2.json 2>> $OUT/pmc.err
+timeout 1300 tools/pmc_cmd.sh rt_fused_kernel $B --fused-minb 1 > $OUT/pmc_fused_p_minb2.json 2>> $OUT/pmc.err
 timeout 1300 tools/pmc_cmd.sh median47_dpp_kernel $B --no-block-fused > $OUT/pmc_median47_half.json 2>> $OUT/pmc.err
 timeout 1300 tools/pmc_cmd.sh median47_dpp_kernel python3 tools/bench_median.py --suite one --rows 25840 --cols 4096 --len 47 --iters 6 --nonneg > $OUT/pmc_median47_whole.json 2>> $OUT/pmc.err
 T=$OUT/hbm_traffic.json; rm -f $T
-python3 tools/traffic_json.py $T "$REV" $OUT/pmc_fused_p.json "rt_fused_kernel<12, 47, 3, true, true>" $((25840*4096)) 25840 4096 "one workgroup per hop, percussive output" >> $OUT/pmc.err 2>&1
-python3 tools/traffic_json.py $T "$REV" $OUT/pmc_fused_hpr.json "rt_fused_kernel<12, 47, 3, false, true>" $((25840*4096)) 25840 4096 "one workgroup per hop, three outputs" >> $OUT/pmc.err 2>&1
-python3 tools/traffic_json.py $T "$REV" $OUT/pmc_fused_p_minb2.json "rt_fused_kernel<12, 47, 2, true, true>" $((25840*4096)) 25840 4096 "the two-workgroups-per-CU build: no scratch -- what the write traffic is without spills" >> $OUT/pmc.err 2>&1
+python3 tools/traffic_json.py $T "$REV" $OUT/pmc_fused_p.json "rt_fused_kernel<12, 47, 3, true, true, true>" $((25840*4096)) 25840 4096 "one workgroup per hop, percussive output" >> $OUT/pmc.err 2>&1
+python3 tools/traffic_json.py $T "$REV" $OUT/pmc_fused_hpr.json "rt_fused_kernel<12, 47, 3, false, true, true>" $((25840*4096)) 25840 4096 "one workgroup per hop, three outputs" >> $OUT/pmc.err 2>&1
+python3 tools/traffic_json.py $T "$REV" $OUT/pmc_fused_p_minb2.json "rt_fused_kernel<12, 47, 1, true, true, true>" $((25840*4096)) 25840 4096 "the register-rich single-hop build run on the block: no scratch -- what the write traffic is without spills" >> $OUT/pmc.err 2>&1
 python3 tools/traffic_json.py $T "$REV" $OUT/pmc_median47_half.json "median47_dpp_kernel<true, 0, true>" $((25840*2072)) 25840 4096 "engine launch: bins 0..2048 and 4073..4095 of every row" >> $OUT/pmc.err 2>&1
 python3 tools/traffic_json.py $T "$REV" $OUT/pmc_median47_whole.json "median47_dpp_kernel<true, 0, false>" $((25840*4096)) 25840 4096 "whole rows (BASELINE's median metric)" >> $OUT/pmc.err 2>&1
 # micro-benchmarks the design decisions lean on

@@ -126,7 +126,10 @@ struct InvIn {
 constexpr int LEAN_PC_WORD = 5184;   // first word of the compact P row (behind the 259 * 20-word magnitude image)
 constexpr int LEAN_PC_TAIL = 2052;   // pc index of bin 3584
 constexpr int LEAN_EDGE_WORD = LEAN_PC_WORD + LEAN_PC_TAIL + 512 + 4; // wave-edge records of median47_core.h
-template <int N, int TF, int MID>
+// HARDP: the percussive output with a hard mask decided by exact comparison (masks.h hard_mask_exact) -- the realtime
+// default; nothing else is compiled in: the generic build carries the soft-mask / divide variants of every element's
+// mask as wave-uniform branches, a few thousand instructions of cold code threaded through the hot path.
+template <int N, int TF, int MID, bool HARDP>
 struct InvInLean {
 	const Regs* r;
 	const int* img; // magnitude image (word = bin + 24, 16-word chunks 20 apart)
@@ -148,9 +151,11 @@ struct InvInLean {
 		const int g = idx + 24;
 		const float mag = __int_as_float(img[(g >> 4) * 20 + (g & 15)]);
 		const float2 z = r->S[slot];
-		// thr is wave-uniform: one branch, no divide on the taken side
-		const float m = thr != 0.0 ? hard_mask_exact(pc[pi], mag + FLT_EPSILON, thr, thr_inclusive)
-		                           : mask_value(which, mag, pc[pi], cfg);
+		float m;
+		if constexpr (HARDP)
+			m = hard_mask_exact(pc[pi], mag + FLT_EPSILON, thr, thr_inclusive);
+		else // thr is wave-uniform: one branch, no divide on the taken side
+			m = thr != 0.0 ? hard_mask_exact(pc[pi], mag + FLT_EPSILON, thr, thr_inclusive) : mask_value(which, mag, pc[pi], cfg);
 		return make_float2(z.x * m, z.y * m); // apply_mask_functor hps.h:58-66
 	}
 };
@@ -158,7 +163,7 @@ struct InvInLean {
 // LEAN build with several outputs (hard masks): the two binary masks of the thread's 16 bins are compared ONCE, between
 // the median stage and the first inverse transform, and kept as two bits per bin (as istft_hard_multi_kernel keeps
 // them); every output's transform then reads nothing but the spectrum registers.  Same values as mask_value().
-template <int N, int TF, int MID>
+template <int N, int TF, int MID, bool HARDP>
 __device__ __forceinline__ unsigned lean_mask_bits(const int* img, const float* pc, int tf, const MaskCfg& cfg, double thr_p,
                                                    double thr_h)
 {
@@ -175,9 +180,16 @@ __device__ __forceinline__ unsigned lean_mask_bits(const int* img, const float* 
 			pi = (idx > N / 2 && idx < N - MID) ? N - idx : (idx > N / 2 ? idx - (N - 512) + LEAN_PC_TAIL : idx);
 		const int g = idx + 24;
 		const float h = __int_as_float(img[(g >> 4) * 20 + (g & 15)]), p = pc[pi]; // H = |S|: causal, SURVEY Q1
-		const HardThr t{thr_p, thr_h, 0, 0};
-		const unsigned pm = cfg.out_p ? (unsigned)(pmask_thr(h, p, cfg, t) != 0.0f) : 0u;
-		const unsigned hm = cfg.out_h ? (unsigned)(hmask_thr(h, p, cfg, t) != 0.0f) : 0u;
+		unsigned pm, hm;
+		if constexpr (HARDP) { // both thresholds are there (the launcher checked): comparisons only, no divide variants compiled in
+			pm = cfg.out_p ? (unsigned)(hard_mask_exact(p, h + FLT_EPSILON, thr_p) != 0.0f) : 0u; // hps.cu:501-505
+			hm = cfg.out_h ? (unsigned)(hard_mask_exact(h, p + FLT_EPSILON, thr_h) != 0.0f) : 0u; // hps.cu:535-540
+		}
+		else {
+			const HardThr t{thr_p, thr_h, 0, 0};
+			pm = cfg.out_p ? (unsigned)(pmask_thr(h, p, cfg, t) != 0.0f) : 0u;
+			hm = cfg.out_h ? (unsigned)(hmask_thr(h, p, cfg, t) != 0.0f) : 0u;
+		}
 		bits |= (pm | (hm << 1)) << (2 * slot);
 	}
 	return bits;
@@ -237,7 +249,7 @@ __device__ __forceinline__ void publish_ready(unsigned* flag, unsigned seq, int 
 
 // SINGLE: exactly one output is enabled (the realtime default, percussive only): the spectrum registers die
 // in the first pass of the one inverse transform instead of living through a loop over outputs.
-template <int LOG2N, int W, int MINB, bool SINGLE, bool LEAN = false>
+template <int LOG2N, int W, int MINB, bool SINGLE, bool LEAN = false, bool HARDP = false>
 __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFusedArgs a)
 {
 	using PL = Plan<LOG2N>;
@@ -256,6 +268,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 	// pieces on top of them spill, 1.19 against 1.13 ms with the generic median stage: one output only)
 	constexpr bool BLOCK47 = (W == 47 && LOG2N == 12 && (SINGLE || LEAN));
 	static_assert(!LEAN || BLOCK47, "the lean layout is the 47-tap kernel (one output, or several with hard masks)");
+	static_assert(!HARDP || LEAN, "the comparison-only mask builds are lean builds");
 	static_assert(!LEAN || (LEAN_EDGE_WORD + 256) * 4 <= PL::LDS_FLOAT2 * 8, "lean layout must fit in the frame image");
 
 	extern __shared__ float2 lds[];       // [FFT image | P row]; the magnitude image aliases the FFT image
@@ -488,7 +501,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		if (a.diag == 2)
 			return;
 		const MaskCfg cfg{a.beta, a.beta_h, 0, a.power, 0, a.out_h, a.out_p};
-		const unsigned bits = lean_mask_bits<N, TF, mid>(img, Prow, tf, cfg, a.thr, a.thr_h);
+		const unsigned bits = lean_mask_bits<N, TF, mid, HARDP>(img, Prow, tf, cfg, a.thr, a.thr_h);
 		__syncthreads(); // the magnitude image and the P row are dead: the transforms overwrite them
 		for (int oi = 0; oi < a.n_out; ++oi) {
 			const int which = a.out_id[oi];
@@ -523,7 +536,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 	else if constexpr (LEAN) { // |S| and P are read inside the first inverse pass, which then meets at a barrier
 		if (a.diag == 2)
 			return;
-		InvInLean<N, TF, mid> in;
+		InvInLean<N, TF, mid, HARDP> in;
 		in.r = &r;
 		in.img = img;
 		in.pc = Prow;
@@ -543,9 +556,9 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		}
 		out.hop = hop;
 		if constexpr (TWC)
-			zfft::fft_frame<LOG2N, true, false, true, InvInLean<N, TF, mid>, OutT, true>(tf, lds, twr, in, out, true);
+			zfft::fft_frame<LOG2N, true, false, true, InvInLean<N, TF, mid, HARDP>, OutT, true>(tf, lds, twr, in, out, true);
 		else
-			zfft::fft_frame<LOG2N, true, false, true, InvInLean<N, TF, mid>, OutT, true>(tf, lds, a.tw, in, out, true);
+			zfft::fft_frame<LOG2N, true, false, true, InvInLean<N, TF, mid, HARDP>, OutT, true>(tf, lds, a.tw, in, out, true);
 		if (out.ready && a.publish_seq)
 			publish_ready(reinterpret_cast<unsigned*>(out.ready + hop), a.seq, tf);
 		if constexpr (MINB == 1) {
@@ -606,13 +619,13 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 	}
 }
 
-template <int LOG2N, int W, int MINB, bool SINGLE, bool LEAN = false>
+template <int LOG2N, int W, int MINB, bool SINGLE, bool LEAN = false, bool HARDP = false>
 int launch_k(const RtFusedArgs& a, hipStream_t stream)
 {
 	using PL = Plan<LOG2N>;
 	const size_t lds = LEAN ? sizeof(float2) * PL::LDS_FLOAT2
 	                        : sizeof(float2) * PL::LDS_FLOAT2 + sizeof(float) * PL::N + (W == 47 && LOG2N == 12 && SINGLE ? 1024 : 0);
-	auto kern = rt_fused_kernel<LOG2N, W, MINB, SINGLE, LEAN>;
+	auto kern = rt_fused_kernel<LOG2N, W, MINB, SINGLE, LEAN, HARDP>;
 	if (lds > 64 * 1024)
 		ZH_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	hipLaunchKernelGGL(kern, dim3((unsigned)((long long)a.n_streams * a.n_frames)), dim3(PL::TF), lds, stream, a);
@@ -634,7 +647,8 @@ int launch_multi_t(const RtFusedArgs& a, hipStream_t stream)
 	if constexpr (LOG2N == 12 && W == 47) {
 		// hard masks, blocks of hops: the lean layout with the masks kept as two bits per bin ("block_fused_minb" = 5:
 		// the roomy layout below, 6: this translation unit's build of the lean kernel, for comparison)
-		if (a.n_frames > 1 && !a.soft && g_opt_block_fused_minb != 5 && g_opt_block_fused_minb != 1 && g_opt_block_fused_minb != 2) {
+		if (a.n_frames > 1 && !a.soft && a.thr != 0.0 && a.thr_h != 0.0 && g_opt_block_fused_minb != 5 && g_opt_block_fused_minb != 1
+		    && g_opt_block_fused_minb != 2) {
 			if (g_opt_block_fused_minb == 6)
 				return launch_k<LOG2N, W, 3, false, true>(a, stream);
 			return launch_rt_fused_multi_lean(a, stream);
@@ -658,11 +672,13 @@ int launch_t(const RtFusedArgs& a, hipStream_t stream)
 		// 0.74 ms against 0.60 ms per 25 840 hops, measured); "block_fused_minb" = 4 selects that build, 5 the
 		// roomy layout below, for comparison.
 		if (a.n_out == 1 && g_opt_block_fused_minb != 5) {
+			// the percussive output with a hard mask by comparison (the realtime default): builds with nothing else in them
+			const bool hardp = a.out_id[0] == 0 && !a.soft && a.thr != 0.0;
 			if (a.n_frames == 1 || g_opt_block_fused_minb == 1) // (1 on a block: the register-rich build, no scratch -- a diagnostic)
-				return launch_k<LOG2N, W, 1, true, true>(a, stream);
+				return hardp ? launch_k<LOG2N, W, 1, true, true, true>(a, stream) : launch_k<LOG2N, W, 1, true, true>(a, stream);
 			if (g_opt_block_fused_minb == 4)
 				return launch_k<LOG2N, W, 4, true, true>(a, stream);
-			return launch_k<LOG2N, W, 3, true, true>(a, stream);
+			return hardp ? launch_k<LOG2N, W, 3, true, true, true>(a, stream) : launch_k<LOG2N, W, 3, true, true>(a, stream);
 		}
 	}
 	if (a.n_frames == 1 || g_opt_block_fused_minb == 1)
@@ -676,7 +692,7 @@ int launch_t(const RtFusedArgs& a, hipStream_t stream)
 } // namespace
 
 #if defined(ZEN_RT_FUSED_MULTI_LEAN)
-int launch_rt_fused_multi_lean(const RtFusedArgs& a, hipStream_t stream) { return launch_k<12, 47, 3, false, true>(a, stream); }
+int launch_rt_fused_multi_lean(const RtFusedArgs& a, hipStream_t stream) { return launch_k<12, 47, 3, false, true, true>(a, stream); }
 #elif defined(ZEN_RT_FUSED_MULTI)
 int launch_rt_fused_multi(int log2n, int freq_len, const RtFusedArgs& a, hipStream_t stream)
 {
