@@ -24,12 +24,38 @@ using zfft::Plan;
 // |S| is exactly Hermitian (fft_dev.h), so H (|S| or its time median / box mean) is mirror symmetric, and so is P
 // except for the p_mid bins next to either end of the row, where the replicate border differs.
 // The upper halves of the H and P rows are therefore never read: they cost no HBM traffic.
+// HARD: hard masks decided by exact comparison (masks.h hard_mask_exact; both thresholds valid: the launcher checks) --
+// the default of every configuration but the soft-mask / SSE ones.  Both comparisons are made for every bin and the
+// output's mask is formed from them with wave-uniform coefficients: m = s0 + s1 * (gh*hm + gp*pm), all operands 0 or
+// +-1, so every operation is exact and the value is mask_value()'s: (gh, gp, s0, s1) = (0, 1, 0, 1) percussive,
+// (1, 0, 0, 1) harmonic, (out_h, out_p, 1, -1) residual = 1 - (hm + pm) (hps.h:35-43).  No branch, and none of the
+// generic build's divide / soft / SSE variants, which it carries as wave-uniform branches around every element.
+struct HardSel {
+	float gh, gp, s0, s1;
+};
+__device__ __forceinline__ HardSel hard_sel(int which, const MaskCfg& c)
+{
+	if (which == 0)
+		return HardSel{0.0f, 1.0f, 0.0f, 1.0f};
+	if (which == 1)
+		return HardSel{1.0f, 0.0f, 0.0f, 1.0f};
+	return HardSel{c.out_h ? 1.0f : 0.0f, c.out_p ? 1.0f : 0.0f, 1.0f, -1.0f};
+}
+__device__ __forceinline__ float hard_mask_sel(float h, float p, const HardThr& t, const HardSel& k)
+{
+	const float pm = hard_mask_exact(p, h + FLT_EPSILON, t.p); // hps.cu:501-505
+	const float hm = hard_mask_exact(h, p + FLT_EPSILON, t.h); // hps.cu:535-540
+	return k.s0 + k.s1 * (k.gh * hm + k.gp * pm);
+}
+
+template <bool HARD>
 struct IstftIn {
 	const float2* S;
 	const float* H;
 	const float* P;
 	MaskCfg cfg;
 	HardThr thr;
+	HardSel sel;
 	int which;
 	int n;
 	int p_mid;
@@ -41,7 +67,7 @@ struct IstftIn {
 		if (mirror)
 			z.y = -z.y;
 		const int pi = (mirror && idx >= n - p_mid) ? idx : lo;
-		const float m = mask_value_thr(which, H[lo], P[pi], cfg, thr);
+		const float m = HARD ? hard_mask_sel(H[lo], P[pi], thr, sel) : mask_value_thr(which, H[lo], P[pi], cfg, thr);
 		return make_float2(z.x * m, z.y * m); // apply_mask_functor hps.h:58-66
 	}
 };
@@ -71,7 +97,7 @@ __device__ __forceinline__ void load_carry(const float* carry, int tf, bool want
 		cv[i] = wanted ? carry[tf + i * TF] : 0.0f;
 }
 
-template <int LOG2N>
+template <int LOG2N, bool HARD>
 __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void istft_kernel(IstftArgs a)
 {
 	using PL = Plan<LOG2N>;
@@ -81,7 +107,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void istft_kernel(IstftArgs a
 	const int f = blockIdx.x * PL::FRAMES_PER_BLOCK + slot;
 	const bool active = f < a.n_frames;
 	const long long ring_row = ((a.crow0 + f) % a.ring_rows) + (long long)s * a.ring_rows;
-	IstftIn in;
+	IstftIn<HARD> in;
 	in.S = a.S + ring_row * a.s_stride;
 	in.n = PL::N;
 	in.H = a.h_is_ring ? a.H + ring_row * PL::N : a.H + (long long)s * a.h_stream_stride + (long long)f * PL::N;
@@ -89,6 +115,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void istft_kernel(IstftArgs a
 	in.cfg = MaskCfg{a.beta, a.beta_h, a.soft, a.power, a.sse, a.out_h, a.out_p};
 	in.thr = HardThr{a.thr_p, a.thr_h, a.thr_p_inc, a.thr_h_inc};
 	in.which = a.out_id[oi];
+	in.sel = hard_sel(in.which, in.cfg);
 	in.p_mid = a.p_mid;
 	IstftOut out;
 	out.Y = a.Y[oi] + (long long)s * a.y_stream_stride + (long long)f * (PL::N / 2);
@@ -119,6 +146,7 @@ struct IstftHardIn {
 	MaskCfg cfg;
 	HardThr thr;
 	unsigned* bits; // bit 2*slot: percussive mask, bit 2*slot + 1: harmonic mask
+	bool cmp_only;  // both hard-mask thresholds are valid (the usual case)
 	int which;
 	int first;
 	int n;
@@ -132,8 +160,15 @@ struct IstftHardIn {
 			z.y = -z.y;
 		if (first) {
 			const float h = H[lo], p = P[(mirror && idx >= n - p_mid) ? idx : lo]; // see IstftIn
-			const unsigned pm = cfg.out_p || which == 0 ? (unsigned)(pmask_thr(h, p, cfg, thr) != 0.0f) : 0u;
-			const unsigned hm = cfg.out_h || which == 1 ? (unsigned)(hmask_thr(h, p, cfg, thr) != 0.0f) : 0u;
+			unsigned pm, hm;
+			if (cmp_only) { // wave-uniform; both thresholds valid: no divide behind it
+				pm = cfg.out_p || which == 0 ? (unsigned)(hard_mask_exact(p, h + FLT_EPSILON, thr.p) != 0.0f) : 0u;
+				hm = cfg.out_h || which == 1 ? (unsigned)(hard_mask_exact(h, p + FLT_EPSILON, thr.h) != 0.0f) : 0u;
+			}
+			else {
+				pm = cfg.out_p || which == 0 ? (unsigned)(pmask_thr(h, p, cfg, thr) != 0.0f) : 0u;
+				hm = cfg.out_h || which == 1 ? (unsigned)(hmask_thr(h, p, cfg, thr) != 0.0f) : 0u;
+			}
 			*bits |= (pm | (hm << 1)) << (2 * slot);
 		}
 		const float pm = (float)((*bits >> (2 * slot)) & 1u), hm = (float)((*bits >> (2 * slot + 1)) & 1u);
@@ -161,6 +196,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void istft_hard_multi_kernel(
 	in.cfg = MaskCfg{a.beta, a.beta_h, 0, a.power, 0, a.out_h, a.out_p};
 	in.thr = HardThr{a.thr_p, a.thr_h, a.thr_p_inc, a.thr_h_inc};
 	in.bits = &bits;
+	in.cmp_only = a.thr_p != 0.0 && a.thr_h != 0.0;
 	in.p_mid = a.p_mid;
 	for (int oi = 0; oi < a.n_out; ++oi) {
 		in.which = a.out_id[oi];
@@ -206,9 +242,16 @@ int launch_istft_t(const IstftArgs& a, hipStream_t stream)
 		ZH_HIP(hipGetLastError());
 		return ZEN_HIP_OK;
 	}
-	auto kern = istft_kernel<LOG2N>;
-	ZH_TRY(set_lds(kern, lds_bytes<LOG2N>()));
 	dim3 grid((unsigned)ceil_div((size_t)a.n_frames, (size_t)PL::FRAMES_PER_BLOCK), (unsigned)a.n_out, (unsigned)a.n_streams);
+	if (!a.soft && !a.sse && a.thr_p != 0.0 && a.thr_h != 0.0) { // hard masks by comparison: the build with nothing else in it
+		auto kern = istft_kernel<LOG2N, true>;
+		ZH_TRY(set_lds(kern, lds_bytes<LOG2N>()));
+		hipLaunchKernelGGL(kern, grid, dim3(PL::THREADS), lds_bytes<LOG2N>(), stream, a);
+		ZH_HIP(hipGetLastError());
+		return ZEN_HIP_OK;
+	}
+	auto kern = istft_kernel<LOG2N, false>;
+	ZH_TRY(set_lds(kern, lds_bytes<LOG2N>()));
 	hipLaunchKernelGGL(kern, grid, dim3(PL::THREADS), lds_bytes<LOG2N>(), stream, a);
 	ZH_HIP(hipGetLastError());
 	return ZEN_HIP_OK;
