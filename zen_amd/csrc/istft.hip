@@ -48,7 +48,9 @@ __device__ __forceinline__ float hard_mask_sel(float h, float p, const HardThr& 
 	return k.s0 + k.s1 * (k.gh * hm + k.gp * pm);
 }
 
-template <bool HARD>
+// MODE 0: any mask (generic); 1: hard masks by comparison, any output; 2: the same for the percussive output alone
+// (pass 2 of the offline configuration, the realtime default): one comparison per bin.
+template <int MODE>
 struct IstftIn {
 	const float2* S;
 	const float* H;
@@ -67,7 +69,13 @@ struct IstftIn {
 		if (mirror)
 			z.y = -z.y;
 		const int pi = (mirror && idx >= n - p_mid) ? idx : lo;
-		const float m = HARD ? hard_mask_sel(H[lo], P[pi], thr, sel) : mask_value_thr(which, H[lo], P[pi], cfg, thr);
+		float m;
+		if constexpr (MODE == 2)
+			m = hard_mask_exact(P[pi], H[lo] + FLT_EPSILON, thr.p); // hps.cu:501-505
+		else if constexpr (MODE == 1)
+			m = hard_mask_sel(H[lo], P[pi], thr, sel);
+		else
+			m = mask_value_thr(which, H[lo], P[pi], cfg, thr);
 		return make_float2(z.x * m, z.y * m); // apply_mask_functor hps.h:58-66
 	}
 };
@@ -97,7 +105,7 @@ __device__ __forceinline__ void load_carry(const float* carry, int tf, bool want
 		cv[i] = wanted ? carry[tf + i * TF] : 0.0f;
 }
 
-template <int LOG2N, bool HARD>
+template <int LOG2N, int MODE>
 __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void istft_kernel(IstftArgs a)
 {
 	using PL = Plan<LOG2N>;
@@ -107,7 +115,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void istft_kernel(IstftArgs a
 	const int f = blockIdx.x * PL::FRAMES_PER_BLOCK + slot;
 	const bool active = f < a.n_frames;
 	const long long ring_row = ((a.crow0 + f) % a.ring_rows) + (long long)s * a.ring_rows;
-	IstftIn<HARD> in;
+	IstftIn<MODE> in;
 	in.S = a.S + ring_row * a.s_stride;
 	in.n = PL::N;
 	in.H = a.h_is_ring ? a.H + ring_row * PL::N : a.H + (long long)s * a.h_stream_stride + (long long)f * PL::N;
@@ -243,14 +251,14 @@ int launch_istft_t(const IstftArgs& a, hipStream_t stream)
 		return ZEN_HIP_OK;
 	}
 	dim3 grid((unsigned)ceil_div((size_t)a.n_frames, (size_t)PL::FRAMES_PER_BLOCK), (unsigned)a.n_out, (unsigned)a.n_streams);
-	if (!a.soft && !a.sse && a.thr_p != 0.0 && a.thr_h != 0.0) { // hard masks by comparison: the build with nothing else in it
-		auto kern = istft_kernel<LOG2N, true>;
+	if (!a.soft && !a.sse && a.thr_p != 0.0 && a.thr_h != 0.0) { // hard masks by comparison: the builds with nothing else in them
+		auto kern = (a.n_out == 1 && a.out_id[0] == 0) ? istft_kernel<LOG2N, 2> : istft_kernel<LOG2N, 1>;
 		ZH_TRY(set_lds(kern, lds_bytes<LOG2N>()));
 		hipLaunchKernelGGL(kern, grid, dim3(PL::THREADS), lds_bytes<LOG2N>(), stream, a);
 		ZH_HIP(hipGetLastError());
 		return ZEN_HIP_OK;
 	}
-	auto kern = istft_kernel<LOG2N, false>;
+	auto kern = istft_kernel<LOG2N, 0>;
 	ZH_TRY(set_lds(kern, lds_bytes<LOG2N>()));
 	hipLaunchKernelGGL(kern, grid, dim3(PL::THREADS), lds_bytes<LOG2N>(), stream, a);
 	ZH_HIP(hipGetLastError());
