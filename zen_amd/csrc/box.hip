@@ -80,20 +80,10 @@ __global__ __launch_bounds__(256) void box_time_kernel(FilterArgs a, int rows_pe
 	const long long ar0 = a.first_row + q0;
 	const int nrows = nq + len - 1;
 	if (col < cols) {
-		// Ring row of tile row i: (clamped absolute row) mod ring_rows.  The 64-bit modulo is taken ONCE, for the thread's
-		// first tile row (a software division: ~100 instructions, which per tile row was three quarters of this kernel's
-		// work); the rows that follow are at most 4 further on, so the index advances by a compare and a subtract.
-		long long r = ar0 - mid + rl;
-		r = r < a.clamp_lo ? a.clamp_lo : (r > a.clamp_hi ? a.clamp_hi : r);
-		long long idx = r % a.ring_rows;
 		for (int i = rl; i < nrows; i += 4) {
-			tile[i * TIME_COLS + lane_col] = pre_of(src[idx * cols + col], a.sse_pre);
-			long long rn = ar0 - mid + i + 4;
-			rn = rn < a.clamp_lo ? a.clamp_lo : (rn > a.clamp_hi ? a.clamp_hi : rn);
-			idx += rn - r; // 0..4
-			r = rn;
-			while (idx >= a.ring_rows) // (a ring shorter than the step wraps more than once)
-				idx -= a.ring_rows;
+			long long r = ar0 - mid + i;
+			r = r < a.clamp_lo ? a.clamp_lo : (r > a.clamp_hi ? a.clamp_hi : r);
+			tile[i * TIME_COLS + lane_col] = pre_of(src[(r % a.ring_rows) * cols + col], a.sse_pre);
 		}
 	}
 	__syncthreads();
