@@ -3,7 +3,7 @@
 
   mfilt -- libzen/mfilt.bench.cu:222-262: dim x dim matrices, dim = 2^5 .. 2^14, filter 11, iota data, both
            directions; device-resident, and the "MEM" variants through mapped host memory (dim <= 2^12).
-  fft   -- libzen/fftw.bench.cu:231-282: one C2C transform of n = 2^8 .. 2^14 (the wrapper's maximum here),
+  fft   -- libzen/fftw.bench.cu:231-282: one C2C transform of n = 2^8 .. 2^15 (the reference's whole sweep),
            forward, inverse, round trip; per-call latency and batched throughput.
   hpr   -- libzen/hps.bench.cu:62-64: HPRRealtime<GPU>(48000, hop, 2.0, P) for hop = 2^5 .. 2^12: per-hop
            call path through mapped memory (the figure docs/cpu_vs_gpu.png plots), and block-mode hops/s.
@@ -56,7 +56,7 @@ def suite_mfilt():
 
 def suite_fft():
     rng = np.random.default_rng(0)
-    for k in range(8, 15):
+    for k in range(8, 16):
         n = 1 << k
         f = zen_amd.FFTC2CWrapperGPU(n)
         f.fft_vec.upload((rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64))

@@ -33,4 +33,6 @@ python3 tools/traffic_json.py $T "$REV" $OUT/pmc_median47_whole.json "median47_d
 # micro-benchmarks the design decisions lean on
 mkdir -p /tmp/ub
 g++ -O2 -std=c++17 -I include tools/rt_latency.cpp -o /tmp/ub/rt -L zen_amd -lzen_hip -Wl,-rpath,$PWD/zen_amd && /tmp/ub/rt 3000 --stamps > $OUT/rt_latency.jsonl 2>&1
+# the shape sweeps of the reference's three bench harnesses on this build
+python3 tools/bench_sweeps.py > $OUT/sweeps.jsonl 2>> $OUT/bench_default.err
 ls -la $OUT
