@@ -206,6 +206,64 @@ __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowM
 }
 
 // -------------------------------------------------------------------------------------------------
+// Hermitian rows (FilterArgs::hermitian; the engine's half rows) that fit one segment: of a row's cols / T chunks of
+// T outputs only the first cols / (2T) + 1 (columns 0 .. cols/2) and the last ceil(mid / T) (the last `mid` columns,
+// whose replicate border is not the mirror image of the first ones') are wanted -- 131 of 256 for every mask of the
+// BASELINE configurations -- and the kernel above leaves the other half of its workgroup idle.  Here a 448-thread
+// workgroup takes THREE rows, one thread per wanted chunk, stages only the columns those chunks read (the mirrored
+// upper half comes from the stored half, row_vec_keys) and stores straight from registers: consecutive threads write
+// consecutive 16-byte vectors.  Same network, same values.
+constexpr int HERM_THREADS = 448;
+
+template <int W, bool NONNEG>
+__global__ __launch_bounds__(HERM_THREADS) void median_net_freq_herm_kernel(FilterArgs a, RowMap rm, int n_lo, int n_tail,
+                                                                            int lwv, int twv)
+{
+	constexpr int T = znet::outputs_per_thread(W), mid = W / 2;
+	static_assert(T >= 4, "16-byte LDS path needs T >= 4");
+	constexpr int MID_AL = (mid + 3) & ~3, DELTA = MID_AL - mid;
+	constexpr int NV = (DELTA + W + T - 1 + 3) / 4, NE = NV * 4;
+	extern __shared__ __attribute__((aligned(16))) int himg[]; // per row: lwv vectors (columns -MID_AL ..), then twv (the tail)
+	const int tid = threadIdx.x, cols = a.cols;
+	const int jobs = n_lo + n_tail, rpw = HERM_THREADS / jobs, row_vecs = lwv + twv;
+	const int row0 = blockIdx.x * rpw;
+	const int c_t0 = cols - n_tail * T; // first column of the tail chunks
+	const float* __restrict__ src = a.src + (long long)blockIdx.y * a.src_stream_stride;
+	for (int v = tid; v < rpw * row_vecs; v += HERM_THREADS) {
+		const int rr = v / row_vecs, vv = v - rr * row_vecs;
+		if (row0 + rr < a.n_out_rows) {
+			const float* srow = src + (long long)map_row(rm, row0 + rr) * cols;
+			const int col = vv < lwv ? 4 * vv - MID_AL : c_t0 - MID_AL + 4 * (vv - lwv);
+			*reinterpret_cast<int4*>(&himg[4 * v]) = row_vec_keys<NONNEG>(srow, col, cols, 1);
+		}
+	}
+	__syncthreads();
+	const int rr = tid / jobs, j = tid - rr * jobs;
+	if (rr >= rpw || row0 + rr >= a.n_out_rows)
+		return;
+	const bool tail = j >= n_lo;
+	const int* mine = &himg[4 * (rr * row_vecs + (tail ? lwv : 0)) + T * (tail ? j - n_lo : j)]; // word 0 = chunk's first column - MID_AL
+	int ld[NE], e[W + T - 1], out[T];
+#pragma unroll
+	for (int v = 0; v < NV; ++v) {
+		const int4 q = *reinterpret_cast<const int4*>(mine + 4 * v);
+		ld[4 * v] = q.x;
+		ld[4 * v + 1] = q.y;
+		ld[4 * v + 2] = q.z;
+		ld[4 * v + 3] = q.w;
+	}
+#pragma unroll
+	for (int q = 0; q < W + T - 1; ++q)
+		e[q] = ld[q + DELTA];
+	znet::medians<W, T, W + T - 1>(e, out);
+	float* d = a.dst + (long long)blockIdx.y * a.dst_stream_stride + (long long)(row0 + rr) * cols + (tail ? c_t0 + T * (j - n_lo) : T * j);
+#pragma unroll
+	for (int v = 0; v < T / 4; ++v)
+		*reinterpret_cast<float4*>(d + 4 * v) = make_float4(from_key<NONNEG>(out[4 * v]), from_key<NONNEG>(out[4 * v + 1]),
+		                                                    from_key<NONNEG>(out[4 * v + 2]), from_key<NONNEG>(out[4 * v + 3]));
+}
+
+// -------------------------------------------------------------------------------------------------
 template <int VC>
 struct VecT;
 template <>
@@ -337,6 +395,23 @@ int launch_freq(const FilterArgs& a, const RowMap& rm, hipStream_t stream)
 	dim3 grid((unsigned)((long long)a.n_out_rows * segs), (unsigned)a.n_streams);
 	if (a.hermitian && !vec_ok)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "median: Hermitian rows need 16-byte aligned rows of a multiple of 4 columns");
+	if (a.hermitian && segs == 1 && a.cols % (2 * T) == 0 && !g_opt_median_general) { // three rows per workgroup: median_net_freq_herm_kernel
+		constexpr int mid = W / 2, MID_AL = (mid + 3) & ~3, DELTA = MID_AL - mid, NV = (DELTA + W + T - 1 + 3) / 4;
+		const int n_lo = a.cols / (2 * T) + 1, n_tail = (mid + T - 1) / T, jobs = n_lo + n_tail;
+		// a chunk's window starts T*j words into its piece of the image and is NV vectors long
+		const int lwv = (T * (n_lo - 1)) / 4 + NV, twv = (T * (n_tail - 1)) / 4 + NV;
+		if (jobs <= HERM_THREADS && a.n_out_rows < 0x3fffffff) {
+			const int rpw = HERM_THREADS / jobs;
+			const size_t lds = sizeof(int) * 4 * (size_t)rpw * (lwv + twv);
+			dim3 g((unsigned)((a.n_out_rows + rpw - 1) / rpw), (unsigned)a.n_streams);
+			if (a.nonneg)
+				hipLaunchKernelGGL((median_net_freq_herm_kernel<W, true>), g, dim3(HERM_THREADS), lds, stream, a, rm, n_lo, n_tail, lwv, twv);
+			else
+				hipLaunchKernelGGL((median_net_freq_herm_kernel<W, false>), g, dim3(HERM_THREADS), lds, stream, a, rm, n_lo, n_tail, lwv, twv);
+			ZH_HIP(hipGetLastError());
+			return ZEN_HIP_OK;
+		}
+	}
 	if constexpr (W == 47) {
 		if (!g_opt_no_median47_neighbour && !a.hermitian) {
 			if (a.nonneg)
