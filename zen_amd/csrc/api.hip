@@ -24,6 +24,7 @@ opt_t g_opt_mask_divide{0};
 opt_t g_opt_no_half_rows{0};
 opt_t g_opt_mfilt_nonneg{0};
 opt_t g_opt_no_persist{0};
+opt_t g_opt_no_direct_out{0};
 std::atomic<unsigned> g_host_free_gen{0};
 
 void set_error(const char* fmt, ...)
@@ -167,7 +168,8 @@ int zen_hip_set_option(const char* name, int value)
 	             {"mask_divide", &g_opt_mask_divide},
 	             {"no_half_rows", &g_opt_no_half_rows},
 	             {"mfilt_nonneg", &g_opt_mfilt_nonneg},
-	             {"no_persist", &g_opt_no_persist}};
+	             {"no_persist", &g_opt_no_persist},
+	             {"no_direct_out", &g_opt_no_direct_out}};
 	for (const auto& t : table) {
 		if (name && !strcmp(name, t.name)) {
 			t.var->store(value, std::memory_order_relaxed);

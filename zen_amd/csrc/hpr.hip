@@ -96,6 +96,8 @@ void free_all(zen_hip_hpr* e)
 	(void)hipFree(e->d_mag);
 	(void)hipFree(e->d_H);
 	(void)hipFree(e->d_P);
+	(void)hipFree(e->d_blk_flag);
+	(void)hipFree(e->d_blk_need);
 	for (int o = 0; o < 3; ++o) {
 		(void)hipFree(e->d_Y[o]);
 		(void)hipFree(e->d_carry[o]);
@@ -251,6 +253,30 @@ int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, H
 		a.bar_parity = (int)(e->wide_calls++ & 1u);
 		e->wide_arrivals += rt_wide_arrivals(e->log2n, a.n_out);
 	}
+	// block calls of the headline configuration: the kernel finishes the hops itself where the caller has said where they go
+	int direct_o = -1;
+	for (int o = 0; o < 3; ++o)
+		e->direct_done[o] = false;
+	if (kind == HOP_FUSED && a.n_out == 1 && e->direct_out[a.out_id[0]] && !g_opt_no_direct_out
+	    && rt_fused_direct_out_available(e->log2n, e->mf, a)) {
+		direct_o = a.out_id[0];
+		if (!e->d_blk_flag) {
+			const size_t bytes = sizeof(unsigned) * e->n_streams * e->max_hops;
+			ZH_HIP(hipMalloc((void**)&e->d_blk_flag, bytes));
+			ZH_HIP(hipMalloc((void**)&e->d_blk_need, bytes));
+			ZH_HIP(hipMemsetAsync(e->d_blk_flag, 0, bytes, e->stream));
+			ZH_HIP(hipMemsetAsync(e->d_blk_need, 0, bytes, e->stream));
+			e->blk_seq = 0;
+		}
+		a.out_direct = e->direct_out[direct_o];
+		a.out_direct_stride = e->direct_stride;
+		a.blk_flag = e->d_blk_flag;
+		a.blk_need = e->d_blk_need;
+		e->blk_seq = (e->blk_seq + 1) & 0x0fffffffu;
+		if (e->blk_seq == 0) // (the words start at zero: sequence number zero is never used)
+			e->blk_seq = 1;
+		a.blk_seq = e->blk_seq;
+	}
 	{
 		ProfScope ps(e, zen_hip_hpr::K_FUSED);
 		if (kind == HOP_WIDE)
@@ -259,6 +285,11 @@ int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, H
 			ZH_TRY(launch_rt_sse(e->log2n, a, e->mt, e->mf, (float)e->l_harm + 1.0F, (float)e->l_perc + 1.0F, e->stream));
 		else
 			ZH_TRY(launch_rt_fused(e->log2n, e->mf, a, e->stream));
+	}
+	if (direct_o >= 0) {
+		ProfScope ps(e, zen_hip_hpr::K_FINALIZE);
+		ZH_TRY(launch_rt_fused_fixup(a, direct_o, e->stream));
+		e->direct_done[direct_o] = true;
 	}
 	e->tail_sel ^= 1;
 	e->abs_frame += (long long)M;
@@ -556,6 +587,9 @@ int grow_buffers(zen_hip_hpr* e, size_t new_hops)
 	e->d_S = nS;
 	e->d_mag = nmag;
 	e->d_H = e->d_P = nullptr; // ensure_estimates
+	(void)hipFree(e->d_blk_flag);
+	(void)hipFree(e->d_blk_need);
+	e->d_blk_flag = e->d_blk_need = nullptr; // run_hop_fused
 	for (int o = 0; o < 3; ++o) {
 		if (e->d_Y[o]) {
 			(void)hipFree(e->d_Y[o]);
@@ -824,10 +858,18 @@ int zen_hip_hpr_process(zen_hip_hpr_t h, const float* in_dev, size_t n_hops, siz
 		ZH_TRY(grow_buffers(h, n_hops < h->max_hops_cap ? n_hops : h->max_hops_cap));
 	for (size_t off = 0; off < n_hops; off += h->max_hops) {
 		const size_t M = (n_hops - off < h->max_hops) ? n_hops - off : h->max_hops;
-		ZH_TRY(run_chunk(h, in_dev + off * h->hop, in_stride, M));
+		for (int o = 0; o < 3; ++o) // (a kernel that finishes hops itself writes them here: run_hop_fused)
+			h->direct_out[o] = outs[o] ? outs[o] + off * h->hop : nullptr;
+		h->direct_stride = (long long)out_stride;
+		const int rc = run_chunk(h, in_dev + off * h->hop, in_stride, M);
 		for (int o = 0; o < 3; ++o)
-			if (outs[o])
+			h->direct_out[o] = nullptr;
+		ZH_TRY(rc);
+		for (int o = 0; o < 3; ++o)
+			if (outs[o] && !h->direct_done[o])
 				ZH_TRY(finalize_output(h, o, outs[o] + off * h->hop, out_stride, M));
+		for (int o = 0; o < 3; ++o)
+			h->direct_done[o] = false;
 	}
 	return ZEN_HIP_OK;
 }

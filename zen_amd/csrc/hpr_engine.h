@@ -40,6 +40,14 @@ struct zen_hip_hpr {
 	int tail_sel = 0;
 	float2* d_S = nullptr;
 	float* d_mag = nullptr;
+	// block calls of the causal one-output hard-mask engine at nfft 4096 / 47 taps: the fused kernel finishes the hops
+	// itself (RtFusedArgs::out_direct); per item a publication word and a "left for the fix-up" mark
+	unsigned* d_blk_flag = nullptr;
+	unsigned* d_blk_need = nullptr;
+	unsigned blk_seq = 0;
+	float* direct_out[3] = {nullptr, nullptr, nullptr}; // set by zen_hip_hpr_process around run_chunk: where output o's hops go
+	long long direct_stride = 0;
+	bool direct_done[3] = {false, false, false};        // run_chunk delivered output o's hops itself: no finalize launch
 	float* d_H = nullptr;
 	float* d_P = nullptr;
 	float* d_Y[3] = {nullptr, nullptr, nullptr};     // 0 percussive, 1 harmonic, 2 residual

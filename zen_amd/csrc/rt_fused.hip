@@ -221,6 +221,24 @@ struct InvOut { // block builds
 			ready[idx] = carry[idx] + y;
 	}
 };
+struct InvOutLo { // block build that finishes hops itself: the first half of the frame also stays in registers
+	float* Y;
+	float cola;
+	float lo[4]; // idx = tf + slot*TF, slot < 4
+	__device__ __forceinline__ void operator()(int idx, float2 x, bool, int slot)
+	{
+		const float y = x.x * cola;
+		Y[idx] = y;
+		if (slot < 4)
+			lo[slot] = y;
+	}
+};
+__device__ __forceinline__ unsigned xcc_id_of_cu()
+{
+	unsigned v;
+	asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+	return v & 15u;
+}
 struct InvOutReg { // the single-hop build
 	float* Y;
 	float cola;
@@ -544,6 +562,52 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		in.which = a.out_id[0];
 		in.thr = (in.which == 0 && !a.soft) ? a.thr : 0.0;
 		in.thr_inclusive = a.thr_inclusive != 0;
+		if constexpr (HARDP && MINB != 1) {
+			// ---- block build: the overlap-add of consecutive hops without a launch of its own (hps.cu:435-449, :526-528).
+			// Output hop f = second half of frame f-1 + first half of frame f.  The workgroup keeps its first half in
+			// registers, writes its Y row, and once the row is in the L2 publishes (sequence number of the call, XCD it runs
+			// on) for its item; then it reads the predecessor's word.  Consecutive items of a launch share an XCD (see the
+			// item order above), so normally the predecessor -- dispatched eight workgroups earlier -- has long published
+			// from the same XCD: its second half is read from the shared L2 (stores are there once the memory counter has
+			// drained; the reader only drops its L1) and the finished hop goes straight to the caller's buffer.  Anything
+			// else -- the first hop of a stream or of an XCD's run, a predecessor on another XCD or not there after a bounded
+			// wait -- is marked and added up by launch_rt_fused_fixup after the kernel: correct wherever the workgroups run.
+			InvOutLo out;
+			out.Y = a.Y[in.which] + (long long)s * a.y_stream_stride + (long long)f * (2 * hop);
+			out.cola = a.cola;
+			zfft::fft_frame<LOG2N, true, false, true, InvInLean<N, TF, mid, HARDP>, InvOutLo, true>(tf, lds, a.tw, in, out, true);
+			if (a.out_direct) {
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				__syncthreads();
+				const unsigned me = xcc_id_of_cu();
+				if (tf == 0)
+					__hip_atomic_store(a.blk_flag + item, (a.blk_seq << 4) | me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				bool ok = false;
+				if (f > 0 && (blockIdx.x >> 3) > 0) {
+					unsigned v = 0;
+					for (int spin = 0; spin < 4096; ++spin) {
+						v = __hip_atomic_load(a.blk_flag + item - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						if ((v >> 4) == a.blk_seq)
+							break;
+						__builtin_amdgcn_s_sleep(4);
+					}
+					ok = (v >> 4) == a.blk_seq && (v & 15u) == me;
+				}
+				ok = __syncthreads_and(ok ? 1 : 0) != 0; // one decision per workgroup
+				if (ok) {
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+					const float* ph = out.Y - hop; // second half of the previous frame's row
+					float* o = a.out_direct + (long long)s * a.out_direct_stride + (long long)f * hop;
+#pragma unroll
+					for (int i = 0; i < 4; ++i)
+						o[tf + i * TF] = ph[tf + i * TF] + out.lo[i];
+				}
+				else if (tf == 0) {
+					a.blk_need[item] = 1u;
+				}
+			}
+			return;
+		}
 		OutT out;
 		out.Y = a.Y[in.which] + (long long)s * a.y_stream_stride + (long long)f * (2 * hop);
 		out.cola = a.cola;
@@ -709,6 +773,42 @@ int launch_rt_fused_multi(int log2n, int freq_len, const RtFusedArgs& a, hipStre
 }
 #else
 opt_t g_opt_block_fused_minb{0}; // 0: default (three workgroups per CU)
+
+namespace {
+// the hops a direct-output launch left (RtFusedArgs::blk_need): out = (previous frame's second half, or the carry for the
+// first hop of the call) + this frame's first half -- finalize_kernel's sum for single hops
+__global__ __launch_bounds__(256) void rt_fused_fixup_kernel(RtFusedArgs a, int which)
+{
+	const int hop = a.hop, total = a.n_streams * a.n_frames;
+	for (int item = blockIdx.x; item < total; item += gridDim.x) {
+		if (!a.blk_need[item]) // (uniform per workgroup)
+			continue;
+		const int s = item / a.n_frames, f = item - s * a.n_frames;
+		const float* Y = a.Y[which] + (long long)s * a.y_stream_stride + (long long)f * (2 * hop);
+		const float* prev = f == 0 ? a.carry[which] + (long long)s * hop : Y - hop;
+		float* o = a.out_direct + (long long)s * a.out_direct_stride + (long long)f * hop;
+		for (int k = threadIdx.x; k < hop; k += 256)
+			o[k] = prev[k] + Y[k];
+		__syncthreads();
+		if (threadIdx.x == 0)
+			a.blk_need[item] = 0u;
+	}
+}
+} // namespace
+
+int launch_rt_fused_fixup(const RtFusedArgs& a, int which, hipStream_t stream)
+{
+	const int total = a.n_streams * a.n_frames;
+	hipLaunchKernelGGL(rt_fused_fixup_kernel, dim3((unsigned)(total < 2048 ? total : 2048)), dim3(256), 0, stream, a, which);
+	ZH_HIP(hipGetLastError());
+	return ZEN_HIP_OK;
+}
+
+bool rt_fused_direct_out_available(int log2n, int freq_len, const RtFusedArgs& a)
+{
+	return log2n == 12 && freq_len == 47 && a.n_out == 1 && a.n_frames > 1 && a.out_id[0] == 0 && !a.soft && a.thr != 0.0
+	       && g_opt_block_fused_minb == 0;
+}
 
 // (transform size, frequency mask) pairs with a fused kernel: hops 128..1024 at 44.1 and 48 kHz
 bool rt_fused_available(int log2n, int freq_len)
