@@ -365,3 +365,40 @@ def test_long_transforms_persistent_kernels(z, hop, n_hops, soft):
     ref2 = ho2.process_stream(x[hop * j:])
     for k in "PHR":
         assert np.array_equal(got[k][hop * (j + 8):], ref2[k][hop * 8:]), k
+
+
+# ---------------------------------------------------------------------------- the fused block kernel that finishes hops itself
+@pytest.mark.parametrize("streams,blocks", [(1, [25840, 25840, 7, 1, 300, 2, 1031, 129, 128, 127]), (3, [50, 700, 1, 9, 1025, 260]),
+                                            (8, [3000, 17, 513])])
+def test_fused_block_kernel_finishes_hops_itself(z, streams, blocks):
+    """Block calls of the headline configuration (hop 1024, P only, hard mask): the workgroup of a hop adds up the hop of
+    the workgroup 128 items before it in its XCD's run from the L2 they share and writes it to the caller's buffer; what
+    it cannot finish (first hops, ends of runs, rows not yet published) a fix-up launch does (rt_fused.hip).  Whatever the
+    block sizes, stream counts (runs that cross stream boundaries) and call sequence: the samples of the same calls with
+    the plain overlap-add launch ("no_direct_out"), which the other tests pin to the oracle -- checked here on a prefix
+    too -- and, 40 times over, of itself (the hand-off is timing dependent: a wrong ordering would show as a flicker)."""
+    hop = 1024
+    n_hops = sum(blocks)
+    rng = np.random.default_rng(streams)
+    x = rng.uniform(-1, 1, (streams, hop * n_hops)).astype(np.float32)
+
+    def run(no_direct):
+        z.set_option("no_direct_out", no_direct)
+        try:
+            g = z.HPR(FS, hop, 2.0, z.OUTPUT_PERCUSSIVE, z.TIME_CAUSAL, True, streams, max(blocks))
+            din = z.DeviceBuffer.from_host(x)
+            dout = z.DeviceBuffer(x.size)
+            off = 0
+            for m in blocks:
+                g.process(din.offset(off * hop), m, x.shape[1], None, dout.offset(off * hop), None, x.shape[1])
+                off += m
+            z.synchronize()
+            return dout.download().reshape(streams, -1)
+        finally:
+            z.set_option("no_direct_out", 0)
+
+    plain = run(1)
+    ref = o.HPR(FS, hop, 2.0, o.OUTPUT_PERCUSSIVE, o.TIME_CAUSAL).process_stream(x[0][:hop * 30])["P"]
+    assert np.array_equal(plain[0][:hop * 30], ref)
+    for rep in range(40 if streams == 1 else 8):
+        assert np.array_equal(run(0), plain), rep

@@ -64,6 +64,14 @@ struct FwdIn {
 	}
 };
 
+// the same with the eight samples and window values of the thread already in registers (nfft 4096: the first pass asks
+// thread tf for idx = slot * 256 + tf, slot < 8): the block build that finishes hops itself issues these loads before it
+// waits for its publication words, so that the two round trips of the hand-off run under this one
+struct FwdInPre {
+	float x[8], w[8];
+	__device__ __forceinline__ float2 operator()(int, int slot) const { return make_float2(x[slot] * w[slot], 0.0f); }
+};
+
 template <int T>
 struct FwdOut {
 	Regs* r;
@@ -219,18 +227,6 @@ struct InvOut { // block builds
 		Y[idx] = y;
 		if (ready && idx < hop)
 			ready[idx] = carry[idx] + y;
-	}
-};
-struct InvOutLo { // block build that finishes hops itself: the first half of the frame also stays in registers
-	float* Y;
-	float cola;
-	float lo[4]; // idx = tf + slot*TF, slot < 4
-	__device__ __forceinline__ void operator()(int idx, float2 x, bool, int slot)
-	{
-		const float y = x.x * cola;
-		Y[idx] = y;
-		if (slot < 4)
-			lo[slot] = y;
 	}
 };
 __device__ __forceinline__ unsigned xcc_id_of_cu()
@@ -405,6 +401,67 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 			cw[i] = SINGLE ? cv1[i] : a.carry[which][(long long)s * hop + tf + i * TF];
 	};
 	stamp(1);
+	// ---- block build that finishes hops itself (RtFusedArgs::out_direct), first part.  Output hop h = second half of
+	// frame h-1 + first half of frame h (hps.cu:435-449, :526-528).  A workgroup cannot wait for its neighbour at its end
+	// (they run side by side: measured 12 % on the whole kernel), so it finishes the hop of the workgroup DIRECT_BACK
+	// items before it in its XCD's run, whose rows were written a generation of workgroups ago: it reads the two
+	// publication words here, the eight samples of the two rows per thread right behind them (agent-scope loads: straight
+	// from the L2 the workgroups of an XCD share, past the L1), both round trips under the latency of its own input
+	// loads, and stores the sums after the forward transform.  A hop whose rows are not both published from this XCD with
+	// this call's sequence number -- or that has no workgroup DIRECT_BACK items behind it -- is marked for
+	// launch_rt_fused_fixup, which adds it up after the kernel: correct wherever and whenever the workgroups run.
+	constexpr bool DIRECT = HARDP && SINGLE && MINB != 1;
+	constexpr int DIRECT_BACK = 128;
+	unsigned dv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	bool dcomb = false;
+	int dh = 0;
+	FwdInPre pre;
+	bool preloaded = false;
+	auto preload_inputs = [&]() {
+		static_assert(!DIRECT || (LOG2N == 12 && TF == 256), "slot <-> index map of FwdInPre");
+		const float* pv = f > 0 ? cur - hop : a.tail_prev + (long long)s * hop;
+#pragma unroll
+		for (int m = 0; m < 8; ++m) {
+			const int idx = m * TF + tf;
+			pre.x[m] = m < 4 ? pv[idx] : cur[idx - hop];
+			pre.w[m] = a.window[idx];
+		}
+		preloaded = true;
+	};
+	if constexpr (DIRECT) {
+		if (a.out_direct) {
+			const int xi = blockIdx.x >> 3, xcount = xq + (xcd < xr ? 1 : 0);
+			if (xi + DIRECT_BACK >= xcount && tf == 0)
+				a.blk_need[item] = 1u; // nobody comes DIRECT_BACK items after this one
+			if (xi >= DIRECT_BACK) {
+				dh = item - DIRECT_BACK;
+				const int hs = dh / a.n_frames, hf = dh - hs * a.n_frames;
+				unsigned v0 = 0, v1 = 0;
+				if (hf > 0) {
+					v0 = __hip_atomic_load(a.blk_flag + dh - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					v1 = __hip_atomic_load(a.blk_flag + dh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+				preload_inputs(); // (issued behind the two words, waited for behind them: see FwdInPre)
+				if (hf > 0) {
+					const unsigned want = (a.blk_seq << 4) | xcc_id_of_cu();
+					dcomb = v0 == want && v1 == want;
+				}
+				if (dcomb) {
+					const int which = a.out_id[0];
+					const unsigned* row = reinterpret_cast<const unsigned*>(a.Y[which] + (long long)hs * a.y_stream_stride
+					                                                        + (long long)hf * (2 * hop));
+#pragma unroll
+					for (int i = 0; i < 4; ++i) {
+						dv[i] = __hip_atomic_load(row - hop + tf + i * TF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // frame h-1, second half
+						dv[4 + i] = __hip_atomic_load(row + tf + i * TF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // frame h, first half
+					}
+				}
+				else {
+					a.blk_need[dh] = 1u; // (every thread that does not add its four samples says so: the decision is per thread)
+				}
+			}
+		}
+	}
 	// Single-hop launches (MINB == 1, registers to spare): every twiddle of both transforms is loaded here, next
 	// to the input samples, instead of in six dependent round trips later (fft_dev.h TwRegs).
 	constexpr bool TWC = (MINB == 1);
@@ -432,12 +489,31 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		out.mid_al = MID_AL;
 		// the last pass overwrites the FFT image with the magnitude image: every thread has read its
 		// inputs of that pass before the barrier inside PassRunner, so the aliasing is safe
-		if constexpr (TWC)
+		if constexpr (DIRECT) {
+			if (!preloaded)
+				preload_inputs();
+			if (in.tail) { // the call's last frame hands its new hop to the next call
+#pragma unroll
+				for (int m = 4; m < 8; ++m)
+					in.tail[(m - 4) * TF + tf] = pre.x[m];
+			}
+			zfft::fft_frame<LOG2N, false, true, false>(tf, lds, a.tw, pre, out, true);
+		}
+		else if constexpr (TWC)
 			zfft::fft_frame<LOG2N, false, true, false>(tf, lds, twr, in, out, true);
 		else
 			zfft::fft_frame<LOG2N, false, true, false>(tf, lds, a.tw, in, out, true);
 	}
 	__syncthreads();
+	if constexpr (DIRECT) {
+		if (dcomb) { // the finished hop of DIRECT_BACK items ago: previous frame's second half + that frame's first half
+			const int hs = dh / a.n_frames, hf = dh - hs * a.n_frames;
+			float* o = a.out_direct + (long long)hs * a.out_direct_stride + (long long)hf * hop;
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+				o[tf + i * TF] = __uint_as_float(dv[i]) + __uint_as_float(dv[4 + i]);
+		}
+	}
 	stamp(2);
 	// replicate border of the magnitude row (ippBorderRepl)
 	{
@@ -562,49 +638,19 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		in.which = a.out_id[0];
 		in.thr = (in.which == 0 && !a.soft) ? a.thr : 0.0;
 		in.thr_inclusive = a.thr_inclusive != 0;
-		if constexpr (HARDP && MINB != 1) {
-			// ---- block build: the overlap-add of consecutive hops without a launch of its own (hps.cu:435-449, :526-528).
-			// Output hop f = second half of frame f-1 + first half of frame f.  The workgroup keeps its first half in
-			// registers, writes its Y row, and once the row is in the L2 publishes (sequence number of the call, XCD it runs
-			// on) for its item; then it reads the predecessor's word.  Consecutive items of a launch share an XCD (see the
-			// item order above), so normally the predecessor -- dispatched eight workgroups earlier -- has long published
-			// from the same XCD: its second half is read from the shared L2 (stores are there once the memory counter has
-			// drained; the reader only drops its L1) and the finished hop goes straight to the caller's buffer.  Anything
-			// else -- the first hop of a stream or of an XCD's run, a predecessor on another XCD or not there after a bounded
-			// wait -- is marked and added up by launch_rt_fused_fixup after the kernel: correct wherever the workgroups run.
-			InvOutLo out;
+		if constexpr (DIRECT) {
+			InvOut out;
 			out.Y = a.Y[in.which] + (long long)s * a.y_stream_stride + (long long)f * (2 * hop);
 			out.cola = a.cola;
-			zfft::fft_frame<LOG2N, true, false, true, InvInLean<N, TF, mid, HARDP>, InvOutLo, true>(tf, lds, a.tw, in, out, true);
-			if (a.out_direct) {
+			out.ready = nullptr;
+			out.carry = nullptr;
+			out.hop = hop;
+			zfft::fft_frame<LOG2N, true, false, true, InvInLean<N, TF, mid, HARDP>, InvOut, true>(tf, lds, a.tw, in, out, true);
+			if (a.out_direct) { // second part: once the row is in the L2 (the memory counter has drained), publish it
 				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 				__syncthreads();
-				const unsigned me = xcc_id_of_cu();
 				if (tf == 0)
-					__hip_atomic_store(a.blk_flag + item, (a.blk_seq << 4) | me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				bool ok = false;
-				if (f > 0 && (blockIdx.x >> 3) > 0) {
-					unsigned v = 0;
-					for (int spin = 0; spin < 4096; ++spin) {
-						v = __hip_atomic_load(a.blk_flag + item - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-						if ((v >> 4) == a.blk_seq)
-							break;
-						__builtin_amdgcn_s_sleep(4);
-					}
-					ok = (v >> 4) == a.blk_seq && (v & 15u) == me;
-				}
-				ok = __syncthreads_and(ok ? 1 : 0) != 0; // one decision per workgroup
-				if (ok) {
-					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-					const float* ph = out.Y - hop; // second half of the previous frame's row
-					float* o = a.out_direct + (long long)s * a.out_direct_stride + (long long)f * hop;
-#pragma unroll
-					for (int i = 0; i < 4; ++i)
-						o[tf + i * TF] = ph[tf + i * TF] + out.lo[i];
-				}
-				else if (tf == 0) {
-					a.blk_need[item] = 1u;
-				}
+					__hip_atomic_store(a.blk_flag + item, (a.blk_seq << 4) | xcc_id_of_cu(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
 			return;
 		}
@@ -779,27 +825,28 @@ namespace {
 // first hop of the call) + this frame's first half -- finalize_kernel's sum for single hops
 __global__ __launch_bounds__(256) void rt_fused_fixup_kernel(RtFusedArgs a, int which)
 {
+	// one wavefront per item: all marks are read side by side (one trip to memory for the whole launch), a marked hop is
+	// added up by its wavefront alone (the marked hops come in runs -- the end of every XCD's run of items -- so a
+	// workgroup that walked through its items one after the other would serialise them)
 	const int hop = a.hop, total = a.n_streams * a.n_frames;
-	for (int item = blockIdx.x; item < total; item += gridDim.x) {
-		if (!a.blk_need[item]) // (uniform per workgroup)
-			continue;
-		const int s = item / a.n_frames, f = item - s * a.n_frames;
-		const float* Y = a.Y[which] + (long long)s * a.y_stream_stride + (long long)f * (2 * hop);
-		const float* prev = f == 0 ? a.carry[which] + (long long)s * hop : Y - hop;
-		float* o = a.out_direct + (long long)s * a.out_direct_stride + (long long)f * hop;
-		for (int k = threadIdx.x; k < hop; k += 256)
-			o[k] = prev[k] + Y[k];
-		__syncthreads();
-		if (threadIdx.x == 0)
-			a.blk_need[item] = 0u;
-	}
+	const int item = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (item >= total || !a.blk_need[item])
+		return;
+	const int s = item / a.n_frames, f = item - s * a.n_frames;
+	const float* Y = a.Y[which] + (long long)s * a.y_stream_stride + (long long)f * (2 * hop);
+	const float* prev = f == 0 ? a.carry[which] + (long long)s * hop : Y - hop;
+	float* o = a.out_direct + (long long)s * a.out_direct_stride + (long long)f * hop;
+	for (int k = lane; k < hop; k += 64)
+		o[k] = prev[k] + Y[k];
+	if (lane == 0)
+		a.blk_need[item] = 0u;
 }
 } // namespace
 
 int launch_rt_fused_fixup(const RtFusedArgs& a, int which, hipStream_t stream)
 {
 	const int total = a.n_streams * a.n_frames;
-	hipLaunchKernelGGL(rt_fused_fixup_kernel, dim3((unsigned)(total < 2048 ? total : 2048)), dim3(256), 0, stream, a, which);
+	hipLaunchKernelGGL(rt_fused_fixup_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, a, which);
 	ZH_HIP(hipGetLastError());
 	return ZEN_HIP_OK;
 }
