@@ -399,7 +399,9 @@ def fused_roofline(run, S, M, steps, n_out, kernel, copy_bw):
     t_f = 1e-3 * fl["ms"] / fl["launches"]
     bph = fused_bytes_per_hop(nfft, HOP, n_out)
     ach = bph * S * M / t_f / 1e9
-    moved = 4 * HOP + n_out * 8 * HOP
+    direct = run["breakdown"]["finalize"]["launches"] == fl["launches"] and \
+        run["breakdown"]["finalize"]["ms"] < 0.5 * 0.05 * fl["launches"]   # the kernel wrote the finished hops itself (one fix-up launch only)
+    moved = 4 * HOP + n_out * 8 * HOP + (n_out * 4 * HOP if direct else 0)
     tr, src = traffic_record(kernel, S * M * nfft)
     return {
         "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
@@ -411,11 +413,14 @@ def fused_roofline(run, S, M, steps, n_out, kernel, copy_bw):
         "algorithmic_bytes_formula": "24*(nfft/2+1) + 4*hop + n_out*4*hop + (n_out-1)*8*(nfft/2+1) (SURVEY 8(d): per-frame "
                                      "minimum of the batched pipeline; 24*(nfft/2+1) + 8*hop for one output)",
         "hbm_bytes_moved_per_hop_by_design": moved, "moved_GBps": moved * S * M / t_f / 1e9,
+        "finishes_hops_itself": direct,
         "avg_launch_ms": 1e3 * t_f, "launches": fl["launches"],
         "share_of_step": (fl["ms"] / 1e3) / run["dt"] if run["dt"] > 0 else None,
         "note": "`achieved`/`frac` price the launch with SURVEY 8(d)'s ALGORITHMIC bytes as the bench contract asks; the "
                 "kernel does not move them: spectrum, |S| and P stay in registers / LDS, its own HBM traffic is 4*hop read "
-                "+ 8*hop written per hop and output (`moved_GBps`, `traffic`).  Its limiter is VALU issue: DESIGN.md section 5"}
+                "+ 8*hop written per hop and output (`moved_GBps`, `traffic`), plus 4*hop per output where it finishes the hops itself "
+                "(the overlap-add through a same-XCD hand-off, no launch of its own).  Its limiter is VALU issue: "
+                "DESIGN.md section 5"}
 
 
 def median_rooflines(zen_amd, run, S, M, copy_bw):

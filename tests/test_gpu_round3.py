@@ -368,9 +368,10 @@ def test_long_transforms_persistent_kernels(z, hop, n_hops, soft):
 
 
 # ---------------------------------------------------------------------------- the fused block kernel that finishes hops itself
+@pytest.mark.parametrize("flags", [o.OUTPUT_PERCUSSIVE, ALL, o.OUTPUT_HARMONIC | o.OUTPUT_RESIDUAL])
 @pytest.mark.parametrize("streams,blocks", [(1, [25840, 25840, 7, 1, 300, 2, 1031, 129, 128, 127]), (3, [50, 700, 1, 9, 1025, 260]),
                                             (8, [3000, 17, 513])])
-def test_fused_block_kernel_finishes_hops_itself(z, streams, blocks):
+def test_fused_block_kernel_finishes_hops_itself(z, streams, blocks, flags):
     """Block calls of the headline configuration (hop 1024, P only, hard mask): the workgroup of a hop adds up the hop of
     the workgroup 128 items before it in its XCD's run from the L2 they share and writes it to the caller's buffer; what
     it cannot finish (first hops, ends of runs, rows not yet published) a fix-up launch does (rt_fused.hip).  Whatever the
@@ -385,20 +386,22 @@ def test_fused_block_kernel_finishes_hops_itself(z, streams, blocks):
     def run(no_direct):
         z.set_option("no_direct_out", no_direct)
         try:
-            g = z.HPR(FS, hop, 2.0, z.OUTPUT_PERCUSSIVE, z.TIME_CAUSAL, True, streams, max(blocks))
+            g = z.HPR(FS, hop, 2.0, flags, z.TIME_CAUSAL, True, streams, max(blocks))
             din = z.DeviceBuffer.from_host(x)
-            dout = z.DeviceBuffer(x.size)
+            outs = {k: z.DeviceBuffer(x.size) for k in "PHR"}
             off = 0
             for m in blocks:
-                g.process(din.offset(off * hop), m, x.shape[1], None, dout.offset(off * hop), None, x.shape[1])
+                g.process(din.offset(off * hop), m, x.shape[1], outs["H"].offset(off * hop), outs["P"].offset(off * hop),
+                          outs["R"].offset(off * hop), x.shape[1])
                 off += m
             z.synchronize()
-            return dout.download().reshape(streams, -1)
+            return np.stack([outs[k].download().reshape(streams, -1) for k in "PHR"])
         finally:
             z.set_option("no_direct_out", 0)
 
     plain = run(1)
-    ref = o.HPR(FS, hop, 2.0, o.OUTPUT_PERCUSSIVE, o.TIME_CAUSAL).process_stream(x[0][:hop * 30])["P"]
-    assert np.array_equal(plain[0][:hop * 30], ref)
-    for rep in range(40 if streams == 1 else 8):
+    ref = o.HPR(FS, hop, 2.0, flags, o.TIME_CAUSAL).process_stream(x[0][:hop * 30])
+    for i, k in enumerate("PHR"):
+        assert np.array_equal(plain[i][0][:hop * 30], ref[k]), k
+    for rep in range(30 if (streams == 1 and flags == o.OUTPUT_PERCUSSIVE) else 6):
         assert np.array_equal(run(0), plain), rep

@@ -257,8 +257,10 @@ int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, H
 	int direct_o = -1;
 	for (int o = 0; o < 3; ++o)
 		e->direct_done[o] = false;
-	if (kind == HOP_FUSED && a.n_out == 1 && e->direct_out[a.out_id[0]] && !g_opt_no_direct_out
-	    && rt_fused_direct_out_available(e->log2n, e->mf, a)) {
+	bool all_dst = a.n_out > 0;
+	for (int i = 0; i < a.n_out; ++i)
+		all_dst = all_dst && e->direct_out[a.out_id[i]] != nullptr;
+	if (kind == HOP_FUSED && all_dst && !g_opt_no_direct_out && rt_fused_direct_out_available(e->log2n, e->mf, a)) {
 		direct_o = a.out_id[0];
 		if (!e->d_blk_flag) {
 			const size_t bytes = sizeof(unsigned) * e->n_streams * e->max_hops;
@@ -268,8 +270,10 @@ int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, H
 			ZH_HIP(hipMemsetAsync(e->d_blk_need, 0, bytes, e->stream));
 			e->blk_seq = 0;
 		}
-		a.out_direct = e->direct_out[direct_o];
+		for (int o = 0; o < 3; ++o)
+			a.out_direct[o] = e->direct_out[o];
 		a.out_direct_stride = e->direct_stride;
+		a.direct_on = 1;
 		a.blk_flag = e->d_blk_flag;
 		a.blk_need = e->d_blk_need;
 		e->blk_seq = (e->blk_seq + 1) & 0x0fffffffu;
@@ -288,8 +292,9 @@ int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, H
 	}
 	if (direct_o >= 0) {
 		ProfScope ps(e, zen_hip_hpr::K_FINALIZE);
-		ZH_TRY(launch_rt_fused_fixup(a, direct_o, e->stream));
-		e->direct_done[direct_o] = true;
+		ZH_TRY(launch_rt_fused_fixup(a, e->stream));
+		for (int i = 0; i < a.n_out; ++i)
+			e->direct_done[a.out_id[i]] = true;
 	}
 	e->tail_sel ^= 1;
 	e->abs_frame += (long long)M;

@@ -47,13 +47,15 @@ struct RtFusedArgs {
 	unsigned bar_base;
 	int bar_parity;         // which of the two placement-vote words this call uses (alternates)
 	unsigned* wide_fail;    // host-mapped word: set (and never cleared by the device) when a grid barrier gave up waiting
-	// Block calls of the one-output hard-mask build (nfft 4096, 47 taps): the workgroup of hop f adds the second half of
-	// frame f-1 (its predecessor's, read from the L2 the two share) to the first half of its own frame and writes the
-	// finished hop to out_direct itself -- no separate overlap-add launch.  blk_flag[item]: (blk_seq << 4) | XCD of the
-	// workgroup that has written item's Y row; blk_need[item] = 1: hop not finished here (first hop of a stream or of an
-	// XCD's run, predecessor on another XCD or late): launch_rt_fused_fixup adds it up afterwards.  Null out_direct: off.
-	float* out_direct;
+	// Block calls of the hard-mask lean builds (nfft 4096, 47 taps; one output or several): a workgroup finishes the hop
+	// of the workgroup 128 items before it in its XCD's run -- second half of that frame's predecessor + its first half,
+	// read from the L2 the workgroups of an XCD share -- and writes it to out_direct[output id] itself: no overlap-add
+	// launch.  blk_flag[item]: (blk_seq << 4) | XCD of the workgroup that has written item's Y rows; blk_need[item] = 1:
+	// hop not finished in the kernel (first hop of a stream or of an XCD's run, end of a run, rows not published from
+	// this XCD): launch_rt_fused_fixup adds it up afterwards.  direct_on = 0: off.
+	float* out_direct[3];
 	long long out_direct_stride;
+	int direct_on;
 	unsigned* blk_flag;
 	unsigned* blk_need;
 	unsigned blk_seq;
@@ -64,8 +66,8 @@ struct RtFusedArgs {
 bool rt_fused_available(int log2n, int freq_len);
 // true if launch_rt_fused(log2n, freq_len, a) will run the build that finishes hops itself (RtFusedArgs::out_direct)
 bool rt_fused_direct_out_available(int log2n, int freq_len, const RtFusedArgs& a);
-// after such a launch: the hops it left (blk_need) through the plain overlap-add; `which` = the output id
-int launch_rt_fused_fixup(const RtFusedArgs& a, int which, hipStream_t stream);
+// after such a launch: the hops it left (blk_need) through the plain overlap-add, every computed output
+int launch_rt_fused_fixup(const RtFusedArgs& a, hipStream_t stream);
 int launch_rt_fused(int log2n, int freq_len, const RtFusedArgs& a, hipStream_t stream);
 int launch_rt_fused_multi(int log2n, int freq_len, const RtFusedArgs& a, hipStream_t stream); // n_out > 1 (rt_fused_multi.hip)
 int launch_rt_fused_multi_lean(const RtFusedArgs& a, hipStream_t stream); // nfft 4096, 47 taps, n_out > 1, hard masks, blocks (rt_fused_multi_lean.hip)

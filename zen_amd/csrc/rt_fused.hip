@@ -410,7 +410,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 	// loads, and stores the sums after the forward transform.  A hop whose rows are not both published from this XCD with
 	// this call's sequence number -- or that has no workgroup DIRECT_BACK items behind it -- is marked for
 	// launch_rt_fused_fixup, which adds it up after the kernel: correct wherever and whenever the workgroups run.
-	constexpr bool DIRECT = HARDP && SINGLE && MINB != 1;
+	constexpr bool DIRECT = HARDP && MINB != 1;
 	constexpr int DIRECT_BACK = 128;
 	unsigned dv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	bool dcomb = false;
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		preloaded = true;
 	};
 	if constexpr (DIRECT) {
-		if (a.out_direct) {
+		if (a.direct_on) {
 			const int xi = blockIdx.x >> 3, xcount = xq + (xcd < xr ? 1 : 0);
 			if (xi + DIRECT_BACK >= xcount && tf == 0)
 				a.blk_need[item] = 1u; // nobody comes DIRECT_BACK items after this one
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 					const unsigned want = (a.blk_seq << 4) | xcc_id_of_cu();
 					dcomb = v0 == want && v1 == want;
 				}
-				if (dcomb) {
+				if (dcomb && SINGLE) {
 					const int which = a.out_id[0];
 					const unsigned* row = reinterpret_cast<const unsigned*>(a.Y[which] + (long long)hs * a.y_stream_stride
 					                                                        + (long long)hf * (2 * hop));
@@ -454,6 +454,30 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 					for (int i = 0; i < 4; ++i) {
 						dv[i] = __hip_atomic_load(row - hop + tf + i * TF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // frame h-1, second half
 						dv[4 + i] = __hip_atomic_load(row + tf + i * TF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // frame h, first half
+					}
+				}
+				else if (dcomb) { // several outputs: all loads in flight, then the sums (no registers to carry them further)
+					unsigned dm[3][8];
+#pragma unroll
+					for (int oi = 0; oi < 3; ++oi) {
+						if (oi < a.n_out) {
+							const unsigned* row = reinterpret_cast<const unsigned*>(a.Y[a.out_id[oi]] + (long long)hs * a.y_stream_stride
+							                                                        + (long long)hf * (2 * hop));
+#pragma unroll
+							for (int i = 0; i < 4; ++i) {
+								dm[oi][i] = __hip_atomic_load(row - hop + tf + i * TF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+								dm[oi][4 + i] = __hip_atomic_load(row + tf + i * TF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							}
+						}
+					}
+#pragma unroll
+					for (int oi = 0; oi < 3; ++oi) {
+						if (oi < a.n_out) {
+							float* o = a.out_direct[a.out_id[oi]] + (long long)hs * a.out_direct_stride + (long long)hf * hop;
+#pragma unroll
+							for (int i = 0; i < 4; ++i)
+								o[tf + i * TF] = __uint_as_float(dm[oi][i]) + __uint_as_float(dm[oi][4 + i]);
+						}
 					}
 				}
 				else {
@@ -505,10 +529,10 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 			zfft::fft_frame<LOG2N, false, true, false>(tf, lds, a.tw, in, out, true);
 	}
 	__syncthreads();
-	if constexpr (DIRECT) {
+	if constexpr (DIRECT && SINGLE) {
 		if (dcomb) { // the finished hop of DIRECT_BACK items ago: previous frame's second half + that frame's first half
 			const int hs = dh / a.n_frames, hf = dh - hs * a.n_frames;
-			float* o = a.out_direct + (long long)hs * a.out_direct_stride + (long long)hf * hop;
+			float* o = a.out_direct[a.out_id[0]] + (long long)hs * a.out_direct_stride + (long long)hf * hop;
 #pragma unroll
 			for (int i = 0; i < 4; ++i)
 				o[tf + i * TF] = __uint_as_float(dv[i]) + __uint_as_float(dv[4 + i]);
@@ -625,6 +649,14 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 				publish_ready(reinterpret_cast<unsigned*>(out.ready + hop), a.seq, tf);
 			__syncthreads(); // the frame image is reused by the next output
 		}
+		if constexpr (DIRECT) {
+			if (a.direct_on) { // every output's row is in the L2 once the memory counter has drained: publish the item
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				__syncthreads();
+				if (tf == 0)
+					__hip_atomic_store(a.blk_flag + item, (a.blk_seq << 4) | xcc_id_of_cu(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
 		return;
 	}
 	else if constexpr (LEAN) { // |S| and P are read inside the first inverse pass, which then meets at a barrier
@@ -638,7 +670,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		in.which = a.out_id[0];
 		in.thr = (in.which == 0 && !a.soft) ? a.thr : 0.0;
 		in.thr_inclusive = a.thr_inclusive != 0;
-		if constexpr (DIRECT) {
+		if constexpr (DIRECT && SINGLE) {
 			InvOut out;
 			out.Y = a.Y[in.which] + (long long)s * a.y_stream_stride + (long long)f * (2 * hop);
 			out.cola = a.cola;
@@ -646,7 +678,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 			out.carry = nullptr;
 			out.hop = hop;
 			zfft::fft_frame<LOG2N, true, false, true, InvInLean<N, TF, mid, HARDP>, InvOut, true>(tf, lds, a.tw, in, out, true);
-			if (a.out_direct) { // second part: once the row is in the L2 (the memory counter has drained), publish it
+			if (a.direct_on) { // second part: once the row is in the L2 (the memory counter has drained), publish it
 				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 				__syncthreads();
 				if (tf == 0)
@@ -823,7 +855,7 @@ opt_t g_opt_block_fused_minb{0}; // 0: default (three workgroups per CU)
 namespace {
 // the hops a direct-output launch left (RtFusedArgs::blk_need): out = (previous frame's second half, or the carry for the
 // first hop of the call) + this frame's first half -- finalize_kernel's sum for single hops
-__global__ __launch_bounds__(256) void rt_fused_fixup_kernel(RtFusedArgs a, int which)
+__global__ __launch_bounds__(256) void rt_fused_fixup_kernel(RtFusedArgs a)
 {
 	// one wavefront per item: all marks are read side by side (one trip to memory for the whole launch), a marked hop is
 	// added up by its wavefront alone (the marked hops come in runs -- the end of every XCD's run of items -- so a
@@ -833,28 +865,32 @@ __global__ __launch_bounds__(256) void rt_fused_fixup_kernel(RtFusedArgs a, int 
 	if (item >= total || !a.blk_need[item])
 		return;
 	const int s = item / a.n_frames, f = item - s * a.n_frames;
-	const float* Y = a.Y[which] + (long long)s * a.y_stream_stride + (long long)f * (2 * hop);
-	const float* prev = f == 0 ? a.carry[which] + (long long)s * hop : Y - hop;
-	float* o = a.out_direct + (long long)s * a.out_direct_stride + (long long)f * hop;
-	for (int k = lane; k < hop; k += 64)
-		o[k] = prev[k] + Y[k];
+	for (int oi = 0; oi < a.n_out; ++oi) {
+		const int which = a.out_id[oi];
+		const float* Y = a.Y[which] + (long long)s * a.y_stream_stride + (long long)f * (2 * hop);
+		const float* prev = f == 0 ? a.carry[which] + (long long)s * hop : Y - hop;
+		float* o = a.out_direct[which] + (long long)s * a.out_direct_stride + (long long)f * hop;
+		for (int k = lane; k < hop; k += 64)
+			o[k] = prev[k] + Y[k];
+	}
 	if (lane == 0)
 		a.blk_need[item] = 0u;
 }
 } // namespace
 
-int launch_rt_fused_fixup(const RtFusedArgs& a, int which, hipStream_t stream)
+int launch_rt_fused_fixup(const RtFusedArgs& a, hipStream_t stream)
 {
 	const int total = a.n_streams * a.n_frames;
-	hipLaunchKernelGGL(rt_fused_fixup_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, a, which);
+	hipLaunchKernelGGL(rt_fused_fixup_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, a);
 	ZH_HIP(hipGetLastError());
 	return ZEN_HIP_OK;
 }
 
 bool rt_fused_direct_out_available(int log2n, int freq_len, const RtFusedArgs& a)
 {
-	return log2n == 12 && freq_len == 47 && a.n_out == 1 && a.n_frames > 1 && a.out_id[0] == 0 && !a.soft && a.thr != 0.0
-	       && g_opt_block_fused_minb == 0;
+	if (log2n != 12 || freq_len != 47 || a.n_frames <= 1 || a.soft || a.thr == 0.0 || g_opt_block_fused_minb != 0)
+		return false;
+	return a.n_out == 1 ? a.out_id[0] == 0 : a.thr_h != 0.0; // (the conditions of launch_t / launch_multi_t for the HARDP builds)
 }
 
 // (transform size, frequency mask) pairs with a fused kernel: hops 128..1024 at 44.1 and 48 kHz
