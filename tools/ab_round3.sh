@@ -1,7 +1,10 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -x -q -m gpu -k "headline or block_fused or blocking or linearity or multi_stream or golden or finishes or hard_mask_outputs" 2>&1 | tail -2
-for opt in "no_direct_out=1" "" "no_direct_out=1" ""; do
-  echo "== HPR $opt"; ZEN_HIP_OPTIONS="$opt" python bench.py --no-legs --outputs HPR --no-cpu-baseline --no-realtime | python -c "
+python -m pytest tests -x -q -m gpu -k "offline or sharded or config or golden or persistent or largest or long_hops or hpr_params or hard_mask_outputs or soft or sse" 2>&1 | tail -3
+for opt in "" "no_split=1"; do
+  echo "== offline_batch $opt"; ZEN_HIP_OPTIONS="$opt" python bench.py --workload offline_batch --steps 10 --warmup 3 --no-cpu-baseline | python -c "
 import json,sys
-j=json.loads(sys.stdin.readline()); print(j['value'], j['ms_per_step'], j['kernel_ms_per_step'])"
+j=json.loads(sys.stdin.readline()); print(j['ms_per_step'], j['x_realtime'], {k: round(v['ms_per_step'],3) for k,v in j['kernels'].items()})"
+  echo "== offline_long $opt"; ZEN_HIP_OPTIONS="$opt" python bench.py --workload offline_long --steps 10 --warmup 3 --no-cpu-baseline | python -c "
+import json,sys
+j=json.loads(sys.stdin.readline()); print(j['ms_per_step'], j['x_realtime'], {k: round(v['ms_per_step'],3) for k,v in j['kernels'].items()})"
 done

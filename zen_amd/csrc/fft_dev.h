@@ -119,15 +119,6 @@ struct TwGlobal {
 	__device__ __forceinline__ float2 get(int, int, int, int idx) const { return p[idx]; }
 };
 
-// The table of a transform TWICE the size, read at the even entries: tw_2N[2j] == tw_N[j] bit for bit (same angle, same
-// construction), so the N-point sub-transforms of a 2N-point one (istft.hip: split synthesis) need no table of their own.
-struct TwGlobalEven {
-	static constexpr bool PLAIN = true;
-	static constexpr bool PACKED = true;
-	const float2* __restrict__ p;
-	__device__ __forceinline__ float2 get(int, int, int, int idx) const { return p[2 * idx]; }
-};
-
 // PLAIN = false: the registers hold something else than the transform's own table (rt_wide.hip's second step)
 template <int LOG2N, bool PLAIN_ = true>
 struct TwRegs {

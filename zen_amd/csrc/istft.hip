@@ -143,77 +143,6 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void istft_kernel(IstftArgs a
 	}
 }
 
-// ------------------------------------------------------------------------------------------------
-// nfft 16384 (pass 1 of the default offline configuration), blocks of frames.  The one-piece kernel keeps a frame's
-// 139 KB image in LDS: ONE 1024-thread workgroup per CU, whose loads (128 KB at the CU's share of the bandwidth), LDS
-// passes and butterflies cannot overlap with anything -- 14.6 us per transform for ~7.5 us of VALU work.  The last
-// radix-2 stage of the decimation-in-time DAG is
-//     x[n] = E[n] + conj(tw[n]) * O[n],  n < N/2,
-// with E / O the N/2-point inverse transforms of the even / odd bins -- and only n < N/2 is wanted (nwin = N/2 real
-// outputs), and of E[n] only the real part.  So a 512-thread workgroup runs the two 8192-point sub-transforms one after
-// the other in ONE 70 KB image (the even one first: its sixteen real parts per thread wait in registers), and the last
-// stage on the thread's own values: same butterflies, same order of operations, bit-identical rows -- and TWO
-// workgroups per CU, whose phases interleave.  The sub-transforms read the 16384-point table at its even entries
-// (fft_dev.h TwGlobalEven).
-template <int MODE, int PARITY>
-struct SplitIn { // bin 2*i + PARITY of the masked spectrum
-	IstftIn<MODE> base;
-	__device__ __forceinline__ float2 operator()(int i, int slot) const { return base(2 * i + PARITY, slot); }
-};
-struct SplitEvenOut { // Re(E[n]), n = tf + slot*TF
-	float* ex;
-	__device__ __forceinline__ void operator()(int, float2 X, bool, int slot) const { ex[slot] = X.x; }
-};
-struct SplitOddOut { // x[n] = E[n] + conj(tw[n]) * O[n]; Y[n] = Re(x[n]) * COLA
-	const float* ex;
-	const float2* tw; // the N-point table
-	float* Y;
-	float cola;
-	__device__ __forceinline__ void operator()(int n, float2 X, bool, int slot) const
-	{
-		const float2 w = tw[n];
-		const float tr = w.x * X.x - (-w.y) * X.y; // the real part of cmul(conj(w), O[n]): two products, one difference, each rounded
-		Y[n] = (ex[slot] + tr) * cola;             // butterfly sum, then the product of overlap_add_functor hps.h:68-80
-	}
-};
-
-template <int MODE>
-__global__ __launch_bounds__(Plan<13>::THREADS, 4) void istft_split14_kernel(IstftArgs a)
-{
-	using PS = Plan<13>; // the sub-transforms
-	constexpr int N = 1 << 14;
-	extern __shared__ float2 lds[];
-	const int tf = threadIdx.x, s = blockIdx.z, oi = blockIdx.y, f = blockIdx.x;
-	const long long ring_row = ((a.crow0 + f) % a.ring_rows) + (long long)s * a.ring_rows;
-	IstftIn<MODE> base;
-	base.S = a.S + ring_row * a.s_stride;
-	base.n = N;
-	base.H = a.h_is_ring ? a.H + ring_row * N : a.H + (long long)s * a.h_stream_stride + (long long)f * N;
-	base.P = a.P + (long long)s * a.p_stream_stride + (long long)f * N;
-	base.cfg = MaskCfg{a.beta, a.beta_h, a.soft, a.power, a.sse, a.out_h, a.out_p};
-	base.thr = HardThr{a.thr_p, a.thr_h, a.thr_p_inc, a.thr_h_inc};
-	base.which = a.out_id[oi];
-	base.sel = hard_sel(base.which, base.cfg);
-	base.p_mid = a.p_mid;
-	const zfft::TwGlobalEven tw2{a.tw};
-	float ex[16];
-	{
-		SplitIn<MODE, 0> in{base};
-		SplitEvenOut out{ex};
-		zfft::PassRunner<13, 0, true, false, false, SplitIn<MODE, 0>, SplitEvenOut, false, zfft::TwGlobalEven>::run(tf, lds, tw2, in, out, true);
-	}
-	// (no barrier: after the last pass's own barrier nobody reads the image any more, and the odd sub-transform writes it
-	// only after its first butterflies)
-	{
-		SplitIn<MODE, 1> in{base};
-		SplitOddOut out{ex, a.tw, a.Y[oi] + (long long)s * a.y_stream_stride + (long long)f * (N / 2), a.cola};
-		// opaque: otherwise the two sub-transforms share every hoisted LDS address and twiddle index in registers
-		int tf_o = tf;
-		asm volatile("" : "+v"(tf_o));
-		zfft::PassRunner<13, 0, true, false, false, SplitIn<MODE, 1>, SplitOddOut, false, zfft::TwGlobalEven>::run(tf_o, lds, tw2, in, out, true);
-	}
-}
-
 // Hard masks with more than one output (HPRIOffline pass 1: H, P and R of every frame): one workgroup
 // synthesises all outputs of its frame.  The two binary masks of a bin are compared once, while the first
 // output loads S, H and P, and kept as two bits per bin in one register; the other outputs re-read only S
@@ -322,17 +251,6 @@ int launch_istft_t(const IstftArgs& a, hipStream_t stream)
 		return ZEN_HIP_OK;
 	}
 	dim3 grid((unsigned)ceil_div((size_t)a.n_frames, (size_t)PL::FRAMES_PER_BLOCK), (unsigned)a.n_out, (unsigned)a.n_streams);
-	if constexpr (LOG2N == 14) { // blocks of frames: two 8192-point sub-transforms per workgroup, two workgroups per CU
-		if (a.n_frames > 1 && !g_opt_no_split) {
-			const size_t lds = lds_bytes<13>();
-			const bool hard = !a.soft && !a.sse && a.thr_p != 0.0 && a.thr_h != 0.0;
-			auto kern = !hard ? istft_split14_kernel<0> : ((a.n_out == 1 && a.out_id[0] == 0) ? istft_split14_kernel<2> : istft_split14_kernel<1>);
-			ZH_TRY(set_lds(kern, lds));
-			hipLaunchKernelGGL(kern, grid, dim3(Plan<13>::THREADS), lds, stream, a);
-			ZH_HIP(hipGetLastError());
-			return ZEN_HIP_OK;
-		}
-	}
 	if (!a.soft && !a.sse && a.thr_p != 0.0 && a.thr_h != 0.0) { // hard masks by comparison: the builds with nothing else in them
 		auto kern = (a.n_out == 1 && a.out_id[0] == 0) ? istft_kernel<LOG2N, 2> : istft_kernel<LOG2N, 1>;
 		ZH_TRY(set_lds(kern, lds_bytes<LOG2N>()));
