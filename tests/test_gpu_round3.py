@@ -405,3 +405,32 @@ def test_fused_block_kernel_finishes_hops_itself(z, streams, blocks, flags):
         assert np.array_equal(plain[i][0][:hop * 30], ref[k]), k
     for rep in range(30 if (streams == 1 and flags == o.OUTPUT_PERCUSSIVE) else 6):
         assert np.array_equal(run(0), plain), rep
+
+
+# ---------------------------------------------------------------------------- `zen offline --sse`: the two-pass path with box filters
+@pytest.mark.parametrize("hop_h,hop_p,n", [(4096, 256, 150000), (1024, 256, 50000), (2048, 512, 90001)])
+def test_offline_sse_filter_whole_and_sharded(z, hop_h, hop_p, n):
+    """HPRIOffline::use_sse_filter (hps.cu:95-100; zen/offline.h --sse): both passes on the SSE (box-filter) path -- no
+    residual, so pass 2's input is P + the reference's all-zero residual accumulator (hps.cu:153-160) -- whole clip and
+    time-sharded for three ranks, against the oracle."""
+    from zen_amd import dist as zdist
+    from tests.test_gpu_parity import music
+    x = music(n, 91)
+    oo = o.HPRIOffline(FS, hop_h, hop_p, 2.0, 2.0)
+    oo.use_sse_filter()
+    rh, rp, rr = oo.process(x)
+    g = z.HPRIOffline(FS, hop_h, hop_p, 2.0, 2.0)
+    g.use_sse_filter()
+    h, p, r = g.process(x)
+    assert np.array_equal(h, rh) and np.array_equal(p, rp) and np.array_equal(r, rr)
+    assert np.any(p != 0) and np.any(h != 0)
+    d_in = z.DeviceBuffer.from_host(x)
+    eng = z.HPRIOffline(FS, hop_h, hop_p, 2.0, 2.0)
+    eng.use_sse_filter()
+    for rank, (b, e) in enumerate(zdist.time_shards(n, 3, hop_h)):
+        if b == e:
+            continue
+        dh, dp = z.DeviceBuffer(e - b), z.DeviceBuffer(e - b)
+        eng.process_range(d_in.ptr, n, b, e, dh.ptr, dp.ptr)
+        z.synchronize()
+        assert np.array_equal(dh.download(), rh[b:e]) and np.array_equal(dp.download(), rp[b:e]), rank
