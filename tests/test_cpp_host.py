@@ -114,6 +114,62 @@ def test_cli_offline_and_fakert_end_to_end(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("flags", [("--sse",), ("--soft-mask",), ("--nocopybord",), ("--soft-mask", "--nocopybord"),
+                                   ("--only-percussive",)])
+def test_cli_mask_filter_and_border_flags(tmp_path, flags):
+    """The option switches of the reference CLI (zen/main.cpp: --sse, --soft-mask, --nocopybord,
+    --only-percussive; zen/offline.h:150-163, :196-258 and zen/fakert.h:88-100): each reaches the engine the way
+    use_sse_filter() / use_soft_mask() / the nocopybord constructor argument do, and --only-percussive writes the
+    percussive file alone."""
+    from oracle import oracle as o
+    fs, n = 22050, 52000
+    rng = np.random.default_rng(11)
+    t = np.arange(n) / fs
+    x = 0.4 * np.sin(2 * np.pi * 523.25 * t) + 0.2 * rng.uniform(-1, 1, n) * (np.arange(n) % 5000 < 200)
+    pcm = np.round(x * 20000).astype(np.int16)
+    wav = str(tmp_path / "in.wav")
+    write_wav_pcm16(wav, pcm, fs)
+    mono = (pcm.astype(np.float32) / np.float32(32767.0)).astype(np.float32)
+    sse, soft, nocopy = "--sse" in flags, "--soft-mask" in flags, "--nocopybord" in flags
+
+    r = subprocess.run([ZEN, "offline", "-i", wav, "--hps", "1024", "2.0", "256", "2.0", "-o", str(tmp_path / "off")]
+                       + list(flags), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert ("mask: soft/Wiener" if soft else "mask: hard/binary") in r.stdout
+    assert ("filter: sse" if sse else "filter: median") in r.stdout
+    ref = o.HPRIOffline(float(fs), 1024, 256, 2.0, 2.0, nocopybord=nocopy)
+    if sse:
+        ref.use_sse_filter()
+    if soft:
+        ref.use_soft_mask()
+    h, p, _ = ref.process(mono)
+    wanted = (("off_perc.wav", p),) if "--only-percussive" in flags else (("off_harm.wav", h), ("off_perc.wav", p))
+    for name, w in wanted:
+        rfs, got = read_wav_pcm16(str(tmp_path / name))
+        peak = max(-w.min(), w.max())
+        assert rfs == fs and np.array_equal(got.astype(np.int64), pcm16(w / np.float32(peak))), (flags, name)
+    if "--only-percussive" in flags:
+        assert sorted(f for f in os.listdir(str(tmp_path)) if f.startswith("off")) == ["off_perc.wav"]
+        return                                                    # fakert has no such switch
+
+    hop = 512
+    r = subprocess.run([ZEN, "fakert", "-i", wav, "--hps", str(hop), "2.0", "-o", str(tmp_path / "rt.wav")]
+                       + list(flags), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    n_chunks = len(range(0, n - hop, hop))
+    eng = o.HPR(float(fs), hop, 2.0, o.OUTPUT_PERCUSSIVE, o.TIME_CAUSAL, copy_bord=not nocopy)
+    if sse:
+        eng.use_sse_filter()
+    if soft:
+        eng.use_soft_mask()
+    w = mono.copy()
+    w[:n_chunks * hop] = eng.process_stream(mono[:n_chunks * hop])["P"]
+    peak = max(-w.min(), w.max())
+    _, got = read_wav_pcm16(str(tmp_path / "rt.wav"))
+    assert np.array_equal(got.astype(np.int64), pcm16(w / np.float32(peak))), flags
+
+
+@pytest.mark.gpu
 def test_cli_batch_directory(tmp_path):
     """`zen batch`: a directory of clips (two lengths) separated in batches == per-clip `zen offline`."""
     fs = 44100
