@@ -292,7 +292,9 @@ struct PassRunner {
 					v[i][m] = make_float2(0.f, 0.f);
 				}
 				else if (FIRST) {
-					v[i][m] = active ? in(m * J + j, /*slot=*/m * NB + i) : make_float2(0.f, 0.f);
+					// (unconditional: an inactive frame reads valid memory too, see fft_frame -- `active ? in() : 0` put every
+					// one of the 16 loads into a branch of its own with a full wait inside: 16 dependent trips to memory)
+					v[i][m] = in(m * J + j, /*slot=*/m * NB + i);
 				}
 				else {
 					v[i][m] = lds[lds_pad((k * R + m) * J + j)];
@@ -333,7 +335,8 @@ struct PassRunner {
 // fact idx < N/2.  `slot` (compile-time, 0..15) numbers a thread's 16 values: idx = tf + slot*TF both for
 // the first pass's inputs and the last pass's outputs, so a spectrum can stay in registers between a
 // forward and an inverse transform (rt_fused.hip).  All threads of the block must call this
-// together (it contains block barriers); inactive frames pass active = false.
+// together (it contains block barriers); inactive frames pass active = false: out() is not called for them, in() IS
+// (its results are dropped), so their `in` must point at readable memory -- the callers clamp the frame index.
 template <int LOG2N, bool INV, bool ZU, bool HALF_OUT, class In, class Out, bool SYNC_FIRST = false>
 __device__ __forceinline__ void fft_frame(int tf, float2* __restrict__ lds, const float2* __restrict__ tw,
                                           In& in, Out& out, bool active)

@@ -96,6 +96,8 @@ void free_all(zen_hip_hpr* e)
 	(void)hipFree(e->d_mag);
 	(void)hipFree(e->d_H);
 	(void)hipFree(e->d_P);
+	(void)hipFree(e->d_bits);
+	(void)hipFree(e->d_bits_t);
 	(void)hipFree(e->d_blk_flag);
 	(void)hipFree(e->d_blk_need);
 	for (int o = 0; o < 3; ++o) {
@@ -494,6 +496,22 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 		ia.thr_p_inc = t.p_inc;
 		ia.thr_h_inc = t.h_inc;
 	}
+	// Blocks of frames with hard masks: the comparisons are made once per bin in a launch of their own and the
+	// synthesis loads two bits per bin instead of H and P (per output, and per mirror image).
+	if (M >= 8 && !ia.soft && !ia.sse && ia.thr_p != 0.0 && ia.thr_h != 0.0 && !g_opt_no_mask_bits) {
+		ia.bits_row_words = mask_bits_row_words((int)N, ia.p_mid);
+		ia.bits_stream_stride = (long long)e->max_hops * ia.bits_row_words;
+		if (!e->d_bits)
+			ZH_HIP(hipMalloc((void**)&e->d_bits, sizeof(unsigned) * S * (size_t)ia.bits_stream_stride));
+		ia.bits = e->d_bits;
+		ia.bits_t_stream_stride = (long long)e->max_hops * (long long)(N / 16);
+		if (!e->d_bits_t)
+			ZH_HIP(hipMalloc((void**)&e->d_bits_t, sizeof(unsigned) * S * (size_t)ia.bits_t_stream_stride));
+		ia.bits_t = e->d_bits_t;
+		ProfScope ps(e, zen_hip_hpr::K_ISTFT);
+		ZH_TRY(launch_mask_bits((int)N, ia, e->d_bits, e->stream));
+		ZH_TRY(launch_mask_bits_transpose((int)N, ia, e->d_bits_t, e->stream));
+	}
 	{
 		ProfScope ps(e, zen_hip_hpr::K_ISTFT);
 		ZH_TRY(launch_istft(e->log2n, ia, e->stream));
@@ -589,9 +607,12 @@ int grow_buffers(zen_hip_hpr* e, size_t new_hops)
 	(void)hipFree(e->d_mag);
 	(void)hipFree(e->d_H);
 	(void)hipFree(e->d_P);
+	(void)hipFree(e->d_bits);
+	(void)hipFree(e->d_bits_t);
 	e->d_S = nS;
 	e->d_mag = nmag;
 	e->d_H = e->d_P = nullptr; // ensure_estimates
+	e->d_bits = e->d_bits_t = nullptr; // run_chunk
 	(void)hipFree(e->d_blk_flag);
 	(void)hipFree(e->d_blk_need);
 	e->d_blk_flag = e->d_blk_need = nullptr; // run_hop_fused

@@ -50,6 +50,8 @@ struct zen_hip_hpr {
 	bool direct_done[3] = {false, false, false};        // run_chunk delivered output o's hops itself: no finalize launch
 	float* d_H = nullptr;
 	float* d_P = nullptr;
+	unsigned* d_bits_t = nullptr; // the same in the synthesis threads' order (IstftArgs::bits_t)
+	unsigned* d_bits = nullptr; // hard masks of the consumed rows as two bits per bin (IstftArgs::bits), blocks of frames only
 	float* d_Y[3] = {nullptr, nullptr, nullptr};     // 0 percussive, 1 harmonic, 2 residual
 	float* d_carry[3] = {nullptr, nullptr, nullptr};
 	long long abs_frame = 0;

@@ -48,21 +48,39 @@ __device__ __forceinline__ float hard_mask_sel(float h, float p, const HardThr& 
 	return k.s0 + k.s1 * (k.gh * hm + k.gp * pm);
 }
 
+// The thread's word of mask bits (two per bin: percussive, harmonic) as two-bit signed codes of the output's mask value:
+// 00 -> 0, 01 -> 1, 11 -> -1 (the residual mask 1 - (hm + pm) where both masks are set, hps.h:35-43).  Wave-uniform, once
+// per thread; per bin the synthesis then needs one signed bit-field extract and one conversion.
+__device__ __forceinline__ unsigned mask_code(unsigned w, int which, const MaskCfg& c)
+{
+	const unsigned E = 0x55555555u;
+	const unsigned pm = w & E, hm = (w >> 1) & E;
+	if (which == 0)
+		return pm;
+	if (which == 1)
+		return hm;
+	const unsigned a = c.out_p ? pm : 0u, b = c.out_h ? hm : 0u; // hps.cu:562-567: a mask that is not computed counts as 0
+	return (~(a ^ b) & E) | ((a & b) << 1);                      // 1 - (a + b): 0 + 0 -> 01, one set -> 00, both -> 11
+}
+
 // MODE 0: any mask (generic); 1: hard masks by comparison, any output; 2: the same for the percussive output alone
-// (pass 2 of the offline configuration, the realtime default): one comparison per bin.
-template <int MODE>
+// (the realtime default): one comparison per bin; 3: hard masks from the bits of launch_mask_bits (blocks of frames).
+template <int MODE, int DIAG = 0>
 struct IstftIn {
 	const float2* S;
 	const float* H;
 	const float* P;
+	unsigned bw;       // MODE 3 / 4: the thread's word of mask bits (IstftArgs::bits_t)
 	MaskCfg cfg;
 	HardThr thr;
 	HardSel sel;
 	int which;
 	int n;
 	int p_mid;
-	__device__ __forceinline__ float2 operator()(int idx, int) const
+	__device__ __forceinline__ float2 operator()(int idx, int slot) const
 	{
+		if constexpr ((DIAG & 1) != 0) // diagnostic: no global loads
+			return make_float2((float)idx * cfg.beta, (float)(idx ^ 5) * cfg.beta_h);
 		const bool mirror = idx > (n >> 1); // upper half: S[n-k] = conj(S[k])
 		const int lo = mirror ? n - idx : idx;
 		float2 z = S[lo];
@@ -70,7 +88,10 @@ struct IstftIn {
 			z.y = -z.y;
 		const int pi = (mirror && idx >= n - p_mid) ? idx : lo;
 		float m;
-		if constexpr (MODE == 2)
+		if constexpr (MODE >= 3) { // the comparisons were made once per bin (launch_mask_bits + _transpose)
+			m = (float)((int)(bw << (30 - 2 * slot)) >> 30); // two bits, sign-extended: 00 -> 0, 01 -> 1, 11 -> -1 (mask_code)
+		}
+		else if constexpr (MODE == 2)
 			m = hard_mask_exact(P[pi], H[lo] + FLT_EPSILON, thr.p); // hps.cu:501-505
 		else if constexpr (MODE == 1)
 			m = hard_mask_sel(H[lo], P[pi], thr, sel);
@@ -80,7 +101,8 @@ struct IstftIn {
 	}
 };
 
-struct IstftOut {
+template <int DIAG = 0>
+struct IstftOutT {
 	float* Y;
 	float cola;
 	float* ready;       // single-frame calls: the finished hop = carry + first half of this frame
@@ -90,11 +112,18 @@ struct IstftOut {
 	__device__ __forceinline__ void operator()(int idx, float2 x, bool, int slot) const
 	{
 		const float y = x.x * cola; // the product of overlap_add_functor hps.h:68-80; the sum is in finalize ...
+		if constexpr ((DIAG & 2) != 0) { // diagnostic: no global stores
+			if (y == 12345.678f)
+				Y[idx] = y;
+			return;
+		}
 		Y[idx] = y;
 		if (ready && idx < hop) // ... or here, when the call is a single hop (hps.cu:341-363 hands out [0, hop))
 			ready[idx] = cv[slot & 3] + y;
 	}
 };
+
+using IstftOut = IstftOutT<0>;
 
 // the four carry samples of thread tf (hop == 4*TF)
 template <int TF>
@@ -105,17 +134,20 @@ __device__ __forceinline__ void load_carry(const float* carry, int tf, bool want
 		cv[i] = wanted ? carry[tf + i * TF] : 0.0f;
 }
 
-template <int LOG2N, int MODE>
-__global__ __launch_bounds__(Plan<LOG2N>::THREADS) void istft_kernel(IstftArgs a)
+// (four waves per SIMD: with every load of the first pass in flight at once the max-ILP schedule otherwise takes 130 to
+// 200 registers -- three or two waves, and at nfft 8192 one workgroup per CU instead of two)
+template <int LOG2N, int MODE, int DIAG = 0>
+__global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) void istft_kernel(IstftArgs a)
 {
 	using PL = Plan<LOG2N>;
 	extern __shared__ float2 lds[];
 	const int tid = threadIdx.x, s = blockIdx.z, oi = blockIdx.y;
 	const int slot = tid / PL::TF, tf = tid - slot * PL::TF;
-	const int f = blockIdx.x * PL::FRAMES_PER_BLOCK + slot;
-	const bool active = f < a.n_frames;
+	const int f_ = blockIdx.x * PL::FRAMES_PER_BLOCK + slot;
+	const bool active = f_ < a.n_frames;
+	const int f = active ? f_ : a.n_frames - 1; // (an inactive slot transforms the last frame again and stores nothing)
 	const long long ring_row = ((a.crow0 + f) % a.ring_rows) + (long long)s * a.ring_rows;
-	IstftIn<MODE> in;
+	IstftIn<MODE, DIAG> in;
 	in.S = a.S + ring_row * a.s_stride;
 	in.n = PL::N;
 	in.H = a.h_is_ring ? a.H + ring_row * PL::N : a.H + (long long)s * a.h_stream_stride + (long long)f * PL::N;
@@ -125,7 +157,10 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void istft_kernel(IstftArgs a
 	in.which = a.out_id[oi];
 	in.sel = hard_sel(in.which, in.cfg);
 	in.p_mid = a.p_mid;
-	IstftOut out;
+	in.bw = 0;
+	if constexpr (MODE >= 3)
+		in.bw = mask_code(a.bits_t[(long long)s * a.bits_t_stream_stride + (long long)f * PL::TF + tf], in.which, in.cfg);
+	IstftOutT<DIAG> out;
 	out.Y = a.Y[oi] + (long long)s * a.y_stream_stride + (long long)f * (PL::N / 2);
 	out.cola = a.cola;
 	out.ready = (a.n_frames == 1 && a.ready[oi]) ? a.ready[oi] + (long long)s * a.hop : nullptr;
@@ -192,8 +227,9 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void istft_hard_multi_kernel(
 	extern __shared__ float2 lds[];
 	const int tid = threadIdx.x, s = blockIdx.z;
 	const int slot = tid / PL::TF, tf = tid - slot * PL::TF;
-	const int f = blockIdx.x * PL::FRAMES_PER_BLOCK + slot;
-	const bool active = f < a.n_frames;
+	const int f_ = blockIdx.x * PL::FRAMES_PER_BLOCK + slot;
+	const bool active = f_ < a.n_frames;
+	const int f = active ? f_ : a.n_frames - 1; // (an inactive slot transforms the last frame again and stores nothing)
 	const long long ring_row = ((a.crow0 + f) % a.ring_rows) + (long long)s * a.ring_rows;
 	unsigned bits = 0;
 	IstftHardIn in;
@@ -236,6 +272,80 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void istft_hard_multi_kernel(
 	}
 }
 
+// ------------------------------------------------------------------------------------------------
+// Both hard masks of every bin the synthesis reads, decided once (hps.cu:501-505, :535-540 through masks.h
+// hard_mask_exact) instead of once per output and mirror image inside the synthesis kernels, which then load two
+// bits per bin instead of H and P.  One thread per four entries; the four lanes of a word combine their bytes.
+__global__ __launch_bounds__(256) void mask_bits_kernel(IstftArgs a, unsigned* bits, int n, int quads_per_row)
+{
+	const long long gid = (long long)blockIdx.x * 256 + threadIdx.x; // (a whole number of wavefronts per launch)
+	const long long row = gid / quads_per_row;
+	const int q = (int)(gid - row * quads_per_row);
+	const bool live = row < (long long)a.n_frames * a.n_streams;
+	unsigned byte = 0;
+	int s = 0, f = 0;
+	if (live) {
+		s = (int)(row / a.n_frames);
+		f = (int)(row - (long long)s * a.n_frames);
+		const long long ring_row = ((a.crow0 + f) % a.ring_rows) + (long long)s * a.ring_rows;
+		const float* H = a.h_is_ring ? a.H + ring_row * n : a.H + (long long)s * a.h_stream_stride + (long long)f * n;
+		const float* P = a.P + (long long)s * a.p_stream_stride + (long long)f * n;
+		const int e0 = 4 * q, half = n >> 1;
+		float h[4], p[4];
+		if (e0 + 3 <= half) {
+			const float4 hv = *reinterpret_cast<const float4*>(H + e0), pv = *reinterpret_cast<const float4*>(P + e0);
+			h[0] = hv.x, h[1] = hv.y, h[2] = hv.z, h[3] = hv.w;
+			p[0] = pv.x, p[1] = pv.y, p[2] = pv.z, p[3] = pv.w;
+		}
+		else {
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				const int e = e0 + i;
+				const int idx = e <= half ? e : n - a.p_mid + (e - half - 1); // the bin; past the last entry: >= n
+				const bool ok = idx < n;
+				h[i] = ok ? H[idx <= half ? idx : n - idx] : 0.0f;
+				p[i] = ok ? P[idx] : 0.0f; // (past the last entry: 0 against 0, no bit set; nobody reads those)
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const unsigned pm = hard_mask_exact(p[i], h[i] + FLT_EPSILON, a.thr_p) != 0.0f ? 1u : 0u;
+			const unsigned hm = hard_mask_exact(h[i], p[i] + FLT_EPSILON, a.thr_h) != 0.0f ? 1u : 0u;
+			byte |= (pm | (hm << 1)) << (2 * i);
+		}
+	}
+	unsigned w = byte << (8 * (threadIdx.x & 3));
+	w |= __shfl_xor(w, 1);
+	w |= __shfl_xor(w, 2);
+	if (live && (threadIdx.x & 3) == 0)
+		bits[(long long)s * a.bits_stream_stride + (long long)f * a.bits_row_words + (q >> 2)] = w;
+}
+
+// natural order -> the synthesis threads' order (IstftArgs::bits_t); the mirrored half and the tail are expanded here
+__global__ __launch_bounds__(256) void mask_bits_transpose_kernel(IstftArgs a, unsigned* bits_t, int n, int log2tf)
+{
+	const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+	const long long row = gid >> log2tf;
+	if (row >= (long long)a.n_frames * a.n_streams)
+		return;
+	const int tf = (int)(gid & ((1 << log2tf) - 1));
+	const int s = (int)(row / a.n_frames), f = (int)(row - (long long)s * a.n_frames);
+	const unsigned* nat = a.bits + (long long)s * a.bits_stream_stride + (long long)f * a.bits_row_words;
+	unsigned w[16];
+#pragma unroll
+	for (int sl = 0; sl < 16; ++sl) { // (all sixteen loads in flight)
+		const int idx = tf + (sl << log2tf);
+		const bool mirror = idx > (n >> 1);
+		const int e = (mirror && idx >= n - a.p_mid) ? (n >> 1) + 1 + idx - (n - a.p_mid) : (mirror ? n - idx : idx);
+		w[sl] = (nat[e >> 4] >> (2 * (e & 15))) & 3u;
+	}
+	unsigned r = 0;
+#pragma unroll
+	for (int sl = 0; sl < 16; ++sl)
+		r |= w[sl] << (2 * sl);
+	bits_t[(long long)s * a.bits_t_stream_stride + ((long long)f << log2tf) + tf] = r;
+}
+
 template <int LOG2N>
 int launch_istft_t(const IstftArgs& a, hipStream_t stream)
 {
@@ -253,6 +363,14 @@ int launch_istft_t(const IstftArgs& a, hipStream_t stream)
 	dim3 grid((unsigned)ceil_div((size_t)a.n_frames, (size_t)PL::FRAMES_PER_BLOCK), (unsigned)a.n_out, (unsigned)a.n_streams);
 	if (!a.soft && !a.sse && a.thr_p != 0.0 && a.thr_h != 0.0) { // hard masks by comparison: the builds with nothing else in them
 		auto kern = (a.n_out == 1 && a.out_id[0] == 0) ? istft_kernel<LOG2N, 2> : istft_kernel<LOG2N, 1>;
+		if (a.bits_t)
+			kern = istft_kernel<LOG2N, 3>;
+		if constexpr (LOG2N == 99) { // TEMPORARY diagnostic builds
+			const int d = (int)g_opt_rt_fused_diag;
+			if (d == 1) kern = (a.n_out == 1 && a.out_id[0] == 0) ? istft_kernel<LOG2N, 2, 1> : istft_kernel<LOG2N, 1, 1>;
+			if (d == 2) kern = (a.n_out == 1 && a.out_id[0] == 0) ? istft_kernel<LOG2N, 2, 2> : istft_kernel<LOG2N, 1, 2>;
+			if (d == 3) kern = (a.n_out == 1 && a.out_id[0] == 0) ? istft_kernel<LOG2N, 2, 3> : istft_kernel<LOG2N, 1, 3>;
+		}
 		ZH_TRY(set_lds(kern, lds_bytes<LOG2N>()));
 		hipLaunchKernelGGL(kern, grid, dim3(PL::THREADS), lds_bytes<LOG2N>(), stream, a);
 		ZH_HIP(hipGetLastError());
@@ -267,6 +385,32 @@ int launch_istft_t(const IstftArgs& a, hipStream_t stream)
 
 
 } // namespace
+
+int launch_mask_bits(int nfft, const IstftArgs& a, unsigned* bits, hipStream_t stream)
+{
+	if (a.n_frames <= 0)
+		return ZEN_HIP_OK;
+	const int quads = a.bits_row_words * 4;
+	const long long threads = (long long)a.n_frames * a.n_streams * quads;
+	hipLaunchKernelGGL(mask_bits_kernel, dim3((unsigned)ceil_div((size_t)threads, (size_t)256)), dim3(256), 0, stream, a, bits, nfft,
+	                   quads);
+	ZH_HIP(hipGetLastError());
+	return ZEN_HIP_OK;
+}
+
+int launch_mask_bits_transpose(int nfft, const IstftArgs& a, unsigned* bits_t, hipStream_t stream)
+{
+	if (a.n_frames <= 0)
+		return ZEN_HIP_OK;
+	int log2tf = 0;
+	while ((16 << log2tf) < nfft)
+		++log2tf;
+	const long long threads = ((long long)a.n_frames * a.n_streams) << log2tf;
+	hipLaunchKernelGGL(mask_bits_transpose_kernel, dim3((unsigned)ceil_div((size_t)threads, (size_t)256)), dim3(256), 0, stream, a, bits_t,
+	                   nfft, log2tf);
+	ZH_HIP(hipGetLastError());
+	return ZEN_HIP_OK;
+}
 
 int launch_istft(int log2n, const IstftArgs& a, hipStream_t stream)
 {

@@ -50,12 +50,15 @@ __global__ __launch_bounds__(256, ZEN_BIG_MINB) void median_big_kernel(FilterArg
 	{
 		constexpr int NVEC = NRAW * 4, NLD = (NVEC + 255) / 256;
 		const int c_lo = col0 - 16 * (G::a + 2);
+		int4 kv[NLD]; // all loads in flight, then the image (a vector past the image reads a replicated column: harmless)
+#pragma unroll
+		for (int i = 0; i < NLD; ++i)
+			kv[i] = row_vec_keys<NONNEG>(srow, c_lo + 4 * (tid + 256 * i), cols, a.hermitian);
 #pragma unroll
 		for (int i = 0; i < NLD; ++i) {
 			const int vi = tid + 256 * i;
-			const int vc = c_lo + 4 * vi;
 			if (vi < NVEC)
-				*reinterpret_cast<int4*>(&raw[(vi >> 2) * RSTR + 4 * (vi & 3)]) = row_vec_keys<NONNEG>(srow, vc, cols, a.hermitian);
+				*reinterpret_cast<int4*>(&raw[(vi >> 2) * RSTR + 4 * (vi & 3)]) = kv[i];
 		}
 	}
 	__syncthreads();

@@ -231,11 +231,10 @@ __global__ __launch_bounds__(HERM_THREADS) void median_net_freq_herm_kernel(Filt
 	const float* __restrict__ src = a.src + (long long)blockIdx.y * a.src_stream_stride;
 	for (int v = tid; v < rpw * row_vecs; v += HERM_THREADS) {
 		const int rr = v / row_vecs, vv = v - rr * row_vecs;
-		if (row0 + rr < a.n_out_rows) {
-			const float* srow = src + (long long)map_row(rm, row0 + rr) * cols;
-			const int col = vv < lwv ? 4 * vv - MID_AL : c_t0 - MID_AL + 4 * (vv - lwv);
-			*reinterpret_cast<int4*>(&himg[4 * v]) = row_vec_keys<NONNEG>(srow, col, cols, 1);
-		}
+		const int rw = row0 + rr < a.n_out_rows ? row0 + rr : a.n_out_rows - 1; // (past the last row: staged again, never used)
+		const float* srow = src + (long long)map_row(rm, rw) * cols;
+		const int col = vv < lwv ? 4 * vv - MID_AL : c_t0 - MID_AL + 4 * (vv - lwv);
+		*reinterpret_cast<int4*>(&himg[4 * v]) = row_vec_keys<NONNEG>(srow, col, cols, 1);
 	}
 	__syncthreads();
 	const int rr = tid / jobs, j = tid - rr * jobs;

@@ -9,27 +9,25 @@ using znet::to_key;
 // Four consecutive logical columns vc..vc+3 (vc a multiple of 4, the row 16-byte aligned and a multiple of 4
 // long) of a source row as ordering keys: replicate border (ippBorderRepl) outside [0, cols); `herm`: only
 // columns 0..cols/2 are stored, column c > cols/2 is column cols - c (FilterArgs::hermitian).
+// Branch-free: ONE 16-byte load from a selected address, the vector assembled by selects.  (Written with a branch per
+// case -- lower half / mirrored / beyond the row -- every call became a load with a full wait inside its branch, and a
+// staging loop of six such calls six dependent trips to memory.)
+typedef float float4_u __attribute__((ext_vector_type(4), aligned(4))); // (the mirrored vector starts at any column)
 template <bool NONNEG>
 __device__ __forceinline__ int4 row_vec_keys(const float* __restrict__ srow, int vc, int cols, int herm)
 {
-	if (herm && vc >= (cols >> 1)) {
-		if (vc >= cols) { // beyond the row: column cols-1, which is column 1
-			const int b = to_key<NONNEG>(srow[1]);
-			return make_int4(b, b, b, b);
-		}
-		// columns cols-vc, cols-vc-1, cols-vc-2, cols-vc-3: one aligned vector and the scalar above it
-		const int mc = cols - vc;
-		const float4 v = *reinterpret_cast<const float4*>(srow + mc - 4);
-		return make_int4(to_key<NONNEG>(srow[mc]), to_key<NONNEG>(v.w), to_key<NONNEG>(v.z), to_key<NONNEG>(v.y));
-	}
+	const bool up = herm && vc >= (cols >> 1); // not stored: the mirror image, or beyond the row
+	const bool mir = up && vc < cols;
+	const int mc = cols - vc;                  // mirrored: columns mc, mc-1, mc-2, mc-3
 	const int vcl = vc < 0 ? 0 : (vc > cols - 4 ? cols - 4 : vc);
-	const float4 x = *reinterpret_cast<const float4*>(srow + vcl);
-	int4 k = make_int4(to_key<NONNEG>(x.x), to_key<NONNEG>(x.y), to_key<NONNEG>(x.z), to_key<NONNEG>(x.w));
-	if (vc < 0)
-		k = make_int4(k.x, k.x, k.x, k.x);
-	else if (vc >= cols)
-		k = make_int4(k.w, k.w, k.w, k.w);
-	return k;
+	const int va = up ? (mir ? mc - 3 : 0) : vcl;
+	const float4_u x = *reinterpret_cast<const float4_u*>(srow + va);
+	const int k0 = to_key<NONNEG>(x.x), k1 = to_key<NONNEG>(x.y), k2 = to_key<NONNEG>(x.z), k3 = to_key<NONNEG>(x.w);
+	// stored: (k0 k1 k2 k3), left of the row k0 x4, right of it k3 x4; mirrored: (k3 k2 k1 k0); Hermitian and beyond the
+	// row: column cols-1, which is column 1: k1 x4
+	const bool lo = vc < 0, hi = !up && vc >= cols, rep = lo || hi || (up && !mir);
+	const int r = lo ? k0 : (hi ? k3 : k1); // the replicated key where there is one
+	return make_int4(rep ? r : (mir ? k3 : k0), rep ? r : (mir ? k2 : k1), rep ? r : (mir ? k1 : k2), rep ? r : (mir ? k0 : k3));
 }
 
 

@@ -67,7 +67,20 @@ struct IstftArgs {
 	// hard masks by exact comparison instead of the division (masks.h HardThr; zeros: divide)
 	double thr_p, thr_h;
 	int thr_p_inc, thr_h_inc;
+	// Hard masks decided once per bin by launch_mask_bits: two bits per bin (bit 0 percussive, bit 1 harmonic), 16 bins
+	// per word; entry e of a row: bins 0..nfft/2 at e = bin, the last p_mid bins (whose P differs from its mirror image)
+	// at e = nfft/2 + 1 + (bin - (nfft - p_mid)).  Null: the synthesis compares H and P itself.
+	const unsigned* bits;
+	long long bits_stream_stride; // words
+	int bits_row_words;
+	// the same bits in the order the synthesis threads want them (launch_mask_bits_transpose): word tf of a row (tf <
+	// nfft/16) holds, at bits 2s and 2s+1, the masks of bin tf + s*nfft/16 -- the thread's sixteen inputs of the first pass
+	const unsigned* bits_t;
+	long long bits_t_stream_stride; // words; a row is nfft/16 words
 };
+
+// words of one row of mask bits (a multiple of four: rows stay 16-byte aligned)
+inline int mask_bits_row_words(int nfft, int p_mid) { return ((nfft / 2 + 1 + p_mid + 15) / 16 + 3) / 4 * 4; }
 
 // overlap-add of consecutive frames (hps.cu:435-449 + :526-528) and copy-out (hps.cu:341-363):
 // out[i*hop + n] = (i ? Y[i-1][hop+n] : carry[n]) + Y[i][n]
@@ -92,6 +105,10 @@ struct FinalizeArgs {
 
 int launch_stft(int log2n, const StftArgs& a, hipStream_t stream);
 int launch_istft(int log2n, const IstftArgs& a, hipStream_t stream);
+// fills IstftArgs::bits (passed as `bits`, writable) for the frames / streams of `a` from its H and P rows
+int launch_mask_bits(int nfft, const IstftArgs& a, unsigned* bits, hipStream_t stream);
+// IstftArgs::bits -> IstftArgs::bits_t (passed as `bits_t`, writable)
+int launch_mask_bits_transpose(int nfft, const IstftArgs& a, unsigned* bits_t, hipStream_t stream);
 int launch_finalize(const FinalizeArgs& a, hipStream_t stream);
 int launch_finalize_spec(const FinalizeArgs& a, hipStream_t stream);
 // FFTC2CWrapperGPU::forward/backward (fftw.h:35-43), `batch` consecutive transforms in place

@@ -32,7 +32,14 @@ struct StftIn {
 	int nv_prev, nv_cur; // samples of `prev` / `cur` that exist (StftArgs::in_valid); the rest of the hop reads as zero
 	__device__ __forceinline__ float2 operator()(int idx, int) const
 	{
-		const float x = idx < hop ? (idx < nv_prev ? prev[idx] : 0.0f) : (idx - hop < nv_cur ? cur[idx - hop] : 0.0f);
+		// (one unconditional load from a selected address -- a sample that does not exist reads the window table instead
+		// and is replaced by zero: `ok ? p[k] : 0` made every load a branch with a full wait inside)
+		const bool first = idx < hop;
+		const int k = first ? idx : idx - hop;
+		const bool ok = k < (first ? nv_prev : nv_cur);
+		const float* p = ok ? (first ? prev : cur) + k : window;
+		const float v = *p;
+		const float x = ok ? v : 0.0f;
 		return make_float2(x * window[idx], 0.0f); // window_functor hps.h:24-33
 	}
 };
@@ -88,8 +95,9 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void stft_kernel(StftArgs a)
 		return;
 	}
 	const int slot = tid / PL::TF, tf = tid - slot * PL::TF;
-	const int f = blockIdx.x * PL::FRAMES_PER_BLOCK + slot;
-	const bool active = f < a.n_frames;
+	const int f_ = blockIdx.x * PL::FRAMES_PER_BLOCK + slot;
+	const bool active = f_ < a.n_frames;
+	const int f = active ? f_ : a.n_frames - 1; // (an inactive slot transforms the last frame again and stores nothing)
 	const float* in_s = a.in + (long long)s * a.in_stride;
 	StftIn<LOG2N> in;
 	in.prev = (f == 0) ? a.tail_prev + (long long)s * hop : in_s + (long long)(f - 1) * hop;
@@ -281,8 +289,9 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void fft_kernel(float2* data,
 	extern __shared__ float2 lds[];
 	const int tid = threadIdx.x;
 	const int slot = tid / PL::TF, tf = tid - slot * PL::TF;
-	const long long f = (long long)blockIdx.x * PL::FRAMES_PER_BLOCK + slot;
-	const bool active = f < batch;
+	const long long f_ = (long long)blockIdx.x * PL::FRAMES_PER_BLOCK + slot;
+	const bool active = f_ < batch;
+	const long long f = active ? f_ : batch - 1;
 	PlainIn in{data + f * PL::N};
 	PlainOut out{data + f * PL::N};
 	zfft::fft_frame<LOG2N, INV, false, false>(tf, lds + slot * PL::LDS_FLOAT2, tw, in, out, active);
