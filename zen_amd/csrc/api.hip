@@ -25,6 +25,7 @@ opt_t g_opt_no_half_rows{0};
 opt_t g_opt_mfilt_nonneg{0};
 opt_t g_opt_no_persist{0};
 opt_t g_opt_no_mask_bits{0};
+opt_t g_opt_no_median_bits{0};
 opt_t g_opt_no_direct_out{0};
 std::atomic<unsigned> g_host_free_gen{0};
 
@@ -171,6 +172,7 @@ int zen_hip_set_option(const char* name, int value)
 	             {"mfilt_nonneg", &g_opt_mfilt_nonneg},
 	             {"no_persist", &g_opt_no_persist},
 	             {"no_mask_bits", &g_opt_no_mask_bits},
+	             {"no_median_bits", &g_opt_no_median_bits},
 	             {"no_direct_out", &g_opt_no_direct_out}};
 	for (const auto& t : table) {
 		if (name && !strcmp(name, t.name)) {

@@ -24,6 +24,7 @@ extern opt_t g_opt_median_general;       // "median_general": force the general 
 extern opt_t g_opt_no_median47_dpp;      // "no_median47_dpp": 4096-bin rows / 47 taps through the generic kernel
 extern opt_t g_opt_no_half_rows;         // "no_half_rows": the three-kernel path stores and filters whole magnitude rows
 extern opt_t g_opt_no_direct_out;       // "no_direct_out": the fused block kernel leaves the overlap-add to finalize_kernel
+extern opt_t g_opt_no_median_bits;      // "no_median_bits": the mask bits always come from mask_bits_kernel, never from a median kernel
 extern opt_t g_opt_no_mask_bits;        // "no_mask_bits": the synthesis kernels compare H and P themselves (no mask_bits_kernel)
 extern opt_t g_opt_no_persist;          // "no_persist": blocks of frames at nfft 8192 / 16384 through the one-frame-per-workgroup kernels
 extern opt_t g_opt_mfilt_nonneg;        // "mfilt_nonneg": zen_hip_mfilt_run's input is promised to be >= +0 (raw-bit ordering keys)

@@ -39,15 +39,27 @@ struct FilterArgs {
 	                        // Kernels that do not know the flag are not offered such rows (filter_supports_hermitian)
 	int pitch;              // floats between consecutive rows of src and dst (0: cols) -- the time-direction
 	                        // kernels filter only the stored half of such rows (cols = nfft/2 + 4, pitch = nfft)
+	// Engine only, Hermitian frequency-direction launches with hard masks (stft.h IstftArgs::bits): a kernel that knows how
+	// compares its result P with the harmonic estimate H right away and writes two mask bits per bin (natural order, see
+	// IstftArgs::bits) INSTEAD of the P row; launch_median(..., &bits_done) tells whether the kernel that ran did (1: `bits`, 2: `bits_t`).
+	// hrows null: H is the source row itself (causal / one-tap time median).
+	unsigned* bits;
+	long long bits_stream_stride; // words
+	int bits_row_words;
+	double thr_p, thr_h;          // masks.h hard_mask_threshold
+	const float* hrows;           // H row i of stream s at hrows[s*h_stream_stride + i*cols]
+	long long h_stream_stride;
+	unsigned* bits_t;             // a kernel that holds whole rows writes IstftArgs::bits_t right away (bits_done = 2)
+	long long bits_t_stream_stride;
 };
 
 // true if launch_median(a) with a.hermitian = 1 is implemented for this (direction, mask, row length)
 bool filter_supports_hermitian(int len, int cols);
 
-int launch_median(const FilterArgs& a, hipStream_t stream);
-int launch_median_net(const FilterArgs& a, hipStream_t stream, bool* handled); // masks <= 63 taps
+int launch_median(const FilterArgs& a, hipStream_t stream, int* bits_done = nullptr);
+int launch_median_net(const FilterArgs& a, hipStream_t stream, bool* handled, int* bits_done = nullptr); // masks <= 63 taps
 int launch_median47_dpp(const FilterArgs& a, hipStream_t stream, bool* handled);  // 47 taps, frequency, 4096-bin rows
-int launch_median_big(const FilterArgs& a, hipStream_t stream, bool* handled); // 65/85/93/129/171/187/255 taps, frequency
+int launch_median_big(const FilterArgs& a, hipStream_t stream, bool* handled, int* bits_done = nullptr); // 65/85/93/129/171/187/255 taps, frequency
 int launch_box(const FilterArgs& a, hipStream_t stream);
 
 } // namespace zen_hip_impl

@@ -398,25 +398,21 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 	fa.clamp_hi = LLONG_MAX / 4;
 	fa.nonneg = 1; // |S| >= +0
 
-	FilterArgs ff = fa; // frequency direction -> P   (hps.cu:496 / :597)
-	ff.dst = e->d_P;
-	ff.len = e->mf;
-	ff.direction = ZEN_HIP_FREQUENCY;
-	ff.hermitian = half ? 1 : 0;
-	{
-		ProfScope ps(e, zen_hip_hpr::K_FREQ);
-		if (e->use_sse) {
-			ff.sse_pre = 1;
-			ff.sse_post = 1;
-			ff.post_factor = (float)e->l_perc + 1.0F; // hps.cu:599-601
-			ZH_TRY(launch_box(ff, e->stream));
-		}
-		else {
-			ZH_TRY(launch_median(ff, e->stream));
-		}
-		if (e->prof) // elements the kernel is asked for: whole rows, or bins 0..nfft/2 and the last mf/2
-			e->prof_elements += (unsigned long long)(M * (half ? N / 2 + 1 + (size_t)(e->mf / 2) : N) * S);
+	// Blocks of frames with hard masks: the comparisons are made once per bin -- by the frequency-direction median kernel
+	// itself where it knows how (FilterArgs::bits: two bits per bin instead of the P row), else in a launch of their own
+	// -- and the synthesis loads two bits per bin instead of H and P (per output, and per mirror image).
+	const float beta_h = e->beta - FLT_EPSILON; // hps.cu:540 hard_mask_functor(beta - Eps)
+	const HardThr thr = hard_mask_thresholds(e->beta, beta_h, g_opt_mask_divide != 0);
+	const bool use_bits = M >= 8 && !e->soft && !e->use_sse && thr.p != 0.0 && thr.h != 0.0 && !g_opt_no_mask_bits;
+	const int p_mid = e->use_sse ? (int)(N / 2) : e->mf / 2;
+	const int bits_row_words = mask_bits_row_words((int)N, p_mid);
+	const long long bits_stream_stride = (long long)e->max_hops * bits_row_words;
+	const long long bits_t_stream_stride = (long long)e->max_hops * (long long)(N / 16);
+	if (use_bits && !e->d_bits) {
+		ZH_HIP(hipMalloc((void**)&e->d_bits, sizeof(unsigned) * S * (size_t)bits_stream_stride));
+		ZH_HIP(hipMalloc((void**)&e->d_bits_t, sizeof(unsigned) * S * (size_t)bits_t_stream_stride));
 	}
+	int bits_done = 0; // 1: the frequency-direction kernel wrote IstftArgs::bits, 2: ::bits_t
 
 	bool h_is_ring = false; // time direction -> H   (hps.cu:495 / :596)
 	FilterArgs ft = fa;
@@ -446,6 +442,39 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 		ZH_TRY(launch_median(ft, e->stream));
 	}
 
+	FilterArgs ff = fa; // frequency direction -> P   (hps.cu:496 / :597)
+	ff.dst = e->d_P;
+	ff.len = e->mf;
+	ff.direction = ZEN_HIP_FREQUENCY;
+	ff.hermitian = half ? 1 : 0;
+	if (use_bits && half && !g_opt_no_median_bits) { // (H: the magnitude row itself, or what the time-direction launch above left)
+		ff.bits = e->d_bits;
+		ff.bits_stream_stride = bits_stream_stride;
+		ff.bits_row_words = bits_row_words;
+		ff.bits_t = e->d_bits_t;
+		ff.bits_t_stream_stride = bits_t_stream_stride;
+		ff.thr_p = thr.p;
+		ff.thr_h = thr.h;
+		if (!h_is_ring) {
+			ff.hrows = e->d_H;
+			ff.h_stream_stride = (long long)(e->max_hops * N);
+		}
+	}
+	{
+		ProfScope ps(e, zen_hip_hpr::K_FREQ);
+		if (e->use_sse) {
+			ff.sse_pre = 1;
+			ff.sse_post = 1;
+			ff.post_factor = (float)e->l_perc + 1.0F; // hps.cu:599-601
+			ZH_TRY(launch_box(ff, e->stream));
+		}
+		else {
+			ZH_TRY(launch_median(ff, e->stream, &bits_done));
+		}
+		if (e->prof) // elements the kernel is asked for: whole rows, or bins 0..nfft/2 and the last mf/2
+			e->prof_elements += (unsigned long long)(M * (half ? N / 2 + 1 + (size_t)(e->mf / 2) : N) * S);
+	}
+
 	// ---- masks, inverse FFT, *COLA
 	IstftArgs ia;
 	memset(&ia, 0, sizeof(ia));
@@ -460,7 +489,7 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 	ia.p_stream_stride = (long long)(e->max_hops * N);
 	// The median is an order statistic: P[k] == P[nfft-k] bit for bit away from the borders.  The SSE box mean
 	// adds its taps in ascending bin order, which the mirrored window reverses: rounding differs, no symmetry.
-	ia.p_mid = e->use_sse ? (int)(N / 2) : e->mf / 2;
+	ia.p_mid = p_mid;
 	ia.tw = e->d_tw;
 	ia.y_stream_stride = (long long)(e->max_hops * e->nwin);
 	ia.n_frames = (int)M;
@@ -482,35 +511,28 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 		ia.seq = ++e->hop_seq;
 	ia.publish_seq = e->ready_host[0] != nullptr;
 	ia.beta = e->beta;
-	ia.beta_h = e->beta - FLT_EPSILON; // hps.cu:540 hard_mask_functor(beta - Eps)
+	ia.beta_h = beta_h;
 	ia.soft = e->soft ? 1 : 0;
 	ia.power = (int)e->beta; // hps.h:117-121 : soft_mask_functor(int _power) truncates beta
 	ia.sse = e->use_sse ? 1 : 0;
 	ia.out_h = e->out_h ? 1 : 0;
 	ia.out_p = e->out_p ? 1 : 0;
 	ia.cola = e->cola;
-	{
-		const HardThr t = hard_mask_thresholds(ia.beta, ia.beta_h, g_opt_mask_divide != 0);
-		ia.thr_p = t.p;
-		ia.thr_h = t.h;
-		ia.thr_p_inc = t.p_inc;
-		ia.thr_h_inc = t.h_inc;
-	}
-	// Blocks of frames with hard masks: the comparisons are made once per bin in a launch of their own and the
-	// synthesis loads two bits per bin instead of H and P (per output, and per mirror image).
-	if (M >= 8 && !ia.soft && !ia.sse && ia.thr_p != 0.0 && ia.thr_h != 0.0 && !g_opt_no_mask_bits) {
-		ia.bits_row_words = mask_bits_row_words((int)N, ia.p_mid);
-		ia.bits_stream_stride = (long long)e->max_hops * ia.bits_row_words;
-		if (!e->d_bits)
-			ZH_HIP(hipMalloc((void**)&e->d_bits, sizeof(unsigned) * S * (size_t)ia.bits_stream_stride));
+	ia.thr_p = thr.p;
+	ia.thr_h = thr.h;
+	ia.thr_p_inc = thr.p_inc;
+	ia.thr_h_inc = thr.h_inc;
+	if (use_bits) {
+		ia.bits_row_words = bits_row_words;
+		ia.bits_stream_stride = bits_stream_stride;
 		ia.bits = e->d_bits;
-		ia.bits_t_stream_stride = (long long)e->max_hops * (long long)(N / 16);
-		if (!e->d_bits_t)
-			ZH_HIP(hipMalloc((void**)&e->d_bits_t, sizeof(unsigned) * S * (size_t)ia.bits_t_stream_stride));
+		ia.bits_t_stream_stride = bits_t_stream_stride;
 		ia.bits_t = e->d_bits_t;
 		ProfScope ps(e, zen_hip_hpr::K_ISTFT);
-		ZH_TRY(launch_mask_bits((int)N, ia, e->d_bits, e->stream));
-		ZH_TRY(launch_mask_bits_transpose((int)N, ia, e->d_bits_t, e->stream));
+		if (bits_done == 0)
+			ZH_TRY(launch_mask_bits((int)N, ia, e->d_bits, e->stream));
+		if (bits_done != 2)
+			ZH_TRY(launch_mask_bits_transpose((int)N, ia, e->d_bits_t, e->stream));
 	}
 	{
 		ProfScope ps(e, zen_hip_hpr::K_ISTFT);

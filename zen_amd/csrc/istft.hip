@@ -352,7 +352,7 @@ int launch_istft_t(const IstftArgs& a, hipStream_t stream)
 	using PL = Plan<LOG2N>;
 	// all outputs of a frame in one workgroup; not at nfft 8192/16384, where a CU holds one or two frames and
 	// three short workgroups per frame schedule better than one long one (measured)
-	if (LOG2N <= 12 && a.n_out > 1 && !a.soft && !a.sse && !g_opt_no_istft_multi) {
+	if (LOG2N <= 12 && a.n_out > 1 && !a.soft && !a.sse && !g_opt_no_istft_multi && !a.bits_t) { // (with mask bits H and P may not exist)
 		auto kern = istft_hard_multi_kernel<LOG2N>;
 		ZH_TRY(set_lds(kern, lds_bytes<LOG2N>()));
 		dim3 grid((unsigned)ceil_div((size_t)a.n_frames, (size_t)PL::FRAMES_PER_BLOCK), 1, (unsigned)a.n_streams);

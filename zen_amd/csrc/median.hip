@@ -264,8 +264,10 @@ int launch_dir(const FilterArgs& a, hipStream_t stream)
 
 } // namespace
 
-int launch_median(const FilterArgs& a, hipStream_t stream)
+int launch_median(const FilterArgs& a, hipStream_t stream, int* bits_done)
 {
+	if (bits_done)
+		*bits_done = 0;
 	if (a.n_out_rows <= 0 || a.cols <= 0 || a.n_streams <= 0)
 		return ZEN_HIP_OK;
 	if (a.len < 1 || !(a.len & 1))
@@ -284,10 +286,10 @@ int launch_median(const FilterArgs& a, hipStream_t stream)
 		ZH_TRY(launch_median47_dpp(a, stream, &handled)); // headline shape: 47 taps on whole 4096-bin rows
 		if (handled)
 			return ZEN_HIP_OK;
-		ZH_TRY(launch_median_net(a, stream, &handled));
+		ZH_TRY(launch_median_net(a, stream, &handled, bits_done));
 		if (handled)
 			return ZEN_HIP_OK;
-		ZH_TRY(launch_median_big(a, stream, &handled)); // block-merge kernel for the long frequency masks
+		ZH_TRY(launch_median_big(a, stream, &handled, bits_done)); // block-merge kernel for the long frequency masks
 		if (handled)
 			return ZEN_HIP_OK;
 	}

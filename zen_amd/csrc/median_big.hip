@@ -5,6 +5,7 @@
 // samples of the segment (with halo) and one sorted copy of every aligned 16-sample block.
 #include "common.h"
 #include "filters.h"
+#include "masks.h"
 #include "median_big.h"
 #include "row_load.h"
 
@@ -25,10 +26,28 @@ using znet::to_key;
 #endif
 // nblk_main: the leading blocks of a row that are filtered (all of them; Hermitian rows: bins 0..cols/2 - 1, the
 // rest is median_big_tail_kernel's).
-template <int W, bool NONNEG>
+// Two mask bits per bin (FilterArgs::bits) of a thread's sixteen outputs: P = the medians, H = the block's own samples
+// (hps.cu:501-505, :535-540 through masks.h hard_mask_exact; non-negative samples: a key is the float's bits)
+__device__ __forceinline__ unsigned mask_word16(const int (&p)[16], const int (&h)[16], double thr_p, double thr_h)
+{
+	unsigned w = 0;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		const float pf = __int_as_float(p[i]), hf = __int_as_float(h[i]);
+		const unsigned pm = hard_mask_exact(pf, hf + FLT_EPSILON, thr_p) != 0.0f ? 1u : 0u;
+		const unsigned hm = hard_mask_exact(hf, pf + FLT_EPSILON, thr_h) != 0.0f ? 1u : 0u;
+		w |= (pm | (hm << 1)) << (2 * i);
+	}
+	return w;
+}
+
+// BITS (Hermitian rows of non-negative samples whose harmonic estimate is the row itself): the mask word of the
+// thread's block is stored instead of its sixteen medians.
+template <int W, bool NONNEG, bool BITS = false>
 __global__ __launch_bounds__(256, ZEN_BIG_MINB) void median_big_kernel(FilterArgs a, int row_base, int ring, int segs_per_row,
                                                                       int nblk_main)
 {
+	static_assert(!BITS || NONNEG, "mask bits: magnitudes only");
 	using G = zbig::Geo<W>;
 	// raw image: chunk c = block c - (a+2) of the segment; sorted image: entry s = block s - a
 	constexpr int NRAW = 256 + G::a + 2 + G::b + 2 - 1;
@@ -86,6 +105,15 @@ __global__ __launch_bounds__(256, ZEN_BIG_MINB) void median_big_kernel(FilterArg
 		} ld{&srt[tid * RSTR], &raw[tid * RSTR]};
 		zbig::medians_big<W>(ld, out);
 	}
+	if constexpr (BITS) {
+		if (wanted) {
+			int h[16];
+			znet::lds_load<16>(&raw[(tid + G::a + 2) * RSTR], h); // the thread's own block
+			a.bits[(long long)st * a.bits_stream_stride + (long long)row * a.bits_row_words + (col0 >> 4) + tid] =
+			    mask_word16(out, h, a.thr_p, a.thr_h);
+		}
+		return;
+	}
 	__syncthreads(); // all reads of the images done: the raw image now collects the results
 	znet::lds_store<16>(&raw[tid * RSTR], out);
 	__syncthreads();
@@ -107,7 +135,7 @@ __global__ __launch_bounds__(256, ZEN_BIG_MINB) void median_big_kernel(FilterArg
 // neighbourhoods of every row are staged and sorted side by side.  (One row per wavefront left 57 of 64 lanes idle
 // through the selection: 0.33 ms of the 12 ms offline batch step.)
 constexpr int TAIL_ROWS = 4;
-template <int W, bool NONNEG>
+template <int W, bool NONNEG, bool BITS = false>
 __global__ __launch_bounds__(64) void median_big_tail_kernel(FilterArgs a, int row_base, int ring)
 {
 	using G = zbig::Geo<W>;
@@ -118,7 +146,11 @@ __global__ __launch_bounds__(64) void median_big_tail_kernel(FilterArgs a, int r
 	constexpr int NSORT_A = 1 + G::NB - 1, NSORT_B = NT + G::NB - 1, NSORT = NSORT_A + NSORT_B;
 	__shared__ __attribute__((aligned(16))) int raw[TAIL_ROWS * NRAW * RSTR];
 	__shared__ __attribute__((aligned(16))) int srt[TAIL_ROWS * NSORT * RSTR];
+	constexpr int TBW = 12; // BITS: the words of a row behind the main kernel's (entries nfft/2 .. nfft/2 + mid, at most 9 + padding)
+	__shared__ unsigned tb[TAIL_ROWS * TBW];
 	const int lane = threadIdx.x;
+	if (BITS && lane < TAIL_ROWS * TBW)
+		tb[lane] = 0u;
 	const int cols = a.cols, nblk = cols >> 4;
 	const int st = blockIdx.y, row0 = blockIdx.x * TAIL_ROWS;
 	const int rows_here = a.n_out_rows - row0 < TAIL_ROWS ? a.n_out_rows - row0 : TAIL_ROWS;
@@ -144,9 +176,10 @@ __global__ __launch_bounds__(64) void median_big_tail_kernel(FilterArgs a, int r
 	}
 	__syncthreads();
 	const int rr = lane >> 4, l = lane & 15;
-	if (rr >= rows_here || l > NT)
+	if (!BITS && (rr >= rows_here || l > NT))
 		return;
-	const int loc = l == 0 ? 0 : l - 1; // block within the piece
+	const bool work = rr < rows_here && l <= NT;
+	const int loc = l == 0 ? 0 : (l <= NT ? l - 1 : 0); // block within the piece
 	struct Loader {
 		const int* srt_t;
 		const int* raw_t;
@@ -155,9 +188,34 @@ __global__ __launch_bounds__(64) void median_big_tail_kernel(FilterArgs a, int r
 		__device__ __forceinline__ void rawr(int j, int* v) const { znet::lds_load<16>(raw_t + (G::a + G::b + 2 + j) * RSTR, v); }
 	} ld{&srt[(rr * NSORT + (l == 0 ? 0 : NSORT_A) + loc) * RSTR], &raw[(rr * NRAW + (l == 0 ? 0 : NRAW_A) + loc) * RSTR]};
 	int out[16];
-	zbig::medians_big<W>(ld, out);
-	float* drow = a.dst + (long long)st * a.dst_stream_stride + (long long)(row0 + rr) * cols;
+	if (!BITS || work)
+		zbig::medians_big<W>(ld, out);
 	const int c = 16 * ((l == 0 ? blkA : blkB) + loc);
+	if constexpr (BITS) {
+		// entry of bin idx: nfft/2 for the middle bin, nfft/2 + 1 + idx - (nfft - mid) for the last mid bins; their H is the
+		// block's own (mirrored) samples.  The lanes of a row OR their bits into the row's words in LDS.
+		if (work) {
+			int h[16];
+			znet::lds_load<16>(ld.raw_t + (G::a + 2) * RSTR, h);
+			const unsigned w = mask_word16(out, h, a.thr_p, a.thr_h);
+			const int e0 = (cols >> 1) - 16 * blkA; // entries relative to the first word behind the main kernel's
+#pragma unroll
+			for (int i = 0; i < 16; ++i) {
+				const int idx = c + i;
+				const int e = l == 0 ? (i == 0 ? e0 : -1) : (idx >= cols - G::m ? e0 + 1 + idx - (cols - G::m) : -1);
+				if (e >= 0)
+					atomicOr(&tb[rr * TBW + (e >> 4)], ((w >> (2 * i)) & 3u) << (2 * (e & 15)));
+			}
+		}
+		__syncthreads();
+		const int nw = a.bits_row_words - blkA; // words behind the main kernel's (the row's padding included)
+		for (int k = lane; k < rows_here * nw; k += 64) {
+			const int r2 = k / nw, w2 = k - r2 * nw;
+			a.bits[(long long)st * a.bits_stream_stride + (long long)(row0 + r2) * a.bits_row_words + blkA + w2] = tb[r2 * TBW + w2];
+		}
+		return;
+	}
+	float* drow = a.dst + (long long)st * a.dst_stream_stride + (long long)(row0 + rr) * cols;
 #pragma unroll
 	for (int v = 0; v < 4; ++v)
 		*reinterpret_cast<float4*>(drow + c + 4 * v) =
@@ -166,12 +224,21 @@ __global__ __launch_bounds__(64) void median_big_tail_kernel(FilterArgs a, int r
 }
 
 template <int W>
-int launch_w(const FilterArgs& a, hipStream_t stream)
+int launch_w(const FilterArgs& a, hipStream_t stream, int* bits_done)
 {
 	const int row_base = (int)(a.first_row % a.ring_rows);
 	const int nblk_main = a.hermitian ? a.cols >> 5 : (a.cols + 15) >> 4; // blocks 0 .. cols/32 - 1 hold bins 0 .. cols/2 - 1
 	const int segs = (nblk_main + 255) / 256;
 	dim3 grid((unsigned)((long long)a.n_out_rows * segs * a.n_streams));
+	// mask bits instead of P: Hermitian magnitude rows that are their own harmonic estimate
+	if (bits_done && a.bits && a.hermitian && a.nonneg && !a.hrows && a.bits_row_words - nblk_main <= 12) {
+		dim3 tgrid((unsigned)((a.n_out_rows + TAIL_ROWS - 1) / TAIL_ROWS), (unsigned)a.n_streams);
+		hipLaunchKernelGGL((median_big_kernel<W, true, true>), grid, dim3(256), 0, stream, a, row_base, (int)a.ring_rows, segs, nblk_main);
+		hipLaunchKernelGGL((median_big_tail_kernel<W, true, true>), tgrid, dim3(64), 0, stream, a, row_base, (int)a.ring_rows);
+		ZH_HIP(hipGetLastError());
+		*bits_done = 1;
+		return ZEN_HIP_OK;
+	}
 	if (a.nonneg)
 		hipLaunchKernelGGL((median_big_kernel<W, true>), grid, dim3(256), 0, stream, a, row_base, (int)a.ring_rows, segs, nblk_main);
 	else
@@ -197,7 +264,7 @@ bool median_big_available(int len)
 } // namespace
 
 // long frequency masks with vector-aligned geometry.  *handled = false: use the general kernel.
-int launch_median_big(const FilterArgs& a, hipStream_t stream, bool* handled)
+int launch_median_big(const FilterArgs& a, hipStream_t stream, bool* handled, int* bits_done)
 {
 	*handled = false;
 	if (a.direction != ZEN_HIP_FREQUENCY || !median_big_available(a.len))
@@ -214,13 +281,13 @@ int launch_median_big(const FilterArgs& a, hipStream_t stream, bool* handled)
 		return ZEN_HIP_OK;
 	*handled = true;
 	switch (a.len) {
-	case 65: return launch_w<65>(a, stream);
-	case 85: return launch_w<85>(a, stream);
-	case 93: return launch_w<93>(a, stream);
-	case 129: return launch_w<129>(a, stream);
-	case 171: return launch_w<171>(a, stream);
-	case 187: return launch_w<187>(a, stream);
-	default: return launch_w<255>(a, stream);
+	case 65: return launch_w<65>(a, stream, bits_done);
+	case 85: return launch_w<85>(a, stream, bits_done);
+	case 93: return launch_w<93>(a, stream, bits_done);
+	case 129: return launch_w<129>(a, stream, bits_done);
+	case 171: return launch_w<171>(a, stream, bits_done);
+	case 187: return launch_w<187>(a, stream, bits_done);
+	default: return launch_w<255>(a, stream, bits_done);
 	}
 }
 

@@ -17,6 +17,7 @@
 // loads, T new rows per step.
 #include "common.h"
 #include "filters.h"
+#include "masks.h"
 #include "median_net.h"
 #include "row_load.h"
 
@@ -215,10 +216,16 @@ __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowM
 // consecutive 16-byte vectors.  Same network, same values.
 constexpr int HERM_THREADS = 448;
 
-template <int W, bool NONNEG>
+// BITS (FilterArgs::bits_t, hard masks of non-negative rows): instead of storing P the thread compares it with the
+// harmonic estimate of its bins (FilterArgs::hrows, stored half) and ORs the two mask bits of every bin into the row's
+// words in LDS, in the synthesis threads' order (stft.h IstftArgs::bits_t): bin k at word k mod cols/16, bits 2*(k /
+// (cols/16)); a bin of the lower half also at its mirror image's place unless that lies among the last `mid` bins, whose
+// own P comes from the tail chunks.  The workgroup holds whole rows, so it writes finished words.
+template <int W, bool NONNEG, bool BITS = false>
 __global__ __launch_bounds__(HERM_THREADS) void median_net_freq_herm_kernel(FilterArgs a, RowMap rm, int n_lo, int n_tail,
                                                                             int lwv, int twv)
 {
+	static_assert(!BITS || NONNEG, "mask bits: magnitudes only");
 	constexpr int T = znet::outputs_per_thread(W), mid = W / 2;
 	static_assert(T >= 4, "16-byte LDS path needs T >= 4");
 	constexpr int MID_AL = (mid + 3) & ~3, DELTA = MID_AL - mid;
@@ -236,12 +243,20 @@ __global__ __launch_bounds__(HERM_THREADS) void median_net_freq_herm_kernel(Filt
 		const int col = vv < lwv ? 4 * vv - MID_AL : c_t0 - MID_AL + 4 * (vv - lwv);
 		*reinterpret_cast<int4*>(&himg[4 * v]) = row_vec_keys<NONNEG>(srow, col, cols, 1);
 	}
+	unsigned* tw = reinterpret_cast<unsigned*>(himg) + 4 * rpw * row_vecs; // BITS: rpw rows of cols/16 words
+	const int tfw = cols >> 4;
+	if constexpr (BITS) {
+		for (int k = tid; k < rpw * tfw; k += HERM_THREADS)
+			tw[k] = 0u;
+	}
 	__syncthreads();
 	const int rr = tid / jobs, j = tid - rr * jobs;
-	if (rr >= rpw || row0 + rr >= a.n_out_rows)
+	const bool work = rr < rpw && row0 + rr < a.n_out_rows;
+	if (!BITS && !work)
 		return;
 	const bool tail = j >= n_lo;
-	const int* mine = &himg[4 * (rr * row_vecs + (tail ? lwv : 0)) + T * (tail ? j - n_lo : j)]; // word 0 = chunk's first column - MID_AL
+	const int rra = rr < rpw ? rr : 0; // (BITS: threads without a chunk stay for the barrier below and read row 0's image)
+	const int* mine = &himg[4 * (rra * row_vecs + (tail ? lwv : 0)) + T * (tail ? j - n_lo : j)]; // word 0 = chunk's first column - MID_AL
 	int ld[NE], e[W + T - 1], out[T];
 #pragma unroll
 	for (int v = 0; v < NV; ++v) {
@@ -254,6 +269,41 @@ __global__ __launch_bounds__(HERM_THREADS) void median_net_freq_herm_kernel(Filt
 #pragma unroll
 	for (int q = 0; q < W + T - 1; ++q)
 		e[q] = ld[q + DELTA];
+	if constexpr (BITS) {
+		if (work) {
+			znet::medians<W, T, W + T - 1>(e, out);
+			const int c0 = tail ? c_t0 + T * (j - n_lo) : T * j; // first bin of the chunk
+			const float* hrow = a.hrows + (long long)blockIdx.y * a.h_stream_stride + (long long)(row0 + rr) * cols;
+			float h[T]; // H of the bins (the tail's from the mirror image: H is symmetric, only its lower half is stored)
+#pragma unroll
+			for (int i = 0; i < T; ++i)
+				h[i] = hrow[tail ? cols - (c0 + i) : c0 + i];
+			int log2tf = 0;
+			while ((1 << log2tf) < tfw)
+				++log2tf;
+			unsigned* trow = tw + rr * tfw;
+#pragma unroll
+			for (int i = 0; i < T; ++i) {
+				const int k = c0 + i;
+				const float pf = __int_as_float(out[i]);
+				const unsigned pm = hard_mask_exact(pf, h[i] + FLT_EPSILON, a.thr_p) != 0.0f ? 1u : 0u;
+				const unsigned hm = hard_mask_exact(h[i], pf + FLT_EPSILON, a.thr_h) != 0.0f ? 1u : 0u;
+				const unsigned code = pm | (hm << 1);
+				const bool wanted = tail ? k >= cols - mid : k <= (cols >> 1);
+				if (wanted && code)
+					atomicOr(&trow[k & (tfw - 1)], code << (2 * (k >> log2tf)));
+				const int km = cols - k; // the mirror image of a bin of the lower half
+				if (!tail && k > mid && k < (cols >> 1) && code)
+					atomicOr(&trow[km & (tfw - 1)], code << (2 * (km >> log2tf)));
+			}
+		}
+		__syncthreads();
+		unsigned* dst_t = a.bits_t + (long long)blockIdx.y * a.bits_t_stream_stride + (long long)row0 * tfw;
+		const int rows_here = a.n_out_rows - row0 < rpw ? a.n_out_rows - row0 : rpw;
+		for (int k = tid; k < rows_here * tfw; k += HERM_THREADS)
+			dst_t[k] = tw[k];
+		return;
+	}
 	znet::medians<W, T, W + T - 1>(e, out);
 	float* d = a.dst + (long long)blockIdx.y * a.dst_stream_stride + (long long)(row0 + rr) * cols + (tail ? c_t0 + T * (j - n_lo) : T * j);
 #pragma unroll
@@ -384,7 +434,7 @@ bool prepare(const FilterArgs& a, RowMap* rm)
 }
 
 template <int W>
-int launch_freq(const FilterArgs& a, const RowMap& rm, hipStream_t stream)
+int launch_freq(const FilterArgs& a, const RowMap& rm, hipStream_t stream, int* bits_done)
 {
 	constexpr int T = znet::outputs_per_thread(W);
 	const int segs = (a.cols + 256 * T - 1) / (256 * T);
@@ -403,6 +453,15 @@ int launch_freq(const FilterArgs& a, const RowMap& rm, hipStream_t stream)
 			const int rpw = HERM_THREADS / jobs;
 			const size_t lds = sizeof(int) * 4 * (size_t)rpw * (lwv + twv);
 			dim3 g((unsigned)((a.n_out_rows + rpw - 1) / rpw), (unsigned)a.n_streams);
+			// mask bits instead of P (power-of-two rows of at least 16 words: every bin's place is a shift and a mask)
+			if (bits_done && a.bits_t && a.hrows && a.nonneg && (a.cols & (a.cols - 1)) == 0 && a.cols >= 256) {
+				const size_t lds_b = lds + sizeof(unsigned) * (size_t)rpw * (a.cols >> 4);
+				hipLaunchKernelGGL((median_net_freq_herm_kernel<W, true, true>), g, dim3(HERM_THREADS), lds_b, stream, a, rm, n_lo, n_tail, lwv,
+				                   twv);
+				ZH_HIP(hipGetLastError());
+				*bits_done = 2;
+				return ZEN_HIP_OK;
+			}
 			if (a.nonneg)
 				hipLaunchKernelGGL((median_net_freq_herm_kernel<W, true>), g, dim3(HERM_THREADS), lds, stream, a, rm, n_lo, n_tail, lwv, twv);
 			else
@@ -486,10 +545,10 @@ int launch_tiny_freq(const FilterArgs& a, const RowMap& rm, hipStream_t stream)
 }
 
 template <int W>
-int launch_freq_guard(const FilterArgs& a, const RowMap& rm, hipStream_t stream)
+int launch_freq_guard(const FilterArgs& a, const RowMap& rm, hipStream_t stream, int* bits_done)
 {
 	if constexpr (W >= 7)
-		return launch_freq<W>(a, rm, stream);
+		return launch_freq<W>(a, rm, stream, bits_done);
 	else
 		return launch_tiny_freq<W>(a, rm, stream);
 }
@@ -528,7 +587,7 @@ int launch_time(const FilterArgs& a, const RowMap& rm, hipStream_t stream)
 	X(33) X(35) X(37) X(39) X(41) X(43) X(45) X(47) X(49) X(51) X(53) X(55) X(57) X(59) X(61) X(63)
 
 // returns ZEN_HIP_OK and sets *handled when the mask length / geometry is covered by the fast path
-int launch_median_net(const FilterArgs& a, hipStream_t stream, bool* handled)
+int launch_median_net(const FilterArgs& a, hipStream_t stream, bool* handled, int* bits_done)
 {
 	*handled = false;
 	RowMap rm;
@@ -540,7 +599,7 @@ int launch_median_net(const FilterArgs& a, hipStream_t stream, bool* handled)
 	*handled = true;
 	switch (a.len) {
 #define X(W) \
-	case W: return freq ? launch_freq_guard<W>(a, rm, stream) : launch_time<W>(a, rm, stream);
+	case W: return freq ? launch_freq_guard<W>(a, rm, stream, bits_done) : launch_time<W>(a, rm, stream);
 		ZH_NET_WIDTHS(X)
 #undef X
 	default: *handled = false; return ZEN_HIP_OK;
