@@ -77,8 +77,9 @@ int zen_hip_event_destroy(void* event);
  * 47-tap frequency masks on 4096-bin rows through the generic sorting-network kernel instead of
  * median47_dpp_kernel, "no_median47_neighbour" = 1 additionally switches off that kernel's DPP exchange of
  * sorted blocks; "no_half_rows" = 1 makes the three-kernel path store and filter whole magnitude rows instead of the
- * non-redundant half (bins 0..nfft/2); "no_persist" = 1 sends blocks of frames at nfft 8192 / 16384 through the
- * one-frame-per-workgroup transform kernels instead of the persistent ones; "no_direct_out" = 1: the fused block kernel
+ * non-redundant half (bins 0..nfft/2); "no_mask_bits" = 1: the synthesis kernels of blocks of frames compare H and P
+ * themselves instead of loading two mask bits per bin, "no_median_bits" = 1: those bits always come from a launch of
+ * their own, never from the frequency-direction median kernel; "no_direct_out" = 1: the fused block kernel
  * of the headline configuration leaves the overlap-add to a launch of its own; "mfilt_nonneg" = 1: the caller promises that every sample handed to
  * zen_hip_mfilt_run is >= +0 (a magnitude matrix), so the filter orders by the raw bits as the engine's own launches do
  * (the kernel build BASELINE's median metric is quoted on); "median47_variant" = 1 lets median47_dpp_kernel store results without the LDS transpose (2, 3: timing

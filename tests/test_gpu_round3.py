@@ -326,45 +326,60 @@ def test_long_hop_single_launch_under_contention(z, hop):
     assert np.array_equal(out, ref)
 
 
-# ---------------------------------------------------------------------------- persistent transform kernels (nfft 8192 / 16384)
-@pytest.mark.parametrize("hop,n_hops,soft", [(2048, 1100, False), (4096, 600, False), (4096, 600, True), (2048, 1100, True)])
-def test_long_transforms_persistent_kernels(z, hop, n_hops, soft):
-    """Blocks of >= 512 / 1024 frames at nfft 16384 / 8192 go through persistent workgroups (a run of consecutive frames
-    each, the next frame's spectrum loaded during the current frame's last pass: stft.hip / istft.hip *_persist_kernel).
-    Same samples as one workgroup per frame ("no_persist"), and as the oracle on a prefix and -- through the state the
-    engine carries from call to call -- on a second call."""
-    from tests.test_gpu_parity import music, same
+# ---------------------------------------------------------------------------- blocks of frames: hard masks as two bits per bin
+@pytest.mark.parametrize("hop,n_hops,soft", [(2048, 1100, False), (4096, 600, False), (4096, 600, True), (2048, 1100, True),
+                                             (256, 700, False), (512, 500, False), (1024, 300, False)])
+@pytest.mark.parametrize("flags", [ALL, o.OUTPUT_PERCUSSIVE, o.OUTPUT_HARMONIC | o.OUTPUT_RESIDUAL])
+def test_blocks_of_frames_mask_bits(z, hop, n_hops, soft, flags):
+    """Blocks of >= 8 anticausal frames with hard masks: the two comparisons of every bin are made once -- by the
+    frequency-direction median kernel itself (median_big.hip / median_net.hip BITS builds) or by mask_bits_kernel -- and
+    the synthesis kernels load two bits per bin (istft.hip MODE 3; hps.cu:501-505, :535-540, :562-567).  Same samples as
+    the builds that compare H and P inside the synthesis ("no_mask_bits") and as mask_bits_kernel ("no_median_bits");
+    as the oracle on a prefix and -- through the state the engine carries from call to call -- on a second, short call."""
+    from tests.test_gpu_parity import music
+    if soft and flags != ALL:
+        pytest.skip("one soft-mask run per geometry")
     x = music(hop * n_hops, 60 + hop)
+    keys = [k for k, f in (("P", o.OUTPUT_PERCUSSIVE), ("H", o.OUTPUT_HARMONIC), ("R", o.OUTPUT_RESIDUAL)) if flags & f]
+    if soft:
+        keys = [k for k in keys if k != "R"]
 
-    def run(no_persist):
-        z.set_option("no_persist", no_persist)
+    def run(opt):
+        if opt:
+            z.set_option(opt, 1)
         try:
-            g = z.HPR(FS, hop, 2.0, ALL, z.TIME_ANTICAUSAL)
+            g = z.HPR(FS, hop, 2.0, flags, z.TIME_ANTICAUSAL)
             if soft:
                 g.use_soft_mask()
-            a = g.process_stream_host(x[:hop * (n_hops - 30)])      # persistent (when allowed)
-            b = g.process_stream_host(x[hop * (n_hops - 30):])      # 30 hops: one workgroup per frame either way
+            a = g.process_stream_host(x[:hop * (n_hops - 30)])      # one block: mask bits (hard masks)
+            b = g.process_stream_host(x[hop * (n_hops - 30):hop * (n_hops - 5)])
+            c = g.process_stream_host(x[hop * (n_hops - 5):])       # 5 hops: fewer than 8 frames, no mask bits
         finally:
-            z.set_option("no_persist", 0)
-        return {k: np.concatenate([a[k], b[k]]) for k in "PHR"}
+            if opt:
+                z.set_option(opt, 0)
+        return {k: np.concatenate([a[k], b[k], c[k]]) for k in keys}
 
-    got, plain = run(0), run(1)
-    assert same(got, plain)
+    got = run(None)
+    if not soft:
+        for opt in ("no_mask_bits", "no_median_bits"):
+            other = run(opt)
+            for k in keys:
+                assert np.array_equal(got[k], other[k]), (opt, k)
     m = 36
-    ho = o.HPR(FS, hop, 2.0, ALL, o.TIME_ANTICAUSAL)
+    ho = o.HPR(FS, hop, 2.0, flags, o.TIME_ANTICAUSAL)
     if soft:
         ho.use_soft_mask()
     ref = ho.process_stream(x[:hop * m])
-    for k in "PHR":
+    for k in keys:
         assert np.array_equal(got[k][:hop * m], ref[k]), k
     # the tail of the stream against an oracle that starts a few hops earlier (state = the last stft_width + 1 hops)
-    j = n_hops - 44
-    ho2 = o.HPR(FS, hop, 2.0, ALL, o.TIME_ANTICAUSAL)
+    j0 = n_hops - 60
+    ho2 = o.HPR(FS, hop, 2.0, flags, o.TIME_ANTICAUSAL)
     if soft:
         ho2.use_soft_mask()
-    ref2 = ho2.process_stream(x[hop * j:])
-    for k in "PHR":
-        assert np.array_equal(got[k][hop * (j + 8):], ref2[k][hop * 8:]), k
+    ref2 = ho2.process_stream(x[hop * j0:])
+    for k in keys:
+        assert np.array_equal(got[k][hop * (j0 + 24):], ref2[k][hop * 24:]), k
 
 
 # ---------------------------------------------------------------------------- the fused block kernel that finishes hops itself

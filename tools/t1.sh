@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_golden_fixtures.py -x -q -m gpu -k "ac_256_HPR" 2>&1 | tail -30
-ZEN_HIP_OPTIONS="no_median_bits=1" python -m pytest tests/test_golden_fixtures.py -x -q -m gpu -k "ac_256" 2>&1 | tail -3
+python -m pytest tests -x -q -m gpu -k "mask_bits or offline or golden or config" 2>&1 | tail -3
+bash tools/prof_offline.sh | cut -c1-150 | grep -i "transpose\|istft_kernel<14\|Name"

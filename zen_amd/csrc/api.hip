@@ -23,7 +23,6 @@ opt_t g_opt_rt_fused_diag{0};
 opt_t g_opt_mask_divide{0};
 opt_t g_opt_no_half_rows{0};
 opt_t g_opt_mfilt_nonneg{0};
-opt_t g_opt_no_persist{0};
 opt_t g_opt_no_mask_bits{0};
 opt_t g_opt_no_median_bits{0};
 opt_t g_opt_no_direct_out{0};
@@ -170,7 +169,6 @@ int zen_hip_set_option(const char* name, int value)
 	             {"mask_divide", &g_opt_mask_divide},
 	             {"no_half_rows", &g_opt_no_half_rows},
 	             {"mfilt_nonneg", &g_opt_mfilt_nonneg},
-	             {"no_persist", &g_opt_no_persist},
 	             {"no_mask_bits", &g_opt_no_mask_bits},
 	             {"no_median_bits", &g_opt_no_median_bits},
 	             {"no_direct_out", &g_opt_no_direct_out}};

@@ -26,7 +26,6 @@ extern opt_t g_opt_no_half_rows;         // "no_half_rows": the three-kernel pat
 extern opt_t g_opt_no_direct_out;       // "no_direct_out": the fused block kernel leaves the overlap-add to finalize_kernel
 extern opt_t g_opt_no_median_bits;      // "no_median_bits": the mask bits always come from mask_bits_kernel, never from a median kernel
 extern opt_t g_opt_no_mask_bits;        // "no_mask_bits": the synthesis kernels compare H and P themselves (no mask_bits_kernel)
-extern opt_t g_opt_no_persist;          // "no_persist": blocks of frames at nfft 8192 / 16384 through the one-frame-per-workgroup kernels
 extern opt_t g_opt_mfilt_nonneg;        // "mfilt_nonneg": zen_hip_mfilt_run's input is promised to be >= +0 (raw-bit ordering keys)
 extern opt_t g_opt_mask_divide;          // "mask_divide": the lean fused kernel forms its hard mask with the IEEE divide
 extern opt_t g_opt_rt_fused_diag;         // "rt_fused_diag": 1 = fused kernel without its median stage, 2 = without synthesis (timing only)

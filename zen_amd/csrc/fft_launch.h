@@ -19,20 +19,6 @@ int set_lds(K kern, size_t bytes)
 	return ZEN_HIP_OK;
 }
 
-// workgroups a persistent transform kernel of this size keeps resident: one per CU at nfft 16384 (139 KB of LDS), two at 8192
-inline int persistent_workgroups(int log2n)
-{
-	static int cus = 0;
-	if (cus == 0) {
-		int dev = 0;
-		hipDeviceProp_t p;
-		cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
-		          ? p.multiProcessorCount
-		          : 256;
-	}
-	return log2n >= 14 ? cus : 2 * cus;
-}
-
 } // namespace zen_hip_impl
 
 #define ZH_DISPATCH_LOG2N(log2n, CALL)                                                     \

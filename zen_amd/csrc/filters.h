@@ -51,6 +51,7 @@ struct FilterArgs {
 	long long h_stream_stride;
 	unsigned* bits_t;             // a kernel that holds whole rows writes IstftArgs::bits_t right away (bits_done = 2)
 	long long bits_t_stream_stride;
+	int need_pm, need_hm;         // which of the two masks some enabled output reads (the other bit stays 0)
 };
 
 // true if launch_median(a) with a.hermitian = 1 is implemented for this (direction, mask, row length)

@@ -403,7 +403,7 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 	// -- and the synthesis loads two bits per bin instead of H and P (per output, and per mirror image).
 	const float beta_h = e->beta - FLT_EPSILON; // hps.cu:540 hard_mask_functor(beta - Eps)
 	const HardThr thr = hard_mask_thresholds(e->beta, beta_h, g_opt_mask_divide != 0);
-	const bool use_bits = M >= 8 && !e->soft && !e->use_sse && thr.p != 0.0 && thr.h != 0.0 && !g_opt_no_mask_bits;
+	const bool use_bits = M >= 8 && N >= 256 && !e->soft && !e->use_sse && thr.p != 0.0 && thr.h != 0.0 && !g_opt_no_mask_bits;
 	const int p_mid = e->use_sse ? (int)(N / 2) : e->mf / 2;
 	const int bits_row_words = mask_bits_row_words((int)N, p_mid);
 	const long long bits_stream_stride = (long long)e->max_hops * bits_row_words;
@@ -413,6 +413,9 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 		ZH_HIP(hipMalloc((void**)&e->d_bits_t, sizeof(unsigned) * S * (size_t)bits_t_stream_stride));
 	}
 	int bits_done = 0; // 1: the frequency-direction kernel wrote IstftArgs::bits, 2: ::bits_t
+	// the masks an enabled output reads: its own, and for the residual those of hps.cu:562-567
+	const int need_pm = (output_computed(e, 0) || (output_computed(e, 2) && e->out_p)) ? 1 : 0;
+	const int need_hm = (output_computed(e, 1) || (output_computed(e, 2) && e->out_h)) ? 1 : 0;
 
 	bool h_is_ring = false; // time direction -> H   (hps.cu:495 / :596)
 	FilterArgs ft = fa;
@@ -455,6 +458,8 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 		ff.bits_t_stream_stride = bits_t_stream_stride;
 		ff.thr_p = thr.p;
 		ff.thr_h = thr.h;
+		ff.need_pm = need_pm;
+		ff.need_hm = need_hm;
 		if (!h_is_ring) {
 			ff.hrows = e->d_H;
 			ff.h_stream_stride = (long long)(e->max_hops * N);
@@ -528,6 +533,8 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 		ia.bits = e->d_bits;
 		ia.bits_t_stream_stride = bits_t_stream_stride;
 		ia.bits_t = e->d_bits_t;
+		ia.need_pm = need_pm;
+		ia.need_hm = need_hm;
 		ProfScope ps(e, zen_hip_hpr::K_ISTFT);
 		if (bits_done == 0)
 			ZH_TRY(launch_mask_bits((int)N, ia, e->d_bits, e->stream));

@@ -65,7 +65,7 @@ __device__ __forceinline__ unsigned mask_code(unsigned w, int which, const MaskC
 
 // MODE 0: any mask (generic); 1: hard masks by comparison, any output; 2: the same for the percussive output alone
 // (the realtime default): one comparison per bin; 3: hard masks from the bits of launch_mask_bits (blocks of frames).
-template <int MODE, int DIAG = 0>
+template <int MODE>
 struct IstftIn {
 	const float2* S;
 	const float* H;
@@ -79,8 +79,6 @@ struct IstftIn {
 	int p_mid;
 	__device__ __forceinline__ float2 operator()(int idx, int slot) const
 	{
-		if constexpr ((DIAG & 1) != 0) // diagnostic: no global loads
-			return make_float2((float)idx * cfg.beta, (float)(idx ^ 5) * cfg.beta_h);
 		const bool mirror = idx > (n >> 1); // upper half: S[n-k] = conj(S[k])
 		const int lo = mirror ? n - idx : idx;
 		float2 z = S[lo];
@@ -101,8 +99,7 @@ struct IstftIn {
 	}
 };
 
-template <int DIAG = 0>
-struct IstftOutT {
+struct IstftOut {
 	float* Y;
 	float cola;
 	float* ready;       // single-frame calls: the finished hop = carry + first half of this frame
@@ -112,18 +109,11 @@ struct IstftOutT {
 	__device__ __forceinline__ void operator()(int idx, float2 x, bool, int slot) const
 	{
 		const float y = x.x * cola; // the product of overlap_add_functor hps.h:68-80; the sum is in finalize ...
-		if constexpr ((DIAG & 2) != 0) { // diagnostic: no global stores
-			if (y == 12345.678f)
-				Y[idx] = y;
-			return;
-		}
 		Y[idx] = y;
 		if (ready && idx < hop) // ... or here, when the call is a single hop (hps.cu:341-363 hands out [0, hop))
 			ready[idx] = cv[slot & 3] + y;
 	}
 };
-
-using IstftOut = IstftOutT<0>;
 
 // the four carry samples of thread tf (hop == 4*TF)
 template <int TF>
@@ -136,7 +126,7 @@ __device__ __forceinline__ void load_carry(const float* carry, int tf, bool want
 
 // (four waves per SIMD: with every load of the first pass in flight at once the max-ILP schedule otherwise takes 130 to
 // 200 registers -- three or two waves, and at nfft 8192 one workgroup per CU instead of two)
-template <int LOG2N, int MODE, int DIAG = 0>
+template <int LOG2N, int MODE>
 __global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) void istft_kernel(IstftArgs a)
 {
 	using PL = Plan<LOG2N>;
@@ -147,7 +137,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) void istft_kernel(IstftArg
 	const bool active = f_ < a.n_frames;
 	const int f = active ? f_ : a.n_frames - 1; // (an inactive slot transforms the last frame again and stores nothing)
 	const long long ring_row = ((a.crow0 + f) % a.ring_rows) + (long long)s * a.ring_rows;
-	IstftIn<MODE, DIAG> in;
+	IstftIn<MODE> in;
 	in.S = a.S + ring_row * a.s_stride;
 	in.n = PL::N;
 	in.H = a.h_is_ring ? a.H + ring_row * PL::N : a.H + (long long)s * a.h_stream_stride + (long long)f * PL::N;
@@ -160,7 +150,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) void istft_kernel(IstftArg
 	in.bw = 0;
 	if constexpr (MODE >= 3)
 		in.bw = mask_code(a.bits_t[(long long)s * a.bits_t_stream_stride + (long long)f * PL::TF + tf], in.which, in.cfg);
-	IstftOutT<DIAG> out;
+	IstftOut out;
 	out.Y = a.Y[oi] + (long long)s * a.y_stream_stride + (long long)f * (PL::N / 2);
 	out.cola = a.cola;
 	out.ready = (a.n_frames == 1 && a.ready[oi]) ? a.ready[oi] + (long long)s * a.hop : nullptr;
@@ -309,8 +299,8 @@ __global__ __launch_bounds__(256) void mask_bits_kernel(IstftArgs a, unsigned* b
 		}
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
-			const unsigned pm = hard_mask_exact(p[i], h[i] + FLT_EPSILON, a.thr_p) != 0.0f ? 1u : 0u;
-			const unsigned hm = hard_mask_exact(h[i], p[i] + FLT_EPSILON, a.thr_h) != 0.0f ? 1u : 0u;
+			const unsigned pm = a.need_pm && hard_mask_exact(p[i], h[i] + FLT_EPSILON, a.thr_p) != 0.0f ? 1u : 0u;
+			const unsigned hm = a.need_hm && hard_mask_exact(h[i], p[i] + FLT_EPSILON, a.thr_h) != 0.0f ? 1u : 0u;
 			byte |= (pm | (hm << 1)) << (2 * i);
 		}
 	}
@@ -321,29 +311,56 @@ __global__ __launch_bounds__(256) void mask_bits_kernel(IstftArgs a, unsigned* b
 		bits[(long long)s * a.bits_stream_stride + (long long)f * a.bits_row_words + (q >> 2)] = w;
 }
 
-// natural order -> the synthesis threads' order (IstftArgs::bits_t); the mirrored half and the tail are expanded here
+// natural order -> the synthesis threads' order (IstftArgs::bits_t); the mirrored half and the tail are expanded here.
+// One thread per sixteen consecutive output words tf0 .. tf0+15 (tf0 a multiple of 16): slot s < 8 of all of them comes
+// from ONE natural word (entries tf0 + s*nfft/16 ..), a mirrored slot from two (entries E0 - t, E0 = (16-s)*nfft/16 - tf0
+// a multiple of 16: t = 0 is the first entry of word E0/16, t = 1..15 the last fifteen of the word before it); the last
+// p_mid bins of the row (slot 15 of the last words) have entries of their own.  24 loads for 16 words.
 __global__ __launch_bounds__(256) void mask_bits_transpose_kernel(IstftArgs a, unsigned* bits_t, int n, int log2tf)
 {
+	const int log2g = log2tf - 4; // groups of sixteen words per row
 	const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-	const long long row = gid >> log2tf;
+	const long long row = gid >> log2g;
 	if (row >= (long long)a.n_frames * a.n_streams)
 		return;
-	const int tf = (int)(gid & ((1 << log2tf) - 1));
+	const int g = (int)(gid & ((1 << log2g) - 1)), tf0 = g << 4;
 	const int s = (int)(row / a.n_frames), f = (int)(row - (long long)s * a.n_frames);
 	const unsigned* nat = a.bits + (long long)s * a.bits_stream_stride + (long long)f * a.bits_row_words;
-	unsigned w[16];
+	const int half = n >> 1, tail0 = n - a.p_mid, wstep = 1 << log2g; // natural words per slot
+	unsigned lo[8], m0[8], m1[8];
 #pragma unroll
-	for (int sl = 0; sl < 16; ++sl) { // (all sixteen loads in flight)
-		const int idx = tf + (sl << log2tf);
-		const bool mirror = idx > (n >> 1);
-		const int e = (mirror && idx >= n - a.p_mid) ? (n >> 1) + 1 + idx - (n - a.p_mid) : (mirror ? n - idx : idx);
-		w[sl] = (nat[e >> 4] >> (2 * (e & 15))) & 3u;
+	for (int sl = 0; sl < 8; ++sl) {
+		lo[sl] = nat[g + sl * wstep];
+		const int w0 = (8 - sl) * wstep - g; // word of entry E0 = (16 - (8 + sl)) * TF - tf0
+		m0[sl] = nat[w0];
+		m1[sl] = nat[w0 - 1];
 	}
-	unsigned r = 0;
+	unsigned out[16];
 #pragma unroll
-	for (int sl = 0; sl < 16; ++sl)
-		r |= w[sl] << (2 * sl);
-	bits_t[(long long)s * a.bits_t_stream_stride + ((long long)f << log2tf) + tf] = r;
+	for (int t = 0; t < 16; ++t) {
+		unsigned r = 0;
+#pragma unroll
+		for (int sl = 0; sl < 8; ++sl) {
+			r |= ((lo[sl] >> (2 * t)) & 3u) << (2 * sl);
+			const unsigned mv = t == 0 ? m0[sl] : (m1[sl] >> (2 * (16 - t)));
+			r |= (mv & 3u) << (2 * (8 + sl));
+		}
+		out[t] = r;
+	}
+	if (tf0 + 15 + (15 << log2tf) >= tail0) { // the row's last p_mid bins: their own entries
+#pragma unroll
+		for (int t = 0; t < 16; ++t) {
+			const int idx = tf0 + t + (15 << log2tf);
+			if (idx >= tail0) {
+				const int e = half + 1 + idx - tail0;
+				out[t] = (out[t] & 0x3fffffffu) | (((nat[e >> 4] >> (2 * (e & 15))) & 3u) << 30);
+			}
+		}
+	}
+	uint4* dst = reinterpret_cast<uint4*>(bits_t + (long long)s * a.bits_t_stream_stride + ((long long)f << log2tf) + tf0);
+#pragma unroll
+	for (int q = 0; q < 4; ++q)
+		dst[q] = make_uint4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
 }
 
 template <int LOG2N>
@@ -365,12 +382,6 @@ int launch_istft_t(const IstftArgs& a, hipStream_t stream)
 		auto kern = (a.n_out == 1 && a.out_id[0] == 0) ? istft_kernel<LOG2N, 2> : istft_kernel<LOG2N, 1>;
 		if (a.bits_t)
 			kern = istft_kernel<LOG2N, 3>;
-		if constexpr (LOG2N == 99) { // TEMPORARY diagnostic builds
-			const int d = (int)g_opt_rt_fused_diag;
-			if (d == 1) kern = (a.n_out == 1 && a.out_id[0] == 0) ? istft_kernel<LOG2N, 2, 1> : istft_kernel<LOG2N, 1, 1>;
-			if (d == 2) kern = (a.n_out == 1 && a.out_id[0] == 0) ? istft_kernel<LOG2N, 2, 2> : istft_kernel<LOG2N, 1, 2>;
-			if (d == 3) kern = (a.n_out == 1 && a.out_id[0] == 0) ? istft_kernel<LOG2N, 2, 3> : istft_kernel<LOG2N, 1, 3>;
-		}
 		ZH_TRY(set_lds(kern, lds_bytes<LOG2N>()));
 		hipLaunchKernelGGL(kern, grid, dim3(PL::THREADS), lds_bytes<LOG2N>(), stream, a);
 		ZH_HIP(hipGetLastError());
@@ -405,7 +416,9 @@ int launch_mask_bits_transpose(int nfft, const IstftArgs& a, unsigned* bits_t, h
 	int log2tf = 0;
 	while ((16 << log2tf) < nfft)
 		++log2tf;
-	const long long threads = ((long long)a.n_frames * a.n_streams) << log2tf;
+	if (log2tf < 4 || (a.bits_t_stream_stride & 3) != 0)
+		ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "mask bits: nfft = %d below 256", nfft); // (the engine asks mask_bits_supported())
+	const long long threads = ((long long)a.n_frames * a.n_streams) << (log2tf - 4);
 	hipLaunchKernelGGL(mask_bits_transpose_kernel, dim3((unsigned)ceil_div((size_t)threads, (size_t)256)), dim3(256), 0, stream, a, bits_t,
 	                   nfft, log2tf);
 	ZH_HIP(hipGetLastError());

@@ -28,14 +28,15 @@ using znet::to_key;
 // rest is median_big_tail_kernel's).
 // Two mask bits per bin (FilterArgs::bits) of a thread's sixteen outputs: P = the medians, H = the block's own samples
 // (hps.cu:501-505, :535-540 through masks.h hard_mask_exact; non-negative samples: a key is the float's bits)
-__device__ __forceinline__ unsigned mask_word16(const int (&p)[16], const int (&h)[16], double thr_p, double thr_h)
+__device__ __forceinline__ unsigned mask_word16(const int (&p)[16], const int (&h)[16], double thr_p, double thr_h, int need_pm,
+                                                int need_hm)
 {
 	unsigned w = 0;
 #pragma unroll
 	for (int i = 0; i < 16; ++i) {
 		const float pf = __int_as_float(p[i]), hf = __int_as_float(h[i]);
-		const unsigned pm = hard_mask_exact(pf, hf + FLT_EPSILON, thr_p) != 0.0f ? 1u : 0u;
-		const unsigned hm = hard_mask_exact(hf, pf + FLT_EPSILON, thr_h) != 0.0f ? 1u : 0u;
+		const unsigned pm = need_pm && hard_mask_exact(pf, hf + FLT_EPSILON, thr_p) != 0.0f ? 1u : 0u;
+		const unsigned hm = need_hm && hard_mask_exact(hf, pf + FLT_EPSILON, thr_h) != 0.0f ? 1u : 0u;
 		w |= (pm | (hm << 1)) << (2 * i);
 	}
 	return w;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256, ZEN_BIG_MINB) void median_big_kernel(FilterArg
 			int h[16];
 			znet::lds_load<16>(&raw[(tid + G::a + 2) * RSTR], h); // the thread's own block
 			a.bits[(long long)st * a.bits_stream_stride + (long long)row * a.bits_row_words + (col0 >> 4) + tid] =
-			    mask_word16(out, h, a.thr_p, a.thr_h);
+			    mask_word16(out, h, a.thr_p, a.thr_h, a.need_pm, a.need_hm);
 		}
 		return;
 	}
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(64) void median_big_tail_kernel(FilterArgs a, int r
 		if (work) {
 			int h[16];
 			znet::lds_load<16>(ld.raw_t + (G::a + 2) * RSTR, h);
-			const unsigned w = mask_word16(out, h, a.thr_p, a.thr_h);
+			const unsigned w = mask_word16(out, h, a.thr_p, a.thr_h, a.need_pm, a.need_hm);
 			const int e0 = (cols >> 1) - 16 * blkA; // entries relative to the first word behind the main kernel's
 #pragma unroll
 			for (int i = 0; i < 16; ++i) {

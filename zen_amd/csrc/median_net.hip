@@ -286,8 +286,8 @@ __global__ __launch_bounds__(HERM_THREADS) void median_net_freq_herm_kernel(Filt
 			for (int i = 0; i < T; ++i) {
 				const int k = c0 + i;
 				const float pf = __int_as_float(out[i]);
-				const unsigned pm = hard_mask_exact(pf, h[i] + FLT_EPSILON, a.thr_p) != 0.0f ? 1u : 0u;
-				const unsigned hm = hard_mask_exact(h[i], pf + FLT_EPSILON, a.thr_h) != 0.0f ? 1u : 0u;
+				const unsigned pm = a.need_pm && hard_mask_exact(pf, h[i] + FLT_EPSILON, a.thr_p) != 0.0f ? 1u : 0u;
+				const unsigned hm = a.need_hm && hard_mask_exact(h[i], pf + FLT_EPSILON, a.thr_h) != 0.0f ? 1u : 0u;
 				const unsigned code = pm | (hm << 1);
 				const bool wanted = tail ? k >= cols - mid : k <= (cols >> 1);
 				if (wanted && code)

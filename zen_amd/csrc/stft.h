@@ -77,6 +77,7 @@ struct IstftArgs {
 	// nfft/16) holds, at bits 2s and 2s+1, the masks of bin tf + s*nfft/16 -- the thread's sixteen inputs of the first pass
 	const unsigned* bits_t;
 	long long bits_t_stream_stride; // words; a row is nfft/16 words
+	int need_pm, need_hm;           // which of the two masks some enabled output reads (the other bit stays 0)
 };
 
 // words of one row of mask bits (a multiple of four: rows stay 16-byte aligned)

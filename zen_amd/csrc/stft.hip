@@ -115,67 +115,6 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void stft_kernel(StftArgs a)
 	zfft::fft_frame<LOG2N, false, true, false>(tf, lds + slot * PL::LDS_FLOAT2, a.tw, in, out, active);
 }
 
-// The same for blocks of frames at nfft 8192 / 16384, where a CU holds one or two frames (70 / 139 KB of LDS each): with
-// one workgroup per frame every CU loads, transforms and stores in lock step with all the others -- the 96-128 KB a
-// frame stores drain at the CU's share of the HBM bandwidth (~5 us) while the CU sits idle until the workgroup has
-// retired.  A persistent workgroup walks through a run of consecutive frames instead: the stores of frame f drain
-// while frame f+1 is transformed, and the hop two consecutive frames share is read from the L2 / L1.
-template <int LOG2N>
-__global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) void stft_persist_kernel(StftArgs a, int per_wg)
-{
-	using PL = Plan<LOG2N>;
-	static_assert(PL::FRAMES_PER_BLOCK == 1, "one frame per workgroup at these sizes");
-	extern __shared__ float2 lds[];
-	const int tid = threadIdx.x, hop = a.hop;
-	if (blockIdx.x == gridDim.x - 1) { // housekeeping block
-		const int nv = valid_in_hop(a.in_valid, a.n_frames - 1, hop);
-		for (int s = 0; s < a.n_streams; ++s) {
-			const float* last = a.in + (long long)s * a.in_stride + (long long)(a.n_frames - 1) * hop;
-			for (int i = tid; i < hop; i += PL::THREADS)
-				a.tail_next[(long long)s * hop + i] = i < nv ? last[i] : 0.0f;
-			if (a.prev_frames > 0) {
-				for (int o = 0; o < 3; ++o) {
-					if (!a.carry[o])
-						continue;
-					const float* y = a.Y[o] + (long long)s * a.y_stream_stride + (long long)(a.prev_frames - 1) * (2 * hop) + hop;
-					for (int i = tid; i < hop; i += PL::THREADS)
-						a.carry[o][(long long)s * hop + i] = y[i];
-				}
-			}
-		}
-		return;
-	}
-	const int total = a.n_streams * a.n_frames;
-	const int first = blockIdx.x * per_wg, last = first + per_wg < total ? first + per_wg : total;
-	for (int item = first; item < last; ++item) {
-		const int s = item / a.n_frames, f = item - s * a.n_frames;
-		const float* in_s = a.in + (long long)s * a.in_stride;
-		StftIn<LOG2N> in;
-		in.prev = (f == 0) ? a.tail_prev + (long long)s * hop : in_s + (long long)(f - 1) * hop;
-		in.cur = in_s + (long long)f * hop;
-		in.window = a.window;
-		in.hop = hop;
-		in.nv_prev = f == 0 ? hop : valid_in_hop(a.in_valid, f - 1, hop);
-		in.nv_cur = valid_in_hop(a.in_valid, f, hop);
-		const long long row = ((a.row0 + f) % a.ring_rows) + (long long)s * a.ring_rows;
-		StftOut out;
-		out.S = a.S + row * a.s_stride;
-		out.mag = a.mag + row * PL::N;
-		out.n = PL::N;
-		out.full = f >= a.mag_full_from;
-		// (no barrier between frames: after the last pass's own barrier nobody reads the image any more, and the next
-		// frame writes it only after its first butterflies)
-		// The thread index and the table pointer are made opaque per frame: otherwise every LDS address and twiddle
-		// index of the transform (all functions of the thread index alone) is hoisted out of the loop and kept in
-		// registers -- 128 VGPRs and 356 bytes of scratch instead of 82 and none at nfft 16384.
-		int tf_o = tid;
-		const float2* tw_o = a.tw;
-		asm volatile("" : "+v"(tf_o));
-		asm volatile("" : "+s"(tw_o));
-		zfft::fft_frame<LOG2N, false, true, false>(tf_o, lds, tw_o, in, out, true);
-	}
-}
-
 // ------------------------------------------------------------------------------------------------
 // VEC: four consecutive samples of a hop per thread, 16-byte accesses (hop is a multiple of 4 and the engine's rows
 // are aligned; the caller's `out` rows must be too: launch_finalize checks)
@@ -301,17 +240,6 @@ template <int LOG2N>
 int launch_stft_t(const StftArgs& a, hipStream_t stream)
 {
 	using PL = Plan<LOG2N>;
-	if constexpr (LOG2N >= 13) {
-		const int total = a.n_streams * a.n_frames, slots = persistent_workgroups(LOG2N);
-		if (a.n_frames > 1 && total >= 2 * slots && !g_opt_no_persist) {
-			auto pk = stft_persist_kernel<LOG2N>;
-			ZH_TRY(set_lds(pk, lds_bytes<LOG2N>()));
-			const int per_wg = (total + slots - 1) / slots, nwg = (total + per_wg - 1) / per_wg;
-			hipLaunchKernelGGL(pk, dim3((unsigned)nwg + 1), dim3(PL::THREADS), lds_bytes<LOG2N>(), stream, a, per_wg);
-			ZH_HIP(hipGetLastError());
-			return ZEN_HIP_OK;
-		}
-	}
 	auto kern = stft_kernel<LOG2N>;
 	ZH_TRY(set_lds(kern, lds_bytes<LOG2N>()));
 	dim3 grid((unsigned)ceil_div((size_t)a.n_frames, (size_t)PL::FRAMES_PER_BLOCK) + 1, (unsigned)a.n_streams);
