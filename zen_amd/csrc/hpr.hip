@@ -126,20 +126,67 @@ void free_all(zen_hip_hpr* e)
 	}
 }
 
+// Up to eight pitched regions zeroed by one launch (reset_state: seven memsets of a few KB to MB each were 0.1 ms of
+// launch gaps per offline step, two engines reset per call).  Everything in 16-byte units: the engine's buffers are.
+struct ZeroJobs {
+	void* p[8];
+	long long pitch16[8], width16[8]; // in 16-byte units
+	int rows[8];
+	int n;
+};
+__global__ __launch_bounds__(256) void zero_regions_kernel(ZeroJobs z)
+{
+	const int j = blockIdx.y;
+	uint4* base = reinterpret_cast<uint4*>(z.p[j]);
+	const long long w = z.width16[j], total = w * z.rows[j];
+	for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+		const long long r = i / w, c = i - r * w;
+		base[r * z.pitch16[j] + c] = make_uint4(0u, 0u, 0u, 0u);
+	}
+}
+bool add_zero_job(ZeroJobs& z, void* p, size_t pitch_bytes, size_t width_bytes, size_t rows)
+{
+	if (!p || width_bytes == 0 || rows == 0)
+		return true;
+	if (z.n >= 8 || ((reinterpret_cast<uintptr_t>(p) | pitch_bytes | width_bytes) & 15) != 0 || rows > 0x7fffffff)
+		return false;
+	z.p[z.n] = p;
+	z.pitch16[z.n] = (long long)(pitch_bytes >> 4);
+	z.width16[z.n] = (long long)(width_bytes >> 4);
+	z.rows[z.n] = (int)rows;
+	++z.n;
+	return true;
+}
+
 int reset_state(zen_hip_hpr* e)
 {
 	const size_t S = e->n_streams;
-	ZH_HIP(hipMemsetAsync(e->d_tail[0], 0, sizeof(float) * S * e->hop, e->stream));
-	ZH_HIP(hipMemsetAsync(e->d_tail[1], 0, sizeof(float) * S * e->hop, e->stream));
 	// Only the W-1 history rows of the rings (absolute rows 0..W-2 of every stream) are read before they are
 	// written; every other ring row, and every Y row, is produced by the call that consumes it.
-	if (e->W > 1) {
-		const size_t srow = sizeof(float2) * e->s_stride, mrow = sizeof(float) * e->nfft;
-		ZH_HIP(hipMemset2DAsync(e->d_S, srow * e->ring_rows, 0, srow * (e->W - 1), S, e->stream));
-		ZH_HIP(hipMemset2DAsync(e->d_mag, mrow * e->ring_rows, 0, mrow * (e->W - 1), S, e->stream));
-	}
+	const size_t srow = sizeof(float2) * e->s_stride, mrow = sizeof(float) * e->nfft, hopb = sizeof(float) * S * e->hop;
+	ZeroJobs z;
+	memset(&z, 0, sizeof(z));
+	bool ok = add_zero_job(z, e->d_tail[0], hopb, hopb, 1) && add_zero_job(z, e->d_tail[1], hopb, hopb, 1);
+	if (e->W > 1)
+		ok = ok && add_zero_job(z, e->d_S, srow * e->ring_rows, srow * (e->W - 1), S)
+		     && add_zero_job(z, e->d_mag, mrow * e->ring_rows, mrow * (e->W - 1), S);
 	for (int o = 0; o < 3; ++o)
-		ZH_HIP(hipMemsetAsync(e->d_carry[o], 0, sizeof(float) * S * e->hop, e->stream));
+		ok = ok && add_zero_job(z, e->d_carry[o], hopb, hopb, 1);
+	if (ok && z.n > 0) {
+		hipLaunchKernelGGL(zero_regions_kernel, dim3(64, (unsigned)z.n), dim3(256), 0, e->stream, z);
+		ZH_HIP(hipGetLastError());
+	}
+	else if (!ok) { // (a hop that is not a multiple of four samples: the seven memsets)
+		ZH_HIP(hipMemsetAsync(e->d_tail[0], 0, hopb, e->stream));
+		ZH_HIP(hipMemsetAsync(e->d_tail[1], 0, hopb, e->stream));
+		if (e->W > 1) {
+			ZH_HIP(hipMemset2DAsync(e->d_S, srow * e->ring_rows, 0, srow * (e->W - 1), S, e->stream));
+			ZH_HIP(hipMemset2DAsync(e->d_mag, mrow * e->ring_rows, 0, mrow * (e->W - 1), S, e->stream));
+		}
+		for (int o = 0; o < 3; ++o)
+			if (e->d_carry[o])
+				ZH_HIP(hipMemsetAsync(e->d_carry[o], 0, hopb, e->stream));
+	}
 	e->tail_sel = 0;
 	e->abs_frame = (long long)e->W - 1; // rows 0..W-2 are the all-zero history of a fresh stream
 	e->last_frames = 0;
