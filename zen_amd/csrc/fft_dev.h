@@ -20,6 +20,7 @@
 // and the products with the twiddles 1 and -i of a first pass (butterfly<..., TRIV>).  Every nonzero value is
 // still the oracle's; an exact zero may carry the other sign.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #pragma clang fp contract(off)
@@ -266,6 +267,14 @@ __device__ __forceinline__ void frame_sync()
 	}
 }
 
+// An input functor may split its work: Raw load(idx, slot) (memory only) and float2 finish(raw, idx, slot).  The first
+// pass then issues the loads of all its elements before it finishes the first one, whatever the scheduler would have
+// made of in(): sixteen loads in flight instead of a trip to memory per element (see istft.hip IstftIn).
+template <class T, class = void>
+struct has_split_input : std::false_type {};
+template <class T>
+struct has_split_input<T, std::void_t<typename T::Raw>> : std::true_type {};
+
 // SYNC_FIRST: in() of the first pass reads LDS that the pass's own stores may overwrite (the fused kernel
 // keeps |S| and P inside the frame image): a barrier separates the two, as in every later pass.
 template <int LOG2N, int PASS, bool INV, bool ZU, bool HALF_OUT, class In, class Out, bool SYNC_FIRST = false,
@@ -282,6 +291,20 @@ struct PassRunner {
 		constexpr bool ZUP = ZU && FIRST;
 
 		float2 v[NB][R];
+		if constexpr (FIRST && !ZUP && has_split_input<In>::value) {
+			typename In::Raw raw[NB][R];
+#pragma unroll
+			for (int i = 0; i < NB; ++i)
+#pragma unroll
+				for (int m = 0; m < R; ++m)
+					raw[i][m] = in.load(m * J + ((tf + i * TF) & (J - 1)), m * NB + i);
+#pragma unroll
+			for (int i = 0; i < NB; ++i)
+#pragma unroll
+				for (int m = 0; m < R; ++m)
+					v[i][m] = in.finish(raw[i][m], m * J + ((tf + i * TF) & (J - 1)), m * NB + i);
+		}
+		else
 #pragma unroll
 		for (int i = 0; i < NB; ++i) {
 			const int b = tf + i * TF;

@@ -64,39 +64,62 @@ __device__ __forceinline__ unsigned mask_code(unsigned w, int which, const MaskC
 }
 
 // MODE 0: any mask (generic); 1: hard masks by comparison, any output; 2: the same for the percussive output alone
-// (the realtime default): one comparison per bin; 3: hard masks from the bits of launch_mask_bits (blocks of frames).
+// (the realtime default): one comparison per bin; 3: hard masks from the bits of launch_mask_bits (blocks of frames);
+// 5: soft masks (harmonic / percussive output).
 template <int MODE>
 struct IstftIn {
 	const float2* S;
 	const float* H;
 	const float* P;
-	unsigned bw;       // MODE 3 / 4: the thread's word of mask bits (IstftArgs::bits_t)
+	unsigned bw;       // MODE 3: the thread's word of mask bits (IstftArgs::bits_t)
 	MaskCfg cfg;
 	HardThr thr;
 	HardSel sel;
 	int which;
 	int n;
 	int p_mid;
-	__device__ __forceinline__ float2 operator()(int idx, int slot) const
+	// Split input (fft_dev.h has_split_input): the first pass issues load() for all sixteen elements, then finish().
+	// Written as one operator() the loads of an element sat behind the mask arithmetic of the one before -- wave-uniform
+	// branches (soft / SSE / which output), a division -- and every element cost its own trip to memory.
+	struct Raw {
+		float2 z;
+		float h, p;
+	};
+	__device__ __forceinline__ Raw load(int idx, int) const
 	{
 		const bool mirror = idx > (n >> 1); // upper half: S[n-k] = conj(S[k])
 		const int lo = mirror ? n - idx : idx;
-		float2 z = S[lo];
-		if (mirror)
+		Raw r;
+		r.z = S[lo];
+		r.h = r.p = 0.0f;
+		if constexpr (MODE != 3) { // (MODE 3: the masks are in the thread's word of bits)
+			r.h = H[lo];
+			r.p = P[(mirror && idx >= n - p_mid) ? idx : lo];
+		}
+		return r;
+	}
+	__device__ __forceinline__ float2 finish(const Raw& r, int idx, int slot) const
+	{
+		float2 z = r.z;
+		if (idx > (n >> 1))
 			z.y = -z.y;
-		const int pi = (mirror && idx >= n - p_mid) ? idx : lo;
 		float m;
-		if constexpr (MODE >= 3) { // the comparisons were made once per bin (launch_mask_bits + _transpose)
+		if constexpr (MODE == 3) // the comparisons were made once per bin (launch_mask_bits + _transpose)
 			m = (float)((int)(bw << (30 - 2 * slot)) >> 30); // two bits, sign-extended: 00 -> 0, 01 -> 1, 11 -> -1 (mask_code)
+		else if constexpr (MODE == 5) { // soft masks alone (soft_mask_functor hps.h:116-129; the residual does not exist with them)
+			const float a = which == 0 ? r.p : r.h, b = which == 0 ? r.h : r.p;
+			const float xp = powi(a, cfg.power), yp = powi(b, cfg.power);
+			m = xp / (xp + yp + FLT_EPSILON);
 		}
 		else if constexpr (MODE == 2)
-			m = hard_mask_exact(P[pi], H[lo] + FLT_EPSILON, thr.p); // hps.cu:501-505
+			m = hard_mask_exact(r.p, r.h + FLT_EPSILON, thr.p); // hps.cu:501-505
 		else if constexpr (MODE == 1)
-			m = hard_mask_sel(H[lo], P[pi], thr, sel);
+			m = hard_mask_sel(r.h, r.p, thr, sel);
 		else
-			m = mask_value_thr(which, H[lo], P[pi], cfg, thr);
+			m = mask_value_thr(which, r.h, r.p, cfg, thr);
 		return make_float2(z.x * m, z.y * m); // apply_mask_functor hps.h:58-66
 	}
+	__device__ __forceinline__ float2 operator()(int idx, int slot) const { return finish(load(idx, slot), idx, slot); }
 };
 
 struct IstftOut {
@@ -126,8 +149,11 @@ __device__ __forceinline__ void load_carry(const float* carry, int tf, bool want
 
 // (four waves per SIMD: with every load of the first pass in flight at once the max-ILP schedule otherwise takes 130 to
 // 200 registers -- three or two waves, and at nfft 8192 one workgroup per CU instead of two)
+// Exactly four: the LDS image (34.8 KB per 256 threads at every size) allows no more, and a scheduler that believes in
+// six or eight waves keeps the registers low by waiting for every load right behind it (the soft-mask build at nfft 1024:
+// 76 registers, one trip to memory per element).
 template <int LOG2N, int MODE>
-__global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) void istft_kernel(IstftArgs a)
+__global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) void istft_kernel(IstftArgs a)
 {
 	using PL = Plan<LOG2N>;
 	extern __shared__ float2 lds[];
@@ -148,7 +174,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) void istft_kernel(IstftArg
 	in.sel = hard_sel(in.which, in.cfg);
 	in.p_mid = a.p_mid;
 	in.bw = 0;
-	if constexpr (MODE >= 3)
+	if constexpr (MODE == 3)
 		in.bw = mask_code(a.bits_t[(long long)s * a.bits_t_stream_stride + (long long)f * PL::TF + tf], in.which, in.cfg);
 	IstftOut out;
 	out.Y = a.Y[oi] + (long long)s * a.y_stream_stride + (long long)f * (PL::N / 2);
@@ -388,6 +414,13 @@ int launch_istft_t(const IstftArgs& a, hipStream_t stream)
 		return ZEN_HIP_OK;
 	}
 	auto kern = istft_kernel<LOG2N, 0>;
+	if (LOG2N <= 13 && a.soft && !a.sse) { // the soft-mask build: nothing but that mask in it (at nfft 16384 it spills 60 bytes
+		bool hp = true;                    // where the generic build spills none: 1.91 against 1.74 ms on the offline-long bench)
+		for (int i = 0; i < a.n_out; ++i)
+			hp = hp && a.out_id[i] < 2;
+		if (hp)
+			kern = istft_kernel<LOG2N, 5>;
+	}
 	ZH_TRY(set_lds(kern, lds_bytes<LOG2N>()));
 	hipLaunchKernelGGL(kern, grid, dim3(PL::THREADS), lds_bytes<LOG2N>(), stream, a);
 	ZH_HIP(hipGetLastError());
