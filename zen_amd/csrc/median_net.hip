@@ -370,12 +370,17 @@ __global__ __launch_bounds__(256) void median_net_time_kernel(FilterArgs a, RowM
 	constexpr int T = znet::outputs_per_thread(W), mid = W / 2, NE = W + T - 1;
 	const int cols = a.cols;
 	const int pitch = a.pitch ? a.pitch : cols; // floats between rows (rows of which only the first cols are filtered)
-	const int c = (blockIdx.x * 256 + threadIdx.x) * VC;
-	if (c >= cols)
+	// thread -> (column vector, block of rows), the column fastest: a row of 516 columns (the stored half of a 1024-bin
+	// spectrum) is 129 vectors, and with one block of rows per workgroup the third wavefront ran for a single lane
+	const int vecs = (cols + VC - 1) / VC;
+	const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+	const int rb = (int)(t / vecs);
+	const int c = (int)(t - (long long)rb * vecs) * VC;
+	const int r0 = rb * rows_per_block;
+	if (r0 >= a.n_out_rows)
 		return;
 	const float* __restrict__ src = a.src + (long long)blockIdx.z * a.src_stream_stride + c;
 	float* __restrict__ dst = a.dst + (long long)blockIdx.z * a.dst_stream_stride + c;
-	const int r0 = blockIdx.y * rows_per_block;
 	int rend = r0 + rows_per_block;
 	rend = rend > a.n_out_rows ? a.n_out_rows : rend;
 
@@ -557,13 +562,14 @@ template <int W, int VC>
 int launch_time_vc(const FilterArgs& a, const RowMap& rm, hipStream_t stream)
 {
 	constexpr int T = znet::outputs_per_thread(W);
-	const int col_blocks = (a.cols + 256 * VC - 1) / (256 * VC);
-	// enough row blocks to fill the chip (>= ~2048 workgroups), but long enough to amortise the W-1 halo
+	const int vecs = (a.cols + VC - 1) / VC; // column vectors of a row
+	// enough blocks of rows to fill the chip (>= ~1024 full workgroups), but long enough to amortise the W-1 halo
 	int rpb = 256;
-	while (rpb > 4 * T && rpb > 32 && (long long)col_blocks * ((a.n_out_rows + rpb - 1) / rpb) * a.n_streams < 2048)
+	while (rpb > 4 * T && rpb > 32 && (long long)vecs * ((a.n_out_rows + rpb - 1) / rpb) * a.n_streams < 1024LL * 256)
 		rpb >>= 1;
 	rpb = (rpb + T - 1) / T * T;
-	dim3 grid((unsigned)col_blocks, (unsigned)((a.n_out_rows + rpb - 1) / rpb), (unsigned)a.n_streams);
+	const long long threads = (long long)vecs * ((a.n_out_rows + rpb - 1) / rpb);
+	dim3 grid((unsigned)((threads + 255) / 256), 1, (unsigned)a.n_streams);
 	hipLaunchKernelGGL((median_net_time_kernel<W, VC>), grid, dim3(256), 0, stream, a, rm, rpb);
 	ZH_HIP(hipGetLastError());
 	return ZEN_HIP_OK;
