@@ -267,7 +267,7 @@ __device__ __forceinline__ void frame_sync()
 	}
 }
 
-// An input functor may split its work: Raw load(idx, slot) (memory only) and float2 finish(raw, idx, slot).  The first
+// An input functor may split its work: Raw load(idx, slot) (memory only), prepare() and float2 finish(raw, idx, slot).  The first
 // pass then issues the loads of all its elements before it finishes the first one, whatever the scheduler would have
 // made of in(): sixteen loads in flight instead of a trip to memory per element (see istft.hip IstftIn).
 template <class T, class = void>
@@ -298,6 +298,7 @@ struct PassRunner {
 #pragma unroll
 				for (int m = 0; m < R; ++m)
 					raw[i][m] = in.load(m * J + ((tf + i * TF) & (J - 1)), m * NB + i);
+			in.prepare(); // (whatever else the functor has to wait for: behind the loads, not in front of them)
 #pragma unroll
 			for (int i = 0; i < NB; ++i)
 #pragma unroll

@@ -85,6 +85,13 @@ struct IstftIn {
 		float2 z;
 		float h, p;
 	};
+	// MODE 3: the thread's word of mask bits was loaded in the kernel's prologue; its first use is here, behind the loads
+	// of the spectrum -- turned into the output's codes in the prologue it cost a trip to memory of its own in front of them
+	__device__ __forceinline__ void prepare()
+	{
+		if constexpr (MODE == 3)
+			bw = mask_code(bw, which, cfg);
+	}
 	__device__ __forceinline__ Raw load(int idx, int) const
 	{
 		const bool mirror = idx > (n >> 1); // upper half: S[n-k] = conj(S[k])
@@ -119,7 +126,7 @@ struct IstftIn {
 			m = mask_value_thr(which, r.h, r.p, cfg, thr);
 		return make_float2(z.x * m, z.y * m); // apply_mask_functor hps.h:58-66
 	}
-	__device__ __forceinline__ float2 operator()(int idx, int slot) const { return finish(load(idx, slot), idx, slot); }
+	__device__ __forceinline__ float2 operator()(int idx, int slot) const { return finish(load(idx, slot), idx, slot); } // (not with MODE 3)
 };
 
 struct IstftOut {
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) __attribute__((amdgpu_wave
 	in.p_mid = a.p_mid;
 	in.bw = 0;
 	if constexpr (MODE == 3)
-		in.bw = mask_code(a.bits_t[(long long)s * a.bits_t_stream_stride + (long long)f * PL::TF + tf], in.which, in.cfg);
+		in.bw = a.bits_t[(long long)s * a.bits_t_stream_stride + (long long)f * PL::TF + tf]; // (-> codes: IstftIn::prepare)
 	IstftOut out;
 	out.Y = a.Y[oi] + (long long)s * a.y_stream_stride + (long long)f * (PL::N / 2);
 	out.cola = a.cola;
