@@ -1,5 +1,10 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -x -q -m gpu -k "offline or sharded or config or golden or hpri or mask_bits" 2>&1 | tail -3
-python bench.py --workload offline_batch --steps 20 --warmup 3 --no-cpu-baseline | python -c "
+python -m pytest tests -x -q -m gpu -k "mask_bits or offline or golden or config or sharded or long_hops or largest" 2>&1 | tail -4
+for opt in "" "no_wave_local=1"; do
+ZEN_HIP_OPTIONS="$opt" python bench.py --workload offline_batch --steps 20 --warmup 3 --no-cpu-baseline | python -c "
 import json,sys
 j=json.loads(sys.stdin.readline()); print(j['ms_per_step'], j['x_realtime'], {k: round(v['ms_per_step'],3) for k,v in j['kernels'].items()})"
+ZEN_HIP_OPTIONS="$opt" python bench.py --workload offline_long --steps 20 --warmup 3 --no-cpu-baseline | python -c "
+import json,sys
+j=json.loads(sys.stdin.readline()); print(j['ms_per_step'], j['x_realtime'], {k: round(v['ms_per_step'],3) for k,v in j['kernels'].items()})"
+done
