@@ -1,10 +1,6 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests -x -q -m gpu -k "mask_bits or offline or golden or config or sharded or long_hops or largest" 2>&1 | tail -4
-for opt in "" "no_wave_local=1"; do
-ZEN_HIP_OPTIONS="$opt" python bench.py --workload offline_batch --steps 20 --warmup 3 --no-cpu-baseline | python -c "
-import json,sys
-j=json.loads(sys.stdin.readline()); print(j['ms_per_step'], j['x_realtime'], {k: round(v['ms_per_step'],3) for k,v in j['kernels'].items()})"
-ZEN_HIP_OPTIONS="$opt" python bench.py --workload offline_long --steps 20 --warmup 3 --no-cpu-baseline | python -c "
-import json,sys
-j=json.loads(sys.stdin.readline()); print(j['ms_per_step'], j['x_realtime'], {k: round(v['ms_per_step'],3) for k,v in j['kernels'].items()})"
+mkdir -p gpurun_out/fuzz
+for seed in 401 402 403; do
+  timeout 200 python tools/fuzz_parity.py --seconds 150 --seed $seed > gpurun_out/fuzz/r03_fuzz_seed$seed.txt 2>&1
+  tail -2 gpurun_out/fuzz/r03_fuzz_seed$seed.txt
 done
