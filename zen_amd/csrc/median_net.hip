@@ -192,8 +192,11 @@ __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowM
 			const int c = col0 + g;
 			if (c < cols && (!herm || c <= (cols >> 1) || c + 4 > cols - mid)) {
 				const int4 k = *reinterpret_cast<const int4*>(&tile[IM::addr(g)]);
-				*reinterpret_cast<float4*>(drow + c) = make_float4(from_key<NONNEG>(k.x), from_key<NONNEG>(k.y),
-				                                                   from_key<NONNEG>(k.z), from_key<NONNEG>(k.w));
+				float* dq = reinterpret_cast<float*>(__builtin_assume_aligned(drow + c, 16)); // streaming store
+				__builtin_nontemporal_store(from_key<NONNEG>(k.x), dq);
+				__builtin_nontemporal_store(from_key<NONNEG>(k.y), dq + 1);
+				__builtin_nontemporal_store(from_key<NONNEG>(k.z), dq + 2);
+				__builtin_nontemporal_store(from_key<NONNEG>(k.w), dq + 3);
 			}
 		}
 	}
@@ -307,9 +310,12 @@ __global__ __launch_bounds__(HERM_THREADS) void median_net_freq_herm_kernel(Filt
 	znet::medians<W, T, W + T - 1>(e, out);
 	float* d = a.dst + (long long)blockIdx.y * a.dst_stream_stride + (long long)(row0 + rr) * cols + (tail ? c_t0 + T * (j - n_lo) : T * j);
 #pragma unroll
-	for (int v = 0; v < T / 4; ++v)
-		*reinterpret_cast<float4*>(d + 4 * v) = make_float4(from_key<NONNEG>(out[4 * v]), from_key<NONNEG>(out[4 * v + 1]),
-		                                                    from_key<NONNEG>(out[4 * v + 2]), from_key<NONNEG>(out[4 * v + 3]));
+	for (int v = 0; v < T / 4; ++v) {
+		float* dq = reinterpret_cast<float*>(__builtin_assume_aligned(d + 4 * v, 16)); // streaming store
+#pragma unroll
+		for (int i = 0; i < 4; ++i)
+			__builtin_nontemporal_store(from_key<NONNEG>(out[4 * v + i]), dq + i);
+	}
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -339,18 +345,24 @@ __device__ __forceinline__ void load_keys(const float* p, int (&k)[VC])
 		k[0] = f2key(x.x);
 		k[1] = f2key(x.y);
 	}
-	else {
-		const float4 x = *reinterpret_cast<const float4*>(p);
-		k[0] = f2key(x.x);
-		k[1] = f2key(x.y);
-		k[2] = f2key(x.z);
-		k[3] = f2key(x.w);
+	else { // (streaming load: aligned rows, the four loads become one 16-byte instruction)
+		const float* q = reinterpret_cast<const float*>(__builtin_assume_aligned(p, 16));
+		k[0] = f2key(__builtin_nontemporal_load(q));
+		k[1] = f2key(__builtin_nontemporal_load(q + 1));
+		k[2] = f2key(__builtin_nontemporal_load(q + 2));
+		k[3] = f2key(__builtin_nontemporal_load(q + 3));
 	}
 }
 
 template <int VC>
 __device__ __forceinline__ void store_keys(float* p, const int (&k)[VC])
 {
+	if constexpr (VC == 4) { // streaming store
+#pragma unroll
+		for (int i = 0; i < 4; ++i)
+			__builtin_nontemporal_store(key2f(k[i]), p + i);
+		return;
+	}
 	if constexpr (VC == 1) {
 		*p = key2f(k[0]);
 	}

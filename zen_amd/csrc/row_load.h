@@ -21,8 +21,11 @@ __device__ __forceinline__ int4 row_vec_keys(const float* __restrict__ srow, int
 	const int mc = cols - vc;                  // mirrored: columns mc, mc-1, mc-2, mc-3
 	const int vcl = vc < 0 ? 0 : (vc > cols - 4 ? cols - 4 : vc);
 	const int va = up ? (mir ? mc - 3 : 0) : vcl;
-	const float4_u x = *reinterpret_cast<const float4_u*>(srow + va);
-	const int k0 = to_key<NONNEG>(x.x), k1 = to_key<NONNEG>(x.y), k2 = to_key<NONNEG>(x.z), k3 = to_key<NONNEG>(x.w);
+	// (streaming: every sample is staged by one workgroup and its halo by the next; nothing gains from staying in a cache)
+	const float* q = srow + va;
+	const float x0 = __builtin_nontemporal_load(q), x1 = __builtin_nontemporal_load(q + 1), x2 = __builtin_nontemporal_load(q + 2),
+	            x3 = __builtin_nontemporal_load(q + 3);
+	const int k0 = to_key<NONNEG>(x0), k1 = to_key<NONNEG>(x1), k2 = to_key<NONNEG>(x2), k3 = to_key<NONNEG>(x3);
 	// stored: (k0 k1 k2 k3), left of the row k0 x4, right of it k3 x4; mirrored: (k3 k2 k1 k0); Hermitian and beyond the
 	// row: column cols-1, which is column 1: k1 x4
 	const bool lo = vc < 0, hi = !up && vc >= cols, rep = lo || hi || (up && !mir);
