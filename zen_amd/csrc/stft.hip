@@ -115,6 +115,22 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void stft_kernel(StftArgs a)
 	zfft::fft_frame<LOG2N, false, true, false>(tf, lds + slot * PL::LDS_FLOAT2, a.tw, in, out, active);
 }
 
+// streaming 16-byte accesses (aligned): the Y rows are read once, the outputs written once
+__device__ __forceinline__ float4 load4_nt(const float* p)
+{
+	const float* q = reinterpret_cast<const float*>(__builtin_assume_aligned(p, 16));
+	return make_float4(__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1), __builtin_nontemporal_load(q + 2),
+	                   __builtin_nontemporal_load(q + 3));
+}
+__device__ __forceinline__ void store4_nt(float* p, float4 v)
+{
+	float* q = reinterpret_cast<float*>(__builtin_assume_aligned(p, 16));
+	__builtin_nontemporal_store(v.x, q);
+	__builtin_nontemporal_store(v.y, q + 1);
+	__builtin_nontemporal_store(v.z, q + 2);
+	__builtin_nontemporal_store(v.w, q + 3);
+}
+
 // ------------------------------------------------------------------------------------------------
 // VEC: four consecutive samples of a hop per thread, 16-byte accesses (hop is a multiple of 4 and the engine's rows
 // are aligned; the caller's `out` rows must be too: launch_finalize checks)
@@ -135,8 +151,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a)
 		const float* prev = (i == 0) ? carry + k : Y + (i - 1) * 2 * hop + hop + k;
 		const float* cur = Y + i * 2 * hop + k;
 		if constexpr (VEC) {
-			const float4 p = *reinterpret_cast<const float4*>(prev), c = *reinterpret_cast<const float4*>(cur);
-			*reinterpret_cast<float4*>(out + i * hop + k) = make_float4(p.x + c.x, p.y + c.y, p.z + c.z, p.w + c.w);
+			const float4 p = load4_nt(prev), c = load4_nt(cur);
+			store4_nt(out + i * hop + k, make_float4(p.x + c.x, p.y + c.y, p.z + c.z, p.w + c.w));
 		}
 		else {
 			out[i * hop + k] = prev[0] + cur[0];
@@ -166,7 +182,7 @@ __global__ __launch_bounds__(256) void finalize_spec_kernel(FinalizeArgs a)
 			const float* prev = (i == 0) ? carry + k : Y + (i - 1) * 2 * hop + hop + k;
 			const float* cur = Y + i * 2 * hop + k;
 			if constexpr (VEC) {
-				const float4 p = *reinterpret_cast<const float4*>(prev), c = *reinterpret_cast<const float4*>(cur);
+				const float4 p = load4_nt(prev), c = load4_nt(cur);
 				v[0] = p.x + c.x, v[1] = p.y + c.y, v[2] = p.z + c.z, v[3] = p.w + c.w;
 			}
 			else {
@@ -177,7 +193,7 @@ __global__ __launch_bounds__(256) void finalize_spec_kernel(FinalizeArgs a)
 			const float* prev = (i == 0) ? carry2 + k : Y2 + (i - 1) * 2 * hop + hop + k;
 			const float* cur = Y2 + i * 2 * hop + k;
 			if constexpr (VEC) {
-				const float4 p = *reinterpret_cast<const float4*>(prev), c = *reinterpret_cast<const float4*>(cur);
+				const float4 p = load4_nt(prev), c = load4_nt(cur);
 				v[0] = v[0] + (p.x + c.x), v[1] = v[1] + (p.y + c.y), v[2] = v[2] + (p.z + c.z), v[3] = v[3] + (p.w + c.w);
 			}
 			else {
@@ -192,7 +208,7 @@ __global__ __launch_bounds__(256) void finalize_spec_kernel(FinalizeArgs a)
 		const long long p0 = a.pos0 + i * hop + k;
 		const long long j = p0 - a.shift;
 		if (VEC && j >= 0 && j + 4 <= a.len) {
-			*reinterpret_cast<float4*>(out + j) = make_float4(v[0], v[1], v[2], v[3]);
+			store4_nt(out + j, make_float4(v[0], v[1], v[2], v[3]));
 		}
 		else {
 #pragma unroll
