@@ -34,6 +34,9 @@ FILE_FLAGS = {"rt_fused.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mll
               "rt_fused_multi.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
               "median47.hip": ["-mllvm", "-amdgpu-use-amdgpu-trackers=1"],
               "istft.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+              # (round 3: with the loads of a frame in flight together the analysis kernels gain from it too: nfft 16384
+              # 1.08 -> 0.99 ms, nfft 1024 0.74 -> 0.64 ms per offline batch step; it lost while they were serialised)
+              "stft.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
               "median_big.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-minreg"],
               "rt_wide.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-minreg"]}
 FILE_FLAGS_ENV = os.environ.get("ZEN_HIP_FILE_FLAGS", "")   # A/B hook: "median_net.hip=-mllvm,-amdgpu-sched-strategy=max-ilp"

@@ -4,7 +4,7 @@
 //                             (only the nwin real outputs that are used are computed), *COLA.
 //   istft_hard_multi_kernel : the same for hard masks with several outputs, one workgroup per frame.
 // Its own translation unit because it is compiled with the max-ILP scheduling strategy (build.py), which
-// helps these kernels (-4 %) and hurts the analysis kernel of stft.hip.
+// helps these kernels (-4 %); since the loads of a frame are in flight together it helps stft.hip's as well.
 #include "common.h"
 #include "fft_dev.h"
 #include "fft_launch.h"
