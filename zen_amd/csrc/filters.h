@@ -41,7 +41,7 @@ struct FilterArgs {
 	                        // kernels filter only the stored half of such rows (cols = nfft/2 + 4, pitch = nfft)
 	// Engine only, Hermitian frequency-direction launches with hard masks (stft.h IstftArgs::bits): a kernel that knows how
 	// compares its result P with the harmonic estimate H right away and writes two mask bits per bin (natural order, see
-	// IstftArgs::bits) INSTEAD of the P row; launch_median(..., &bits_done) tells whether the kernel that ran did (1: `bits`, 2: `bits_t`).
+	// IstftArgs::bits) INSTEAD of the P row; launch_median(..., &bits_done) tells whether the kernel that ran did (1: `bits`, 2: `bits_t`, 3: soft-mask rows, below).
 	// hrows null: H is the source row itself (causal / one-tap time median).
 	unsigned* bits;
 	long long bits_stream_stride; // words
@@ -52,6 +52,14 @@ struct FilterArgs {
 	unsigned* bits_t;             // a kernel that holds whole rows writes IstftArgs::bits_t right away (bits_done = 2)
 	long long bits_t_stream_stride;
 	int need_pm, need_hm;         // which of the two masks some enabled output reads (the other bit stays 0)
+	// Soft masks, same launches (bits_done = 3): instead of P the kernel stores the percussive soft mask of every wanted
+	// bin where P would have gone (dst), and the harmonic one in mh_dst (same layout), soft_mask_functor hps.h:116-129 with
+	// the integer exponent `soft_power`; the synthesis then loads one mask value per bin and output instead of H and P
+	// and divides nothing (stft.h IstftArgs::mask_rows).  need_pm / need_hm as above.
+	int soft_rows;
+	int soft_power;
+	float* mh_dst;                // null unless need_hm
+	long long mh_stream_stride;
 };
 
 // true if launch_median(a) with a.hermitian = 1 is implemented for this (direction, mask, row length)

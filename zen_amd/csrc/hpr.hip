@@ -98,6 +98,7 @@ void free_all(zen_hip_hpr* e)
 	(void)hipFree(e->d_P);
 	(void)hipFree(e->d_bits);
 	(void)hipFree(e->d_bits_t);
+	(void)hipFree(e->d_Mh);
 	(void)hipFree(e->d_blk_flag);
 	(void)hipFree(e->d_blk_need);
 	for (int o = 0; o < 3; ++o) {
@@ -512,6 +513,25 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 			ff.h_stream_stride = (long long)(e->max_hops * N);
 		}
 	}
+	// Soft masks, blocks of frames: the median kernel that knows how leaves the masks themselves (the percussive one where
+	// P would go, the harmonic one in d_Mh) and the synthesis loads one value per bin and output instead of H and P.
+	const bool use_soft_rows = M >= 8 && e->soft && !e->use_sse && half && !g_opt_no_mask_bits && !g_opt_no_median_bits;
+	if (use_soft_rows) {
+		ff.soft_rows = 1;
+		ff.soft_power = (int)e->beta; // hps.h:117-121: soft_mask_functor(int _power) truncates beta
+		ff.need_pm = need_pm;
+		ff.need_hm = need_hm;
+		if (need_hm) {
+			if (!e->d_Mh)
+				ZH_HIP(hipMalloc((void**)&e->d_Mh, sizeof(float) * S * e->max_hops * N));
+			ff.mh_dst = e->d_Mh;
+			ff.mh_stream_stride = (long long)(e->max_hops * N);
+		}
+		if (!h_is_ring) {
+			ff.hrows = e->d_H;
+			ff.h_stream_stride = (long long)(e->max_hops * N);
+		}
+	}
 	{
 		ProfScope ps(e, zen_hip_hpr::K_FREQ);
 		if (e->use_sse) {
@@ -574,6 +594,10 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 	ia.thr_h = thr.h;
 	ia.thr_p_inc = thr.p_inc;
 	ia.thr_h_inc = thr.h_inc;
+	if (bits_done == 3) { // the frequency-direction launch left the soft masks
+		ia.mask_rows = 1;
+		ia.Hm = e->d_Mh;
+	}
 	if (use_bits) {
 		ia.bits_row_words = bits_row_words;
 		ia.bits_stream_stride = bits_stream_stride;
@@ -685,6 +709,8 @@ int grow_buffers(zen_hip_hpr* e, size_t new_hops)
 	(void)hipFree(e->d_P);
 	(void)hipFree(e->d_bits);
 	(void)hipFree(e->d_bits_t);
+	(void)hipFree(e->d_Mh);
+	e->d_Mh = nullptr;
 	e->d_S = nS;
 	e->d_mag = nmag;
 	e->d_H = e->d_P = nullptr; // ensure_estimates

@@ -50,6 +50,7 @@ struct zen_hip_hpr {
 	bool direct_done[3] = {false, false, false};        // run_chunk delivered output o's hops itself: no finalize launch
 	float* d_H = nullptr;
 	float* d_P = nullptr;
+	float* d_Mh = nullptr;        // soft masks computed by the median kernel: the harmonic mask's rows (the percussive one's go where P would)
 	unsigned* d_bits_t = nullptr; // the same in the synthesis threads' order (IstftArgs::bits_t)
 	unsigned* d_bits = nullptr; // hard masks of the consumed rows as two bits per bin (IstftArgs::bits), blocks of frames only
 	float* d_Y[3] = {nullptr, nullptr, nullptr};     // 0 percussive, 1 harmonic, 2 residual

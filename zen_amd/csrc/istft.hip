@@ -65,7 +65,7 @@ __device__ __forceinline__ unsigned mask_code(unsigned w, int which, const MaskC
 
 // MODE 0: any mask (generic); 1: hard masks by comparison, any output; 2: the same for the percussive output alone
 // (the realtime default): one comparison per bin; 3: hard masks from the bits of launch_mask_bits (blocks of frames);
-// 5: soft masks (harmonic / percussive output).
+// 5: soft masks (harmonic / percussive output); 7: soft masks read from the rows the median kernel left (IstftArgs::mask_rows).
 template <int MODE>
 struct IstftIn {
 	const float2* S;
@@ -99,7 +99,10 @@ struct IstftIn {
 		Raw r;
 		r.z = S[lo];
 		r.h = r.p = 0.0f;
-		if constexpr (MODE != 3) { // (MODE 3: the masks are in the thread's word of bits)
+		if constexpr (MODE == 7) { // the output's soft mask, computed by the median kernel: one value per bin (H: that row)
+			r.p = H[(mirror && idx >= n - p_mid) ? idx : lo];
+		}
+		else if constexpr (MODE != 3) { // (MODE 3: the masks are in the thread's word of bits)
 			r.h = H[lo];
 			r.p = P[(mirror && idx >= n - p_mid) ? idx : lo];
 		}
@@ -113,6 +116,8 @@ struct IstftIn {
 		float m;
 		if constexpr (MODE == 3) // the comparisons were made once per bin (launch_mask_bits + _transpose)
 			m = (float)((int)(bw << (30 - 2 * slot)) >> 30); // two bits, sign-extended: 00 -> 0, 01 -> 1, 11 -> -1 (mask_code)
+		else if constexpr (MODE == 7)
+			m = r.p;
 		else if constexpr (MODE == 5) { // soft masks alone (soft_mask_functor hps.h:116-129; the residual does not exist with them)
 			const float a = which == 0 ? r.p : r.h, b = which == 0 ? r.h : r.p;
 			const float xp = powi(a, cfg.power), yp = powi(b, cfg.power);
@@ -183,6 +188,8 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) __attribute__((amdgpu_wave
 	in.bw = 0;
 	if constexpr (MODE == 3)
 		in.bw = a.bits_t[(long long)s * a.bits_t_stream_stride + (long long)f * PL::TF + tf]; // (-> codes: IstftIn::prepare)
+	if constexpr (MODE == 7) // the row of this output's soft mask (percussive: where P would be; harmonic: Hm), laid out as P
+		in.H = (in.which == 0 ? a.P : a.Hm) + (long long)s * a.p_stream_stride + (long long)f * PL::N;
 	IstftOut out;
 	out.Y = a.Y[oi] + (long long)s * a.y_stream_stride + (long long)f * (PL::N / 2);
 	out.cola = a.cola;
@@ -421,7 +428,10 @@ int launch_istft_t(const IstftArgs& a, hipStream_t stream)
 		return ZEN_HIP_OK;
 	}
 	auto kern = istft_kernel<LOG2N, 0>;
-	if (LOG2N <= 13 && a.soft && !a.sse) { // the soft-mask build: nothing but that mask in it (at nfft 16384 it spills 60 bytes
+	if (a.mask_rows) { // soft masks computed by the median kernel
+		kern = istft_kernel<LOG2N, 7>;
+	}
+	else if (LOG2N <= 13 && a.soft && !a.sse) { // the soft-mask build: nothing but that mask in it (at nfft 16384 it spills 60 bytes
 		bool hp = true;                    // where the generic build spills none: 1.91 against 1.74 ms on the offline-long bench)
 		for (int i = 0; i < a.n_out; ++i)
 			hp = hp && a.out_id[i] < 2;

@@ -42,9 +42,23 @@ __device__ __forceinline__ unsigned mask_word16(const int (&p)[16], const int (&
 	return w;
 }
 
+// FilterArgs::soft_rows: the medians replaced by the percussive soft mask of their bins (as keys: a mask is >= +0), the
+// harmonic one in mh[] (masks.h pmask_value / hmask_value: the very functions the synthesis would call)
+__device__ __forceinline__ void soft_masks16(int (&p)[16], const int (&h)[16], int power, int need_pm, int need_hm, float (&mh)[16])
+{
+	const MaskCfg c{0.0f, 0.0f, 1, power, 0, 0, 0};
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		const float pf = __int_as_float(p[i]), hf = __int_as_float(h[i]);
+		mh[i] = need_hm ? hmask_value(hf, pf, c) : 0.0f;
+		p[i] = __float_as_int(need_pm ? pmask_value(hf, pf, c) : 0.0f);
+	}
+}
+
 // BITS (Hermitian rows of non-negative samples whose harmonic estimate is the row itself): the mask word of the
 // thread's block is stored instead of its sixteen medians.
-template <int W, bool NONNEG, bool BITS = false>
+// SOFT (same rows): soft masks instead of the medians (soft_masks16).
+template <int W, bool NONNEG, bool BITS = false, bool SOFT = false>
 __global__ __launch_bounds__(256, ZEN_BIG_MINB) void median_big_kernel(FilterArgs a, int row_base, int ring, int segs_per_row,
                                                                       int nblk_main)
 {
@@ -115,6 +129,20 @@ __global__ __launch_bounds__(256, ZEN_BIG_MINB) void median_big_kernel(FilterArg
 		}
 		return;
 	}
+	if constexpr (SOFT) {
+		if (wanted) {
+			int h[16];
+			float mh[16];
+			znet::lds_load<16>(&raw[(tid + G::a + 2) * RSTR], h); // the thread's own block
+			soft_masks16(out, h, a.soft_power, a.need_pm, a.need_hm, mh);
+			if (a.mh_dst) {
+				float* mrow = a.mh_dst + (long long)st * a.mh_stream_stride + (long long)row * cols + col0 + 16 * tid;
+#pragma unroll
+				for (int v = 0; v < 4; ++v)
+					*reinterpret_cast<float4*>(mrow + 4 * v) = make_float4(mh[4 * v], mh[4 * v + 1], mh[4 * v + 2], mh[4 * v + 3]);
+			}
+		}
+	}
 	__syncthreads(); // all reads of the images done: the raw image now collects the results
 	znet::lds_store<16>(&raw[tid * RSTR], out);
 	__syncthreads();
@@ -136,7 +164,7 @@ __global__ __launch_bounds__(256, ZEN_BIG_MINB) void median_big_kernel(FilterArg
 // neighbourhoods of every row are staged and sorted side by side.  (One row per wavefront left 57 of 64 lanes idle
 // through the selection: 0.33 ms of the 12 ms offline batch step.)
 constexpr int TAIL_ROWS = 4;
-template <int W, bool NONNEG, bool BITS = false>
+template <int W, bool NONNEG, bool BITS = false, bool SOFT = false>
 __global__ __launch_bounds__(64) void median_big_tail_kernel(FilterArgs a, int row_base, int ring)
 {
 	using G = zbig::Geo<W>;
@@ -216,6 +244,18 @@ __global__ __launch_bounds__(64) void median_big_tail_kernel(FilterArgs a, int r
 		}
 		return;
 	}
+	if constexpr (SOFT) {
+		int h[16];
+		float mh[16];
+		znet::lds_load<16>(ld.raw_t + (G::a + 2) * RSTR, h); // the block's own samples (the tail's: mirrored = H of those bins)
+		soft_masks16(out, h, a.soft_power, a.need_pm, a.need_hm, mh);
+		if (a.mh_dst) {
+			float* mrow = a.mh_dst + (long long)st * a.mh_stream_stride + (long long)(row0 + rr) * cols + c;
+#pragma unroll
+			for (int v = 0; v < 4; ++v)
+				*reinterpret_cast<float4*>(mrow + 4 * v) = make_float4(mh[4 * v], mh[4 * v + 1], mh[4 * v + 2], mh[4 * v + 3]);
+		}
+	}
 	float* drow = a.dst + (long long)st * a.dst_stream_stride + (long long)(row0 + rr) * cols;
 #pragma unroll
 	for (int v = 0; v < 4; ++v)
@@ -238,6 +278,15 @@ int launch_w(const FilterArgs& a, hipStream_t stream, int* bits_done)
 		hipLaunchKernelGGL((median_big_tail_kernel<W, true, true>), tgrid, dim3(64), 0, stream, a, row_base, (int)a.ring_rows);
 		ZH_HIP(hipGetLastError());
 		*bits_done = 1;
+		return ZEN_HIP_OK;
+	}
+	// soft masks instead of P (same rows)
+	if (bits_done && a.soft_rows && a.hermitian && a.nonneg && !a.hrows) {
+		dim3 tgrid((unsigned)((a.n_out_rows + TAIL_ROWS - 1) / TAIL_ROWS), (unsigned)a.n_streams);
+		hipLaunchKernelGGL((median_big_kernel<W, true, false, true>), grid, dim3(256), 0, stream, a, row_base, (int)a.ring_rows, segs, nblk_main);
+		hipLaunchKernelGGL((median_big_tail_kernel<W, true, false, true>), tgrid, dim3(64), 0, stream, a, row_base, (int)a.ring_rows);
+		ZH_HIP(hipGetLastError());
+		*bits_done = 3;
 		return ZEN_HIP_OK;
 	}
 	if (a.nonneg)

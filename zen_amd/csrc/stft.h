@@ -78,6 +78,10 @@ struct IstftArgs {
 	const unsigned* bits_t;
 	long long bits_t_stream_stride; // words; a row is nfft/16 words
 	int need_pm, need_hm;           // which of the two masks some enabled output reads (the other bit stays 0)
+	// Soft masks computed by the frequency-direction median kernel (FilterArgs::soft_rows): P holds the percussive mask
+	// of every bin the synthesis reads, Hm the harmonic one (rows laid out as P's); H is not read.
+	int mask_rows;
+	const float* Hm;
 };
 
 // words of one row of mask bits (a multiple of four: rows stay 16-byte aligned)
