@@ -515,7 +515,10 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 	}
 	// Soft masks, blocks of frames: the median kernel that knows how leaves the masks themselves (the percussive one where
 	// P would go, the harmonic one in d_Mh) and the synthesis loads one value per bin and output instead of H and P.
-	const bool use_soft_rows = M >= 8 && e->soft && !e->use_sse && half && !g_opt_no_mask_bits && !g_opt_no_median_bits;
+	// (Only where the harmonic estimate is the magnitude row itself -- the long-mask kernel of pass 1: in the sorting-network
+	// kernel of pass 2 the extra H row, the divisions and the second row of stores cost 0.13 ms per offline-long step, twice
+	// what the synthesis gained.)
+	const bool use_soft_rows = M >= 8 && e->soft && !e->use_sse && half && h_is_ring && !g_opt_no_mask_bits && !g_opt_no_median_bits;
 	if (use_soft_rows) {
 		ff.soft_rows = 1;
 		ff.soft_power = (int)e->beta; // hps.h:117-121: soft_mask_functor(int _power) truncates beta
@@ -526,10 +529,6 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 				ZH_HIP(hipMalloc((void**)&e->d_Mh, sizeof(float) * S * e->max_hops * N));
 			ff.mh_dst = e->d_Mh;
 			ff.mh_stream_stride = (long long)(e->max_hops * N);
-		}
-		if (!h_is_ring) {
-			ff.hrows = e->d_H;
-			ff.h_stream_stride = (long long)(e->max_hops * N);
 		}
 	}
 	{

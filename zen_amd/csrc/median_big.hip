@@ -129,18 +129,23 @@ __global__ __launch_bounds__(256, ZEN_BIG_MINB) void median_big_kernel(FilterArg
 		}
 		return;
 	}
+	int mhk[16]; // SOFT: the harmonic masks of the thread's bins (as keys), stored like the results below
 	if constexpr (SOFT) {
+#pragma unroll
+		for (int i = 0; i < 16; ++i)
+			mhk[i] = 0;
 		if (wanted) {
 			int h[16];
 			float mh[16];
 			znet::lds_load<16>(&raw[(tid + G::a + 2) * RSTR], h); // the thread's own block
 			soft_masks16(out, h, a.soft_power, a.need_pm, a.need_hm, mh);
-			if (a.mh_dst) {
-				float* mrow = a.mh_dst + (long long)st * a.mh_stream_stride + (long long)row * cols + col0 + 16 * tid;
 #pragma unroll
-				for (int v = 0; v < 4; ++v)
-					*reinterpret_cast<float4*>(mrow + 4 * v) = make_float4(mh[4 * v], mh[4 * v + 1], mh[4 * v + 2], mh[4 * v + 3]);
-			}
+			for (int i = 0; i < 16; ++i)
+				mhk[i] = __float_as_int(mh[i]);
+		}
+		if (a.mh_dst) { // (the sorted image is dead: it collects the harmonic masks the way the raw image collects the results)
+			__syncthreads();
+			znet::lds_store<16>(&srt[tid * RSTR], mhk);
 		}
 	}
 	__syncthreads(); // all reads of the images done: the raw image now collects the results
@@ -154,6 +159,14 @@ __global__ __launch_bounds__(256, ZEN_BIG_MINB) void median_big_kernel(FilterArg
 			const int4 k = *reinterpret_cast<const int4*>(&raw[(g >> 4) * RSTR + (g & 15)]);
 			*reinterpret_cast<float4*>(drow + c) =
 			    make_float4(from_key<NONNEG>(k.x), from_key<NONNEG>(k.y), from_key<NONNEG>(k.z), from_key<NONNEG>(k.w));
+			if constexpr (SOFT) {
+				if (a.mh_dst) {
+					const int4 m = *reinterpret_cast<const int4*>(&srt[(g >> 4) * RSTR + (g & 15)]);
+					float* mrow = a.mh_dst + (long long)st * a.mh_stream_stride + (long long)row * cols;
+					*reinterpret_cast<float4*>(mrow + c) =
+					    make_float4(__int_as_float(m.x), __int_as_float(m.y), __int_as_float(m.z), __int_as_float(m.w));
+				}
+			}
 		}
 	}
 }

@@ -224,9 +224,7 @@ constexpr int HERM_THREADS = 448;
 // words in LDS, in the synthesis threads' order (stft.h IstftArgs::bits_t): bin k at word k mod cols/16, bits 2*(k /
 // (cols/16)); a bin of the lower half also at its mirror image's place unless that lies among the last `mid` bins, whose
 // own P comes from the tail chunks.  The workgroup holds whole rows, so it writes finished words.
-// SOFT (FilterArgs::soft_rows): the soft masks of the chunk's bins instead of P (H read as for BITS), stored where P
-// would have gone; the harmonic mask in FilterArgs::mh_dst.
-template <int W, bool NONNEG, bool BITS = false, bool SOFT = false>
+template <int W, bool NONNEG, bool BITS = false>
 __global__ __launch_bounds__(HERM_THREADS) void median_net_freq_herm_kernel(FilterArgs a, RowMap rm, int n_lo, int n_tail,
                                                                             int lwv, int twv)
 {
@@ -310,24 +308,6 @@ __global__ __launch_bounds__(HERM_THREADS) void median_net_freq_herm_kernel(Filt
 		return;
 	}
 	znet::medians<W, T, W + T - 1>(e, out);
-	if constexpr (SOFT) {
-		const int c0 = tail ? c_t0 + T * (j - n_lo) : T * j;
-		const float* hrow = a.hrows + (long long)blockIdx.y * a.h_stream_stride + (long long)(row0 + rr) * cols;
-		const MaskCfg mc{0.0f, 0.0f, 1, a.soft_power, 0, 0, 0};
-		float mh[T];
-#pragma unroll
-		for (int i = 0; i < T; ++i) {
-			const float hf = hrow[tail ? cols - (c0 + i) : c0 + i], pf = __int_as_float(out[i]);
-			mh[i] = a.need_hm ? hmask_value(hf, pf, mc) : 0.0f;
-			out[i] = __float_as_int(a.need_pm ? pmask_value(hf, pf, mc) : 0.0f);
-		}
-		if (a.mh_dst) {
-			float* dm = a.mh_dst + (long long)blockIdx.y * a.mh_stream_stride + (long long)(row0 + rr) * cols + c0;
-#pragma unroll
-			for (int i = 0; i < T; ++i)
-				dm[i] = mh[i];
-		}
-	}
 	float* d = a.dst + (long long)blockIdx.y * a.dst_stream_stride + (long long)(row0 + rr) * cols + (tail ? c_t0 + T * (j - n_lo) : T * j);
 #pragma unroll
 	for (int v = 0; v < T / 4; ++v) {
@@ -497,13 +477,6 @@ int launch_freq(const FilterArgs& a, const RowMap& rm, hipStream_t stream, int* 
 				                   twv);
 				ZH_HIP(hipGetLastError());
 				*bits_done = 2;
-				return ZEN_HIP_OK;
-			}
-			if (bits_done && a.soft_rows && a.hrows && a.nonneg) { // soft masks instead of P
-				hipLaunchKernelGGL((median_net_freq_herm_kernel<W, true, false, true>), g, dim3(HERM_THREADS), lds, stream, a, rm, n_lo, n_tail,
-				                   lwv, twv);
-				ZH_HIP(hipGetLastError());
-				*bits_done = 3;
 				return ZEN_HIP_OK;
 			}
 			if (a.nonneg)
