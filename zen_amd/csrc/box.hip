@@ -43,10 +43,19 @@ __global__ __launch_bounds__(256) void box_freq_kernel(FilterArgs a, int segs_pe
 	const float* __restrict__ srow = a.src + (long long)blockIdx.y * a.src_stream_stride + ring_row * cols;
 	float* __restrict__ drow = a.dst + (long long)blockIdx.y * a.dst_stream_stride + (long long)row * cols;
 	const int span = FREQ_OUTS + len - 1;
-	for (int g = tid; g < span; g += 256) {
-		int c = col0 - mid + g;
-		c = c < 0 ? 0 : (c > cols - 1 ? cols - 1 : c); // replicate border (ippBorderRepl)
-		tile[g] = pre_of(srow[c], a.sse_pre);
+	{ // all staging loads in flight together (span <= FREQ_OUTS + MAX_LEN - 1: five turns of 256)
+		constexpr int NT = (FREQ_OUTS + MAX_LEN - 1 + 255) / 256;
+		float v[NT];
+#pragma unroll
+		for (int u = 0; u < NT; ++u) {
+			int c = col0 - mid + tid + 256 * u;
+			c = c < 0 ? 0 : (c > cols - 1 ? cols - 1 : c); // replicate border (ippBorderRepl); past the span: not stored
+			v[u] = srow[c];
+		}
+#pragma unroll
+		for (int u = 0; u < NT; ++u)
+			if (tid + 256 * u < span)
+				tile[tid + 256 * u] = pre_of(v[u], a.sse_pre);
 	}
 	__syncthreads();
 	const float flen = (float)len;
@@ -80,10 +89,21 @@ __global__ __launch_bounds__(256) void box_time_kernel(FilterArgs a, int rows_pe
 	const long long ar0 = a.first_row + q0;
 	const int nrows = nq + len - 1;
 	if (col < cols) {
-		for (int i = rl; i < nrows; i += 4) {
-			long long r = ar0 - mid + i;
-			r = r < a.clamp_lo ? a.clamp_lo : (r > a.clamp_hi ? a.clamp_hi : r);
-			tile[i * TIME_COLS + lane_col] = pre_of(src[(r % a.ring_rows) * cols + col], a.sse_pre);
+		// eight rows per turn, their loads in flight together (one row per turn was a trip to memory per row: up to 36 in
+		// a row); a row past the tile reads the tile's last row again and is not stored
+		for (int i0 = rl; i0 < nrows; i0 += 32) {
+			float v[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				const int i = i0 + 4 * u < nrows ? i0 + 4 * u : nrows - 1;
+				long long r = ar0 - mid + i;
+				r = r < a.clamp_lo ? a.clamp_lo : (r > a.clamp_hi ? a.clamp_hi : r);
+				v[u] = src[(r % a.ring_rows) * cols + col];
+			}
+#pragma unroll
+			for (int u = 0; u < 8; ++u)
+				if (i0 + 4 * u < nrows)
+					tile[(i0 + 4 * u) * TIME_COLS + lane_col] = pre_of(v[u], a.sse_pre);
 		}
 	}
 	__syncthreads();
