@@ -198,13 +198,25 @@ __global__ __launch_bounds__(64) void median_big_tail_kernel(FilterArgs a, int r
 	const int rows_here = a.n_out_rows - row0 < TAIL_ROWS ? a.n_out_rows - row0 : TAIL_ROWS;
 	const float* src_s = a.src + (long long)st * a.src_stream_stride;
 	const int blkA = nblk >> 1, blkB = nblk - NT; // first output block of either piece
-	for (int wi = lane; wi < rows_here * NRAW * 4; wi += 64) {
-		const int rr = wi / (NRAW * 4), vi = wi - rr * (NRAW * 4);
-		const float* srow = src_s + (long long)((row_base + row0 + rr) % ring) * cols;
-		const bool pb = vi >= NRAW_A * 4;
-		const int v = pb ? vi - NRAW_A * 4 : vi;
-		const int vc = 16 * ((pb ? blkB : blkA) - HALO_L) + 4 * v;
-		*reinterpret_cast<int4*>(&raw[(rr * NRAW + (vi >> 2)) * RSTR + 4 * (vi & 3)]) = row_vec_keys<NONNEG>(srow, vc, cols, 1);
+	for (int w0 = lane; w0 < rows_here * NRAW * 4; w0 += 256) { // four vectors per turn, their loads in flight together
+		int4 kv[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const int wi = w0 + 64 * u < rows_here * NRAW * 4 ? w0 + 64 * u : rows_here * NRAW * 4 - 1; // (past the end: loaded again, not stored)
+			const int rr = wi / (NRAW * 4), vi = wi - rr * (NRAW * 4);
+			const float* srow = src_s + (long long)((row_base + row0 + rr) % ring) * cols;
+			const bool pb = vi >= NRAW_A * 4;
+			const int v = pb ? vi - NRAW_A * 4 : vi;
+			kv[u] = row_vec_keys<NONNEG>(srow, 16 * ((pb ? blkB : blkA) - HALO_L) + 4 * v, cols, 1);
+		}
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const int wi = w0 + 64 * u;
+			if (wi < rows_here * NRAW * 4) {
+				const int rr = wi / (NRAW * 4), vi = wi - rr * (NRAW * 4);
+				*reinterpret_cast<int4*>(&raw[(rr * NRAW + (vi >> 2)) * RSTR + 4 * (vi & 3)]) = kv[u];
+			}
+		}
 	}
 	__syncthreads();
 	for (int ws = lane; ws < rows_here * NSORT; ws += 64) { // sorted entry s of a piece = raw chunk s + 2 of that piece
