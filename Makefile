@@ -13,7 +13,7 @@ test-gpu: build   ## bit-exact parity through the C-ABI (needs an MI355X)
 	$(PY) -m pytest tests -q -m gpu
 
 test-asan:        ## oracle + WAV reader under ASAN+UBSAN here; add the C++ host mirror on a GPU box (pytest -m gpu)
-	$(PY) -m pytest tests/test_sanitizers.py -q
+	$(PY) -m pytest tests/test_sanitizers.py -q -m "not gpu"
 
 test-ubsan:       ## the restatement alone under UBSAN (same driver, prints the checksum)
 	$(MAKE) -s -C oracle san_driver_ubsan && oracle/san_driver_ubsan
