@@ -51,14 +51,19 @@ struct Plan {
 		return a;
 	}
 	static constexpr int TF = N / 16;            // threads per frame: 16 complex values each
-	static constexpr int LDS_FLOAT2 = N + N / 16; // padded frame image in LDS
+	// One 8-byte slot of padding per 2^PAD_SHIFT keeps the stride-R accesses of the late passes off a single bank: per
+	// 16 up to nfft 4096 (34.8 KB per 256 threads: four workgroups per CU); per 8 at nfft 8192 / 16384, where a CU holds
+	// two / one frame anyway (73.7 / 147 KB) and the denser padding measured -3.5 % (synthesis) / -2.6 % (analysis) per
+	// offline batch step (at the small sizes it measured +3 %, in the fused kernel +11 %; none: +25..60 %)
+	static constexpr int PAD_SHIFT = LOG2N >= 13 ? 3 : 4;
+	static constexpr int LDS_FLOAT2 = N + (N >> PAD_SHIFT); // padded frame image in LDS
+	static __device__ __forceinline__ int pad(int i) { return i + (i >> PAD_SHIFT); }
 	static constexpr int FRAMES_PER_BLOCK = (TF >= 256) ? 1 : 256 / TF;
 	static constexpr int THREADS = TF * FRAMES_PER_BLOCK;
 };
 
-// one 8-byte slot of padding per 16 keeps the stride-R reads of the late passes off a single bank
-// (an unpadded XOR-swizzled image, 5 instead of 4 workgroups per CU, measured no faster)
-__device__ __forceinline__ int lds_pad(int i) { return i + (i >> 4); }
+// (Plan::pad: the padded position of element i of a frame image; an unpadded XOR-swizzled image, 5 instead of 4
+// workgroups per CU, measured no faster)
 
 // PK: two-lane float arithmetic, which the backend maps to the packed instructions (v_pk_mul_f32 / v_pk_add_f32: two
 // results per lane and cycle); every lane's product and sum is rounded separately, as in the scalar form.  The
@@ -321,7 +326,7 @@ struct PassRunner {
 					v[i][m] = in(m * J + j, /*slot=*/m * NB + i);
 				}
 				else {
-					v[i][m] = lds[lds_pad((k * R + m) * J + j)];
+					v[i][m] = lds[PL::pad((k * R + m) * J + j)];
 				}
 			}
 		}
@@ -342,7 +347,7 @@ struct PassRunner {
 					}
 				}
 				else {
-					lds[lds_pad(idx)] = v[i][c];
+					lds[PL::pad(idx)] = v[i][c];
 				}
 			}
 		}
