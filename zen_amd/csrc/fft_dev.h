@@ -51,13 +51,13 @@ struct Plan {
 		return a;
 	}
 	static constexpr int TF = N / 16;            // threads per frame: 16 complex values each
-	// One 8-byte slot of padding per 2^PAD_SHIFT keeps the stride-R accesses of the late passes off a single bank.  Per 8
-	// where a late pass reads runs of 8 values (nfft 1024, 2048, 8192, 16384: with one slot per 16 two such runs share
-	// banks): nfft 16384 synthesis -3.5 % (soft masks -10 %), analysis -2.6 %, nfft 1024 analysis -3.5 % per offline batch
-	// step; a CU still holds four workgroups of 256 threads (36.9 KB each), two frames of 8192, one of 16384 (147 KB).  Per
-	// 16 elsewhere: at nfft 4096 the denser padding cost the fused kernel 11 % (its lean layout lives inside the image);
-	// no padding at all: +25..60 %.
-	static constexpr int PAD_SHIFT = (LOG2N >= 13 || LOG2N == 10 || LOG2N == 11) ? 3 : 4;
+	// One 8-byte slot of padding per 2^PAD_SHIFT keeps the stride-R accesses of the late passes off a single bank: per
+	// 16 up to nfft 4096 (34.8 KB per 256 threads: four workgroups per CU); per 8 at nfft 8192 / 16384, where a late pass
+	// reads runs of 8 values (with one slot per 16 two such runs share banks) and a CU holds two / one frame anyway (73.7
+	// / 147 KB): synthesis -3.5 % (soft masks -10 %), analysis -2.6 % per offline batch step.  At nfft 1024 / 2048 the
+	// same padding gains 3.5 % in the analysis and loses 20 % in the soft-mask synthesis (its build then spills); at
+	// nfft 4096 it costs the fused kernel 11 % (its lean layout lives inside the image); no padding at all: +25..60 %.
+	static constexpr int PAD_SHIFT = LOG2N >= 13 ? 3 : 4;
 	static constexpr int LDS_FLOAT2 = N + (N >> PAD_SHIFT); // padded frame image in LDS
 	static __device__ __forceinline__ int pad(int i) { return i + (i >> PAD_SHIFT); }
 	static constexpr int FRAMES_PER_BLOCK = (TF >= 256) ? 1 : 256 / TF;
