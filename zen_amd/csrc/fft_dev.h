@@ -127,6 +127,15 @@ struct TwGlobal {
 	__device__ __forceinline__ float2 get(int, int, int, int idx) const { return p[idx]; }
 };
 
+// the table staged in LDS by the kernel (synthesis at nfft <= 2048: a table read costs the LDS a cycle, not the vector
+// memory path 8 bytes per lane -- per frame the three passes ask it for 12 KB of twiddles, more than the spectrum)
+struct TwLds {
+	static constexpr bool PLAIN = true;
+	static constexpr bool PACKED = true;
+	const float2* p;
+	__device__ __forceinline__ float2 get(int, int, int, int idx) const { return p[idx]; }
+};
+
 // PLAIN = false: the registers hold something else than the transform's own table (rt_wide.hip's second step)
 template <int LOG2N, bool PLAIN_ = true>
 struct TwRegs {
@@ -374,6 +383,12 @@ __device__ __forceinline__ void fft_frame(int tf, float2* __restrict__ lds, cons
 {
 	const TwGlobal g{tw};
 	PassRunner<LOG2N, 0, INV, ZU, HALF_OUT, In, Out, SYNC_FIRST, TwGlobal>::run(tf, lds, g, in, out, active);
+}
+// the same with the table in LDS (TwLds)
+template <int LOG2N, bool INV, bool ZU, bool HALF_OUT, class In, class Out, bool SYNC_FIRST = false>
+__device__ __forceinline__ void fft_frame(int tf, float2* __restrict__ lds, const TwLds& tw, In& in, Out& out, bool active)
+{
+	PassRunner<LOG2N, 0, INV, ZU, HALF_OUT, In, Out, SYNC_FIRST, TwLds>::run(tf, lds, tw, in, out, active);
 }
 // the same with the twiddles already in registers (TwRegs::fill)
 template <int LOG2N, bool INV, bool ZU, bool HALF_OUT, class In, class Out, bool SYNC_FIRST = false>

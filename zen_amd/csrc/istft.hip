@@ -159,6 +159,11 @@ __device__ __forceinline__ void load_carry(const float* carry, int tf, bool want
 		cv[i] = wanted ? carry[tf + i * TF] : 0.0f;
 }
 
+// nfft 512 .. 2048: the twiddle table lives in LDS (4 / 8 KB behind the 34.8 KB of frame images: still four workgroups per CU)
+constexpr bool istft_tw_in_lds(int log2n) { return log2n >= 9 && log2n <= 10; }
+template <int LOG2N>
+constexpr size_t istft_lds_bytes() { return lds_bytes<LOG2N>() + (istft_tw_in_lds(LOG2N) ? sizeof(float2) * (size_t)(Plan<LOG2N>::N / 2) : 0); }
+
 // (four waves per SIMD: with every load of the first pass in flight at once the max-ILP schedule otherwise takes 130 to
 // 200 registers -- three or two waves, and at nfft 8192 one workgroup per CU instead of two)
 // Exactly four: the LDS image (34.8 KB per 256 threads at every size) allows no more, and a scheduler that believes in
@@ -168,6 +173,7 @@ template <int LOG2N, int MODE>
 __global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) void istft_kernel(IstftArgs a)
 {
 	using PL = Plan<LOG2N>;
+	constexpr bool TW_IN_LDS = istft_tw_in_lds(LOG2N);
 	extern __shared__ float2 lds[];
 	const int tid = threadIdx.x, s = blockIdx.z, oi = blockIdx.y;
 	const int slot = tid / PL::TF, tf = tid - slot * PL::TF;
@@ -198,7 +204,17 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) __attribute__((amdgpu_wave
 	load_carry<PL::TF>(a.carry[oi] + (long long)s * a.hop, tf, out.ready != nullptr, cv);
 	out.cv = cv;
 	out.hop = a.hop;
-	zfft::fft_frame<LOG2N, true, false, true>(tf, lds + slot * PL::LDS_FLOAT2, a.tw, in, out, active);
+	if constexpr (TW_IN_LDS) { // the twiddle table (nfft/2 entries) behind the frame images, staged by the workgroup
+		float2* twl = lds + PL::FRAMES_PER_BLOCK * PL::LDS_FLOAT2;
+		for (int i = tid; i < PL::N / 2; i += PL::THREADS)
+			twl[i] = a.tw[i];
+		__syncthreads();
+		const zfft::TwLds tl{twl};
+		zfft::fft_frame<LOG2N, true, false, true>(tf, lds + slot * PL::LDS_FLOAT2, tl, in, out, active);
+	}
+	else {
+		zfft::fft_frame<LOG2N, true, false, true>(tf, lds + slot * PL::LDS_FLOAT2, a.tw, in, out, active);
+	}
 	if (a.n_frames == 1 && a.publish_seq && a.ready[oi]) { // see rt_fused.hip publish_ready (a.n_frames == 1: one frame per block)
 		__threadfence_system();
 		__syncthreads();
@@ -422,8 +438,8 @@ int launch_istft_t(const IstftArgs& a, hipStream_t stream)
 		auto kern = (a.n_out == 1 && a.out_id[0] == 0) ? istft_kernel<LOG2N, 2> : istft_kernel<LOG2N, 1>;
 		if (a.bits_t)
 			kern = istft_kernel<LOG2N, 3>;
-		ZH_TRY(set_lds(kern, lds_bytes<LOG2N>()));
-		hipLaunchKernelGGL(kern, grid, dim3(PL::THREADS), lds_bytes<LOG2N>(), stream, a);
+		ZH_TRY(set_lds(kern, istft_lds_bytes<LOG2N>()));
+		hipLaunchKernelGGL(kern, grid, dim3(PL::THREADS), istft_lds_bytes<LOG2N>(), stream, a);
 		ZH_HIP(hipGetLastError());
 		return ZEN_HIP_OK;
 	}
@@ -438,8 +454,8 @@ int launch_istft_t(const IstftArgs& a, hipStream_t stream)
 		if (hp)
 			kern = istft_kernel<LOG2N, 5>;
 	}
-	ZH_TRY(set_lds(kern, lds_bytes<LOG2N>()));
-	hipLaunchKernelGGL(kern, grid, dim3(PL::THREADS), lds_bytes<LOG2N>(), stream, a);
+	ZH_TRY(set_lds(kern, istft_lds_bytes<LOG2N>()));
+	hipLaunchKernelGGL(kern, grid, dim3(PL::THREADS), istft_lds_bytes<LOG2N>(), stream, a);
 	ZH_HIP(hipGetLastError());
 	return ZEN_HIP_OK;
 }
