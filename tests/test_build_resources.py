@@ -59,3 +59,26 @@ def test_every_kernel_fits_the_lds(usage):
     for src, ks in usage.items():
         for name, k in ks.items():
             assert k.get("lds", 0) <= 160 * 1024, (src, name)
+
+
+def test_offline_transform_kernels_keep_four_waves_and_do_not_spill(usage):
+    """The block builds of the synthesis kernel the offline path runs (mask bits: MODE 3; soft-mask rows: MODE 7 at nfft
+    16384) and the analysis kernels: at most 128 VGPRs (four waves per SIMD: what their LDS images allow) and no scratch.
+    Round 3 found them waiting for sixteen dependent loads per frame; with the loads in flight together the register
+    allocation is what decides between 0.55 and 0.68 ms (the soft-mask build at nfft 1024 under a denser image padding)."""
+    for name in ("istft_kernel<10, 3>", "istft_kernel<14, 3>", "istft_kernel<13, 3>", "istft_kernel<10, 5>"):
+        k = kernel(usage, "istft.hip", name)
+        assert k["vgprs"] <= 128 and k["scratch"] == 0, (name, k)
+    k = kernel(usage, "istft.hip", "istft_kernel<14, 7>")
+    assert k["vgprs"] <= 128 and k["scratch"] <= 48, k      # 36 bytes as measured (1.30 ms per offline-long step)
+    for name in ("stft_kernel<10>", "stft_kernel<14>"):
+        k = kernel(usage, "stft.hip", name)
+        assert k["vgprs"] <= 128 and k["scratch"] == 0, (name, k)
+
+
+def test_long_mask_kernel_budget(usage):
+    """median_big_kernel<187>: 256 VGPRs, two workgroups per CU, a handful of spilled registers (0.94 -> 0.73 ms when the
+    minimum-register scheduler brought 56 spilled registers down to 4, round 2)."""
+    for name in ("median_big_kernel<187, true, true, false>", "median_big_kernel<187, true, false, true>"):
+        k = kernel(usage, "median_big.hip", name)
+        assert k["occupancy"] >= 2 and k["scratch"] <= 48, (name, k)
