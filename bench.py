@@ -195,7 +195,7 @@ def cpu_baseline_offline_all_cores(hop_h, hop_p, seconds=4.0):
             "host_threads_visible": os.cpu_count(), "host_threads_usable": cores}
 
 
-def offline_rooflines(prof, steps, frames, nfft, hop, n_out1, copy_bw, freq_mask):
+def offline_rooflines(prof, steps, frames, nfft, hop, n_out1, copy_bw, freq_mask, soft=False):
     """Per-kernel HBM rooflines of the two offline passes from the engines' HIP-event timings.
 
     Algorithmic bytes per frame (SURVEY 8(d) accounting: compulsory traffic of each
@@ -204,7 +204,10 @@ def offline_rooflines(prof, steps, frames, nfft, hop, n_out1, copy_bw, freq_mask
       freq_filter : 8 B per element (4 read + 4 written) of the frames x nfft matrix; where the engine filters
                     half rows of the frames x (nfft/2 + 1 + mask/2) it needs
       time_filter : 8 B per element of frames x nfft, or of frames x (nfft/2 + 1) with half rows
-      istft       : per output 8*(nfft/2+1) spectrum + 8*(nfft/2+1) H and P in + 4*nwin out
+      istft       : what the kernel moves since the masks travel as bits (round 3): the spectrum ONCE 8*(nfft/2+1), one
+                    word of mask bits per 16 bins (nfft/4 bytes), and per output 4*nwin = 8*hop written.  Soft masks: pass 1
+                    loads one mask value per bin and output (4*(nfft/2+1) each) instead of the bits, pass 2 loads H and P
+                    (8*(nfft/2+1)).  (Rounds 1-3 priced it as S + H + P per OUTPUT, which the kernels no longer read.)
       finalize    : per output 12*hop (two half frames in, one hop out)"""
     out = {}
     for ps in ("pass1", "pass2"):
@@ -215,7 +218,9 @@ def offline_rooflines(prof, steps, frames, nfft, hop, n_out1, copy_bw, freq_mask
         per_frame = {"stft": 4 * h + 12 * (N // 2 + 1),
                      "freq_filter": 8 * (N // 2 + 1 + mf // 2) if half else 8 * N,
                      "time_filter": 8 * (N // 2 + 1) if half else 8 * N,
-                     "istft": nout * (16 * (N // 2 + 1) + 8 * h), "finalize": nout * 12 * h}
+                     "istft": 8 * (N // 2 + 1) + nout * 8 * h
+                     + ((nout * 4 * (N // 2 + 1) if ps == "pass1" else 8 * (N // 2 + 1)) if soft else N // 4),
+                     "finalize": nout * 12 * h}
         for k, v in prof[ps].items():
             if not v["launches"] or k not in per_frame:
                 continue
@@ -233,6 +238,16 @@ def offline_rooflines(prof, steps, frames, nfft, hop, n_out1, copy_bw, freq_mask
             "share_of_kernel_time": d["ms_per_step"] / sum(v["ms_per_step"] for v in out.values()),
             "note": "dominant kernel of the step by HIP-event time; every kernel's line is in `kernels`"}
     return roof, out
+
+
+def whole_step_roofline(frames, nfft, hop, n_out, ms_per_step):
+    """The whole offline step on SURVEY 8(d)'s per-frame minimum (fused_bytes_per_hop: 24*(nfft/2+1) + 8*hop for one
+    output, every further output reads the spectrum again and writes its hop), both passes, over the step's wall time."""
+    tot = sum(frames[ps] * fused_bytes_per_hop(nfft[ps], hop[ps], n_out[ps]) for ps in frames)
+    ach = tot / (ms_per_step * 1e-3) / 1e9
+    return {"bound": "hbm", "algorithmic_bytes_per_step": tot, "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+            "per_frame_bytes": {ps: fused_bytes_per_hop(nfft[ps], hop[ps], n_out[ps]) for ps in frames},
+            "note": "SURVEY 8(d) per-frame minimum of the batched pipeline x frames of both passes / wall time of the step"}
 
 
 def device_copy_bandwidth(zen_amd, n_floats=1 << 28, iters=10):
@@ -340,6 +355,21 @@ def traffic_record(kernel, elems):
                                          "FETCH doubled per the gfx950 correction; build %s)" % (TRAFFIC_FILE, tj.get("build", "?")))
 
 
+def valu_issue_frac(kernel, elems, launch_s):
+    """Share of the chip's VALU issue slots a launch uses: SQ_INSTS_VALU (wave instructions per launch, from the committed
+    PMC pass of this exact kernel and shape) x 2 cycles per wave64 instruction (MI355X_MICROARCH.md: 32 lanes per cycle)
+    over 1024 SIMDs x 2.4 GHz x the launch duration measured in THIS run.  Half-rate instructions (v_min / v_max / v_med3,
+    f64) take two such slots each, so a kernel made of them saturates well below 1.0; null without a record."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE))).get("kernels", {}).get(kernel)
+    except (OSError, ValueError):
+        return None
+    if not rec or int(rec.get("elements", -1)) != int(elems) or launch_s <= 0:
+        return None
+    n = rec.get("sq_counters_per_launch", {}).get("SQ_INSTS_VALU")
+    return None if not n else 2.0 * n / (1024 * 2.4e9 * launch_s)
+
+
 def fused_bytes_per_hop(nfft, hop, n_out):
     """SURVEY 8(d) per-frame minimum of the batched pipeline: 4*hop in, spectrum written + read 2*8*(nfft/2+1),
     magnitude written + read 2*4*(nfft/2+1), 4*hop out -- 24*(nfft/2+1) + 8*hop for one output; every further
@@ -401,11 +431,16 @@ def fused_roofline(run, S, M, steps, n_out, kernel, copy_bw):
     ach = bph * S * M / t_f / 1e9
     direct = run["breakdown"]["finalize"]["launches"] == fl["launches"] and \
         run["breakdown"]["finalize"]["ms"] < 0.5 * 0.05 * fl["launches"]   # the kernel wrote the finished hops itself (one fix-up launch only)
-    moved = 4 * HOP + n_out * 8 * HOP + (n_out * 4 * HOP if direct else 0)
+    # HBM-side bytes the launch asks for per hop: the hop's input (4*hop; the previous hop it also reads is the neighbouring
+    # workgroup's and comes from L2), per output the Y row of the frame (8*hop written) and -- where the kernel finishes the
+    # hops itself -- the two half rows of the hop 128 items back read again (8*hop) and the finished hop written (4*hop):
+    # 4*hop + n_out*20*hop (24 576 B for one output; DESIGN.md section 5 uses the same figure)
+    moved = 4 * HOP + n_out * 8 * HOP + (n_out * 12 * HOP if direct else 0)
     tr, src = traffic_record(kernel, S * M * nfft)
     return {
         "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-        "limiter": "valu-issue", "device_copy_GBps": copy_bw, "frac_of_device_copy": ach / copy_bw if copy_bw else None,
+        "limiter": "valu-issue", "valu_issue_frac": valu_issue_frac(kernel, S * M * nfft, t_f),
+        "device_copy_GBps": copy_bw, "frac_of_device_copy": ach / copy_bw if copy_bw else None,
         "traffic": tr, "traffic_source": src,
         "kernel": kernel + " (one workgroup per hop: STFT, |S|, 47-tap median, hard mask%s, iSTFT%s)"
                   % ("s" if n_out > 1 else "", " x%d" % n_out if n_out > 1 else ""),
@@ -417,16 +452,18 @@ def fused_roofline(run, S, M, steps, n_out, kernel, copy_bw):
         "avg_launch_ms": 1e3 * t_f, "launches": fl["launches"],
         "share_of_step": (fl["ms"] / 1e3) / run["dt"] if run["dt"] > 0 else None,
         "note": "`achieved`/`frac` price the launch with SURVEY 8(d)'s ALGORITHMIC bytes as the bench contract asks; the "
-                "kernel does not move them: spectrum, |S| and P stay in registers / LDS, its own HBM traffic is 4*hop read "
-                "+ 8*hop written per hop and output (`moved_GBps`, `traffic`), plus 4*hop per output where it finishes the hops itself "
-                "(the overlap-add through a same-XCD hand-off, no launch of its own).  Its limiter is VALU issue: "
-                "DESIGN.md section 5"}
+                "kernel does not move them: spectrum, |S| and P stay in registers / LDS, its own HBM-side traffic is 4*hop read "
+                "+ 8*hop written per hop and output, plus 8*hop read back and 4*hop written per output where it finishes the "
+                "hops itself (`hbm_bytes_moved_per_hop_by_design`, `moved_GBps`, `traffic`).  Its limiter is VALU issue "
+                "(`valu_issue_frac`: wave instructions x 2 cycles over the SIMD-cycles of the launch; half-rate min/max/med3 "
+                "and f64 instructions take two slots): DESIGN.md section 5"}
 
 
 def median_rooflines(zen_amd, run, S, M, copy_bw):
     """BASELINE's second metric.  burst: the kernel inside the three-kernel path of the engine (whole rows), 10 launches;
-    sustained: >= 1 s of back-to-back launches of the same kernel build through the drop-in wrapper on a magnitude
-    matrix (option "mfilt_nonneg"); cold: a 512 MiB write between launches, each launch timed on its own."""
+    sustained: >= 1 s of back-to-back launches through the plain drop-in wrapper (zen_hip_mfilt_run, no option, no
+    promise: the kernel checks the sign bits of every row it stages) on a magnitude matrix; cold: a 512 MiB write
+    between launches, each launch timed on its own."""
     eng, step = run["eng"], run["step"]
     zen_amd.set_option("no_block_fused", 1)
 
@@ -466,7 +503,6 @@ def median_rooflines(zen_amd, run, S, M, copy_bw):
     mat = rng.random((rows, cols), dtype=np.float32)       # magnitudes: >= +0
     src, dst = zen_amd.DeviceBuffer.from_host(mat), zen_amd.DeviceBuffer(rows * cols)
     del mat
-    zen_amd.set_option("mfilt_nonneg", 1)
     f = zen_amd.MedianFilterGPU(rows, cols, 47, zen_amd.FREQUENCY)
     for _ in range(5):
         f.filter(src, dst)
@@ -496,7 +532,6 @@ def median_rooflines(zen_amd, run, S, M, copy_bw):
         f.filter(src, dst)
         b.record()
         cold.append(a.elapsed_ms(b))
-    zen_amd.set_option("mfilt_nonneg", 0)
     for bfr in (src, dst, flush):
         bfr.free()
     cold.sort()
@@ -576,10 +611,10 @@ def offline_batch_run(zen_amd, zdist, grp, rank, world, C, clip_seconds, steps, 
                       "parallelism": "clips sharded x%d, no data-path collective" % world},
            "checksum": chk}
     if rooflines and rank == 0:
-        roof, kern = offline_rooflines(prof, steps, {"pass1": C * n1, "pass2": C * n2},
-                                       {"pass1": 4 * hop_h, "pass2": 4 * hop_p}, {"pass1": hop_h, "pass2": hop_p},
-                                       3, None, {"pass1": 187, "pass2": 13})
-        res.update({"roofline": roof, "kernels": kern})
+        fr, nf, hp = {"pass1": C * n1, "pass2": C * n2}, {"pass1": 4 * hop_h, "pass2": 4 * hop_p}, {"pass1": hop_h, "pass2": hop_p}
+        roof, kern = offline_rooflines(prof, steps, fr, nf, hp, 3, None, {"pass1": 187, "pass2": 13})
+        res.update({"roofline": roof, "kernels": kern,
+                    "whole_step": whole_step_roofline(fr, nf, hp, {"pass1": 3, "pass2": 1}, res["ms_per_step"])})
     first_clip = x[0].copy()
     eng = None
     for b in (d_in, d_h, d_p):
@@ -633,14 +668,257 @@ def offline_long_run(zen_amd, zdist, grp, rank, world, steps, warmup, settle_ms,
                       "parallelism": "each channel time-sharded x%d with warm-up halos, no exchange" % world},
            "checksum": chk}
     if rank == 0 and world == 1:
-        roof, kern = offline_rooflines(prof, steps, {"pass1": 2 * n1, "pass2": 2 * n2}, {"pass1": 4 * hop_h, "pass2": 4 * hop_p},
-                                       {"pass1": hop_h, "pass2": hop_p}, 2, None, {"pass1": 187, "pass2": 13})
-        res.update({"roofline": roof, "kernels": kern})
+        fr, nf, hp = {"pass1": 2 * n1, "pass2": 2 * n2}, {"pass1": 4 * hop_h, "pass2": 4 * hop_p}, {"pass1": hop_h, "pass2": hop_p}
+        roof, kern = offline_rooflines(prof, steps, fr, nf, hp, 2, None, {"pass1": 187, "pass2": 13}, soft=True)
+        res.update({"roofline": roof, "kernels": kern,
+                    "whole_step": whole_step_roofline(fr, nf, hp, {"pass1": 2, "pass2": 1}, res["ms_per_step"])})
     ch0 = chans[0]
     eng = None
     for bfr in d_in + [d_h, d_p]:
         bfr.free()
     return res, ch0, (n1, n2)
+
+
+def link_roof(zen_amd, n, reps=5):
+    """The host link's share of HPRIOffline::process on an n-sample clip, measured on this box with pinned buffers
+    through the library's own copies: 4n bytes up, 8n bytes down -- each alone, and both at once on two streams (the
+    roof of `offline_host`)."""
+    import ctypes as C
+    lib = zen_amd.load()
+    up, dn = zen_amd.IOGPU(n), [zen_amd.IOGPU(n), zen_amd.IOGPU(n)]     # host_out: plain pinned host memory
+    up.host_out[:] = 0.25
+    for d in dn:
+        d.host_out[:] = 0
+    d_up, d_dn = zen_amd.DeviceBuffer(n), zen_amd.DeviceBuffer(2 * n)
+    d_dn.zero()
+    s1, s2 = C.c_void_p(), C.c_void_p()
+    lib.zen_hip_stream_create(C.byref(s1))
+    lib.zen_hip_stream_create(C.byref(s2))
+
+    def run(do_up, do_down):
+        best = 1e30
+        for _ in range(reps):
+            zen_amd.synchronize()
+            t0 = time.perf_counter()
+            if do_up:
+                lib.zen_hip_memcpy_h2d_async(d_up.ptr, up.host_out.ctypes.data, 4 * n, s1)
+            if do_down:
+                for i, d in enumerate(dn):
+                    lib.zen_hip_memcpy_d2h_async(d.host_out.ctypes.data, d_dn.offset(i * n), 4 * n, s2)
+            zen_amd.synchronize(s1)
+            zen_amd.synchronize(s2)
+            best = min(best, time.perf_counter() - t0)
+        return 1e3 * best
+
+    res = {"h2d_ms": run(True, False), "d2h_ms": run(False, True), "both_ms": run(True, True)}
+    res["h2d_GBps"] = 4e-6 * n / res["h2d_ms"]
+    res["d2h_GBps"] = 8e-6 * n / res["d2h_ms"]
+    res["both_GBps"] = 12e-6 * n / res["both_ms"]
+    lib.zen_hip_stream_destroy(s1)
+    lib.zen_hip_stream_destroy(s2)
+    d_up.free()
+    d_dn.free()
+    del up, dn
+    return res
+
+
+def cpp_process_ms(seconds, reps=3):
+    """HPRIOffline<GPU>::process(std::vector<float>) through the C++ host mirror (zen_amd/libzen), timed like
+    zen/offline.h:141-147 by tools/offline_host.cpp: the by-value copy of the clip and the three result vectors included."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(tempfile.gettempdir(), "zen_offline_host_%d" % os.getpid())
+    zdir = os.path.join(ROOT, "zen_amd")
+    try:
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(zdir, "libzen"),
+                               os.path.join(ROOT, "tools", "offline_host.cpp"), "-o", exe, "-L", zdir, "-lzen", "-lzen_hip",
+                               "-Wl,-rpath," + zdir], stderr=subprocess.DEVNULL)
+        txt = subprocess.run([exe, str(seconds), str(reps)], capture_output=True, text=True, timeout=300).stdout
+        os.remove(exe)
+        return next(json.loads(ln) for ln in txt.splitlines() if ln.startswith("{"))
+    except Exception as exc:
+        return {"error": str(exc)[:200]}
+
+
+def offline_host_run(zen_amd, seconds=3600.0, reps=4, cpu_baseline=True, variants=False):
+    """What the reference's `zen offline` times (zen/offline.h:141-147): HPRIOffline<GPU>::process on HOST vectors,
+    wall clock, copies included -- zen_hip_hpri_process on a `seconds`-long mono S-music clip in plain (pageable) numpy
+    arrays, 4096/256, beta 2, hard masks.  Beside it: the link's roof measured on this box (4 B up + 8 B down per sample,
+    pinned, both directions at once), the kernels alone on the same time ranges (resident), the C++ mirror's
+    process(std::vector<float>) with its allocations, and the oracle timed the same way on a bounded sample."""
+    n = int(seconds * FS)
+    base = s_music(int(60 * FS), seed=4242)
+    x = np.tile(base, -(-n // base.size))[:n].copy()
+    outs = [np.zeros(n, np.float32) for _ in range(3)]                 # allocated and touched, like the caller's vectors
+    eng = zen_amd.HPRIOffline(FS, 4096, 256, BETA, BETA)
+    n1, n2 = eng.hop_counts(n)
+
+    def timed(opt=None, bufs=None):
+        for k, v in (opt or {}).items():
+            zen_amd.set_option(k, v)
+        try:
+            src, dst = (x, outs) if bufs is None else bufs
+            eng.process(src, out=tuple(dst))                           # warm-up: staging buffers, engine growth
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                eng.process(src, out=tuple(dst))
+                ts.append(1e3 * (time.perf_counter() - t0))
+            return {"wall_ms_min": min(ts), "wall_ms_median": sorted(ts)[len(ts) // 2], "x_realtime": seconds / (1e-3 * min(ts)),
+                    "stats": eng.host_stats()}
+        finally:
+            for k in (opt or {}):
+                zen_amd.set_option(k, 0)
+
+    main = timed()
+    chk = float(np.abs(outs[1][:4096]).sum())
+    res = {"metric": "x real time, HPRIOffline<GPU>::process on host vectors (zen/offline.h:141-147)", "unit": "x_realtime",
+           "clip_seconds": seconds, "value": main["x_realtime"], "wall_ms": main["wall_ms_min"], "wall_ms_median": main["wall_ms_median"], "reps": reps,
+           "hops_per_s": (n1 + n2) / (1e-3 * main["wall_ms_min"]), "host_stats": main["stats"], "checksum": chk,
+           "config": {"workload": "HPRIOffline<GPU>(44100, 4096, 256, 2.0, 2.0).process on a %.0f s mono S-music clip in pageable host "
+                                  "memory (numpy), three host outputs; zen_hip_hpri_process" % seconds,
+                      "samples": n, "hops_pass1": n1, "hops_pass2": n2, "bytes_up": 4 * n, "bytes_down": 8 * n}}
+    # ---- the serial path of rounds 1-3 (one range: up, both passes, down), same build
+    res["serial_one_range"] = timed({"offline_range": 1 << 30})
+    res["speedup_over_serial"] = res["serial_one_range"]["wall_ms_min"] / main["wall_ms_min"]
+    if variants:
+        res["no_register"] = timed({"offline_no_register": 1})
+        for r in (1 << 20, 1 << 21, 1 << 22, 1 << 24):
+            res["range_%d" % r] = timed({"offline_range": r})
+        try:
+            io = [zen_amd.IOGPU(n) for _ in range(3)]
+            io[0].host_out[:] = x
+            res["pinned_caller_buffers"] = timed(bufs=(io[0].host_out, [io[1].host_out, io[2].host_out, None]))
+            del io
+        except Exception as exc:
+            res["pinned_caller_buffers"] = {"error": str(exc)[:200]}
+    # ---- the kernels alone, same ranges, everything resident
+    st = main["stats"]
+    d_in, d_h, d_p = zen_amd.DeviceBuffer.from_host(x), zen_amd.DeviceBuffer(n), zen_amd.DeviceBuffer(n)
+    rng = int(st["range_samples"])
+
+    def compute():
+        for b in range(0, n, rng):
+            e = min(b + rng, n)
+            eng.process_range(d_in.ptr, n, b, e, d_h.offset(b), d_p.offset(b))
+        zen_amd.synchronize()
+
+    compute()
+    tc = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        compute()
+        tc.append(1e3 * (time.perf_counter() - t0))
+    for b in (d_in, d_h, d_p):
+        b.free()
+    eng = None
+    res["compute_ms"] = min(tc)
+    link = link_roof(zen_amd, n)
+    res["link"] = link
+    # The link is full duplex: the roof is the slower direction at the rate a pinned copy of that size gets on this box
+    # (8 B down per sample).  Two whole-clip copies issued at once on two streams do NOT overlap on this runtime (both_ms =
+    # the sum); the pipeline's 32 / 64 MB pieces do, which is why the call beats that figure.
+    roof_ms = max(link["h2d_ms"], link["d2h_ms"])
+    res["roofline"] = {"bound": "host link (PCIe, full duplex), pinned copies on this box", "roof_ms": roof_ms,
+                       "achieved_ms": main["wall_ms_min"], "frac": roof_ms / main["wall_ms_min"],
+                       "bytes_per_sample": {"up": 4, "down": 8}, "down_GBps_at_roof": link["d2h_GBps"],
+                       "achieved_down_GBps": 8e-6 * n / main["wall_ms_min"],
+                       "split_ms": {"h2d_alone": link["h2d_ms"], "d2h_alone": link["d2h_ms"], "both_issued_at_once": link["both_ms"],
+                                    "kernels_alone": res["compute_ms"]},
+                       "note": "roof = max(4 B up, 8 B down per sample) through pinned buffers at the rates measured in this run; "
+                               "the call itself works on the caller's pageable vectors (registered for the call)"}
+    res["cpp_process"] = cpp_process_ms(seconds)
+    if cpu_baseline:
+        from oracle import oracle as o
+        m = int(20 * FS)
+        ro = o.HPRIOffline(FS, 4096, 256, BETA, BETA)
+        t0 = time.perf_counter()
+        ro.process(x[:m])
+        dt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": (m / FS) / dt, "unit": "x_realtime", "cores": 1, "kind": "port",
+                               "sample": "first 20 s of the same clip, oracle HPRIOffline 4096/256 hard mask process() on host "
+                                         "vectors, 1 thread", "wall_s": dt, "host_cpu": host_cpu_name()}
+        res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+    return res
+
+
+def compact_line(full):
+    """The one line the driver keeps (it stores the contract keys, `config`, `roofline`, `cpu_baseline` and only the NAMES of
+    anything else, and cuts the tail of long lines): everything both BASELINE metrics and the north-star targets need sits
+    inside those four; the per-kernel tables of every leg go to the detail file (`--detail`: print them instead)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "x_realtime", "ranks_reported", "checksum")
+    line = {k: full[k] for k in keep if k in full}
+    cfg = dict(full.get("config", {}))
+    legs = {}
+    for name in ("offline_batch", "offline_long", "offline_batch_sharded"):
+        leg = full.get(name)
+        if leg:
+            cfg[name + "_x_realtime"] = leg.get("x_realtime")
+            legs[name] = {"x_realtime": leg.get("x_realtime"), "ms_per_step": leg.get("ms_per_step"), "hops_per_s": leg.get("value"),
+                          "whole_step_frac_of_hbm_roof": leg.get("whole_step", {}).get("frac")}
+            if name == "offline_batch_sharded":
+                cfg["offline_batch_sharded_ranks_reported"] = leg.get("ranks_reported")
+                cfg["offline_batch_sharded_clips_total"] = leg.get("config", {}).get("clips_total")
+    oh = full.get("offline_host")
+    if oh:
+        cfg["offline_host_x_realtime"] = oh.get("value")
+        legs["offline_host"] = {"x_realtime": oh.get("value"), "wall_ms": oh.get("wall_ms"), "clip_seconds": oh.get("clip_seconds"),
+                                "frac_of_link_roof": oh.get("roofline", {}).get("frac"),
+                                "link_roof_ms": oh.get("roofline", {}).get("roof_ms"), "kernels_alone_ms": oh.get("compute_ms"),
+                                "serial_one_range_ms": oh.get("serial_one_range", {}).get("wall_ms_min"),
+                                "cpp_process_ms": oh.get("cpp_process", {}).get("ms_min"),
+                                "cpp_process_moved_ms": oh.get("cpp_process", {}).get("moved_ms_min"),
+                                "cpu_oracle_x_realtime": oh.get("cpu_baseline", {}).get("value")}
+    for name in ("all_outputs", "s_noise", "sse_block"):
+        if name in full:
+            cfg[name + "_hops_per_s"] = full[name].get("value")
+    if "realtime" in full:
+        cfg["per_hop_api_us"] = full["realtime"].get("us_per_hop")
+        cfg["per_hop_api_hops_per_s"] = full["realtime"].get("hops_per_s")
+    line["config"] = cfg
+    if legs:
+        line["legs"] = legs
+    if "roofline" in full:
+        r = full["roofline"]
+        roof = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "limiter", "valu_issue_frac",
+                                      "avg_launch_ms", "launches", "hops_per_launch", "algorithmic_bytes_per_hop",
+                                      "hbm_bytes_moved_per_hop_by_design", "device_copy_GBps", "algorithmic_bytes_per_frame",
+                                      "frames_per_step", "roof_ms", "achieved_ms", "split_ms", "elements_per_launch") if k in r}
+        m = full.get("roofline_median")
+        if m:      # BASELINE's second metric, where the driver's record keeps it
+            roof["median47"] = {"kernel": K_MEDIAN_WHOLE, "shape": "%d x %d, 47 taps, frequency direction" % (m["rows"], m["cols"]),
+                                "algorithmic_bytes_per_element": 8, "frac": m["frac"], "GBps": m["achieved"],
+                                "sustained": {"frac": m["sustained"]["frac"], "avg_launch_us": 1e3 * m["sustained"]["avg_launch_ms"],
+                                              "launches": m["sustained"]["launches"], "seconds": m["sustained"]["seconds"]},
+                                "burst_frac": m["burst"]["frac"], "cold_frac": m["cold"]["frac"],
+                                "traffic": m.get("traffic"), "frac_of_device_copy": m.get("frac_of_device_copy"),
+                                "through": "plain zen_hip_mfilt_run, no option, no promise"}
+        line["roofline"] = roof
+    if "cpu_baseline" in full:
+        c = full["cpu_baseline"]
+        line["cpu_baseline"] = {k: c.get(k) for k in ("value", "unit", "cores", "kind", "sample", "host_cpu") if k in c}
+        if "gpu_over_cpu" in full:
+            line["gpu_over_cpu"] = full["gpu_over_cpu"]
+    return line
+
+
+def emit(full, detail):
+    """Rank 0: the compact line on stdout; the full record to gpurun_out/bench_detail.json when that directory can be
+    written (it is what profiles/rNN_*_bench_default.json is copied from), or instead of the compact line with --detail."""
+    if detail:
+        print(json.dumps(full))
+        return
+    line = compact_line(full)
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "bench_detail.json"), "w") as f:
+            json.dump(full, f)
+        line["detail"] = "gpurun_out/bench_detail.json (per-kernel tables of every leg; `--detail` prints it)"
+    except OSError:
+        pass
+    print(json.dumps(line))
 
 
 def dry_main(args, zdist):
@@ -691,7 +969,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="realtime_block", choices=["realtime_block", "offline_batch", "offline_long"])
+    ap.add_argument("--workload", default="realtime_block", choices=["realtime_block", "offline_batch", "offline_long", "offline_host"])
+    ap.add_argument("--host-seconds", type=float, default=3600.0, help="offline_host: length of the clip")
+    ap.add_argument("--host-variants", action="store_true", help="offline_host: also time range lengths / unregistered / pinned buffers")
     ap.add_argument("--hops", type=int, default=25840, help="hops per step per stream (25840 = 10 min)")
     ap.add_argument("--streams", type=int, default=1, help="independent streams per GPU")
     ap.add_argument("--clips", type=int, default=64, help="offline_batch: clips per GPU")
@@ -714,6 +994,7 @@ def main():
                          "settled when the timed region starts (the timed region is still exactly K steps)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (nccl = RCCL over xGMI; gloo for the CPU plumbing test)")
+    ap.add_argument("--detail", action="store_true", help="print the full record (every leg's per-kernel tables) instead of the compact line")
     ap.add_argument("--dry", action="store_true",
                     help="no GPU: run only the launch / sharding / aggregation plumbing with empty steps "
                          "(CPU tests; the line says dry: true and is not a measurement)")
@@ -742,7 +1023,8 @@ def main():
         # on one device); never a measurement configuration
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    grp = zdist.Group(args.backend, torch.device("cuda", local_rank) if args.backend == "nccl" else None)
+    grp = zdist.Group(args.backend, torch.device("cuda", local_rank) if args.backend == "nccl" else None,
+                      force=bool(os.environ.get("ZEN_FORCE_PROCESS_GROUP")))
 
     import zen_amd
     zen_amd.init(local_rank)
@@ -860,6 +1142,8 @@ def main():
                 if not args.no_cpu_baseline:
                     ol["cpu_baseline"] = cpu_baseline_offline(ch0, 4096, 256, m1 + m2, seconds=4.0, beta=2.5, soft=True)
                 out["offline_long"] = ol
+                # -- the reference's own offline entry point: process() on host vectors, copies included
+                out["offline_host"] = offline_host_run(zen_amd, args.host_seconds, 4, not args.no_cpu_baseline)
             elif world > 1:
                 # -- the path that shards: the offline batch, clips dealt to the ranks, no data-path collective
                 ob, _, _ = offline_batch_run(zen_amd, zdist, grp, rank, world, args.leg_clips, args.clip_seconds, ls, lw, 100.0,
@@ -880,8 +1164,14 @@ def main():
             out.update(res)
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_offline(ch0, 4096, 256, n1 + n2, seconds=4.0, beta=2.5, soft=True)
+    elif args.workload == "offline_host":
+        if rank == 0:
+            res = offline_host_run(zen_amd, args.host_seconds, max(args.leg_steps, 3), not args.no_cpu_baseline, args.host_variants)
+            out.update(res)
+            out["ms_per_step"] = res["wall_ms"]
+            out["steps"], out["warmup"] = res["reps"], 1
     if rank == 0:
-        print(json.dumps(out))
+        emit(out, args.detail)
     grp.close()
 
 

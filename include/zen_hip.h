@@ -68,7 +68,9 @@ int zen_hip_event_create(void** event);
 int zen_hip_event_record(void* event, void* stream);
 int zen_hip_event_elapsed_ms(void* start, void* stop, float* ms);
 int zen_hip_event_destroy(void* event);
-/* process-wide tuning/debug switches (no reference counterpart; atomics, may be set from any thread).
+/* process-wide tuning switches (no reference counterpart; atomics, may be set from any thread).  Every one of them
+ * selects between implementations with IDENTICAL results (the tests run the alternatives against each other and against
+ * the oracle); none changes what a call returns.
  * "median_general" = 1 forces the general wave-cooperative median kernel even where the sorting-network
  * fast paths apply; "no_rt_fused" = 1 sends causal calls through the three-kernel path instead of the fused
  * kernel of rt_fused.hip, "no_block_fused" = 1 does so only for calls of more than one hop;
@@ -80,10 +82,12 @@ int zen_hip_event_destroy(void* event);
  * non-redundant half (bins 0..nfft/2); "no_mask_bits" = 1: the synthesis kernels of blocks of frames compare H and P
  * themselves instead of loading two mask bits per bin, "no_median_bits" = 1: those bits always come from a launch of
  * their own, never from the frequency-direction median kernel; "no_direct_out" = 1: the fused block kernel
- * of the headline configuration leaves the overlap-add to a launch of its own; "mfilt_nonneg" = 1: the caller promises that every sample handed to
- * zen_hip_mfilt_run is >= +0 (a magnitude matrix), so the filter orders by the raw bits as the engine's own launches do
- * (the kernel build BASELINE's median metric is quoted on); "median47_variant" = 1 lets median47_dpp_kernel store results without the LDS transpose (2, 3: timing
- * diagnostics whose outputs are not medians). */
+ * of the headline configuration leaves the overlap-add to a launch of its own; "median47_variant" = 1 lets
+ * median47_dpp_kernel store results without the LDS transpose; "offline_range" / "offline_no_register": see
+ * zen_hip_hpri_process.
+ * Timing diagnostics whose outputs are NOT the reference's ("median47_variant" 2..4, "rt_fused_diag") and the
+ * divide-based cross-check of the hard masks ("mask_divide") exist in -DZEN_HIP_DIAG builds of the library only; the
+ * shipped build answers ZEN_HIP_E_UNSUPPORTED. */
 int zen_hip_set_option(const char* name, int value);
 
 /* device memory + copies: what thrust::device_vector / thrust::copy are to the reference
@@ -94,6 +98,9 @@ int zen_hip_memset(void* dev, int value, size_t bytes, void* stream);
 int zen_hip_memcpy_h2d(void* dev, const void* host, size_t bytes); /* synchronises */
 int zen_hip_memcpy_d2h(void* host, const void* dev, size_t bytes); /* synchronises */
 int zen_hip_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+/* on a stream: asynchronous where the host range is pinned (zen_hip_host_alloc_mapped), else returns when the bytes moved */
+int zen_hip_memcpy_h2d_async(void* dev, const void* host, size_t bytes, void* stream);
+int zen_hip_memcpy_d2h_async(void* host, const void* dev, size_t bytes, void* stream);
 
 /* zen::io::IOGPU (libzen/libzen/io.h:16-81): pinned, mapped, portable host buffer and its device
  * alias; write_combined != 0 for host_in (io.h:33-35), the buffer the host only writes: on a large-BAR system
@@ -107,6 +114,8 @@ int zen_hip_host_free(void* host);
  * In-place unnormalised complex DFT of `nfft` points (interleaved re,im floats), batch of 1 as in
  * cufftPlan1d(&plan, nfft, CUFFT_C2C, 1) (fftw.h:32).  inverse != 0 <=> CUFFT_INVERSE (fftw.h:40-43).
  * zen_hip_fft_exec_batched transforms `batch` consecutive nfft-point rows (the offline STFT).
+ * nfft <= 16384 runs in place and a handle may be used from several streams at once; a 32768-point handle owns one
+ * scratch buffer (two kernels exchange through it): its calls must be ordered on one stream, or otherwise not overlap.
  * ------------------------------------------------------------------------------------------- */
 int zen_hip_fft_create(size_t nfft, zen_hip_fft_t* h);
 int zen_hip_fft_exec(zen_hip_fft_t h, float* inout_dev, int inverse, void* stream);
@@ -121,6 +130,12 @@ int zen_hip_fft_destroy(zen_hip_fft_t h);
 int zen_hip_mfilt_create(int time, int frequency, int filter_len, int direction, int copy_bord,
                          zen_hip_mfilt_t* h);
 int zen_hip_mfilt_run(zen_hip_mfilt_t h, const float* src_dev, float* dst_dev, void* stream);
+/* Per-handle promise (no reference counterpart, default off): every sample this handle will be given is >= +0 -- a
+ * magnitude matrix -- so its kernels may order by the raw bit patterns as the engine's own launches do.  A handle that
+ * breaks the promise gets wrong medians; no other handle is affected.  The 47-tap kernel on 4096-bin rows (BASELINE's
+ * median metric) does not need it: it looks at the sign bits of every row it stages and re-keys only rows that hold a
+ * negative sample. */
+int zen_hip_mfilt_assume_nonneg(zen_hip_mfilt_t h, int nonneg);
 int zen_hip_mfilt_destroy(zen_hip_mfilt_t h);
 
 /* BoxFilterGPU   (libzen/box.h:30-215; ctor :55-58, filter() :182-214): mean over the mask. */
@@ -178,7 +193,9 @@ int zen_hip_hpr_copy_output_async(zen_hip_hpr_t h, unsigned which, float* out_de
 
 /* Block form.  in_dev: n_streams rows of n_hops*hop floats, `in_stride` floats apart.  Each non-NULL
  * out_*_dev receives n_streams rows of n_hops*hop floats, `out_stride` apart: exactly what n_hops
- * calls of process_next_hop + copy_* would have produced.  Asynchronous. */
+ * calls of process_next_hop + copy_* would have produced.  Asynchronous.  An output may BE the input (same pointer
+ * and stride: in place; the engine then leaves that call's outputs to a launch that runs after every read of the chunk);
+ * any other overlap of an output range with the input range is undefined, as are overlapping outputs. */
 int zen_hip_hpr_process(zen_hip_hpr_t h, const float* in_dev, size_t n_hops, size_t in_stride,
                         float* out_harm_dev, float* out_perc_dev, float* out_resid_dev, size_t out_stride);
 
@@ -206,10 +223,25 @@ int zen_hip_hpri_destroy(zen_hip_hpri_t h);
 int zen_hip_hpri_set_stream(zen_hip_hpri_t h, void* stream);
 int zen_hip_hpri_use_sse_filter(zen_hip_hpri_t h); /* hps.cu:95-100 */
 int zen_hip_hpri_use_soft_mask(zen_hip_hpri_t h);  /* hps.cu:102-107 */
-/* HPRIOffline::process(std::vector<float>) (hps.cu:128-221): host buffers, n samples each;
- * any output may be NULL.  Synchronises. */
+/* HPRIOffline::process(std::vector<float>) (hps.cu:128-221; the call zen/offline.h:141-147 times): host buffers, n
+ * samples each; any output may be NULL.  Synchronises.  Clips of 8 Mi samples and more run as a pipeline over time
+ * ranges (zen_hip_hpri_process_range): the upload of range k+1 and the download of range k-1 under the kernels of range
+ * k, bit-identical to the whole clip.  Buffers the runtime does not know (plain malloc / std::vector) are registered
+ * with hipHostRegister for the duration of the call so that their copies are asynchronous; where that fails the copies
+ * block and only overlap the kernels.  resid_host is filled with zeros by host threads (the reference never
+ * writes pass 2's residual), nothing is copied for it.  Options: "offline_range" = samples per range (0: default, 4 or 8 Mi),
+ * "offline_no_register" = 1: never register. */
 int zen_hip_hpri_process(zen_hip_hpri_t h, const float* audio_host, size_t n, float* harm_host,
                          float* perc_host, float* resid_host);
+/* what the last zen_hip_hpri_process call of this handle did, for the harness (bench.py offline_host) */
+typedef struct {
+	size_t n_ranges, range_samples;
+	int input_pinned, outputs_pinned; /* known to the runtime, or registered for the call: asynchronous copies */
+	double setup_ms;                  /* staging buffers + registration */
+	double enqueue_ms;                /* the host loop that feeds the three streams */
+	double total_ms;                  /* the whole call */
+} zen_hip_hpri_host_stats;
+int zen_hip_hpri_host_stats_get(zen_hip_hpri_t h, zen_hip_hpri_host_stats* out);
 /* Device-resident batch of n_clips equal-length clips (rows `stride` floats apart, n samples used).
  * Outputs may be NULL.  Asynchronous. */
 int zen_hip_hpri_process_device(zen_hip_hpri_t h, const float* audio_dev, size_t n, size_t stride,

@@ -1,0 +1,222 @@
+"""GPU parity tests added in round 4.  Every call goes through the C-ABI (libzen_hip.so via ctypes) and is compared
+BIT-EXACTLY (tolerance 0) with the CPU oracle."""
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+
+pytestmark = pytest.mark.gpu
+ALL = o.OUTPUT_HARMONIC | o.OUTPUT_PERCUSSIVE | o.OUTPUT_RESIDUAL
+FS = 44100.0
+
+
+@pytest.fixture(scope="module")
+def z():
+    import zen_amd
+    zen_amd.init(0)
+    return zen_amd
+
+
+# ---------------------------------------------------------------------------- low sample rates: long frequency masks on short rows
+@pytest.mark.parametrize("fs,hop", [(2000.0, 64), (2500.0, 64), (3000.0, 128), (2000.0, 128), (4000.0, 256)])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("flags", [ALL, o.OUTPUT_PERCUSSIVE])
+def test_low_sample_rate_blocks_vs_oracle(z, fs, hop, causal, flags):
+    """l_perc is 500 Hz of bins (hps.h:229): at fs 2000, hop 64 the frequency mask is 65 taps on 256-bin rows, and the
+    row's last mf/2 = 32 bins (replicate border) no longer fit slot 15 of the transposed mask-bit layout
+    (nfft/16 = 16 bins).  Blocks of >= 8 frames with hard masks must take the H / P rows path there
+    (stft.h mask_bits_supported) and give the oracle's samples, like the per-hop path."""
+    hh = o.HPR(fs, hop, 2.0, flags, o.TIME_CAUSAL if causal else o.TIME_ANTICAUSAL)
+    n_hops = 2 * hh.stft_width + 40
+    rng = np.random.default_rng(int(fs) + hop)
+    t = np.arange(hop * n_hops) / fs
+    x = (0.3 * np.sin(2 * np.pi * 0.11 * fs * t) + 0.3 * rng.uniform(-1, 1, t.size)).astype(np.float32)
+    x[::hop * 5 + 3] += 0.9
+    ref = hh.process_stream(x)
+    keys = "PHR" if flags == ALL else "P"
+    cz = z.TIME_CAUSAL if causal else z.TIME_ANTICAUSAL
+    block = z.HPR(fs, hop, 2.0, flags, cz).process_stream_host(x)          # one block call: >= 8 frames
+    g = z.HPR(fs, hop, 2.0, flags, cz)
+    per_hop = [g.process_stream_host(x[i * hop:(i + 1) * hop]) for i in range(n_hops)]
+    for k in keys:
+        assert np.any(ref[k] != 0)
+        assert np.array_equal(block[k], ref[k]), ("block", k)
+        assert np.array_equal(np.concatenate([p[k] for p in per_hop]), ref[k]), ("per hop", k)
+
+
+# ---------------------------------------------------------------------------- HPRIOffline::process on host vectors: the pipeline
+def _clip(n, seed):
+    from tests.test_gpu_parity import music
+    return music(n, seed)
+
+
+@pytest.mark.parametrize("hop_h,hop_p,n,rng_samples", [(4096, 256, 161571, 40960), (1024, 256, 70001, 8192),
+                                                      (4096, 256, 4096 * 20 + 11, 4096), (512, 128, 30000, 30000 - 1)])
+@pytest.mark.parametrize("mode", ["hard", "soft", "sse"])
+@pytest.mark.parametrize("register", [True, False])
+def test_host_process_pipeline_vs_oracle(z, hop_h, hop_p, n, rng_samples, mode, register):
+    """zen_hip_hpri_process (HPRIOffline<GPU>::process, hps.cu:128-221) as a pipeline over time ranges -- forced onto
+    short clips with "offline_range" so that the oracle can check every sample: registered (asynchronous copies) and
+    unregistered (blocking copies, upload of range k+1 before the download of range k) caller buffers, hard / soft / SSE,
+    a last range of a few samples, outputs left out."""
+    x = _clip(n, 7 + n % 5)
+    ro = o.HPRIOffline(FS, hop_h, hop_p, 2.0, 2.0)
+    if mode == "soft":
+        ro.use_soft_mask()
+    if mode == "sse":
+        ro.use_sse_filter()
+    rh, rp, rr = ro.process(x)
+    z.set_option("offline_range", rng_samples)
+    z.set_option("offline_no_register", 0 if register else 1)
+    try:
+        g = z.HPRIOffline(FS, hop_h, hop_p, 2.0, 2.0)
+        if mode == "soft":
+            g.use_soft_mask()
+        if mode == "sse":
+            g.use_sse_filter()
+        for rep in range(2):                      # the second call reuses the staging buffers, streams and events
+            h, p, r = (np.full(n, np.nan, np.float32) for _ in range(3))
+            g.process(x, out=(h, p, r))
+            st = g.host_stats()
+            assert st["n_ranges"] > 1 and st["range_samples"] % hop_h == 0
+            assert bool(st["input_pinned"]) == register and bool(st["outputs_pinned"]) == register
+            assert np.array_equal(h, rh) and np.array_equal(p, rp) and np.array_equal(r, rr)
+        p2 = np.full(n, np.nan, np.float32)       # percussive alone (zen offline --only-percussive)
+        g.process(x, out=(None, p2, None))
+        assert np.array_equal(p2, rp)
+    finally:
+        z.set_option("offline_range", 0)
+        z.set_option("offline_no_register", 0)
+    assert np.all(rr == 0)
+
+
+def test_host_process_pinned_caller_buffers_and_default_ranges(z):
+    """The default range length (4 Mi samples for a clip of 9 Mi) with caller buffers that are already pinned
+    (hipHostMalloc through zen_hip_host_alloc_mapped): no registration, asynchronous copies; equal to the whole clip in
+    one range, and to plain numpy buffers registered for the call."""
+    n = 9 * (1 << 20) + 123
+    x = _clip(1 << 20, 3)
+    x = np.tile(x, 10)[:n].copy()
+    g = z.HPRIOffline(FS, 4096, 256, 2.0, 2.0)
+    z.set_option("offline_range", 1 << 30)
+    try:
+        ref_h, ref_p, ref_r = g.process(x)                          # one range: up, both passes, down
+        assert g.host_stats()["n_ranges"] == 1
+    finally:
+        z.set_option("offline_range", 0)
+    bufs = [z.IOGPU(n) for _ in range(3)]                           # (host_out: plain pinned host memory)
+    bufs[0].host_out[:] = x
+    h, p = bufs[1].host_out, bufs[2].host_out
+    h[:] = np.nan
+    p[:] = np.nan
+    g.process(bufs[0].host_out, out=(h, p, None))
+    st = g.host_stats()
+    assert st["n_ranges"] == 3 and st["input_pinned"] and st["outputs_pinned"]
+    assert np.array_equal(h, ref_h) and np.array_equal(p, ref_p)
+    hh, pp, rr = g.process(x)                                       # plain numpy arrays: registered for the call
+    assert g.host_stats()["n_ranges"] == 3
+    assert np.array_equal(hh, ref_h) and np.array_equal(pp, ref_p) and np.all(rr == 0) and np.all(ref_r == 0)
+
+
+# ---------------------------------------------------------------------------- MedianFilterGPU: rows with and without negative samples
+@pytest.mark.parametrize("variant", [0, 1])
+def test_median47_rows_rekeyed_only_where_negative(z, variant):
+    """median47_dpp_kernel (47 taps on 4096-bin rows, the shape of BASELINE's median metric) stages every row as raw bits
+    and re-keys only rows in which some sample has its sign bit set: magnitude matrices run at the engine's speed through
+    the plain zen_hip_mfilt_run, signed data stays exact.  Rows of every kind next to each other: all positive, one
+    negative sample (in the middle, in the first and in the last column: the replicate border, mfilt.h:270-342), -0.0
+    among positives, all negative, +/-inf; against the oracle (MedianFilterCPU semantics) bit for bit; and a handle with
+    zen_hip_mfilt_assume_nonneg on the non-negative rows alone."""
+    rows, cols = 64, 4096
+    rng = np.random.default_rng(47)
+    a = rng.random((rows, cols), dtype=np.float32)                      # >= +0
+    a[1, 2000] = -0.5
+    a[2, 0] = -1e-30
+    a[3, cols - 1] = -3.0
+    a[4, 17] = -0.0
+    a[5] = -a[5]
+    a[6] = rng.uniform(-1, 1, cols).astype(np.float32)
+    a[7, 100:130] = np.inf
+    a[8, 100:130] = -np.inf
+    a[9, ::2] = 0.0
+    a[10] = 0.0
+    a[11] = -0.0
+    for r in range(12, rows, 3):
+        a[r] = rng.uniform(-1, 1, cols).astype(np.float32)
+    z.set_option("median47_variant", variant)
+    try:
+        got = z.MedianFilterGPU(rows, cols, 47, z.FREQUENCY).filter_host(a)
+        f = z.MedianFilterGPU(rows, cols, 47, z.FREQUENCY)
+        f.assume_nonneg()
+        pos = np.abs(a)                                                  # (abs clears the sign of -0.0 too)
+        got_pos = f.filter_host(pos)
+    finally:
+        z.set_option("median47_variant", 0)
+    ref = o.median_filter(a, 47, o.FREQUENCY)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert np.array_equal(got_pos.view(np.uint32), o.median_filter(pos, 47, o.FREQUENCY).view(np.uint32))
+
+
+def test_diagnostic_options_are_not_in_the_shipped_library(z):
+    """Timing diagnostics whose outputs are not medians / not the reference's masks exist in -DZEN_HIP_DIAG builds only;
+    the process-wide "mfilt_nonneg" is gone (per handle: zen_hip_mfilt_assume_nonneg)."""
+    for name, val in (("median47_variant", 2), ("median47_variant", 3), ("rt_fused_diag", 1), ("mask_divide", 1),
+                      ("mfilt_nonneg", 1)):
+        with pytest.raises(z.ZenHipError):
+            z.set_option(name, val)
+    z.set_option("median47_variant", 1)
+    z.set_option("median47_variant", 0)
+
+
+# ---------------------------------------------------------------------------- the N-GPU plumbing on one GPU
+def _run_py(code, env_extra=None, timeout=300):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, "-c", code], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          timeout=timeout)
+
+
+def test_rccl_process_group_world_of_one():
+    """zen_amd.dist.Group with the `nccl` backend (= RCCL) at WORLD_SIZE 1: communicator bound to the device, all-reduce
+    MAX and SUM of the scalars bench.py exchanges, barrier, destroy -- what every rank of the 8-GPU run does first and last
+    (SURVEY 8(e)); a fresh interpreter, as the launcher starts them."""
+    code = (
+        "import torch\n"
+        "from zen_amd import dist as zd\n"
+        "torch.cuda.set_device(0)\n"
+        "g = zd.Group('nccl', torch.device('cuda', 0), force=True)\n"
+        "assert g.dist is not None and g.world == 1\n"
+        "g.barrier()\n"
+        "assert g.max(3.5) == 3.5\n"
+        "assert g.sum([1.0, 2.5]) == [1.0, 2.5]\n"
+        "import zen_amd\n"
+        "zen_amd.init(0)\n"
+        "g.barrier()\n"
+        "g.close()\n"
+        "print('RCCL_OK')\n")
+    r = _run_py(code)
+    assert r.returncode == 0 and b"RCCL_OK" in r.stdout, r.stderr.decode()[-2000:]
+
+
+def test_bench_under_the_launcher_path_with_rccl():
+    """`bench.py --gpus 1` started the way `--gpus N` starts its ranks (zen_amd.dist.spawn_ranks: fresh interpreter, RANK /
+    WORLD_SIZE / MASTER_* in the environment) with the process group forced on: RCCL init, the barriers and all-reduces
+    around the timed region, the sharded-units arithmetic and the one JSON line -- on the one GPU this box has."""
+    import json
+    code = (
+        "import sys\n"
+        "from zen_amd import dist as zd\n"
+        "sys.exit(zd.spawn_ranks([sys.executable, 'bench.py', '--gpus', '1', '--steps', '2', '--warmup', '1', '--hops', '2048',\n"
+        "                         '--no-legs', '--no-cpu-baseline', '--no-realtime', '--settle-ms', '0'], 1, timeout=240,\n"
+        "                        env_extra={'ZEN_FORCE_PROCESS_GROUP': '1'}))\n")
+    r = _run_py(code)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["ranks_reported"] == 1 and j["value"] > 0 and j["roofline"]["frac"] > 0

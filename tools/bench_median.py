@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import zen_amd  # noqa: E402
 
 
-def run(rows, cols, flen, direction, iters, general=False, nonneg=True):
+def run(rows, cols, flen, direction, iters, general=False, nonneg=False):
     zen_amd.set_option("median_general", int(general))
     rng = np.random.default_rng(0)
     d = rng.uniform(0, 1, (rows, cols)).astype(np.float32)
@@ -22,6 +22,8 @@ def run(rows, cols, flen, direction, iters, general=False, nonneg=True):
         d -= 0.5
     src, dst = zen_amd.DeviceBuffer.from_host(d), zen_amd.DeviceBuffer(d.size)
     f = zen_amd.MedianFilterGPU(rows, cols, flen, direction)
+    if nonneg:
+        f.assume_nonneg()
     for _ in range(3):
         f.filter(src, dst)
     zen_amd.synchronize()
@@ -33,7 +35,8 @@ def run(rows, cols, flen, direction, iters, general=False, nonneg=True):
     gbs = 8.0 * rows * cols / dt / 1e9
     return {"rows": rows, "cols": cols, "filter_len": flen,
             "direction": "frequency" if direction == zen_amd.FREQUENCY else "time",
-            "kernel": "general" if general else "auto", "ms": 1e3 * dt, "GBps": gbs, "frac_of_8TBps": gbs / 8000.0}
+            "kernel": "general" if general else "auto", "assume_nonneg": bool(nonneg),
+            "data": "signed" if os.environ.get("ZEN_BENCH_SIGNED") else "non-negative", "ms": 1e3 * dt, "GBps": gbs, "frac_of_8TBps": gbs / 8000.0}
 
 
 if __name__ == "__main__":
@@ -45,12 +48,11 @@ if __name__ == "__main__":
     ap.add_argument("--len", type=int, default=47)
     ap.add_argument("--dir", default="frequency")
     ap.add_argument("--nonneg", action="store_true",
-                    help="option mfilt_nonneg: the input is a magnitude matrix (>= +0), ordering keys are the raw bits -- the "
-                         "kernel build the engine launches and BASELINE's median metric is quoted on")
+                    help="zen_hip_mfilt_assume_nonneg on the handle: the input is a magnitude matrix (>= +0), ordering keys are "
+                         "the raw bits -- the kernel builds the engine launches (the 47-tap kernel on 4096-bin rows finds "
+                         "that out by itself)")
     args = ap.parse_args()
     zen_amd.init(0)
-    if args.nonneg:
-        zen_amd.set_option("mfilt_nonneg", 1)
     for opt in ("median47_blocks", "median47_shared"):
         if os.environ.get("ZEN_" + opt.upper()):
             zen_amd.set_option(opt, int(os.environ["ZEN_" + opt.upper()]))
@@ -63,4 +65,4 @@ if __name__ == "__main__":
     else:                        # libzen/mfilt.bench.cu:222-262
         cases = [(1 << k, 1 << k, 11, d) for k in range(5, 15) for d in (F, Tm)]
     for rows, cols, flen, direction in cases:
-        print(json.dumps(run(rows, cols, flen, direction, args.iters)), flush=True)
+        print(json.dumps(run(rows, cols, flen, direction, args.iters, nonneg=args.nonneg)), flush=True)

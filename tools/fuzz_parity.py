@@ -23,7 +23,7 @@ def run(seconds, seed):
     n_ok = n_bad = n_skip = 0
     seen = set()
     while time.time() < t_end:
-        fs = float(rng.choice([8000, 11025, 16000, 22050, 24000, 32000, 44100, 48000, 88200, 96000]))
+        fs = float(rng.choice([2000, 3000, 4000, 8000, 11025, 16000, 22050, 24000, 32000, 44100, 48000, 88200, 96000]))
         hop = int(rng.choice([32, 64, 128, 256, 512, 1024, 2048, 4096]))
         beta = float(rng.choice([1.5, 2.0, 2.5, 3.0]))
         flags = int(rng.integers(1, 8))

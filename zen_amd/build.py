@@ -141,7 +141,7 @@ def build_host(verbose=False):
         hdrs += [os.path.join(d, f) for f in fs]
     hdrs.append(os.path.join(root, "include", "zen_hip.h"))
     if stale(libzen, hdrs + [OUT]):
-        subprocess.check_call(cxx + inc + ["-shared", src, "-o", libzen] + link_hip)
+        subprocess.check_call(cxx + inc + ["-shared", "-pthread", src, "-o", libzen] + link_hip)
     os.makedirs(os.path.join(HERE, "bin"), exist_ok=True)
     cli = os.path.join(HERE, "bin", "zen")
     cli_src = [os.path.join(HERE, "cli", "main.cpp"), os.path.join(HERE, "cli", "wav.h")]

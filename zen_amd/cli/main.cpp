@@ -104,6 +104,7 @@ int run_offline(const OfflineParams& p)
 	zen::wav::AudioData fd;
 	std::vector<float> audio = load_mono(p.infile, fd);
 	std::array<std::vector<float>, 3> all_out;
+	const std::size_t n_audio = audio.size();
 	if (p.do_hps) {
 		std::cout << "Processing input signal of size " << audio.size()
 		          << " with HPR-I separation using harmonic params: " << p.hop_h << "," << p.beta_h
@@ -115,7 +116,7 @@ int run_offline(const OfflineParams& p)
 		if (p.soft_mask)
 			hpss.use_soft_mask();
 		auto t1 = std::chrono::high_resolution_clock::now();
-		all_out = hpss.process(audio);
+		all_out = hpss.process(std::move(audio)); // (offline.h:144 passes an lvalue: a copy of the clip the tool never reads again)
 		auto t2 = std::chrono::high_resolution_clock::now();
 		auto dur = std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count();
 		std::cout << "GPU/HIP/gfx950: 2-pass HPR-I-Offline took " << dur << " ms" << std::endl;
@@ -128,7 +129,7 @@ int run_offline(const OfflineParams& p)
 		for (int i = 0; i < 3; ++i) {
 			if (p.only_percussive && i != 1)
 				continue;
-			peak_normalise(all_out[i], audio.size());
+			peak_normalise(all_out[i], n_audio);
 			zen::wav::encode_pcm16_mono(all_out[i], fd.sampleRate, p.outfile_prefix + suffix[i]);
 		}
 	}

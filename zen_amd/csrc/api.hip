@@ -22,10 +22,12 @@ opt_t g_opt_median47_variant{0};
 opt_t g_opt_rt_fused_diag{0};
 opt_t g_opt_mask_divide{0};
 opt_t g_opt_no_half_rows{0};
-opt_t g_opt_mfilt_nonneg{0};
 opt_t g_opt_no_mask_bits{0};
 opt_t g_opt_no_median_bits{0};
 opt_t g_opt_no_direct_out{0};
+opt_t g_opt_no_istft_xcd_map{0};
+opt_t g_opt_offline_range{0};
+opt_t g_opt_offline_no_register{0};
 std::atomic<unsigned> g_host_free_gen{0};
 
 void set_error(const char* fmt, ...)
@@ -113,6 +115,7 @@ struct zen_hip_fft {
 struct zen_hip_filter {
 	int time, frequency, len, direction;
 	bool is_box;
+	bool assume_nonneg; // zen_hip_mfilt_assume_nonneg
 };
 
 extern "C" {
@@ -165,13 +168,21 @@ int zen_hip_set_option(const char* name, int value)
 	             {"block_fused_minb", &g_opt_block_fused_minb},
 	             {"no_median47_dpp", &g_opt_no_median47_dpp},
 	             {"median47_variant", &g_opt_median47_variant},
+#ifdef ZEN_HIP_DIAG
 	             {"rt_fused_diag", &g_opt_rt_fused_diag},
 	             {"mask_divide", &g_opt_mask_divide},
+#endif
 	             {"no_half_rows", &g_opt_no_half_rows},
-	             {"mfilt_nonneg", &g_opt_mfilt_nonneg},
 	             {"no_mask_bits", &g_opt_no_mask_bits},
 	             {"no_median_bits", &g_opt_no_median_bits},
-	             {"no_direct_out", &g_opt_no_direct_out}};
+	             {"no_direct_out", &g_opt_no_direct_out},
+	             {"no_istft_xcd_map", &g_opt_no_istft_xcd_map},
+	             {"offline_range", &g_opt_offline_range},
+	             {"offline_no_register", &g_opt_offline_no_register}};
+#ifndef ZEN_HIP_DIAG
+	if (name && (!strcmp(name, "rt_fused_diag") || !strcmp(name, "mask_divide") || (!strcmp(name, "median47_variant") && value > 1)))
+		ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "zen_hip_set_option: '%s' = %d is a diagnostic of -DZEN_HIP_DIAG builds", name, value);
+#endif
 	for (const auto& t : table) {
 		if (name && !strcmp(name, t.name)) {
 			t.var->store(value, std::memory_order_relaxed);
@@ -276,6 +287,17 @@ int zen_hip_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream)
 	return ZEN_HIP_OK;
 }
 
+int zen_hip_memcpy_h2d_async(void* dev, const void* host, size_t bytes, void* stream)
+{
+	ZH_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+	return ZEN_HIP_OK;
+}
+int zen_hip_memcpy_d2h_async(void* host, const void* dev, size_t bytes, void* stream)
+{
+	ZH_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+	return ZEN_HIP_OK;
+}
+
 // Input buffers that live in HBM (see zen_hip_host_alloc_mapped): remembered so that zen_hip_host_free can
 // tell them from pinned host memory.
 static std::mutex g_bar_mu;
@@ -365,7 +387,9 @@ int zen_hip_fft_exec_batched(zen_hip_fft_t h, float* inout_dev, size_t batch, in
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "fft_exec: null argument");
 	if (h->log2n > 14) { // one frame does not fit a workgroup's LDS: two steps through a scratch buffer
 		if (batch > h->xch_batch) {
-			ZH_HIP(hipStreamSynchronize((hipStream_t)stream));
+			// the buffer may still be in use by an earlier call on ANOTHER stream: wait for the device, not for `stream`
+			// (a 32768-point handle has one scratch buffer: its calls must not overlap across streams, zen_hip.h)
+			ZH_HIP(hipDeviceSynchronize());
 			(void)hipFree(h->xch);
 			h->xch = nullptr;
 			h->xch_batch = 0;
@@ -408,6 +432,7 @@ static int filter_create(int time, int frequency, int filter_len, int direction,
 	f->len = odd;
 	f->direction = direction;
 	f->is_box = is_box;
+	f->assume_nonneg = false;
 	*h = f;
 	return ZEN_HIP_OK;
 }
@@ -429,7 +454,7 @@ static int filter_run(zen_hip_filter* h, const float* src, float* dst, void* str
 	a.clamp_hi = h->time - 1;
 	a.len = h->len;
 	a.direction = h->direction;
-	a.nonneg = (!h->is_box && g_opt_mfilt_nonneg) ? 1 : 0; // "mfilt_nonneg": the caller's promise (magnitudes)
+	a.nonneg = (!h->is_box && h->assume_nonneg) ? 1 : 0; // zen_hip_mfilt_assume_nonneg: this handle's promise (magnitudes)
 	return h->is_box ? launch_box(a, (hipStream_t)stream) : launch_median(a, (hipStream_t)stream);
 }
 
@@ -442,6 +467,13 @@ int zen_hip_mfilt_create(int time, int frequency, int filter_len, int direction,
 int zen_hip_mfilt_run(zen_hip_mfilt_t h, const float* src_dev, float* dst_dev, void* stream)
 {
 	return filter_run(h, src_dev, dst_dev, stream);
+}
+int zen_hip_mfilt_assume_nonneg(zen_hip_mfilt_t h, int nonneg)
+{
+	if (!h || h->is_box)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "mfilt_assume_nonneg: not a median filter handle");
+	h->assume_nonneg = nonneg != 0;
+	return ZEN_HIP_OK;
 }
 int zen_hip_mfilt_destroy(zen_hip_mfilt_t h)
 {

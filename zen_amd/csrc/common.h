@@ -24,9 +24,19 @@ extern opt_t g_opt_median_general;       // "median_general": force the general 
 extern opt_t g_opt_no_median47_dpp;      // "no_median47_dpp": 4096-bin rows / 47 taps through the generic kernel
 extern opt_t g_opt_no_half_rows;         // "no_half_rows": the three-kernel path stores and filters whole magnitude rows
 extern opt_t g_opt_no_direct_out;       // "no_direct_out": the fused block kernel leaves the overlap-add to finalize_kernel
+extern opt_t g_opt_offline_range;       // "offline_range": samples per range of zen_hip_hpri_process's pipeline (0: default)
+extern opt_t g_opt_offline_no_register; // "offline_no_register": zen_hip_hpri_process never hipHostRegisters the caller's buffers
+extern opt_t g_opt_no_istft_xcd_map;    // "no_istft_xcd_map": several outputs: a grid of frames x outputs instead of same-XCD groups
 extern opt_t g_opt_no_median_bits;      // "no_median_bits": the mask bits always come from mask_bits_kernel, never from a median kernel
 extern opt_t g_opt_no_mask_bits;        // "no_mask_bits": the synthesis kernels compare H and P themselves (no mask_bits_kernel)
-extern opt_t g_opt_mfilt_nonneg;        // "mfilt_nonneg": zen_hip_mfilt_run's input is promised to be >= +0 (raw-bit ordering keys)
+// Diagnostics whose results are not the reference's (timing experiments) or that only exist to cross-check a formulation
+// are compiled into -DZEN_HIP_DIAG builds only (ZEN_HIP_EXTRA_FLAGS=-DZEN_HIP_DIAG python zen_amd/build.py --force); the
+// shipped library refuses their names (zen_hip_set_option) and reads them as 0.
+#ifdef ZEN_HIP_DIAG
+#define ZH_DIAG_OPT(x) ((int)(x))
+#else
+#define ZH_DIAG_OPT(x) 0
+#endif
 extern opt_t g_opt_mask_divide;          // "mask_divide": the lean fused kernel forms its hard mask with the IEEE divide
 extern opt_t g_opt_rt_fused_diag;         // "rt_fused_diag": 1 = fused kernel without its median stage, 2 = without synthesis (timing only)
 extern opt_t g_opt_median47_variant;    // "median47_variant": median47_dpp_kernel build (0 default, 1 direct stores, 2/3 diagnostics)

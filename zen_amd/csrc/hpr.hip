@@ -276,9 +276,9 @@ int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, H
 	a.power = (int)e->beta;
 	a.out_h = e->out_h ? 1 : 0;
 	a.out_p = e->out_p ? 1 : 0;
-	a.thr = g_opt_mask_divide ? 0.0 : hard_mask_threshold(e->beta, &a.thr_inclusive);
-	a.thr_h = g_opt_mask_divide ? 0.0 : hard_mask_threshold(a.beta_h, &a.thr_h_inclusive);
-	a.diag = g_opt_rt_fused_diag;
+	a.thr = ZH_DIAG_OPT(g_opt_mask_divide) ? 0.0 : hard_mask_threshold(e->beta, &a.thr_inclusive);
+	a.thr_h = ZH_DIAG_OPT(g_opt_mask_divide) ? 0.0 : hard_mask_threshold(a.beta_h, &a.thr_h_inclusive);
+	a.diag = ZH_DIAG_OPT(g_opt_rt_fused_diag);
 	a.stamps = e->dbg_stamps;
 	if (kind == HOP_WIDE) {
 		ZH_TRY(ensure_estimates(e, false));
@@ -450,9 +450,10 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 	// itself where it knows how (FilterArgs::bits: two bits per bin instead of the P row), else in a launch of their own
 	// -- and the synthesis loads two bits per bin instead of H and P (per output, and per mirror image).
 	const float beta_h = e->beta - FLT_EPSILON; // hps.cu:540 hard_mask_functor(beta - Eps)
-	const HardThr thr = hard_mask_thresholds(e->beta, beta_h, g_opt_mask_divide != 0);
-	const bool use_bits = M >= 8 && N >= 256 && !e->soft && !e->use_sse && thr.p != 0.0 && thr.h != 0.0 && !g_opt_no_mask_bits;
+	const HardThr thr = hard_mask_thresholds(e->beta, beta_h, ZH_DIAG_OPT(g_opt_mask_divide) != 0);
 	const int p_mid = e->use_sse ? (int)(N / 2) : e->mf / 2;
+	const bool use_bits = M >= 8 && mask_bits_supported((int)N, p_mid) && !e->soft && !e->use_sse && thr.p != 0.0 && thr.h != 0.0
+	                      && !g_opt_no_mask_bits;
 	const int bits_row_words = mask_bits_row_words((int)N, p_mid);
 	const long long bits_stream_stride = (long long)e->max_hops * bits_row_words;
 	const long long bits_t_stream_stride = (long long)e->max_hops * (long long)(N / 16);
@@ -983,10 +984,25 @@ int zen_hip_hpr_process(zen_hip_hpr_t h, const float* in_dev, size_t n_hops, siz
 	float* outs[3] = {out_perc_dev, out_harm_dev, out_resid_dev};
 	if (n_hops > h->max_hops && h->max_hops < h->max_hops_cap)
 		ZH_TRY(grow_buffers(h, n_hops < h->max_hops_cap ? n_hops : h->max_hops_cap));
+	// A kernel that finishes hops itself stores them while other workgroups of the same launch still read the input: an
+	// output that overlaps the input (in place, or shifted) is left to the overlap-add launch, which runs after every
+	// read of the chunk -- as safe as before the kernel learned to write the outputs.
+	bool aliased = false;
+	{
+		const size_t S = h->n_streams;
+		const char* in0 = (const char*)in_dev;
+		const char* in1 = (const char*)(in_dev + (S - 1) * in_stride + n_hops * h->hop);
+		for (int o = 0; o < 3; ++o)
+			if (outs[o]) {
+				const char* o0 = (const char*)outs[o];
+				const char* o1 = (const char*)(outs[o] + (S - 1) * out_stride + n_hops * h->hop);
+				aliased = aliased || (o0 < in1 && in0 < o1);
+			}
+	}
 	for (size_t off = 0; off < n_hops; off += h->max_hops) {
 		const size_t M = (n_hops - off < h->max_hops) ? n_hops - off : h->max_hops;
 		for (int o = 0; o < 3; ++o) // (a kernel that finishes hops itself writes them here: run_hop_fused)
-			h->direct_out[o] = outs[o] ? outs[o] + off * h->hop : nullptr;
+			h->direct_out[o] = (outs[o] && !aliased) ? outs[o] + off * h->hop : nullptr;
 		h->direct_stride = (long long)out_stride;
 		const int rc = run_chunk(h, in_dev + off * h->hop, in_stride, M);
 		for (int o = 0; o < 3; ++o)

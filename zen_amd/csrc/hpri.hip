@@ -12,6 +12,10 @@
 #include <cfloat>
 #include <climits>
 #include <cmath>
+#include <chrono>
+#include <cstring>
+#include <thread>
+#include <vector>
 
 using namespace zen_hip_impl;
 
@@ -26,8 +30,12 @@ struct zen_hip_hpri {
 	// scratch, grown on demand: pass 2's input (the only intermediate that has to exist in memory)
 	size_t cap2 = 0;
 	float* in2 = nullptr;
-	float *stage_in = nullptr, *stage_out[3] = {nullptr, nullptr, nullptr};
+	float *stage_in = nullptr, *stage_out[2] = {nullptr, nullptr}; // whole-clip device images: input, harmonic, percussive
 	size_t stage_cap = 0;
+	// zen_hip_hpri_process (host buffers): the copy streams of its pipeline and the events that order them
+	hipStream_t s_in = nullptr, s_out = nullptr;
+	std::vector<hipEvent_t> events;
+	zen_hip_hpri_host_stats stats = {};
 };
 
 namespace {
@@ -85,8 +93,14 @@ int zen_hip_hpri_destroy(zen_hip_hpri_t h)
 		zen_hip_hpr_destroy(h->ep);
 		hpri_free_scratch(h);
 		(void)hipFree(h->stage_in);
-		for (int i = 0; i < 3; ++i)
+		for (int i = 0; i < 2; ++i)
 			(void)hipFree(h->stage_out[i]);
+		for (hipEvent_t e : h->events)
+			(void)hipEventDestroy(e);
+		if (h->s_in)
+			(void)hipStreamDestroy(h->s_in);
+		if (h->s_out)
+			(void)hipStreamDestroy(h->s_out);
 		delete h;
 	}
 	return ZEN_HIP_OK;
@@ -347,6 +361,95 @@ int zen_hip_hpri_profile_get_all(zen_hip_hpri_t h, int pass, double ms[6], unsig
 	return zen_hip_hpr_profile_get_all(pass == 1 ? h->eh : h->ep, ms, launches);
 }
 
+// ---- HPRIOffline<GPU>::process on host vectors (hps.cu:128-221) ----------------------------------------
+// What the reference times (zen/offline.h:141-147) is this call, copies included.  Resident in HBM the two passes take
+// ~13 ms per hour of audio; the host link needs 4 bytes in and 8 bytes out per sample (~11 + ~22 ms per hour at the
+// ~57 GB/s a pinned copy gets), so the call is a pipeline over time ranges of the clip: the input of range k+1 goes up
+// and the outputs of range k-1 come down under the kernels of range k (zen_hip_hpri_process_range: bit-identical to the
+// whole clip, each range from its own warm-up halo).  Three streams -- copy in, the handle's stream, copy out -- and one
+// event per range and edge.  The third output is all zeros: written by the host, never moved.
+extern "C++" {
+namespace {
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// Is this host range known to the runtime (hipHostMalloc / hipHostRegister)?  Copies from / to such memory are
+// asynchronous; from / to pageable memory hipMemcpyAsync returns when the bytes have moved.
+bool host_pinned(const void* p)
+{
+	hipPointerAttribute_t at;
+	if (hipPointerGetAttributes(&at, p) == hipSuccess)
+		return at.type == hipMemoryTypeHost;
+	(void)hipGetLastError();
+	return false;
+}
+
+struct Registered { // a caller's buffer pinned for the duration of one call
+	void* p = nullptr;
+	bool pinned = false;
+	void take(const void* q, size_t bytes, bool try_register)
+	{
+		if (!q)
+			return;
+		if (host_pinned(q)) {
+			pinned = true;
+			return;
+		}
+		if (try_register && hipHostRegister(const_cast<void*>(q), bytes, hipHostRegisterDefault) == hipSuccess) {
+			p = const_cast<void*>(q);
+			pinned = true;
+			return;
+		}
+		(void)hipGetLastError();
+	}
+	~Registered()
+	{
+		if (p)
+			(void)hipHostUnregister(p);
+	}
+};
+
+void zero_host(float* dst, size_t n) // the reference's never-written residual_out (hps.cu:45-48, :200-204)
+{
+	const size_t bytes = n * sizeof(float), piece = (size_t)64 << 20;
+	unsigned k = (unsigned)(bytes / piece);
+	const unsigned hw = std::thread::hardware_concurrency();
+	if (k > 8)
+		k = 8;
+	if (hw && k > hw / 2)
+		k = hw / 2;
+	if (k < 2) {
+		memset(dst, 0, bytes);
+		return;
+	}
+	std::vector<std::thread> th;
+	const size_t per = (n / k + 1023) & ~(size_t)1023;
+	for (unsigned i = 0; i < k; ++i) {
+		const size_t a = (size_t)i * per, b = a + per < n ? a + per : n;
+		if (a < b)
+			th.emplace_back([=] { memset(dst + a, 0, (b - a) * sizeof(float)); });
+	}
+	for (auto& t : th)
+		t.join();
+}
+
+int ensure_copy_streams(zen_hip_hpri* h, size_t n_events)
+{
+	if (!h->s_in)
+		ZH_HIP(hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
+	if (!h->s_out)
+		ZH_HIP(hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
+	while (h->events.size() < n_events) {
+		hipEvent_t e;
+		ZH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+		h->events.push_back(e);
+	}
+	return ZEN_HIP_OK;
+}
+
+} // namespace
+} // extern "C++"
+
 int zen_hip_hpri_process(zen_hip_hpri_t h, const float* audio_host, size_t n, float* harm_host,
                          float* perc_host, float* resid_host)
 {
@@ -358,29 +461,122 @@ int zen_hip_hpri_process(zen_hip_hpri_t h, const float* audio_host, size_t n, fl
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_process: null argument");
 	if (h->n_clips != 1)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_process(host) needs a handle created with n_clips == 1");
+	const double t_start = now_ms();
 	if (n > h->stage_cap) {
 		ZH_HIP(hipStreamSynchronize(h->stream));
 		(void)hipFree(h->stage_in);
 		h->stage_in = nullptr; // a failed allocation below must not leave freed pointers behind a stale capacity
-		for (int i = 0; i < 3; ++i) {
+		for (int i = 0; i < 2; ++i) {
 			(void)hipFree(h->stage_out[i]);
 			h->stage_out[i] = nullptr;
 		}
 		h->stage_cap = 0;
 		ZH_HIP(hipMalloc((void**)&h->stage_in, sizeof(float) * n));
-		for (int i = 0; i < 3; ++i)
+		for (int i = 0; i < 2; ++i)
 			ZH_HIP(hipMalloc((void**)&h->stage_out[i], sizeof(float) * n));
 		h->stage_cap = n;
 	}
-	ZH_HIP(hipMemcpyAsync(h->stage_in, audio_host, sizeof(float) * n, hipMemcpyHostToDevice, h->stream));
-	ZH_TRY(zen_hip_hpri_process_device(h, h->stage_in, n, n, harm_host ? h->stage_out[0] : nullptr,
-	                                   perc_host ? h->stage_out[1] : nullptr,
-	                                   resid_host ? h->stage_out[2] : nullptr, n));
-	float* hosts[3] = {harm_host, perc_host, resid_host};
-	for (int i = 0; i < 3; ++i)
-		if (hosts[i])
-			ZH_HIP(hipMemcpyAsync(hosts[i], h->stage_out[i], sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
+	float* hosts[2] = {harm_host, perc_host};
+	// ranges of the pipeline: equal lengths (the first is never the shortest: the engines' buffers grow once), a multiple of hop_h
+	size_t want = (size_t)g_opt_offline_range.load(std::memory_order_relaxed);
+	if (want == 0) {
+		// 8 Mi samples (32 MB up, 64 MB down, ~0.6 + ~1.1 ms on the link, ~0.8 ms of kernels), 4 Mi for clips that would
+		// otherwise be two or three ranges; shorter ranges cost more in kernels than they hide in copies (a one-hour clip:
+		// 25.7 ms in ranges of 8 Mi, 38 in ranges of 4 Mi, 88 in ranges of 2 Mi: each range re-runs its warm-up halo, resets
+		// the engines and launches grids too small for 256 CUs), and under 8 Mi samples (3 minutes) the clip is one range
+		want = n >= ((size_t)1 << 25) ? (size_t)1 << 23 : (size_t)1 << 22;
+		if (n < ((size_t)1 << 23))
+			want = n;
+	}
+	size_t n_ranges = ceil_div(n, want);
+	size_t range = ceil_div(ceil_div(n, n_ranges), h->hop_h) * h->hop_h;
+	n_ranges = ceil_div(n, range);
+	zen_hip_hpri_host_stats& st = h->stats;
+	memset(&st, 0, sizeof(st));
+	st.n_ranges = n_ranges;
+	st.range_samples = range;
+	std::thread zero_thread;
+	if (resid_host)
+		zero_thread = std::thread([=] { zero_host(resid_host, n); });
+	struct Joiner {
+		std::thread& t;
+		~Joiner()
+		{
+			if (t.joinable())
+				t.join();
+		}
+	} joiner{zero_thread};
+	if (n_ranges == 1) { // a short clip: up, both passes, down
+		ZH_HIP(hipMemcpyAsync(h->stage_in, audio_host, sizeof(float) * n, hipMemcpyHostToDevice, h->stream));
+		ZH_TRY(zen_hip_hpri_process_device(h, h->stage_in, n, n, harm_host ? h->stage_out[0] : nullptr,
+		                                   perc_host ? h->stage_out[1] : nullptr, nullptr, n));
+		for (int i = 0; i < 2; ++i)
+			if (hosts[i])
+				ZH_HIP(hipMemcpyAsync(hosts[i], h->stage_out[i], sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
+		ZH_HIP(hipStreamSynchronize(h->stream));
+		st.total_ms = now_ms() - t_start;
+		return ZEN_HIP_OK;
+	}
+	ZH_TRY(ensure_copy_streams(h, 2 * n_ranges + 1));
+	const bool try_register = g_opt_offline_no_register.load(std::memory_order_relaxed) == 0;
+	Registered reg_in, reg_out[2];
+	reg_in.take(audio_host, sizeof(float) * n, try_register);
+	for (int i = 0; i < 2; ++i)
+		reg_out[i].take(hosts[i], sizeof(float) * n, try_register);
+	st.input_pinned = reg_in.pinned;
+	st.outputs_pinned = (!hosts[0] || reg_out[0].pinned) && (!hosts[1] || reg_out[1].pinned);
+	st.setup_ms = now_ms() - t_start;
+	// With every buffer known to the runtime all copies are asynchronous and the loop below only enqueues.  A copy from /
+	// to pageable memory blocks this thread until it is done: the loop then issues the upload of range k+1 BEFORE the
+	// download of range k, so that the thread is never stuck behind kernels it has not fed yet.
+	size_t uploaded = 0;
+	auto upload_to = [&](size_t k) -> int { // input samples range k reads, beyond what is up already; event 2k
+		size_t b = k * range, e = b + range < n ? b + range : n, in_b, in_e;
+		ZH_TRY(zen_hip_hpri_range_halo(h, n, b, e, &in_b, &in_e));
+		if (in_e > uploaded) {
+			ZH_HIP(hipMemcpyAsync(h->stage_in + uploaded, audio_host + uploaded, sizeof(float) * (in_e - uploaded),
+			                      hipMemcpyHostToDevice, h->s_in));
+			uploaded = in_e;
+		}
+		ZH_HIP(hipEventRecord(h->events[2 * k], h->s_in));
+		return ZEN_HIP_OK;
+	};
+	auto download = [&](size_t k) -> int {
+		const size_t b = k * range, e = b + range < n ? b + range : n;
+		ZH_HIP(hipStreamWaitEvent(h->s_out, h->events[2 * k + 1], 0));
+		for (int i = 0; i < 2; ++i)
+			if (hosts[i])
+				ZH_HIP(hipMemcpyAsync(hosts[i] + b, h->stage_out[i] + b, sizeof(float) * (e - b), hipMemcpyDeviceToHost, h->s_out));
+		return ZEN_HIP_OK;
+	};
+	// the copy streams do not know the handle's stream: order them behind whatever the caller queued there (and behind an
+	// earlier call's kernels, which may still read the stage buffers)
+	ZH_HIP(hipEventRecord(h->events[2 * n_ranges], h->stream));
+	ZH_HIP(hipStreamWaitEvent(h->s_in, h->events[2 * n_ranges], 0));
+	ZH_TRY(upload_to(0));
+	for (size_t k = 0; k < n_ranges; ++k) {
+		const size_t b = k * range, e = b + range < n ? b + range : n;
+		ZH_HIP(hipStreamWaitEvent(h->stream, h->events[2 * k], 0));
+		ZH_TRY(zen_hip_hpri_process_range(h, h->stage_in, n, b, e, harm_host ? h->stage_out[0] + b : nullptr,
+		                                  perc_host ? h->stage_out[1] + b : nullptr));
+		ZH_HIP(hipEventRecord(h->events[2 * k + 1], h->stream));
+		if (k + 1 < n_ranges)
+			ZH_TRY(upload_to(k + 1));
+		ZH_TRY(download(k));
+	}
+	st.enqueue_ms = now_ms() - t_start - st.setup_ms;
+	ZH_HIP(hipStreamSynchronize(h->s_out));
 	ZH_HIP(hipStreamSynchronize(h->stream));
+	ZH_HIP(hipStreamSynchronize(h->s_in));
+	st.total_ms = now_ms() - t_start;
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpri_host_stats_get(zen_hip_hpri_t h, zen_hip_hpri_host_stats* out)
+{
+	if (!h || !out)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_host_stats_get: null argument");
+	*out = h->stats;
 	return ZEN_HIP_OK;
 }
 

@@ -175,9 +175,23 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) __attribute__((amdgpu_wave
 	using PL = Plan<LOG2N>;
 	constexpr bool TW_IN_LDS = istft_tw_in_lds(LOG2N);
 	extern __shared__ float2 lds[];
-	const int tid = threadIdx.x, s = blockIdx.z, oi = blockIdx.y;
+	const int tid = threadIdx.x, s = blockIdx.z;
 	const int slot = tid / PL::TF, tf = tid - slot * PL::TF;
-	const int f_ = blockIdx.x * PL::FRAMES_PER_BLOCK + slot;
+	// Which frames and which output.  One output: blockIdx.x counts groups of frames.  Several outputs (grid_map != 0): the
+	// workgroups that synthesise the outputs of one group of frames read the same spectrum rows, so they are given ids 8
+	// apart -- the same XCD (workgroups go to the XCDs round robin), one after the other -- and all but the first find the
+	// rows in that XCD's L2: id = 8*(g*n_out + oi) + x handles frame group 8*g + x, output oi.  (As a grid of frames x
+	// outputs the three workgroups of a frame were a whole clip apart: pass 1 of the offline batch fetched every
+	// spectrum row three times, 4.1 GB per step where 1.4 are compulsory.)
+	int fb = blockIdx.x, oi = blockIdx.y;
+	if (a.grid_map) {
+		const int b = blockIdx.x, j = b >> 3;
+		oi = j % a.n_out;
+		fb = ((j / a.n_out) << 3) + (b & 7);
+		if (fb * PL::FRAMES_PER_BLOCK >= a.n_frames)
+			return; // (the grid is rounded up to whole groups of eight; nobody waits for this workgroup)
+	}
+	const int f_ = fb * PL::FRAMES_PER_BLOCK + slot;
 	const bool active = f_ < a.n_frames;
 	const int f = active ? f_ : a.n_frames - 1; // (an inactive slot transforms the last frame again and stores nothing)
 	const long long ring_row = ((a.crow0 + f) % a.ring_rows) + (long long)s * a.ring_rows;
@@ -434,12 +448,17 @@ int launch_istft_t(const IstftArgs& a, hipStream_t stream)
 		return ZEN_HIP_OK;
 	}
 	dim3 grid((unsigned)ceil_div((size_t)a.n_frames, (size_t)PL::FRAMES_PER_BLOCK), (unsigned)a.n_out, (unsigned)a.n_streams);
+	IstftArgs am = a; // (the kernels below are launched with `am`)
+	if (a.n_out > 1 && a.n_frames > 1 && !g_opt_no_istft_xcd_map) { // the outputs of a frame on one XCD, back to back (istft_kernel)
+		am.grid_map = 1;
+		grid = dim3((unsigned)(ceil_div((size_t)grid.x, (size_t)8) * 8 * (size_t)a.n_out), 1, (unsigned)a.n_streams);
+	}
 	if (!a.soft && !a.sse && a.thr_p != 0.0 && a.thr_h != 0.0) { // hard masks by comparison: the builds with nothing else in them
 		auto kern = (a.n_out == 1 && a.out_id[0] == 0) ? istft_kernel<LOG2N, 2> : istft_kernel<LOG2N, 1>;
 		if (a.bits_t)
 			kern = istft_kernel<LOG2N, 3>;
 		ZH_TRY(set_lds(kern, istft_lds_bytes<LOG2N>()));
-		hipLaunchKernelGGL(kern, grid, dim3(PL::THREADS), istft_lds_bytes<LOG2N>(), stream, a);
+		hipLaunchKernelGGL(kern, grid, dim3(PL::THREADS), istft_lds_bytes<LOG2N>(), stream, am);
 		ZH_HIP(hipGetLastError());
 		return ZEN_HIP_OK;
 	}
@@ -455,7 +474,7 @@ int launch_istft_t(const IstftArgs& a, hipStream_t stream)
 			kern = istft_kernel<LOG2N, 5>;
 	}
 	ZH_TRY(set_lds(kern, istft_lds_bytes<LOG2N>()));
-	hipLaunchKernelGGL(kern, grid, dim3(PL::THREADS), istft_lds_bytes<LOG2N>(), stream, a);
+	hipLaunchKernelGGL(kern, grid, dim3(PL::THREADS), istft_lds_bytes<LOG2N>(), stream, am);
 	ZH_HIP(hipGetLastError());
 	return ZEN_HIP_OK;
 }
@@ -482,8 +501,8 @@ int launch_mask_bits_transpose(int nfft, const IstftArgs& a, unsigned* bits_t, h
 	int log2tf = 0;
 	while ((16 << log2tf) < nfft)
 		++log2tf;
-	if (log2tf < 4 || (a.bits_t_stream_stride & 3) != 0)
-		ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "mask bits: nfft = %d below 256", nfft); // (the engine asks mask_bits_supported())
+	if (!mask_bits_supported(nfft, a.p_mid) || (a.bits_t_stream_stride & 3) != 0) // (the engine asks the same question first)
+		ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "mask bits: nfft = %d, p_mid = %d outside the transposed layout", nfft, a.p_mid);
 	const long long threads = ((long long)a.n_frames * a.n_streams) << (log2tf - 4);
 	hipLaunchKernelGGL(mask_bits_transpose_kernel, dim3((unsigned)ceil_div((size_t)threads, (size_t)256)), dim3(256), 0, stream, a, bits_t,
 	                   nfft, log2tf);

@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void median47_dpp_kernel(M47Args p)
 	// per wave: [0,16) pieces of the block left of lane 0; [16,32) sorted block right of lane 63,
 	// [32,48) its pieces; [48,64) pieces of the block after that
 	__shared__ __attribute__((aligned(16))) int edge[4][64];
+	__shared__ __attribute__((aligned(16))) int negf[4]; // !NONNEG: wave w loaded a sample with its sign bit set
 
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -110,24 +111,65 @@ __global__ __launch_bounds__(256) void median47_dpp_kernel(M47Args p)
 				x[i] = NT ? load_nt(srow + 4 * tid + 1024 * i) : *reinterpret_cast<const float4*>(srow + 4 * tid + 1024 * i);
 			}
 		}
+		// Keys.  NONNEG (the engine: magnitudes): the raw bits order like the values.  Otherwise the row is staged as raw
+		// bits all the same while every wave ORs the sign bits of what it loaded; only a row that holds a negative sample
+		// (any set sign bit: -0 and negative NaNs included) is re-keyed in place below.  A caller's magnitude matrix thus
+		// runs at the engine's speed without any promise, signed data stays exact (two VALU operations per staged value
+		// and per result was the whole difference between the two builds: 0.63 against 0.74 of the HBM roof).
 		int* wr = unit_ptr(img, tid + 6);
+		if constexpr (!NONNEG) {
+			int o = 0;
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+				o |= __float_as_int(x[i].x) | __float_as_int(x[i].y) | __float_as_int(x[i].z) | __float_as_int(x[i].w);
+			const bool wneg = __builtin_amdgcn_ballot_w64(o < 0) != 0ull;
+			if (lane == 0)
+				negf[wave] = wneg ? 1 : 0;
+		}
 #pragma unroll
 		for (int i = 0; i < 4; ++i)
-			*reinterpret_cast<int4*>(wr + i * 64 * RSTR) = make_int4(to_key<NONNEG>(x[i].x), to_key<NONNEG>(x[i].y),
-			                                                         to_key<NONNEG>(x[i].z), to_key<NONNEG>(x[i].w));
+			*reinterpret_cast<int4*>(wr + i * 64 * RSTR) = make_int4(to_key<true>(x[i].x), to_key<true>(x[i].y),
+			                                                         to_key<true>(x[i].z), to_key<true>(x[i].w));
 		// replicate border (ippBorderRepl): words 0..23 = x[0], words 4120..4143 = x[4095]
 		if (wave == 0) {
-			const int b = __builtin_amdgcn_readfirstlane(to_key<NONNEG>(x[0].x));
+			const int b = __builtin_amdgcn_readfirstlane(to_key<true>(x[0].x));
 			if (lane < 6)
 				*reinterpret_cast<int4*>(unit_ptr(img, lane)) = make_int4(b, b, b, b);
 		}
 		if (wave == 3) {
-			const int b = __builtin_amdgcn_readlane(to_key<NONNEG>(x[3].w), 63);
+			const int b = __builtin_amdgcn_readlane(to_key<true>(x[3].w), 63);
 			if (lane < 6)
 				*reinterpret_cast<int4*>(unit_ptr(img, 1030 + lane)) = make_int4(b, b, b, b);
 		}
 	}
 	__syncthreads();
+	bool signed_row = false; // workgroup-uniform
+	// every thread re-keys the words it staged (and the border copies): the monotone key of median_net.h f2key
+	auto rekey_image = [&]() {
+		auto rekey = [](int* q) {
+			int4 v = *reinterpret_cast<int4*>(q);
+			v.x ^= (v.x >> 31) & 0x7fffffff;
+			v.y ^= (v.y >> 31) & 0x7fffffff;
+			v.z ^= (v.z >> 31) & 0x7fffffff;
+			v.w ^= (v.w >> 31) & 0x7fffffff;
+			*reinterpret_cast<int4*>(q) = v;
+		};
+		int* wr = unit_ptr(img, tid + 6);
+#pragma unroll
+		for (int i = 0; i < 4; ++i)
+			rekey(wr + i * 64 * RSTR);
+		if (wave == 0 && lane < 6)
+			rekey(unit_ptr(img, lane));
+		if (wave == 3 && lane < 6)
+			rekey(unit_ptr(img, 1030 + lane));
+		__syncthreads();
+	};
+	if constexpr (!NONNEG && (HERM || VARIANT == 2)) { // (the whole-row build reads the flags together with its own block, below)
+		const int4 f = *reinterpret_cast<const int4*>(negf);
+		signed_row = __builtin_amdgcn_readfirstlane(f.x | f.y | f.z | f.w) != 0;
+		if (signed_row)
+			rekey_image();
+	}
 
 	int out[16];
 	int out_blk = tid;     // the block whose 16 outputs this thread holds
@@ -160,6 +202,17 @@ __global__ __launch_bounds__(256) void median47_dpp_kernel(M47Args p)
 		{
 			int raw[16];
 			znet::lds_load<16>(&img[(tid + 1) * RSTR], raw);
+			if constexpr (!NONNEG) { // the sign flags of the four waves come back with the block: no LDS round trip of their own
+				const int4 f = *reinterpret_cast<const int4*>(negf);
+				signed_row = __builtin_amdgcn_readfirstlane(f.x | f.y | f.z | f.w) != 0;
+				if (signed_row) { // the block in registers was staged (as raw bits) by other threads: same map, then the image
+#pragma unroll
+					for (int i = 0; i < 16; ++i)
+						raw[i] ^= (raw[i] >> 31) & 0x7fffffff;
+					__syncthreads(); // (every thread has read its block before anyone rewrites the image)
+					rekey_image();
+				}
+			}
 			znet::pyramid16(raw, s16, oct, quad);
 		}
 		// pieces wanted by the lanes to the left (they sit two and one blocks below this one) ...
@@ -265,12 +318,25 @@ __global__ __launch_bounds__(256) void median47_dpp_kernel(M47Args p)
 		}
 	}
 
+	// a signed row's results go back through the key map: one workgroup-uniform branch per group of values (written as a
+	// block so that the compiler keeps it a branch; as a select per value it costs every row three operations per result)
+	auto unkey4 = [signed_row](int4& k) {
+		if (signed_row) {
+			k.x ^= (k.x >> 31) & 0x7fffffff;
+			k.y ^= (k.y >> 31) & 0x7fffffff;
+			k.z ^= (k.z >> 31) & 0x7fffffff;
+			k.w ^= (k.w >> 31) & 0x7fffffff;
+		}
+	};
 	if constexpr (DIRECT) {
 #pragma unroll
 		for (int v = 0; v < 4; ++v)
+		{
+			int4 k = make_int4(out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]);
+			unkey4(k);
 			*reinterpret_cast<float4*>(drow + 16 * tid + 4 * v) =
-			    make_float4(from_key<NONNEG>(out[4 * v]), from_key<NONNEG>(out[4 * v + 1]),
-			                from_key<NONNEG>(out[4 * v + 2]), from_key<NONNEG>(out[4 * v + 3]));
+			    make_float4(__int_as_float(k.x), __int_as_float(k.y), __int_as_float(k.z), __int_as_float(k.w));
+		}
 	}
 	else {
 		__syncthreads(); // every flank is in registers: the image can take the results
@@ -285,8 +351,9 @@ __global__ __launch_bounds__(256) void median47_dpp_kernel(M47Args p)
 			const int c = 4 * tid + 1024 * i;
 			if (HERM && c > 2048 && c < 4064) // Hermitian rows: nobody reads these columns
 				continue;
-			const int4 k = *reinterpret_cast<const int4*>(rd + i * 64 * RSTR);
-			const float4 r = make_float4(from_key<NONNEG>(k.x), from_key<NONNEG>(k.y), from_key<NONNEG>(k.z), from_key<NONNEG>(k.w));
+			int4 k = *reinterpret_cast<const int4*>(rd + i * 64 * RSTR);
+			unkey4(k);
+			const float4 r = make_float4(__int_as_float(k.x), __int_as_float(k.y), __int_as_float(k.z), __int_as_float(k.w));
 			if (NT)
 				store_nt(drow + 4 * tid + 1024 * i, r);
 			else
@@ -332,18 +399,22 @@ int launch_median47_dpp(const FilterArgs& a, hipStream_t stream, bool* handled)
 	else if (a.nonneg) {
 		switch (variant) {
 		case 1: ZH_M47(true, 1); break;
+#ifdef ZEN_HIP_DIAG
 		case 2: ZH_M47(true, 2); break;
 		case 3: ZH_M47(true, 3); break;
 		case 4: ZH_M47(true, 4); break;
+#endif
 		default: ZH_M47(true, 0); break;
 		}
 	}
 	else {
 		switch (variant) {
 		case 1: ZH_M47(false, 1); break;
+#ifdef ZEN_HIP_DIAG
 		case 2: ZH_M47(false, 2); break;
 		case 3: ZH_M47(false, 3); break;
 		case 4: ZH_M47(false, 4); break;
+#endif
 		default: ZH_M47(false, 0); break;
 		}
 	}

@@ -410,6 +410,16 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 	// loads, and stores the sums after the forward transform.  A hop whose rows are not both published from this XCD with
 	// this call's sequence number -- or that has no workgroup DIRECT_BACK items behind it -- is marked for
 	// launch_rt_fused_fixup, which adds it up after the kernel: correct wherever and whenever the workgroups run.
+	// What the hand-off leans on, none of it expressed in the memory model (the row stores are plain, the publication word
+	// relaxed): on gfx942 / gfx950 (i) a store counted off by s_waitcnt vmcnt(0) has reached the L2 of its XCD, (ii) an
+	// agent-scope (sc1) load bypasses the L1 and is served by that L2 when issued from the same XCD, (iii) XCC_ID is bits
+	// 3:0 of hwreg 20 (xcc_id_of_cu), which is how a reader knows the writer shared its L2.  The Y-row stores of InvOut
+	// must therefore stay plain stores (a nontemporal / streaming store may sit in a write-combining buffer past the wait).
+	// Anything that does not hold falls back to the fix-up launch only if it shows up as an unpublished word: keep the
+	// 40-repetition test (tests/test_gpu_round3.py test_fused_block_kernel_finishes_hops_itself) in the GPU tier.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "rt_fused.hip: the same-XCD hand-off of the block build is written for gfx942 / gfx950"
+#endif
 	constexpr bool DIRECT = HARDP && MINB != 1;
 	constexpr int DIRECT_BACK = 128;
 	unsigned dv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -652,6 +662,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		if constexpr (DIRECT) {
 			if (a.direct_on) { // every output's row is in the L2 once the memory counter has drained: publish the item
 				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // no instruction on gfx950; keeps the compiler from moving stores below
 				__syncthreads();
 				if (tf == 0)
 					__hip_atomic_store(a.blk_flag + item, (a.blk_seq << 4) | xcc_id_of_cu(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -680,6 +691,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 			zfft::fft_frame<LOG2N, true, false, true, InvInLean<N, TF, mid, HARDP>, InvOut, true>(tf, lds, a.tw, in, out, true);
 			if (a.direct_on) { // second part: once the row is in the L2 (the memory counter has drained), publish it
 				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // no instruction on gfx950; keeps the compiler from moving stores below
 				__syncthreads();
 				if (tf == 0)
 					__hip_atomic_store(a.blk_flag + item, (a.blk_seq << 4) | xcc_id_of_cu(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

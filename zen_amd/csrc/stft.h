@@ -82,10 +82,16 @@ struct IstftArgs {
 	// of every bin the synthesis reads, Hm the harmonic one (rows laid out as P's); H is not read.
 	int mask_rows;
 	const float* Hm;
+	int grid_map;           // set by launch_istft: blockIdx.x encodes (group of frames, output), see istft_kernel
 };
 
 // words of one row of mask bits (a multiple of four: rows stay 16-byte aligned)
 inline int mask_bits_row_words(int nfft, int p_mid) { return ((nfft / 2 + 1 + p_mid + 15) / 16 + 3) / 4 * 4; }
+// The transposed layout gives the row's last p_mid bins (replicate border: not mirror images) entries of their
+// own in slot 15 only: the masks-as-bits path covers geometries whose tail fits there.  mf is about 500 Hz of bins
+// (hps.h:229), so this fails below fs of roughly 4 kHz (fs 2000, hop 64: nfft 256, mf 65, p_mid 32 against 16); those take
+// the H / P rows path.
+inline bool mask_bits_supported(int nfft, int p_mid) { return nfft >= 256 && p_mid <= nfft / 16; }
 
 // overlap-add of consecutive frames (hps.cu:435-449 + :526-528) and copy-out (hps.cu:341-363):
 // out[i*hop + n] = (i ? Y[i-1][hop+n] : carry[n]) + Y[i][n]

@@ -127,14 +127,22 @@ def time_shards(n_samples, world, align=1):
 class Group:
     """Thin wrapper over torch.distributed (or nothing, for world == 1)."""
 
-    def __init__(self, backend=None, device=None):
+    def __init__(self, backend=None, device=None, force=False):
+        """force: initialise the process group for a world of one too (RCCL communicator, all-reduce, barrier, destroy on
+        ONE GPU: the plumbing of the 8-GPU run, exercised where only one GPU exists -- tests/test_gpu_round4.py and
+        ZEN_FORCE_PROCESS_GROUP=1 python bench.py)."""
         self.rank, self.local_rank, self.world = env_world()
         self.dist = None
         self.device = device
-        if self.world > 1:
+        if self.world > 1 or force:
             import torch
             import torch.distributed as dist
             self.torch = torch
+            if not launched_by_torchrun():            # a plain process: give torch.distributed the rendezvous of a world of one
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", str(_free_port()))
+                os.environ.setdefault("RANK", "0")
+                os.environ.setdefault("WORLD_SIZE", "1")
             if not dist.is_initialized():
                 kw = {}
                 if backend == "nccl" and device is not None:

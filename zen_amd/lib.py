@@ -35,6 +35,12 @@ class _Params(C.Structure):
                 ("n_streams", C.c_size_t), ("max_hops_per_chunk", C.c_size_t)]
 
 
+class _HostStats(C.Structure):
+    _fields_ = [("n_ranges", C.c_size_t), ("range_samples", C.c_size_t), ("input_pinned", C.c_int),
+                ("outputs_pinned", C.c_int), ("setup_ms", C.c_double), ("enqueue_ms", C.c_double),
+                ("total_ms", C.c_double)]
+
+
 # every symbol include/zen_hip.h declares: (name, restype, argtypes)
 _vp, _sz, _i, _u, _f = C.c_void_p, C.c_size_t, C.c_int, C.c_uint, C.c_float
 _pvp = C.POINTER(C.c_void_p)
@@ -58,6 +64,8 @@ SYMBOLS = [
     ("zen_hip_memcpy_h2d", _i, [_vp, _vp, _sz]),
     ("zen_hip_memcpy_d2h", _i, [_vp, _vp, _sz]),
     ("zen_hip_memcpy_d2d", _i, [_vp, _vp, _sz, _vp]),
+    ("zen_hip_memcpy_h2d_async", _i, [_vp, _vp, _sz, _vp]),
+    ("zen_hip_memcpy_d2h_async", _i, [_vp, _vp, _sz, _vp]),
     ("zen_hip_host_alloc_mapped", _i, [_sz, _i, _pvp, _pvp]),
     ("zen_hip_host_free", _i, [_vp]),
     ("zen_hip_fft_create", _i, [_sz, _pvp]),
@@ -66,6 +74,7 @@ SYMBOLS = [
     ("zen_hip_fft_destroy", _i, [_vp]),
     ("zen_hip_mfilt_create", _i, [_i, _i, _i, _i, _i, _pvp]),
     ("zen_hip_mfilt_run", _i, [_vp, _vp, _vp, _vp]),
+    ("zen_hip_mfilt_assume_nonneg", _i, [_vp, _i]),
     ("zen_hip_mfilt_destroy", _i, [_vp]),
     ("zen_hip_box_create", _i, [_i, _i, _i, _i, _pvp]),
     ("zen_hip_box_run", _i, [_vp, _vp, _vp, _vp]),
@@ -92,6 +101,7 @@ SYMBOLS = [
     ("zen_hip_hpri_use_sse_filter", _i, [_vp]),
     ("zen_hip_hpri_use_soft_mask", _i, [_vp]),
     ("zen_hip_hpri_process", _i, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    ("zen_hip_hpri_host_stats_get", _i, [_vp, C.POINTER(_HostStats)]),
     ("zen_hip_hpri_process_device", _i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _sz]),
     ("zen_hip_hpri_range_halo", _i, [_vp, _sz, _sz, _sz, C.POINTER(_sz), C.POINTER(_sz)]),
     ("zen_hip_hpri_process_range", _i, [_vp, _vp, _sz, _sz, _sz, _vp, _vp]),
@@ -270,6 +280,10 @@ class _Filter:
         else:
             _ck(L.zen_hip_box_create(time, frequency, filter_len, direction, C.byref(h)))
         self._h = h.value
+
+    def assume_nonneg(self, on=True):
+        """Per-handle promise that every input sample is >= +0 (zen_hip_mfilt_assume_nonneg); median handles only."""
+        _ck(load().zen_hip_mfilt_assume_nonneg(self._h, int(bool(on))))
 
     def filter(self, src, dst):
         """src, dst: DeviceBuffer or raw device pointers (time x frequency floats)."""
@@ -469,14 +483,23 @@ class HPRIOffline:
         _ck(load().zen_hip_hpri_hop_counts(self._h, n, C.byref(a), C.byref(b)))
         return a.value, b.value
 
-    def process(self, audio):
-        """std::array<std::vector<float>,3> process(std::vector<float>) : (harm, perc, resid)."""
+    def process(self, audio, out=None):
+        """std::array<std::vector<float>,3> process(std::vector<float>) : (harm, perc, resid).
+        out: optional (harm, perc, resid) float32 arrays of the clip's length to fill (any may be None)."""
         audio = np.ascontiguousarray(audio, dtype=np.float32)
         n = audio.size
-        h, p, r = (np.empty(n, np.float32) for _ in range(3))
-        _ck(load().zen_hip_hpri_process(self._h, audio.ctypes.data, n, h.ctypes.data, p.ctypes.data,
-                                        r.ctypes.data))
+        h, p, r = out if out is not None else (np.empty(n, np.float32) for _ in range(3))
+        for a in (h, p, r):
+            assert a is None or (a.dtype == np.float32 and a.size == n and a.flags.c_contiguous)
+        _ck(load().zen_hip_hpri_process(self._h, audio.ctypes.data, n, *(a.ctypes.data if a is not None else None
+                                                                         for a in (h, p, r))))
         return h, p, r
+
+    def host_stats(self):
+        """What the last process() call did: ranges, pinned or not, setup / enqueue / total ms."""
+        st = _HostStats()
+        _ck(load().zen_hip_hpri_host_stats_get(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in _HostStats._fields_}
 
     def range_halo(self, n, begin, end):
         a, b = C.c_size_t(), C.c_size_t()
