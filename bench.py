@@ -557,8 +557,11 @@ def median_rooflines(zen_amd, run, S, M, copy_bw):
 
 def sse_rooflines(prof, steps, frames, nfft, hop):
     """Per-kernel lines of the SSE block path (BASELINE configs[4]); whole rows: the box mean is not mirror symmetric."""
+    fused = not prof.get("time_filter", {}).get("launches")     # sse_block.hip: both boxes + masks + synthesis in one launch
     per_frame = {"stft": 4 * hop + 8 * (nfft // 2 + 1) + 4 * nfft, "freq_filter": 8 * nfft, "time_filter": 8 * nfft,
                  "istft": 8 * (nfft // 2 + 1) + 8 * nfft + 8 * hop, "finalize": 12 * hop}
+    if fused:    # the spectrum row and the magnitude row once each (the neighbours' rows of the time box are re-reads), one Y row
+        per_frame.update({"stft": 4 * hop + 12 * (nfft // 2 + 1), "istft": 12 * (nfft // 2 + 1) + 8 * hop})
     out = {}
     for k, v in prof.items():
         if v["launches"] and k in per_frame:
@@ -567,7 +570,9 @@ def sse_rooflines(prof, steps, frames, nfft, hop):
             out[k] = {"ms_per_step": ms, "algorithmic_bytes_per_frame": per_frame[k], "achieved": ach, "frac": ach / 8000.0}
     dom = max(out, key=lambda k: out[k]["ms_per_step"])
     return {"bound": "hbm", "achieved": out[dom]["achieved"], "peak": 8000.0, "unit": "GB/s", "frac": out[dom]["frac"],
-            "traffic": None, "kernel": dom, "note": "dominant kernel of the step by HIP-event time"}, out
+            "traffic": None, "kernel": dom + (" (sse_synth_kernel: time box + frequency box + Wiener mask + inverse transform)" if fused and dom == "istft" else ""),
+            "launches_per_step": sum(1 for v in prof.values() if v["launches"]),
+            "note": "dominant kernel of the step by HIP-event time"}, out
 
 
 def offline_batch_run(zen_amd, zdist, grp, rank, world, C, clip_seconds, steps, warmup, settle_ms, barrier, rooflines=True):

@@ -220,3 +220,86 @@ def test_bench_under_the_launcher_path_with_rccl():
     assert len(lines) == 1
     j = json.loads(lines[0])
     assert j["n_gpus"] == 1 and j["ranks_reported"] == 1 and j["value"] > 0 and j["roofline"]["frac"] > 0
+
+
+# ---------------------------------------------------------------------------- SSE path, blocks of frames: analysis + ONE fused launch
+@pytest.mark.parametrize("hop", [128, 256, 512, 1024])
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("flags", [ALL, o.OUTPUT_PERCUSSIVE, o.OUTPUT_HARMONIC])
+def test_sse_blocks_fused_synthesis_vs_oracle_and_four_launch_path(z, hop, causal, flags):
+    """apply_sse_filter (hps.cu:582-652) for blocks of frames: sse_synth_kernel (time box, frequency box, Wiener masks
+    and the inverse transforms of a frame in one workgroup; no H / P rows) against the oracle, against the four-launch
+    path it replaces ("no_sse_block") and against per-hop calls; two streams, uneven blocks (history rows of the time
+    box come from the previous call's ring rows), a switch to SSE in mid-stream."""
+    cz, co = (z.TIME_CAUSAL, o.TIME_CAUSAL) if causal else (z.TIME_ANTICAUSAL, o.TIME_ANTICAUSAL)
+    ho = o.HPR(FS, hop, 2.0, flags, co)
+    ho.use_sse_filter()
+    n_hops = 3 * ho.stft_width + 31
+    x = np.stack([_clip(hop * n_hops, 5 + hop), _clip(hop * n_hops, 6 + hop)])
+    refs = []
+    for s in range(2):
+        h = o.HPR(FS, hop, 2.0, flags, co)
+        h.use_sse_filter()
+        refs.append(h.process_stream(x[s]))
+    keys = [k for k, f in (("P", o.OUTPUT_PERCUSSIVE), ("H", o.OUTPUT_HARMONIC)) if flags & f]    # no residual with SSE
+
+    def run(opt, block):
+        if opt:
+            z.set_option(opt, 1)
+        try:
+            g = z.HPR(FS, hop, 2.0, flags, cz, False, 2)
+            g.use_sse_filter()
+            return g.process_stream_host(x, block=block)
+        finally:
+            if opt:
+                z.set_option(opt, 0)
+
+    for block in (None, 7, 2):
+        got = run(None, block)
+        old = run("no_sse_block", block)
+        for k in keys:
+            for s in range(2):
+                assert np.array_equal(got[k][s], refs[s][k]), (block, k, s)
+                assert np.any(refs[s][k] != 0)
+            assert np.array_equal(got[k], old[k]), ("no_sse_block", block, k)
+    # median path first, SSE from hop `first` on (hps.h:289: use_sse_filter may be called at any time)
+    first = ho.stft_width + 9
+    h = o.HPR(FS, hop, 2.0, flags, co)
+    ra = h.process_stream(x[0][:first * hop])
+    h.use_sse_filter()
+    rb = h.process_stream(x[0][first * hop:])
+    g = z.HPR(FS, hop, 2.0, flags, cz)
+    ga = g.process_stream_host(x[0][:first * hop], block=first)
+    g.use_sse_filter()
+    gb = g.process_stream_host(x[0][first * hop:], block=11)
+    for k in keys:
+        assert np.array_equal(ga[k], ra[k]) and np.array_equal(gb[k], rb[k]), ("switch", k)
+
+
+def test_sse_bench_block_windows_vs_oracle(z):
+    """BASELINE configs[4] at the size bench.py times it: ONE zen_hip_hpr_process call of 51 680 hops (hop 512, SSE,
+    nocopybord, percussive output) against the oracle on windows at its start, middle and end.  A causal SSE output hop
+    depends on the stft_width - 1 frames before it (time box) and on the hop before it (overlap-add): an oracle started
+    stft_width + 2 hops early from zero state is exact from the window's first hop on -- except that zero history rows
+    are 1/0 = inf for the oracle's first frames, which is what a fresh stream sees too, so the windows away from the start
+    compare only hops whose time box holds no pre-start row."""
+    hop, M, K = 512, 51680, 20
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    x = b.s_music(M * hop, seed=0)
+    g = z.HPR(FS, hop, 2.0, o.OUTPUT_PERCUSSIVE, z.TIME_CAUSAL, False, 1, M)
+    g.use_sse_filter()
+    got = g.process_stream_host(x)["P"]
+    W = o.HPR(FS, hop, 2.0, o.OUTPUT_PERCUSSIVE, o.TIME_CAUSAL).stft_width
+    for first in (0, M // 2, M - K):
+        j = max(first - (W + 2), 0)
+        ho = o.HPR(FS, hop, 2.0, o.OUTPUT_PERCUSSIVE, o.TIME_CAUSAL, False)
+        ho.use_sse_filter()
+        ref = ho.process_stream(x[j * hop:(first + K) * hop])["P"]
+        skip = first - j
+        assert np.array_equal(got[first * hop:(first + K) * hop], ref[skip * hop:], equal_nan=True), first
+        assert np.any(np.nan_to_num(ref[skip * hop:]) != 0)

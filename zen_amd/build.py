@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libzen_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 RESOURCES = os.path.join(HERE, "kernel_resources.json")   # per-kernel registers / scratch / LDS of the last build
-SOURCES = ["api.hip", "hpr.hip", "hpri.hip", "stft.hip", "istft.hip", "median.hip", "median_net.hip", "median47.hip", "median_big.hip", "rt_fused.hip", "rt_fused_multi.hip", "rt_fused_multi_lean.hip", "rt_sse.hip", "rt_wide.hip", "box.hip", "fft_big.hip"]
+SOURCES = ["api.hip", "hpr.hip", "hpri.hip", "stft.hip", "istft.hip", "median.hip", "median_net.hip", "median47.hip", "median_big.hip", "rt_fused.hip", "rt_fused_multi.hip", "rt_fused_multi_lean.hip", "rt_sse.hip", "rt_wide.hip", "box.hip", "fft_big.hip", "sse_block.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 EXTRA = os.environ.get("ZEN_HIP_EXTRA_FLAGS", "").split()
 FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
@@ -37,6 +37,7 @@ FILE_FLAGS = {"rt_fused.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mll
               # (round 3: with the loads of a frame in flight together the analysis kernels gain from it too: nfft 16384
               # 1.08 -> 0.99 ms, nfft 1024 0.74 -> 0.64 ms per offline batch step; it lost while they were serialised)
               "stft.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+              "sse_block.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
               "median_big.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-minreg"],
               "rt_wide.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-minreg"]}
 FILE_FLAGS_ENV = os.environ.get("ZEN_HIP_FILE_FLAGS", "")   # A/B hook: "median_net.hip=-mllvm,-amdgpu-sched-strategy=max-ilp"

@@ -18,6 +18,7 @@
 #include "common.h"
 #include "filters.h"
 #include "hpr_engine.h"
+#include "sse_block.h"
 #include "masks.h"
 #include "rt_fused.h"
 #include "stft.h"
@@ -393,7 +394,14 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 	// kernel on the way does not know such rows.  The last W-1 frames of a chunk keep whole magnitude rows: a
 	// later use_sse_filter() (hps.h:289) reads them.
 	const bool time_identity = (e->causality == ZEN_HIP_TIME_CAUSAL || e->mt == 1);
-	ZH_TRY(ensure_estimates(e, e->use_sse || !time_identity));
+	// SSE path, blocks of frames: both box filters, the masks and the synthesis in one launch behind the analysis
+	// (sse_block.hip); no H / P rows at all
+	int n_computed = 0;
+	for (int o = 0; o < 3; ++o)
+		n_computed += output_computed(e, o) ? 1 : 0;
+	const bool sse_block = e->use_sse && M >= 2 && sse_block_available(e->log2n, e->mt, e->mf, n_computed, e->ring_rows);
+	if (!sse_block)
+		ZH_TRY(ensure_estimates(e, e->use_sse || !time_identity));
 	for (int o = 0; o < 3; ++o)
 		if (output_computed(e, o))
 			ZH_TRY(ensure_rows(e, o));
@@ -412,7 +420,7 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 	sa.S = e->d_S;
 	sa.s_stride = (long long)e->s_stride;
 	sa.mag = e->d_mag;
-	sa.mag_full_from = half ? (int)M - ((int)e->W - 1) : 0;
+	sa.mag_full_from = (half || sse_block) ? (int)M - ((int)e->W - 1) : 0; // (sse_block reads bins 0..nfft/2 only)
 	sa.ring_rows = e->ring_rows;
 	sa.row0 = e->abs_frame;
 	sa.n_frames = (int)M;
@@ -432,6 +440,51 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 
 	// ---- harmonic / percussive estimates of the consumed rows (row W-lag of the sliding matrix)
 	const long long crow0 = e->abs_frame - (e->lag - 1);
+	if (sse_block) {
+		SseBlockArgs sb;
+		memset(&sb, 0, sizeof(sb));
+		IstftArgs& ia = sb.ia;
+		ia.S = e->d_S;
+		ia.s_stride = (long long)e->s_stride;
+		ia.ring_rows = e->ring_rows;
+		ia.crow0 = crow0;
+		ia.tw = e->d_tw;
+		ia.y_stream_stride = (long long)(e->max_hops * e->nwin);
+		ia.n_frames = (int)M;
+		ia.n_streams = (int)S;
+		ia.hop = (int)e->hop;
+		for (int o = 0; o < 3; ++o) {
+			e->ready_valid[o] = false;
+			if (output_computed(e, o)) {
+				ia.Y[ia.n_out] = e->d_Y[o];
+				ia.out_id[ia.n_out] = o;
+				++ia.n_out;
+			}
+		}
+		ia.beta = e->beta;
+		ia.beta_h = e->beta - FLT_EPSILON;
+		ia.soft = e->soft ? 1 : 0;
+		ia.power = (int)e->beta;
+		ia.sse = 1;
+		ia.out_h = e->out_h ? 1 : 0;
+		ia.out_p = e->out_p ? 1 : 0;
+		ia.cola = e->cola;
+		sb.mag = e->d_mag;
+		sb.clamp_lo = 0; // as the FilterArgs of the box launches below
+		sb.clamp_hi = LLONG_MAX / 4;
+		sb.len_t = e->mt;
+		sb.len_f = e->mf;
+		sb.causal_self = (e->causality == ZEN_HIP_TIME_CAUSAL) ? 1 : 0;
+		sb.fac_h = (float)e->l_harm + 1.0F; // hps.cu:602-604
+		sb.fac_p = (float)e->l_perc + 1.0F; // hps.cu:599-601
+		{
+			ProfScope ps(e, zen_hip_hpr::K_ISTFT);
+			ZH_TRY(launch_sse_block(e->log2n, sb, e->stream));
+		}
+		e->abs_frame += (long long)M;
+		e->last_frames = M;
+		return ZEN_HIP_OK;
+	}
 	FilterArgs fa;
 	memset(&fa, 0, sizeof(fa));
 	fa.src = e->d_mag;

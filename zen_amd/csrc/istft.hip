@@ -449,7 +449,11 @@ int launch_istft_t(const IstftArgs& a, hipStream_t stream)
 	}
 	dim3 grid((unsigned)ceil_div((size_t)a.n_frames, (size_t)PL::FRAMES_PER_BLOCK), (unsigned)a.n_out, (unsigned)a.n_streams);
 	IstftArgs am = a; // (the kernels below are launched with `am`)
-	if (a.n_out > 1 && a.n_frames > 1 && !g_opt_no_istft_xcd_map) { // the outputs of a frame on one XCD, back to back (istft_kernel)
+	// the outputs of a frame on one XCD, back to back (istft_kernel).  One stream only: measured on the offline workloads
+	// (pass 1, nfft 16384), a single clip gains 4 % (1.32 -> 1.26 ms per 12 922 frames x 2 outputs), a batch of 64 clips
+	// LOSES 6 % (2.47 -> 2.62 ms per 20 736 x 3): there the re-reads of a spectrum row were served by the Infinity Cache
+	// anyway (the kernel is bound by its workgroup's lock step, not by HBM) and the plain grid schedules better.
+	if (a.n_out > 1 && a.n_frames > 1 && a.n_streams == 1 && !g_opt_no_istft_xcd_map) {
 		am.grid_map = 1;
 		grid = dim3((unsigned)(ceil_div((size_t)grid.x, (size_t)8) * 8 * (size_t)a.n_out), 1, (unsigned)a.n_streams);
 	}
