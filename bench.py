@@ -304,8 +304,19 @@ def realtime_leg(zen_amd, x, n_hops=400):
                                os.path.join(ROOT, "zen_amd"), "-lzen_hip", "-Wl,-rpath," + os.path.join(ROOT, "zen_amd")],
                               stderr=subprocess.DEVNULL)
         lines = subprocess.run([exe, "2000"], capture_output=True, text=True, timeout=120).stdout.splitlines()
+        # the same loop with the opt-in resident kernel (zen_hip_hpr_set_resident): no launch per hop
+        res_lines = subprocess.run([exe, "2000"], capture_output=True, text=True, timeout=120,
+                                   env=dict(os.environ, ZEN_RT_RESIDENT="100")).stdout.splitlines()
         os.remove(exe)
         sweep = [json.loads(ln) for ln in lines if ln.startswith("{")]
+        rsweep = [json.loads(ln) for ln in res_lines if ln.startswith("{")]
+        res["resident_us_by_hop"] = {str(r["hop"]): r["us_per_hop"] for r in rsweep if r.get("resident")}
+        rat = [r for r in rsweep if r.get("resident") and r["hop"] == HOP]
+        if rat:
+            res["resident_us_per_hop"] = rat[0]["us_per_hop"]
+            res["resident_hops_per_s"] = 1e6 / rat[0]["us_per_hop"]
+            res["resident_note"] = ("opt-in zen_hip_hpr_set_resident(idle 100 ms): one workgroup stays on the device and takes each "
+                                    "hop from a mailbox; same samples (tests/test_gpu_round4.py)")
         res["per_hop_us_by_hop"] = {("sse_" if r["sse"] else "") + str(r["hop"]): r["us_per_hop"] for r in sweep}
         at = [r for r in sweep if r["hop"] == HOP and not r["sse"]]
         if at:
@@ -881,6 +892,7 @@ def compact_line(full):
     if "realtime" in full:
         cfg["per_hop_api_us"] = full["realtime"].get("us_per_hop")
         cfg["per_hop_api_hops_per_s"] = full["realtime"].get("hops_per_s")
+        cfg["per_hop_api_resident_us"] = full["realtime"].get("resident_us_per_hop")
     line["config"] = cfg
     if legs:
         line["legs"] = legs

@@ -191,6 +191,19 @@ int zen_hip_hpr_process_next_hop(zen_hip_hpr_t h, const float* in_dev);
 int zen_hip_hpr_copy_output(zen_hip_hpr_t h, unsigned which, float* out_dev);
 int zen_hip_hpr_copy_output_async(zen_hip_hpr_t h, unsigned which, float* out_dev);
 
+/* Resident kernel for the per-hop path (an MI355X extension, off by default).  idle_ms > 0: single-hop calls of a causal
+ * one-stream, one-output median-path engine whose hop sizes the fused kernel covers (hops 128..1024) no longer cost a
+ * launch each: ONE workgroup is started by the first zen_hip_hpr_process_next_hop and stays on its CU, taking every
+ * further hop from a mailbox in device-visible memory and publishing it behind the same sequence word
+ * zen_hip_hpr_copy_output polls; it leaves by itself after idle_ms without a hop (at most 2000), when anything else is
+ * asked of the engine (block calls, use_*, reset, set_stream, profile, destroy), and is started again by the next hop.
+ * Same samples as the per-launch path, hop for hop.  While it is resident it occupies one CU, and device-wide
+ * synchronising calls of the process (hipFree, hipDeviceSynchronize) wait for it to leave -- at most idle_ms.
+ * idle_ms == 0 switches the mode off (and sends a resident kernel home). */
+int zen_hip_hpr_set_resident(zen_hip_hpr_t h, int idle_ms);
+/* launches of the resident kernel so far, hops processed by those that have ended, whether one is resident now */
+int zen_hip_hpr_resident_stats(zen_hip_hpr_t h, unsigned long long* launches, unsigned long long* hops, int* active);
+
 /* Block form.  in_dev: n_streams rows of n_hops*hop floats, `in_stride` floats apart.  Each non-NULL
  * out_*_dev receives n_streams rows of n_hops*hop floats, `out_stride` apart: exactly what n_hops
  * calls of process_next_hop + copy_* would have produced.  Asynchronous.  An output may BE the input (same pointer

@@ -111,6 +111,13 @@ def test_cli_offline_and_fakert_end_to_end(tmp_path):
     peak = max(-ref.min(), ref.max())
     _, got = read_wav_pcm16(str(tmp_path / "rt.wav"))
     assert np.array_equal(got.astype(np.int64), pcm16(ref / np.float32(peak)))
+    # the same stream through the resident kernel (MI355X extension, HPRRealtime::use_resident_kernel): the same file
+    r = subprocess.run([ZEN, "fakert", "-i", wav, "--hps", str(hop), "2.0", "-o", str(tmp_path / "rt_res.wav"), "--resident", "50"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    assert "average processing duration(us)" in r.stdout
+    _, got_res = read_wav_pcm16(str(tmp_path / "rt_res.wav"))
+    assert np.array_equal(got_res, got)
 
 
 @pytest.mark.gpu

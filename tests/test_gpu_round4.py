@@ -303,3 +303,65 @@ def test_sse_bench_block_windows_vs_oracle(z):
         skip = first - j
         assert np.array_equal(got[first * hop:(first + K) * hop], ref[skip * hop:], equal_nan=True), first
         assert np.any(np.nan_to_num(ref[skip * hop:]) != 0)
+
+
+# ---------------------------------------------------------------------------- the per-hop API through a resident kernel
+def _per_hop(z, rt, io, x, hop, n_hops, copy, pause_every=0, pause_s=0.0):
+    import time
+    out = np.zeros(hop * n_hops, np.float32)
+    for i in range(n_hops):
+        io.host_in[:] = x[i * hop:(i + 1) * hop]
+        rt.process_next_hop(io.device_in)
+        copy(io.device_out)
+        out[i * hop:(i + 1) * hop] = io.host_out
+        if pause_every and i % pause_every == pause_every - 1:
+            time.sleep(pause_s)
+    return out
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("hop", [128, 256, 512, 1024])
+@pytest.mark.parametrize("flags,key", [(o.OUTPUT_PERCUSSIVE, "P"), (o.OUTPUT_HARMONIC, "H")])
+def test_resident_kernel_per_hop_calls_vs_oracle(z, hop, flags, key):
+    """zen_hip_hpr_set_resident: process_next_hop + copy_* (libzen/hps.cu:334-363, the loop of zen/fakert.h:221-247)
+    served by ONE workgroup that stays on the device and takes each hop from a mailbox.  Same samples as the oracle hop for
+    hop: back to back; with pauses longer than the idle time (the kernel leaves and is launched again, more than once);
+    with a block call, a reset and per-launch hops in between; and two hops posted without a copy between them."""
+    n_hops = 72
+    x = _clip(hop * n_hops, 11 + hop)
+    ref = o.HPR(FS, hop, 2.0, flags, o.TIME_CAUSAL).process_stream(x)[key]
+    io = z.IOGPU(hop)
+    rt = z.HPRRealtime(FS, hop, 2.0, flags)
+    copy = rt.copy_percussive if key == "P" else rt.copy_harmonic
+    eng = rt.p_impl
+    eng.set_resident(200)
+    got = _per_hop(z, rt, io, x, hop, n_hops, copy)
+    st = eng.resident_stats()
+    assert np.array_equal(got, ref) and np.any(ref != 0)
+    assert st["launches"] == 1 and st["active"]
+    # the kernel leaves after 5 ms without a hop: pauses of 40 ms every 9 hops
+    eng.reset_buffers()
+    eng.set_resident(5)
+    got = _per_hop(z, rt, io, x, hop, n_hops, copy, pause_every=9, pause_s=0.04)
+    assert np.array_equal(got, ref)
+    assert eng.resident_stats()["launches"] >= 1 + 8      # (the first part's one; then one per pause but the last)
+    # a block call and per-launch hops in the middle of the stream; then resident again
+    eng.reset_buffers()
+    eng.set_resident(100)
+    a = _per_hop(z, rt, io, x, hop, 20, copy)
+    blk = eng.process_stream_host(x[20 * hop:40 * hop])[key]                  # (sends the kernel home first)
+    eng.set_resident(0)
+    b = _per_hop(z, rt, io, x[40 * hop:], hop, 10, copy)
+    eng.set_resident(100)
+    c = _per_hop(z, rt, io, x[50 * hop:], hop, n_hops - 50, copy)
+    assert np.array_equal(np.concatenate([a, blk, b, c]), ref)
+    # two hops posted back to back, one copy: the second post waits for the first hop, the copy hands out the second
+    eng.reset_buffers()
+    io2 = z.IOGPU(hop)
+    io.host_in[:] = x[:hop]
+    io2.host_in[:] = x[hop:2 * hop]
+    rt.process_next_hop(io.device_in)
+    rt.process_next_hop(io2.device_in)
+    copy(io.device_out)
+    assert np.array_equal(io.host_out, ref[hop:2 * hop])
+    del rt, eng                                                                # destroy with the kernel resident

@@ -2,7 +2,8 @@
 // does (copy the hop into the mapped input buffer, process_next_hop, copy_percussive, copy the hop out),
 // without an interpreter in the loop.  Prints one JSON line per hop size.
 // Arguments: [hops per configuration, default 2000] [--stamps: also print the phase stamps of one single-hop kernel
-// of every kind].  Environment: ZEN_RT_ONLY_SSE=1 (only the SSE configurations), ZEN_RT_DIAG=<n> (sets the library's
+// of every kind].  Environment: ZEN_RT_RESIDENT=<idle ms>: the per-hop calls go through the resident kernel
+// (zen_hip_hpr_set_resident; hops 256..1024 of the median path, "resident": 1 in their lines); ZEN_RT_ONLY_SSE=1 (only the SSE configurations), ZEN_RT_DIAG=<n> (sets the library's
 // "rt_fused_diag" option: timing diagnostics, results not valid; 4 = agent-scope grid barriers in rt_wide.hip).
 //   g++ -O2 -std=c++17 -I include tools/rt_latency.cpp -o /tmp/rt_latency -L zen_amd -lzen_hip -Wl,-rpath,$PWD/zen_amd
 #include <chrono>
@@ -44,6 +45,10 @@ int main(int argc, char** argv)
 			CK(zen_hip_hpr_create(44100.f, hop, 2.0f, ZEN_HIP_OUTPUT_PERCUSSIVE, ZEN_HIP_TIME_CAUSAL, 1, 1, 64, &h));
 			if (sse)
 				CK(zen_hip_hpr_use_sse_filter(h));
+			const int resident_ms = std::getenv("ZEN_RT_RESIDENT") ? std::atoi(std::getenv("ZEN_RT_RESIDENT")) : 0;
+			const bool resident = resident_ms > 0 && !sse && hop <= 1024 && !(argc > 2);
+			if (resident)
+				CK(zen_hip_hpr_set_resident(h, resident_ms));
 			void *hin, *din, *hout, *dout;
 			CK(zen_hip_host_alloc_mapped(hop * 4, 1, &hin, &din));
 			CK(zen_hip_host_alloc_mapped(hop * 4, 0, &hout, &dout));
@@ -120,9 +125,12 @@ int main(int argc, char** argv)
 				            hop, (st[1] - st[0]) / 100.0, (st[2] - st[1]) / 100.0, (st[3] - st[2]) / 100.0,
 				            (st[5] - st[3]) / 100.0, (st[5] - st[0]) / 100.0);
 			}
-			std::printf("{\"hop\": %zu, \"sse\": %d, \"us_per_hop\": %.2f, \"us_process_call\": %.2f, \"us_copy_call\": %.2f, "
-			            "\"hops\": %d, \"pct_of_hop_period\": %.4f}\n",
-			            hop, sse, t_all / n_hops, t_proc / n_hops, t_copy / n_hops, n_hops,
+			unsigned long long res_launches = 0;
+			if (resident)
+				CK(zen_hip_hpr_resident_stats(h, &res_launches, nullptr, nullptr));
+			std::printf("{\"hop\": %zu, \"sse\": %d, \"resident\": %d, \"resident_launches\": %llu, \"us_per_hop\": %.2f, "
+			            "\"us_process_call\": %.2f, \"us_copy_call\": %.2f, \"hops\": %d, \"pct_of_hop_period\": %.4f}\n",
+			            hop, sse, resident ? 1 : 0, res_launches, t_all / n_hops, t_proc / n_hops, t_copy / n_hops, n_hops,
 			            100.0 * (t_all / n_hops) / (1e6 * hop / 44100.0));
 			zen_hip_host_free(hin);
 			zen_hip_host_free(hout);

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libzen_hip.so")
 OBJDIR = os.path.join(HERE, "build")
 RESOURCES = os.path.join(HERE, "kernel_resources.json")   # per-kernel registers / scratch / LDS of the last build
-SOURCES = ["api.hip", "hpr.hip", "hpri.hip", "stft.hip", "istft.hip", "median.hip", "median_net.hip", "median47.hip", "median_big.hip", "rt_fused.hip", "rt_fused_multi.hip", "rt_fused_multi_lean.hip", "rt_sse.hip", "rt_wide.hip", "box.hip", "fft_big.hip", "sse_block.hip"]
+SOURCES = ["api.hip", "hpr.hip", "hpri.hip", "stft.hip", "istft.hip", "median.hip", "median_net.hip", "median47.hip", "median_big.hip", "rt_fused.hip", "rt_fused_multi.hip", "rt_fused_multi_lean.hip", "rt_sse.hip", "rt_wide.hip", "box.hip", "fft_big.hip", "sse_block.hip", "rt_resident.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 EXTRA = os.environ.get("ZEN_HIP_EXTRA_FLAGS", "").split()
 FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
@@ -56,7 +56,7 @@ def _deps():
 def _compile(src):
     obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
     srcp = os.path.join(CSRC, src)
-    extra = [os.path.join(CSRC, "rt_fused.hip")] if src.startswith("rt_fused_multi") else []   # they include that file
+    extra = [os.path.join(CSRC, "rt_fused.hip")] if src.startswith(("rt_fused_multi", "rt_resident")) else []   # they include that file
     newest = max(os.path.getmtime(p) for p in [srcp] + extra + _deps())
     if os.path.exists(obj) and os.path.getmtime(obj) >= newest:
         return obj, False

@@ -36,6 +36,7 @@ struct FakeRtParams { // zen/fakert.h:39-49
 	bool do_hps = false, cpu = false, nocopybord = false, use_sse = false, soft_mask = false;
 	std::size_t hop = 256;
 	float beta = 2.0;
+	int resident_ms = 0; // --resident <ms>: the MI355X resident-kernel extension (HPRRealtime::use_resident_kernel); 0: off
 };
 
 void usage(std::ostream& os)
@@ -44,6 +45,7 @@ void usage(std::ostream& os)
 	      "  zen offline -i <infile> [--hps [<hop-h> [<beta-h> [<hop-p> [<beta-p>]]]]] [-o <outfile_prefix>]\n"
 	      "      [--sse] [--only-percussive] [--soft-mask] [--nocopybord]\n"
 	      "  zen fakert -i <infile> [--hps [<hop> [<beta>]]] [-o <outfile>] [--sse] [--soft-mask] [--nocopybord]\n"
+	      "      [--resident <idle-ms>]\n"
 	      "  zen batch -i <indir> -o <outdir> [--hps [<hop-h> [<beta-h> [<hop-p> [<beta-p>]]]]] [--sse] [--soft-mask]\n"
 	      "      [--gpus <n>]\n"
 	      "      (MI355X extension: every .wav of <indir>, equal-length clips separated together in one batch;\n"
@@ -371,6 +373,8 @@ int run_fakert(const FakeRtParams& p)
 	if (p.soft_mask)
 		hpss.use_soft_mask();
 	hpss.warmup(io);
+	if (p.resident_ms > 0) // after the warm-up (its reset would send the kernel home anyway)
+		hpss.use_resident_kernel(p.resident_ms);
 
 	float iters = 0.0F;
 	long time_tot = 0;
@@ -455,6 +459,7 @@ int main(int argc, char* argv[])
 		else if (s == "--sse") op.use_sse = fp.use_sse = true;
 		else if (s == "--soft-mask") op.soft_mask = fp.soft_mask = true;
 		else if (s == "--nocopybord") op.nocopybord = fp.nocopybord = true;
+		else if (s == "--resident" && cmd == "fakert" && next_is_number()) fp.resident_ms = std::atoi(a[++i].c_str());
 		else if (s == "--only-percussive" && cmd == "offline") op.only_percussive = true;
 		else {
 			usage(std::cerr);

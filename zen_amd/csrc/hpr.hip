@@ -89,6 +89,13 @@ bool output_computed(const zen_hip_hpr* e, int o)
 
 void free_all(zen_hip_hpr* e)
 {
+	if (e->res_ctl) {
+		(void)zen_hip_host_free(e->res_ctl);
+		(void)hipHostFree(e->res_out);
+		(void)hipStreamDestroy(e->res_stream);
+		(void)hipEventDestroy(e->res_event);
+		e->res_ctl = nullptr;
+	}
 	(void)hipFree(e->d_window);
 	(void)hipFree(e->d_tw);
 	(void)hipFree(e->d_tail[0]);
@@ -232,13 +239,9 @@ int ensure_rows(zen_hip_hpr* e, int o)
 // causal, median path: M hops of every stream in one launch, one workgroup per hop (rt_fused.hip)
 enum HopKernel { HOP_FUSED = 0, HOP_SSE = 1, HOP_WIDE = 2 };
 
-int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, HopKernel kind = HOP_FUSED)
+// the arguments of a fused causal launch of M hops per stream (side effects: the call's sequence number, ready_valid)
+void fused_args(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, RtFusedArgs& a)
 {
-	const bool sse = kind == HOP_SSE;
-	for (int o = 0; o < 3; ++o)
-		if (output_computed(e, o))
-			ZH_TRY(ensure_rows(e, o));
-	RtFusedArgs a;
 	memset(&a, 0, sizeof(a));
 	a.in = in;
 	a.in_stride = (long long)in_stride;
@@ -281,6 +284,16 @@ int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, H
 	a.thr_h = ZH_DIAG_OPT(g_opt_mask_divide) ? 0.0 : hard_mask_threshold(a.beta_h, &a.thr_h_inclusive);
 	a.diag = ZH_DIAG_OPT(g_opt_rt_fused_diag);
 	a.stamps = e->dbg_stamps;
+}
+
+int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, HopKernel kind = HOP_FUSED)
+{
+	const bool sse = kind == HOP_SSE;
+	for (int o = 0; o < 3; ++o)
+		if (output_computed(e, o))
+			ZH_TRY(ensure_rows(e, o));
+	RtFusedArgs a;
+	fused_args(e, in, in_stride, M, a);
 	if (kind == HOP_WIDE) {
 		ZH_TRY(ensure_estimates(e, false));
 		if (!e->d_wide_xch) {
@@ -372,9 +385,136 @@ int advance_drain(zen_hip_hpr* e)
 	return ZEN_HIP_OK;
 }
 
+// ---- resident single-hop kernel (zen_hip_hpr_set_resident; rt_resident.hip) --------------------------------------
+// Host side of the mailbox protocol.  Posting a hop: its arguments are remembered (res_args), the kernel is launched if
+// none is there, the input pointer and then the sequence word go to the mailbox (store fences in between: the mailbox
+// and the caller's input buffer may be write-combined device memory behind the BAR).  A kernel that has left -- idle
+// for res_idle_ms, or the hop posted in the window between its last look and its exit word -- is noticed by whoever
+// waits for a hop (resident_kick) and launched again with the remembered arguments: no hop is lost, none runs twice
+// (the exit word carries the last sequence number the kernel processed).
+inline void store_fence() { __builtin_ia32_sfence(); }
+
+bool resident_eligible(const zen_hip_hpr* e)
+{
+	int n_out = 0, o1 = -1;
+	for (int o = 0; o < 3; ++o)
+		if (output_computed(e, o)) {
+			++n_out;
+			o1 = o;
+		}
+	return e->res_idle_ms > 0 && e->causality == ZEN_HIP_TIME_CAUSAL && !e->use_sse && !g_opt_no_rt_fused && e->n_streams == 1
+	       && n_out == 1 && e->ready_host[o1] != nullptr && rt_fused_available(e->log2n, e->mf) && !e->prof && !e->dbg_stamps
+	       && !(e->drain[0] | e->drain[1] | e->drain[2]);
+}
+
+int resident_launch(zen_hip_hpr* e) // from res_args: the hop whose number is res_args.seq is the first the kernel will see
+{
+	if (!e->res_ctl) {
+		void *h = nullptr, *d = nullptr;
+		ZH_TRY(zen_hip_host_alloc_mapped(sizeof(ResidentCtl), 1, &h, &d)); // device memory behind the BAR where there is one
+		e->res_ctl = (ResidentCtl*)h;
+		e->res_ctl_dev = (ResidentCtl*)d;
+		ZH_HIP(hipHostMalloc((void**)&e->res_out, sizeof(ResidentOut), hipHostMallocMapped | hipHostMallocPortable));
+		ZH_HIP(hipHostGetDevicePointer(&d, e->res_out, 0));
+		e->res_out_dev = (ResidentOut*)d;
+		ZH_HIP(hipStreamCreateWithFlags(&e->res_stream, hipStreamNonBlocking));
+		ZH_HIP(hipEventCreateWithFlags(&e->res_event, hipEventDisableTiming));
+		e->res_ctl->seq = 0;
+		e->res_ctl->stop = 0;
+		e->res_ctl->pad = 0;
+	}
+	const unsigned seq_start = e->res_args.seq - 1u;
+	if (e->res_ctl->seq != e->res_args.seq) // (a relaunch finds the pending hop's number already there)
+		e->res_ctl->seq = seq_start;
+	e->res_ctl->stop = 0;
+	store_fence();
+	__atomic_store_n(&e->res_out->exited, 0u, __ATOMIC_RELEASE);
+	// behind whatever the engine's own stream still has in flight (an earlier per-launch hop, a reset)
+	ZH_HIP(hipEventRecord(e->res_event, e->stream));
+	ZH_HIP(hipStreamWaitEvent(e->res_stream, e->res_event, 0));
+	const unsigned long long ticks = (unsigned long long)e->res_idle_ms * 100000ull; // s_memrealtime: 100 MHz
+	ZH_TRY(launch_rt_fused_resident(e->log2n, e->mf, e->res_args, e->res_ctl_dev, e->res_out_dev, seq_start, ticks, 0x7fffffffu,
+	                                e->res_stream));
+	e->res_active = true;
+	++e->res_launches;
+	return ZEN_HIP_OK;
+}
+
+// has the kernel left?  If so, and the hop posted last was not processed, launch it again (with that hop pending).
+int resident_kick(zen_hip_hpr* e)
+{
+	if (!e->res_active || !__atomic_load_n(&e->res_out->exited, __ATOMIC_ACQUIRE))
+		return ZEN_HIP_OK;
+	e->res_active = false;
+	e->res_hops += e->res_out->hops;
+	if (e->res_out->last_seq != e->res_args.seq)
+		ZH_TRY(resident_launch(e));
+	return ZEN_HIP_OK;
+}
+
+// wait until the hop posted last is in its host-mapped buffer (the sequence word behind it)
+int resident_wait(zen_hip_hpr* e)
+{
+	if (!e->res_active)
+		return ZEN_HIP_OK;
+	const int o = e->res_args.out_id[0];
+	const unsigned* flag = reinterpret_cast<const unsigned*>(e->ready_host[o] + e->hop);
+	for (long spin = 0; spin < 2000000000L; ++spin) {
+		if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == e->res_args.seq)
+			return ZEN_HIP_OK;
+		if ((spin & 63) == 63)
+			ZH_TRY(resident_kick(e));
+		__builtin_ia32_pause();
+	}
+	ZH_FAIL(ZEN_HIP_E_HIP, "resident kernel: hop %u never arrived", e->res_args.seq);
+}
+
+// every entry point that touches the engine in any other way first sends the kernel home
+int resident_stop(zen_hip_hpr* e)
+{
+	if (!e->res_ctl)
+		return ZEN_HIP_OK;
+	if (e->res_active) {
+		ZH_TRY(resident_wait(e)); // (the hop in flight, if any, is finished by whoever holds it)
+		e->res_ctl->stop = 1;
+		store_fence();
+		ZH_HIP(hipStreamSynchronize(e->res_stream));
+		e->res_hops += e->res_out->hops;
+		e->res_active = false;
+		e->res_ctl->stop = 0;
+		store_fence();
+	}
+	return ZEN_HIP_OK;
+}
+
+int resident_post(zen_hip_hpr* e, const float* in)
+{
+	for (int o = 0; o < 3; ++o)
+		if (output_computed(e, o))
+			ZH_TRY(ensure_rows(e, o));
+	ZH_TRY(resident_wait(e)); // the mailbox holds one hop: the one before must have been taken (and finished)
+	if (e->res_active && e->res_args.in != in) // the kernel reads the input buffer it was launched with (IOGPU::device_in,
+		ZH_TRY(resident_stop(e));              // normally the same for every hop): another buffer, another launch
+	fused_args(e, in, e->hop, 1, e->res_args);
+	e->res_args.stamps = nullptr;
+	ZH_TRY(resident_kick(e));
+	if (!e->res_active)
+		ZH_TRY(resident_launch(e));
+	store_fence(); // the caller's samples (write-combined stores, possibly) before the word
+	__atomic_store_n(&e->res_ctl->seq, e->res_args.seq, __ATOMIC_RELEASE);
+	store_fence();
+	e->tail_sel ^= 1;
+	e->abs_frame += 1;
+	e->last_frames = 1;
+	return ZEN_HIP_OK;
+}
+
 int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long long in_valid = LLONG_MAX)
 {
 	const size_t S = e->n_streams, N = e->nfft;
+	if (M == 1 && in_stride == e->hop && resident_eligible(e))
+		return resident_post(e, in);
+	ZH_TRY(resident_stop(e));
 	if (e->drain[0] | e->drain[1] | e->drain[2])
 		ZH_TRY(advance_drain(e));
 	if (e->causality == ZEN_HIP_TIME_CAUSAL && !e->use_sse && !g_opt_no_rt_fused && (M == 1 || !g_opt_no_block_fused)
@@ -969,6 +1109,7 @@ int zen_hip_hpr_create(float fs, size_t hop, float beta, unsigned output_flags, 
 int zen_hip_hpr_destroy(zen_hip_hpr_t h)
 {
 	if (h) {
+		(void)resident_stop(h);
 		(void)hipStreamSynchronize(h->stream);
 		free_all(h);
 		delete h;
@@ -999,6 +1140,7 @@ int zen_hip_hpr_set_stream(zen_hip_hpr_t h, void* stream)
 {
 	if (!h)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpr_set_stream: null handle");
+	ZH_TRY(resident_stop(h));
 	ZH_HIP(hipStreamSynchronize(h->stream));
 	h->stream = (hipStream_t)stream;
 	return ZEN_HIP_OK;
@@ -1008,6 +1150,7 @@ int zen_hip_hpr_use_sse_filter(zen_hip_hpr_t h)
 {
 	if (!h)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null handle");
+	ZH_TRY(resident_stop(h));
 	const bool before[3] = {output_computed(h, 0), output_computed(h, 1), output_computed(h, 2)};
 	h->use_sse = true;
 	return park_dropped_outputs(h, before);
@@ -1017,15 +1160,40 @@ int zen_hip_hpr_use_soft_mask(zen_hip_hpr_t h)
 {
 	if (!h)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null handle");
+	ZH_TRY(resident_stop(h));
 	const bool before[3] = {output_computed(h, 0), output_computed(h, 1), output_computed(h, 2)};
 	h->soft = true;
 	return park_dropped_outputs(h, before);
+}
+
+int zen_hip_hpr_set_resident(zen_hip_hpr_t h, int idle_ms)
+{
+	if (!h || idle_ms < 0 || idle_ms > 2000)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpr_set_resident: idle time must be 0 (off) .. 2000 ms");
+	ZH_TRY(resident_stop(h));
+	h->res_idle_ms = idle_ms;
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_hpr_resident_stats(zen_hip_hpr_t h, unsigned long long* launches, unsigned long long* hops, int* active)
+{
+	if (!h)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null handle");
+	ZH_TRY(resident_kick(h));
+	if (launches)
+		*launches = h->res_launches;
+	if (hops)
+		*hops = h->res_hops; // (of the launches that have ended)
+	if (active)
+		*active = h->res_active ? 1 : 0;
+	return ZEN_HIP_OK;
 }
 
 int zen_hip_hpr_reset_buffers(zen_hip_hpr_t h)
 {
 	if (!h)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null handle");
+	ZH_TRY(resident_stop(h));
 	return reset_state(h);
 }
 
@@ -1134,6 +1302,8 @@ static int copy_output_impl(zen_hip_hpr_t h, unsigned which, float* out_dev, boo
 					seen = true;
 					break;
 				}
+				if (h->res_active && (spin & 63) == 63) // a resident kernel that left with this hop pending is launched again
+					ZH_TRY(resident_kick(h));
 				__builtin_ia32_pause();
 			}
 			if (!seen || h->async_pending) { // a fault or a hang: let the runtime report it; or earlier asynchronous copies
@@ -1144,9 +1314,11 @@ static int copy_output_impl(zen_hip_hpr_t h, unsigned which, float* out_dev, boo
 			memcpy(host, h->ready_host[o], bytes);
 			return ZEN_HIP_OK;
 		}
+		ZH_TRY(resident_wait(h)); // (a resident kernel works on a stream of its own: the hop must be there before the copy is queued)
 		ZH_HIP(hipMemcpyAsync(out_dev, h->ready_dev[o], bytes, hipMemcpyDefault, h->stream));
 	}
 	else {
+		ZH_TRY(resident_stop(h));
 		const size_t M = h->last_frames;
 		ZH_TRY(finalize_output(h, o, out_dev, M * h->hop, M));
 	}
@@ -1189,6 +1361,7 @@ int zen_hip_hpr_debug_stamps(zen_hip_hpr_t h, unsigned long long** host_stamps)
 {
 	if (!h || !host_stamps)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null argument");
+	ZH_TRY(resident_stop(h));
 	if (!h->dbg_stamps_host) {
 		void* dev = nullptr;
 		ZH_HIP(hipHostMalloc((void**)&h->dbg_stamps_host, 16 * sizeof(unsigned long long), hipHostMallocMapped));
@@ -1204,6 +1377,7 @@ int zen_hip_hpr_profile(zen_hip_hpr_t h, int enable)
 {
 	if (!h)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "null handle");
+	ZH_TRY(resident_stop(h));
 	ZH_TRY(prof_drain(h));
 	h->prof = enable != 0;
 	if (enable) {

@@ -2,6 +2,7 @@
 // C-ABI) and hpri.hip (the two-pass offline driver built on two engines).
 #pragma once
 #include "common.h"
+#include "rt_fused.h"
 
 #include <utility>
 #include <vector>
@@ -85,6 +86,19 @@ struct zen_hip_hpr {
 	bool async_pending = false;          // a copy_output_async since the last stream synchronise: the polling fast path of
 	                                     // the synchronous copy_* synchronises first, so that "everything before is done" holds
 	unsigned out_query_gen = 0;          // zen_hip_host_free count at the time of the lookup (a freed buffer's address may be reused)
+
+	// Resident single-hop kernel (zen_hip_hpr_set_resident; rt_resident.hip): one workgroup stays on the device between the
+	// hops of the stream and takes each hop from a mailbox instead of a launch.
+	int res_idle_ms = 0;       // 0: off.  Else: the kernel leaves after this long without a hop (and is launched again by the next)
+	bool res_active = false;   // launched and not yet seen to have left
+	zen_hip_impl::ResidentCtl* res_ctl = nullptr;     // mailbox: host address == device address (fine-grained device memory), or
+	zen_hip_impl::ResidentCtl* res_ctl_dev = nullptr; // pinned host memory and its device alias
+	zen_hip_impl::ResidentOut* res_out = nullptr;     // pinned host memory
+	zen_hip_impl::ResidentOut* res_out_dev = nullptr;
+	hipStream_t res_stream = nullptr;
+	hipEvent_t res_event = nullptr;
+	zen_hip_impl::RtFusedArgs res_args;               // the arguments of the hop posted last: what a relaunch starts from
+	unsigned long long res_launches = 0, res_hops = 0; // statistics (zen_hip_hpr_resident_stats)
 
 	// profiling hook (bench.py): HIP events around every launch, per kernel class
 	enum { K_STFT = 0, K_FREQ = 1, K_TIME = 2, K_ISTFT = 3, K_FINALIZE = 4, K_FUSED = 5, K_COUNT = 6 };

@@ -63,6 +63,22 @@ struct RtFusedArgs {
 	unsigned long long* stamps; // diagnostic: 8 s_memrealtime stamps (100 MHz) of workgroup 0's phases, or null
 };
 
+// rt_resident.hip: the mailbox the host writes (device-visible: fine-grained device memory behind the BAR, or pinned host
+// memory) and the word the kernel leaves behind (pinned host memory).  See rt_fused_resident_kernel.
+struct ResidentCtl {
+	unsigned seq;              // number of the hop to process; the kernel acts when it differs from the last one it did
+	unsigned stop;             // != 0: leave at the next look
+	unsigned long long pad;    // (seq and stop are read as one 8-byte word)
+};
+struct ResidentOut {
+	unsigned exited;           // 1: the kernel has left (written last, system-scope release)
+	unsigned last_seq;         // the last sequence number it processed (the launch's seq_start if none)
+	unsigned hops;             // hops it processed
+	unsigned pad;
+};
+int launch_rt_fused_resident(int log2n, int freq_len, const RtFusedArgs& a, const ResidentCtl* ctl, ResidentOut* ro, unsigned seq_start,
+                             unsigned long long idle_ticks, unsigned max_hops, hipStream_t stream);
+
 bool rt_fused_available(int log2n, int freq_len);
 // true if launch_rt_fused(log2n, freq_len, a) will run the build that finishes hops itself (RtFusedArgs::out_direct)
 bool rt_fused_direct_out_available(int log2n, int freq_len, const RtFusedArgs& a);

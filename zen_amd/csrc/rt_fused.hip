@@ -263,8 +263,36 @@ __device__ __forceinline__ void publish_ready(unsigned* flag, unsigned seq, int 
 
 // SINGLE: exactly one output is enabled (the realtime default, percussive only): the spectrum registers die
 // in the first pass of the one inverse transform instead of living through a loop over outputs.
-template <int LOG2N, int W, int MINB, bool SINGLE, bool LEAN = false, bool HARDP = false>
-__global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFusedArgs a)
+// (the kernel's body as a device function: rt_fused_kernel runs it once per workgroup, the resident kernel of
+// rt_resident.hip once per hop it is handed; `bid` is the workgroup's place in the launch, blockIdx.x for the former)
+// What changes from hop to hop of a stream: taken from the launch's arguments (HopOfArgs: one launch per call), or handed
+// in by the resident kernel, which derives it for every hop it is given (HopVar).
+struct HopOfArgs {
+	const RtFusedArgs& a;
+	__device__ __forceinline__ const float* in() const { return a.in; }
+	__device__ __forceinline__ unsigned seq() const { return a.seq; }
+	__device__ __forceinline__ long long row0() const { return a.row0; }
+	__device__ __forceinline__ const float* tail_prev() const { return a.tail_prev; }
+	__device__ __forceinline__ float* tail_next() const { return a.tail_next; }
+	__device__ __forceinline__ int prev_frames() const { return a.prev_frames; }
+};
+struct HopVar {
+	const float* in_;
+	unsigned seq_;
+	long long row0_;
+	const float* tail_prev_;
+	float* tail_next_;
+	int prev_frames_;
+	__device__ __forceinline__ const float* in() const { return in_; }
+	__device__ __forceinline__ unsigned seq() const { return seq_; }
+	__device__ __forceinline__ long long row0() const { return row0_; }
+	__device__ __forceinline__ const float* tail_prev() const { return tail_prev_; }
+	__device__ __forceinline__ float* tail_next() const { return tail_next_; }
+	__device__ __forceinline__ int prev_frames() const { return prev_frames_; }
+};
+
+template <int LOG2N, int W, int MINB, bool SINGLE, bool LEAN = false, bool HARDP = false, class HV = HopOfArgs>
+__device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsigned bid, const HV& hv)
 {
 	using PL = Plan<LOG2N>;
 	constexpr int N = PL::N, TF = PL::TF;
@@ -295,8 +323,8 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 	// (b % 8) * (total / 8) + b / 8 of the launch: the workgroups of one XCD walk through consecutive hops, and the
 	// shared hop is an L2 hit instead of a second fetch from memory by another XCD (measured before the change: 220 MB
 	// read per 25 840-hop launch for 106 MB of input).  Any other placement is only slower, not wrong.
-	const int total = a.n_streams * a.n_frames, xq = total >> 3, xr = total & 7, xcd = blockIdx.x & 7;
-	const int item = xcd * xq + (xcd < xr ? xcd : xr) + (blockIdx.x >> 3);
+	const int total = a.n_streams * a.n_frames, xq = total >> 3, xr = total & 7, xcd = (int)(bid & 7);
+	const int item = xcd * xq + (xcd < xr ? xcd : xr) + (bid >> 3);
 	const int s = item / a.n_frames, f = item - s * a.n_frames;
 	// diagnostic hook (tools/rt_latency.cpp --stamps): phase times of a single-hop call (100 MHz), kept in scalar
 	// registers until the end -- a store to the host-mapped stamp buffer in front of a barrier would be waited for
@@ -310,13 +338,13 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 				stamps[k] = __builtin_amdgcn_s_memrealtime();
 		}
 		else {
-			if (a.stamps && blockIdx.x == 0 && tf == 0)
+			if (a.stamps && bid == 0 && tf == 0)
 				a.stamps[k] = __builtin_amdgcn_s_memrealtime();
 		}
 	};
 	auto flush_stamps = [&]() {
 		if constexpr (MINB == 1) {
-			if (a.stamps && blockIdx.x == 0 && tf == 0) {
+			if (a.stamps && bid == 0 && tf == 0) {
 #pragma unroll
 				for (int k = 0; k < 6; ++k)
 					a.stamps[k] = stamps[k];
@@ -324,7 +352,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		}
 	};
 	stamp(0);
-	const float* cur = a.in + (long long)s * a.in_stride + (long long)f * hop;
+	const float* cur = hv.in() + (long long)s * a.in_stride + (long long)f * hop;
 
 	// ---- housekeeping (as the extra block of stft_kernel): overlap-add carries, input tail.  The carry is
 	// the second half of the previous call's last Y row; the workgroup that will overwrite that row (or, if
@@ -332,7 +360,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 	// (hop == 4*TF: four elements per thread.)
 	float cv1[4] = {0.f, 0.f, 0.f, 0.f}; // single-hop calls with one output: the carries of this hop
 	if constexpr (MINB == 1) {
-		const bool do_carry = a.prev_frames > 0 && f == (a.prev_frames - 1 < a.n_frames - 1 ? a.prev_frames - 1 : a.n_frames - 1);
+		const bool do_carry = hv.prev_frames() > 0 && f == (hv.prev_frames() - 1 < a.n_frames - 1 ? hv.prev_frames() - 1 : a.n_frames - 1);
 		// Single-hop launches: all loads first, then the stores.  A store between two loads makes the second wait
 		// for the first (the compiler cannot know they do not alias): stored from inside the transform's input
 		// functor, the tail cost such a call eight dependent trips to memory.
@@ -342,7 +370,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 			for (int o = 0; o < 3; ++o) {
 				if (!a.carry[o])
 					continue;
-				const float* y = a.Y[o] + (long long)s * a.y_stream_stride + (long long)(a.prev_frames - 1) * (2 * hop) + hop;
+				const float* y = a.Y[o] + (long long)s * a.y_stream_stride + (long long)(hv.prev_frames() - 1) * (2 * hop) + hop;
 #pragma unroll
 				for (int i = 0; i < 4; ++i)
 					sv[o][i] = y[tf + i * TF];
@@ -350,7 +378,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		}
 		if constexpr (SINGLE) { // the carries the synthesis will add: from the previous call's Y row or the carry buffer
 			const int w0 = a.out_id[0];
-			const float* y = do_carry ? a.Y[w0] + (long long)s * a.y_stream_stride + (long long)(a.prev_frames - 1) * (2 * hop) + hop
+			const float* y = do_carry ? a.Y[w0] + (long long)s * a.y_stream_stride + (long long)(hv.prev_frames() - 1) * (2 * hop) + hop
 			                          : a.carry[w0] + (long long)s * hop;
 #pragma unroll
 			for (int i = 0; i < 4; ++i)
@@ -374,14 +402,14 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		if (f == a.n_frames - 1) {
 #pragma unroll
 			for (int i = 0; i < 4; ++i)
-				a.tail_next[(long long)s * hop + tf + i * TF] = tv[i];
+				hv.tail_next()[(long long)s * hop + tf + i * TF] = tv[i];
 		}
 	}
-	else if (a.prev_frames > 0 && f == (a.prev_frames - 1 < a.n_frames - 1 ? a.prev_frames - 1 : a.n_frames - 1)) {
+	else if (hv.prev_frames() > 0 && f == (hv.prev_frames() - 1 < a.n_frames - 1 ? hv.prev_frames() - 1 : a.n_frames - 1)) {
 		for (int o = 0; o < 3; ++o) {
 			if (!a.carry[o])
 				continue;
-			const float* y = a.Y[o] + (long long)s * a.y_stream_stride + (long long)(a.prev_frames - 1) * (2 * hop) + hop;
+			const float* y = a.Y[o] + (long long)s * a.y_stream_stride + (long long)(hv.prev_frames() - 1) * (2 * hop) + hop;
 			float v[4];
 #pragma unroll
 			for (int i = 0; i < 4; ++i)
@@ -429,7 +457,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 	bool preloaded = false;
 	auto preload_inputs = [&]() {
 		static_assert(!DIRECT || (LOG2N == 12 && TF == 256), "slot <-> index map of FwdInPre");
-		const float* pv = f > 0 ? cur - hop : a.tail_prev + (long long)s * hop;
+		const float* pv = f > 0 ? cur - hop : hv.tail_prev() + (long long)s * hop;
 #pragma unroll
 		for (int m = 0; m < 8; ++m) {
 			const int idx = m * TF + tf;
@@ -440,7 +468,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 	};
 	if constexpr (DIRECT) {
 		if (a.direct_on) {
-			const int xi = blockIdx.x >> 3, xcount = xq + (xcd < xr ? 1 : 0);
+			const int xi = bid >> 3, xcount = xq + (xcd < xr ? 1 : 0);
 			if (xi + DIRECT_BACK >= xcount && tf == 0)
 				a.blk_need[item] = 1u; // nobody comes DIRECT_BACK items after this one
 			if (xi >= DIRECT_BACK) {
@@ -506,12 +534,12 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 	Regs r;
 	{
 		FwdIn<LOG2N> in;
-		in.prev = f > 0 ? cur - hop : a.tail_prev + (long long)s * hop;
+		in.prev = f > 0 ? cur - hop : hv.tail_prev() + (long long)s * hop;
 		in.cur = cur;
 		in.window = a.window;
-		in.tail = (MINB == 1 || f != a.n_frames - 1) ? nullptr : a.tail_next + (long long)s * hop;
+		in.tail = (MINB == 1 || f != a.n_frames - 1) ? nullptr : hv.tail_next() + (long long)s * hop;
 		in.hop = hop;
-		const long long row = ((a.row0 + f) % a.ring_rows) + (long long)s * a.ring_rows;
+		const long long row = ((hv.row0() + f) % a.ring_rows) + (long long)s * a.ring_rows;
 		FwdOut<T> out;
 		out.r = &r;
 		out.S = a.S ? a.S + row * a.s_stride : nullptr;
@@ -656,7 +684,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 			else
 				zfft::fft_frame<LOG2N, true, false, true>(tf_o, lds, tw_o, in, out, true);
 			if (out.ready && a.publish_seq)
-				publish_ready(reinterpret_cast<unsigned*>(out.ready + hop), a.seq, tf);
+				publish_ready(reinterpret_cast<unsigned*>(out.ready + hop), hv.seq(), tf);
 			__syncthreads(); // the frame image is reused by the next output
 		}
 		if constexpr (DIRECT) {
@@ -714,7 +742,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		else
 			zfft::fft_frame<LOG2N, true, false, true, InvInLean<N, TF, mid, HARDP>, OutT, true>(tf, lds, a.tw, in, out, true);
 		if (out.ready && a.publish_seq)
-			publish_ready(reinterpret_cast<unsigned*>(out.ready + hop), a.seq, tf);
+			publish_ready(reinterpret_cast<unsigned*>(out.ready + hop), hv.seq(), tf);
 		if constexpr (MINB == 1) {
 			stamp(4);
 			stamp(5);
@@ -752,7 +780,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 		else
 			zfft::fft_frame<LOG2N, true, false, true>(tf, lds, a.tw, in, out, true);
 		if (out.ready && a.publish_seq)
-			publish_ready(reinterpret_cast<unsigned*>(out.ready + hop), a.seq, tf);
+			publish_ready(reinterpret_cast<unsigned*>(out.ready + hop), hv.seq(), tf);
 	};
 	if (a.diag == 2) { // timing diagnostic: no synthesis
 		if (tf == 0)
@@ -771,6 +799,12 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFused
 			__syncthreads();
 		}
 	}
+}
+
+template <int LOG2N, int W, int MINB, bool SINGLE, bool LEAN = false, bool HARDP = false>
+__global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFusedArgs a)
+{
+	rt_fused_body<LOG2N, W, MINB, SINGLE, LEAN, HARDP>(a, blockIdx.x, HopOfArgs{a});
 }
 
 template <int LOG2N, int W, int MINB, bool SINGLE, bool LEAN = false, bool HARDP = false>
@@ -794,6 +828,102 @@ int launch_k(const RtFusedArgs& a, hipStream_t stream)
 #if defined(ZEN_RT_FUSED_MULTI_LEAN)
 // (rt_fused_multi_lean.hip: the several-output lean kernel alone, compiled with the default scheduler -- no scratch
 // there, 12 bytes per lane under the max-ILP strategy the other several-output builds want)
+#elif defined(ZEN_RT_RESIDENT)
+// ---- rt_resident.hip: the single-hop, one-output builds of the body inside a kernel that STAYS on its CU between hops.
+// A per-hop call of the reference API costs ~18 us of which the kernel is ~11: the rest is the launch and the completion
+// poll.  Here one workgroup is launched once and then handed hop after hop through a mailbox the host writes (fine-grained
+// device memory behind the BAR, or pinned host memory): thread 0 polls the sequence word while the other waves sleep at
+// a barrier; a new number -> acquire fence (the host wrote the hop's samples before the word), the per-hop arguments are
+// derived from the launch's (input-tail buffers alternate, the ring row advances, the previous call was one frame), the
+// body runs and publishes the finished hop behind its own sequence word as every single-hop launch does.  The kernel's
+// life is bounded: it leaves when `stop` is set, when nothing has arrived for idle_ticks of the 100 MHz clock, or after
+// max_hops; its last act is to tell the host how far it got (ResidentOut), and a hop posted in the window between its
+// last look at the mailbox and that word is simply picked up by the next launch (hpr.hip resident_*).
+template <int LOG2N, int W, bool LEAN>
+constexpr size_t resident_lds_bytes() // launch_k's formula for the single-hop, one-output builds
+{
+	return LEAN ? sizeof(float2) * Plan<LOG2N>::LDS_FLOAT2
+	            : sizeof(float2) * Plan<LOG2N>::LDS_FLOAT2 + sizeof(float) * Plan<LOG2N>::N + (W == 47 && LOG2N == 12 ? 1024 : 0);
+}
+
+template <int LOG2N, int W, bool LEAN, bool HARDP>
+__global__ __launch_bounds__(Plan<LOG2N>::TF, 1) void rt_fused_resident_kernel(RtFusedArgs a0, const ResidentCtl* ctl, ResidentOut* ro,
+                                                                               unsigned seq_start, unsigned long long idle_ticks,
+                                                                               unsigned max_hops)
+{
+	extern __shared__ float2 lds_all[]; // (the body's image; the two command words sit behind it: no static LDS in front of the 16-byte accesses)
+	unsigned* s_cmd = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds_all) + resident_lds_bytes<LOG2N, W, LEAN>());
+	unsigned last = seq_start, k = 0;
+	for (;;) {
+		if (threadIdx.x == 0) {
+			const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+			unsigned cmd = 2, sq = last; // 1: a hop, 2: leave
+			for (;;) { // one 8-byte look per turn: the sequence word and the stop word side by side
+				const unsigned long long w =
+				    __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&ctl->seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				sq = (unsigned)w;
+				if (sq != last) {
+					cmd = 1;
+					break;
+				}
+				if ((unsigned)(w >> 32) != 0u)
+					break;
+				if (__builtin_amdgcn_s_memrealtime() - t0 > idle_ticks)
+					break;
+				__builtin_amdgcn_s_sleep(1);
+			}
+			s_cmd[0] = k >= max_hops ? 2u : cmd;
+			s_cmd[1] = sq;
+		}
+		__syncthreads();
+		const unsigned cmd = s_cmd[0], sq = s_cmd[1];
+		if (cmd != 1u)
+			break;
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); // the samples the host wrote before the word; our own rows of the last hop
+		HopVar hv; // run_hop_fused's per-call arguments, for hop k of this launch (a0 itself stays in the kernel-argument segment)
+		hv.in_ = a0.in; // (the input buffer of the launch: a caller that hands over another pointer gets another launch, hpr.hip)
+		hv.seq_ = sq;
+		hv.row0_ = a0.row0 + k;
+		hv.tail_prev_ = (k & 1u) ? a0.tail_next : a0.tail_prev; // the two input-tail buffers flip with every call
+		hv.tail_next_ = (k & 1u) ? const_cast<float*>(a0.tail_prev) : a0.tail_next;
+		hv.prev_frames_ = k > 0u ? 1 : a0.prev_frames;
+		rt_fused_body<LOG2N, W, 1, true, LEAN, HARDP, HopVar>(a0, 0u, hv);
+		__syncthreads(); // (every path of the body ends behind its last LDS access; s_cmd is rewritten next)
+		last = sq;
+		++k;
+	}
+	if (threadIdx.x == 0) {
+		ro->last_seq = last;
+		ro->hops = k;
+		__hip_atomic_store(&ro->exited, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+}
+
+template <int LOG2N, int W, bool LEAN, bool HARDP>
+int launch_res_k(const RtFusedArgs& a, const ResidentCtl* ctl, ResidentOut* ro, unsigned seq_start, unsigned long long idle_ticks,
+                 unsigned max_hops, hipStream_t stream)
+{
+	using PL = Plan<LOG2N>;
+	const size_t lds = resident_lds_bytes<LOG2N, W, LEAN>() + 16;
+	auto kern = rt_fused_resident_kernel<LOG2N, W, LEAN, HARDP>;
+	if (lds > 60 * 1024)
+		ZH_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	hipLaunchKernelGGL(kern, dim3(1), dim3(PL::TF), lds, stream, a, ctl, ro, seq_start, idle_ticks, max_hops);
+	ZH_HIP(hipGetLastError());
+	return ZEN_HIP_OK;
+}
+
+template <int LOG2N, int W>
+int launch_res_t(const RtFusedArgs& a, const ResidentCtl* ctl, ResidentOut* ro, unsigned seq_start, unsigned long long idle_ticks,
+                 unsigned max_hops, hipStream_t stream)
+{
+	if constexpr (LOG2N == 12 && W == 47) { // the builds launch_t picks for a single hop with one output
+		const bool hardp = a.out_id[0] == 0 && !a.soft && a.thr != 0.0;
+		return hardp ? launch_res_k<LOG2N, W, true, true>(a, ctl, ro, seq_start, idle_ticks, max_hops, stream)
+		             : launch_res_k<LOG2N, W, true, false>(a, ctl, ro, seq_start, idle_ticks, max_hops, stream);
+	}
+	return launch_res_k<LOG2N, W, false, false>(a, ctl, ro, seq_start, idle_ticks, max_hops, stream);
+}
 #elif defined(ZEN_RT_FUSED_MULTI)
 template <int LOG2N, int W>
 int launch_multi_t(const RtFusedArgs& a, hipStream_t stream)
@@ -847,6 +977,23 @@ int launch_t(const RtFusedArgs& a, hipStream_t stream)
 
 #if defined(ZEN_RT_FUSED_MULTI_LEAN)
 int launch_rt_fused_multi_lean(const RtFusedArgs& a, hipStream_t stream) { return launch_k<12, 47, 3, false, true, true>(a, stream); }
+#elif defined(ZEN_RT_RESIDENT)
+int launch_rt_fused_resident(int log2n, int freq_len, const RtFusedArgs& a, const ResidentCtl* ctl, ResidentOut* ro, unsigned seq_start,
+                             unsigned long long idle_ticks, unsigned max_hops, hipStream_t stream)
+{
+	if (a.n_out != 1 || a.n_frames != 1 || a.n_streams != 1 || !a.publish_seq)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "resident kernel: one stream, one output, single hops, host-mapped hop buffer");
+	switch (log2n * 100 + freq_len) {
+	case 907: return launch_res_t<9, 7>(a, ctl, ro, seq_start, idle_ticks, max_hops, stream);
+	case 1011: return launch_res_t<10, 11>(a, ctl, ro, seq_start, idle_ticks, max_hops, stream);
+	case 1013: return launch_res_t<10, 13>(a, ctl, ro, seq_start, idle_ticks, max_hops, stream);
+	case 1121: return launch_res_t<11, 21>(a, ctl, ro, seq_start, idle_ticks, max_hops, stream);
+	case 1123: return launch_res_t<11, 23>(a, ctl, ro, seq_start, idle_ticks, max_hops, stream);
+	case 1243: return launch_res_t<12, 43>(a, ctl, ro, seq_start, idle_ticks, max_hops, stream);
+	case 1247: return launch_res_t<12, 47>(a, ctl, ro, seq_start, idle_ticks, max_hops, stream);
+	default: ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "no resident realtime kernel for nfft 2^%d, mask %d", log2n, freq_len);
+	}
+}
 #elif defined(ZEN_RT_FUSED_MULTI)
 int launch_rt_fused_multi(int log2n, int freq_len, const RtFusedArgs& a, hipStream_t stream)
 {

@@ -86,6 +86,8 @@ SYMBOLS = [
     ("zen_hip_hpr_use_sse_filter", _i, [_vp]),
     ("zen_hip_hpr_use_soft_mask", _i, [_vp]),
     ("zen_hip_hpr_reset_buffers", _i, [_vp]),
+    ("zen_hip_hpr_set_resident", _i, [_vp, _i]),
+    ("zen_hip_hpr_resident_stats", _i, [_vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_int)]),
     ("zen_hip_hpr_process_next_hop", _i, [_vp, _vp]),
     ("zen_hip_hpr_copy_output", _i, [_vp, _u, _vp]),
     ("zen_hip_hpr_copy_output_async", _i, [_vp, _u, _vp]),
@@ -350,6 +352,15 @@ class HPR:
 
     def reset_buffers(self):
         _ck(load().zen_hip_hpr_reset_buffers(self._h))
+
+    def set_resident(self, idle_ms):
+        """Per-hop calls through a resident kernel (zen_hip_hpr_set_resident); 0 switches it off."""
+        _ck(load().zen_hip_hpr_set_resident(self._h, int(idle_ms)))
+
+    def resident_stats(self):
+        a, b, c = C.c_ulonglong(), C.c_ulonglong(), C.c_int()
+        _ck(load().zen_hip_hpr_resident_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"launches": a.value, "hops_of_ended_launches": b.value, "active": bool(c.value)}
 
     def set_stream(self, stream):
         _ck(load().zen_hip_hpr_set_stream(self._h, stream))

@@ -212,6 +212,12 @@ namespace hps {
 	}
 
 	template <>
+	void HPRRealtime<Backend::GPU>::use_resident_kernel(int idle_ms)
+	{
+		throw_or_die(zen_hip_hpr_set_resident(p_impl->engine, idle_ms), "use_resident_kernel");
+	}
+
+	template <>
 	void HPRRealtime<Backend::GPU>::warmup(zen::io::IOGPU& io)
 	{
 		// reference hps.cu:392-408: 1000 hops of iota through the mapped buffers, then a reset

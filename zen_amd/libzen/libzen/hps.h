@@ -62,6 +62,10 @@ namespace hps {
 		void warmup(zen::io::IOGPU& io); // 1000 throw-away hops, then a state reset
 		void warmup();
 
+		// MI355X extension (off by default): serve process_next_hop / copy_* from one workgroup that stays on the device
+		// between hops instead of a launch per hop; it leaves after idle_ms without a hop (0: off).  Same samples.
+		void use_resident_kernel(int idle_ms);
+
 		// MI355X extension: n_hops consecutive hops in one call (bit-identical to n_hops single calls);
 		// null output pointers are skipped
 		void process_hops(thrust::device_ptr<float> in, std::size_t n_hops, thrust::device_ptr<float> harm,
