@@ -52,10 +52,11 @@ FS = 44100.0
 HOP = 1024
 BETA = 2.0
 # HBM bytes per launch measured with rocprofv3 --pmc (tools/pmc_cmd.sh); re-collected whenever a kernel changes
-TRAFFIC_FILE = "r03_hbm_traffic.json"   # {demangled kernel name: {elements, rows, cols, hbm_bytes_per_launch, ...}}
+TRAFFIC_FILE = "r04_hbm_traffic.json"   # {demangled kernel name: {elements, rows, cols, hbm_bytes_per_launch, ...}}
 K_FUSED_P = "rt_fused_kernel<12, 47, 3, true, true, true>"
 K_FUSED_HPR = "rt_fused_kernel<12, 47, 3, false, true, true>"
-K_MEDIAN_WHOLE = "median47_dpp_kernel<true, 0, false>"
+K_MEDIAN_WHOLE = "median47_dpp_kernel<false, 0, false>"   # through plain zen_hip_mfilt_run: the build that checks sign bits
+K_MEDIAN_WHOLE_ENGINE = "median47_dpp_kernel<true, 0, false>"   # the engine's own launches on whole rows (burst leg)
 K_MEDIAN_HALF = "median47_dpp_kernel<true, 0, true>"
 
 
@@ -221,6 +222,11 @@ def offline_rooflines(prof, steps, frames, nfft, hop, n_out1, copy_bw, freq_mask
                      "istft": 8 * (N // 2 + 1) + nout * 8 * h
                      + ((nout * 4 * (N // 2 + 1) if ps == "pass1" else 8 * (N // 2 + 1)) if soft else N // 4),
                      "finalize": nout * 12 * h}
+        if mf <= 63 and not prof[ps].get("time_filter", {}).get("launches") and prof[ps].get("freq_filter", {}).get("launches") \
+                and ps == "pass2":
+            # median_tf_herm_bits_kernel: both medians in one launch.  SURVEY 8(d): "fused H+P stage (one read of abs(S), two
+            # writes): 12 B per element" -- the kernel writes two mask bits per bin instead of the two rows
+            per_frame["freq_filter"] = 12 * (N // 2 + 1)
         for k, v in prof[ps].items():
             if not v["launches"] or k not in per_frame:
                 continue
@@ -561,7 +567,7 @@ def median_rooflines(zen_amd, run, S, M, copy_bw):
                  "note": "512 MiB written elsewhere before every launch: nothing of the input is left in the Infinity Cache"},
         "device_copy_GBps": copy_bw, "frac_of_device_copy": sus / copy_bw if copy_bw else None,
         "traffic": tr, "traffic_source": tsrc,
-        "kernel": K_MEDIAN_WHOLE + " (frequency direction, 47 taps, whole 4096-bin rows, non-negative keys)",
+        "kernel": K_MEDIAN_WHOLE + " (frequency direction, 47 taps, whole 4096-bin rows; rows without a set sign bit keep raw-bit keys)",
         "elements_per_launch": el, "rows": rows, "cols": cols, "algorithmic_bytes_per_element": 8}
     return roof, three
 

@@ -82,3 +82,19 @@ def test_long_mask_kernel_budget(usage):
     for name in ("median_big_kernel<187, true, true, false>", "median_big_kernel<187, true, false, true>"):
         k = kernel(usage, "median_big.hip", name)
         assert k["occupancy"] >= 2 and k["scratch"] <= 48, (name, k)
+
+
+def test_round4_kernels(usage):
+    """The 47-tap kernel build that checks sign bits itself (plain zen_hip_mfilt_run: BASELINE's median metric) keeps the
+    occupancy of the non-negative build; the fused SSE synthesis (sse_block.hip) runs three workgroups per CU without
+    scratch; the resident single-hop kernels (rt_resident.hip) hold everything in registers; and wrapping the fused
+    kernel's body for the resident kernel left the per-launch builds where they were (checked above by their own limits)."""
+    auto = [v for k, v in usage["median47.hip"].items() if "median47_dpp_kernel<false, 0, false>" in k]
+    assert auto and auto[0]["vgprs"] <= 72 and auto[0]["scratch"] == 0
+    for name, k in usage["sse_block.hip"].items():
+        assert k["scratch"] == 0 and k["vgprs"] <= 176, (name, k)
+    k11 = kernel(usage, "sse_block.hip", "sse_synth_kernel<11>")
+    assert k11["occupancy"] >= 3
+    assert len(usage["rt_resident.hip"]) == 9
+    for name, k in usage["rt_resident.hip"].items():
+        assert k["scratch"] == 0, (name, k)

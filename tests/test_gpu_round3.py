@@ -365,7 +365,7 @@ def test_blocks_of_frames_mask_bits(z, hop, n_hops, soft, flags):
         for k in keys:
             assert np.array_equal(got[k], other[k]), ("no_mask_bits", k)
     else:
-        for opt in ("no_mask_bits", "no_median_bits"):
+        for opt in ("no_mask_bits", "no_median_bits", "no_median_tf"):
             other = run(opt)
             for k in keys:
                 assert np.array_equal(got[k], other[k]), (opt, k)

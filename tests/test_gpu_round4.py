@@ -365,3 +365,38 @@ def test_resident_kernel_per_hop_calls_vs_oracle(z, hop, flags, key):
     copy(io.device_out)
     assert np.array_equal(io.host_out, ref[hop:2 * hop])
     del rt, eng                                                                # destroy with the kernel resident
+
+
+# ---------------------------------------------------------------------------- time median + frequency median + mask bits in one launch
+@pytest.mark.parametrize("fs,hop", [(44100.0, 256), (48000.0, 256), (44100.0, 512), (48000.0, 512)])
+@pytest.mark.parametrize("flags", [ALL, o.OUTPUT_PERCUSSIVE])
+def test_time_and_frequency_median_in_one_launch(z, fs, hop, flags):
+    """Anticausal blocks with hard masks at the geometries of pass 2 (11 / 13 taps at 44.1 kHz, 13 / 11 at 48 kHz, hop 256;
+    7 / 23 and 7 / 21 at hop 512): median_tf_herm_bits_kernel computes the harmonic estimate (time median, mfilt.h:310-314)
+    and the percussive one (frequency median, :316-318) of the same rows and writes only the mask bits (hps.cu:501-505,
+    :535-540).  Against the oracle, against the two-launch path ("no_median_tf"), two streams, block lengths that are not
+    multiples of the kernel's twelve rows, state carried from call to call."""
+    ho = o.HPR(fs, hop, 2.0, flags, o.TIME_ANTICAUSAL)
+    assert (ho.l_harm | 1, ho.l_perc | 1) in ((11, 13), (13, 11), (7, 23), (7, 21))
+    n_hops = 3 * ho.stft_width + 53
+    x = np.stack([_clip(hop * n_hops, 3 + hop, ), _clip(hop * n_hops, 4 + hop)])
+    refs = [o.HPR(fs, hop, 2.0, flags, o.TIME_ANTICAUSAL).process_stream(x[s]) for s in range(2)]
+    keys = [k for k, f in (("P", o.OUTPUT_PERCUSSIVE), ("H", o.OUTPUT_HARMONIC), ("R", o.OUTPUT_RESIDUAL)) if flags & f]
+
+    def run(opt, block):
+        if opt:
+            z.set_option(opt, 1)
+        try:
+            return z.HPR(fs, hop, 2.0, flags, z.TIME_ANTICAUSAL, True, 2).process_stream_host(x, block=block)
+        finally:
+            if opt:
+                z.set_option(opt, 0)
+
+    for block in (None, 29, 13, 8):
+        got = run(None, block)
+        old = run("no_median_tf", block)
+        for k in keys:
+            for s in range(2):
+                assert np.array_equal(got[k][s], refs[s][k]), (block, k, s)
+            assert np.array_equal(got[k], old[k]), ("no_median_tf", block, k)
+            assert np.any(refs[0][k] != 0)

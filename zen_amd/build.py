@@ -120,7 +120,25 @@ def build(force=False, verbose=False):
                 usage[os.path.basename(o).replace(".o", ".hip")] = json.load(f)
     with open(RESOURCES, "w") as f:
         json.dump(usage, f, indent=1, sort_keys=True)
+    _stamp_revision()
     return OUT
+
+
+def _stamp_revision():
+    """.build_rev (git-ignored, travels to the GPU box with the built library): the commit the library was built from, with
+    a mark when the kernel sources differ from it.  tools/collect_profiles.sh labels every record it writes with this; the
+    box has no .git, so the label is taken here, at build time, never written by hand."""
+    root = os.path.dirname(HERE)
+    try:
+        rev = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                             universal_newlines=True, check=True).stdout.strip()
+        dirty = subprocess.run(["git", "status", "--porcelain", "--", "zen_amd/csrc", "include", "zen_amd/build.py"], cwd=root,
+                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, universal_newlines=True, check=True).stdout.split("\n")
+        n = len([d for d in dirty if d.strip()])
+        with open(os.path.join(root, ".build_rev"), "w") as f:
+            f.write(rev + ("+%d-uncommitted-source-files" % n if n else "") + "\n")
+    except (OSError, subprocess.CalledProcessError):
+        pass          # no git here (the GPU box): the stamp written where the library was built stays
 
 
 def build_host(verbose=False):

@@ -28,6 +28,7 @@ extern opt_t g_opt_offline_range;       // "offline_range": samples per range of
 extern opt_t g_opt_offline_no_register; // "offline_no_register": zen_hip_hpri_process never hipHostRegisters the caller's buffers
 extern opt_t g_opt_no_istft_xcd_map;    // "no_istft_xcd_map": several outputs: a grid of frames x outputs instead of same-XCD groups
 extern opt_t g_opt_no_sse_block;        // "no_sse_block": blocks of frames on the SSE path through the four-launch path
+extern opt_t g_opt_no_median_tf;        // "no_median_tf": time median and frequency median + mask bits as two launches
 extern opt_t g_opt_no_median_bits;      // "no_median_bits": the mask bits always come from mask_bits_kernel, never from a median kernel
 extern opt_t g_opt_no_mask_bits;        // "no_mask_bits": the synthesis kernels compare H and P themselves (no mask_bits_kernel)
 // Diagnostics whose results are not the reference's (timing experiments) or that only exist to cross-check a formulation

@@ -56,6 +56,9 @@ struct FilterArgs {
 	// bin where P would have gone (dst), and the harmonic one in mh_dst (same layout), soft_mask_functor hps.h:116-129 with
 	// the integer exponent `soft_power`; the synthesis then loads one mask value per bin and output instead of H and P
 	// and divides nothing (stft.h IstftArgs::mask_rows).  need_pm / need_hm as above.
+	// Engine only, with bits_t: the harmonic estimate is the time median of `time_len` taps of the SAME source rows; a kernel
+	// that knows how computes it itself instead of reading hrows (median_tf_herm_bits_kernel; median_tf_fused_available)
+	int time_len;
 	int soft_rows;
 	int soft_power;
 	float* mh_dst;                // null unless need_hm
@@ -64,6 +67,7 @@ struct FilterArgs {
 
 // true if launch_median(a) with a.hermitian = 1 is implemented for this (direction, mask, row length)
 bool filter_supports_hermitian(int len, int cols);
+bool median_tf_fused_available(int time_len, int freq_len, int cols);
 
 int launch_median(const FilterArgs& a, hipStream_t stream, int* bits_done = nullptr);
 int launch_median_net(const FilterArgs& a, hipStream_t stream, bool* handled, int* bits_done = nullptr); // masks <= 63 taps

@@ -660,6 +660,7 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 	const int need_hm = (output_computed(e, 1) || (output_computed(e, 2) && e->out_h)) ? 1 : 0;
 
 	bool h_is_ring = false; // time direction -> H   (hps.cu:495 / :596)
+	bool fuse_tf = false;
 	FilterArgs ft = fa;
 	ft.dst = e->d_H;
 	ft.len = e->mt;
@@ -682,6 +683,9 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 		// (SURVEY Q1).  mt == 1: a one-tap median.  No launch.
 		h_is_ring = true;
 	}
+	else if (use_bits && half && !g_opt_no_median_bits && median_tf_fused_available(e->mt, e->mf, (int)N)) {
+		fuse_tf = true; // the frequency-direction launch below computes H itself (median_tf_herm_bits_kernel): no H rows
+	}
 	else {
 		ProfScope ps(e, zen_hip_hpr::K_TIME);
 		ZH_TRY(launch_median(ft, e->stream));
@@ -702,7 +706,10 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 		ff.thr_h = thr.h;
 		ff.need_pm = need_pm;
 		ff.need_hm = need_hm;
-		if (!h_is_ring) {
+		if (fuse_tf) {
+			ff.time_len = e->mt;
+		}
+		else if (!h_is_ring) {
 			ff.hrows = e->d_H;
 			ff.h_stream_stride = (long long)(e->max_hops * N);
 		}

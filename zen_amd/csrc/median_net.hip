@@ -319,6 +319,127 @@ __global__ __launch_bounds__(HERM_THREADS) void median_net_freq_herm_kernel(Filt
 }
 
 // -------------------------------------------------------------------------------------------------
+// Time median AND frequency median of the same rows in one launch (pass 2 of the offline path: 11 / 13 taps on 1024-bin
+// half rows): the harmonic estimate never reaches HBM.  The two-launch form wrote H (a row of the stored half per frame)
+// from median_net_time_kernel and read it back here next to the magnitudes; now a workgroup of HERM_THREADS
+//   A. computes H for GROUPS * TT consecutive rows -- thread (g, c): TT rows of four adjacent columns from WT + TT - 1
+//      magnitude rows, the sorting-network scheme of median_net_time_kernel -- and leaves them in LDS;
+//   B. runs median_net_freq_herm_kernel<WF, true, BITS>'s stage over the same rows, three at a time: stage the columns the
+//      wanted chunks read, frequency medians, compare with H from LDS, OR the two mask bits of every bin into the rows'
+//      words (the synthesis threads' order, stft.h IstftArgs::bits_t), store the finished words.
+// Same comparisons on the same values: bit-identical masks ("no_median_tf": the two launches).  The magnitude rows are read
+// (WT + TT - 1) / TT times in phase A and once in phase B, from L2 after the first touch; HBM sees them ~1.2 times.
+template <int WT, int WF>
+__global__ __launch_bounds__(HERM_THREADS) void median_tf_herm_bits_kernel(FilterArgs a, RowMap rm, int n_lo, int n_tail, int lwv, int twv)
+{
+	constexpr int TT = znet::outputs_per_thread(WT), midT = WT / 2, NET = WT + TT - 1, GROUPS = 3, RWG = TT * GROUPS;
+	constexpr int T = znet::outputs_per_thread(WF), mid = WF / 2;
+	static_assert(T >= 4, "16-byte LDS path needs T >= 4");
+	constexpr int MID_AL = (mid + 3) & ~3, DELTA = MID_AL - mid;
+	constexpr int NV = (DELTA + WF + T - 1 + 3) / 4, NE = NV * 4;
+	extern __shared__ __attribute__((aligned(16))) int himg[]; // [3 rows of the frequency stage | their bit words | H of RWG rows]
+	const int tid = threadIdx.x, cols = a.cols;
+	const int jobs = n_lo + n_tail, rpw = HERM_THREADS / jobs, row_vecs = lwv + twv;
+	const int tfw = cols >> 4;
+	unsigned* tw = reinterpret_cast<unsigned*>(himg) + 4 * rpw * row_vecs; // rpw rows of cols/16 words
+	const int hs = (cols >> 1) + 8;                                          // floats per H row (bins 0..cols/2, rounded up to vectors)
+	float* Hs = reinterpret_cast<float*>(tw + rpw * tfw);
+	const int row0 = blockIdx.x * RWG;
+	const float* __restrict__ src = a.src + (long long)blockIdx.y * a.src_stream_stride;
+
+	// ---- A: the time medians of rows row0 .. row0 + RWG - 1, stored half of every row
+	{
+		const int vecs = ((cols >> 1) + 4) >> 2; // column vectors of the stored half (bins 0..cols/2, rounded up)
+		if (tid < GROUPS * vecs) {
+			const int g = tid / vecs, c = (tid - g * vecs) << 2;
+			const int r0 = row0 + g * TT;
+			int e[4][NET];
+#pragma unroll
+			for (int q = 0; q < NET; ++q) { // taps r0 - midT .. r0 + midT + TT - 1 (replicate border: map_row clamps)
+				const float4 x = *reinterpret_cast<const float4*>(src + (long long)map_row(rm, r0 - midT + q) * cols + c);
+				e[0][q] = __float_as_int(x.x); // |S| >= +0: the bits are the ordering key
+				e[1][q] = __float_as_int(x.y);
+				e[2][q] = __float_as_int(x.z);
+				e[3][q] = __float_as_int(x.w);
+			}
+			int out[4][TT];
+#pragma unroll
+			for (int v = 0; v < 4; ++v)
+				znet::medians<WT, TT, NET>(e[v], out[v]);
+#pragma unroll
+			for (int gI = 0; gI < TT; ++gI)
+				*reinterpret_cast<float4*>(Hs + (g * TT + gI) * hs + c) =
+				    make_float4(__int_as_float(out[0][gI]), __int_as_float(out[1][gI]), __int_as_float(out[2][gI]), __int_as_float(out[3][gI]));
+		}
+	}
+	// ---- B: the frequency stage, rpw rows per turn
+	const int c_t0 = cols - n_tail * T; // first column of the tail chunks
+	int log2tf = 0;
+	while ((1 << log2tf) < tfw)
+		++log2tf;
+	const int rr = tid / jobs, j = tid - rr * jobs;
+	const bool tail = j >= n_lo;
+	const int rra = rr < rpw ? rr : 0; // (threads without a chunk stay for the barriers and read row 0's image)
+	for (int rb = 0; rb < RWG; rb += rpw) {
+		const int rowb = row0 + rb;
+		if (rowb >= a.n_out_rows)
+			break; // (workgroup-uniform)
+		__syncthreads(); // H is complete (first turn); the last turn's words are stored and its image is free
+		for (int v = tid; v < rpw * row_vecs; v += HERM_THREADS) {
+			const int r1 = v / row_vecs, vv = v - r1 * row_vecs;
+			const int rw = rowb + r1 < a.n_out_rows ? rowb + r1 : a.n_out_rows - 1; // (past the last row: staged again, never used)
+			const float* srow = src + (long long)map_row(rm, rw) * cols;
+			const int col = vv < lwv ? 4 * vv - MID_AL : c_t0 - MID_AL + 4 * (vv - lwv);
+			*reinterpret_cast<int4*>(&himg[4 * v]) = row_vec_keys<true>(srow, col, cols, 1);
+		}
+		for (int k = tid; k < rpw * tfw; k += HERM_THREADS)
+			tw[k] = 0u;
+		__syncthreads();
+		const bool work = rr < rpw && rb + rr < RWG && rowb + rr < a.n_out_rows;
+		if (work) {
+			const int* mine = &himg[4 * (rra * row_vecs + (tail ? lwv : 0)) + T * (tail ? j - n_lo : j)];
+			int ld[NE], e[WF + T - 1], out[T];
+#pragma unroll
+			for (int v = 0; v < NV; ++v) {
+				const int4 q = *reinterpret_cast<const int4*>(mine + 4 * v);
+				ld[4 * v] = q.x;
+				ld[4 * v + 1] = q.y;
+				ld[4 * v + 2] = q.z;
+				ld[4 * v + 3] = q.w;
+			}
+#pragma unroll
+			for (int q = 0; q < WF + T - 1; ++q)
+				e[q] = ld[q + DELTA];
+			znet::medians<WF, T, WF + T - 1>(e, out);
+			const int c0 = tail ? c_t0 + T * (j - n_lo) : T * j; // first bin of the chunk
+			const float* hrow = Hs + (rb + rr) * hs;
+			unsigned* trow = tw + rr * tfw;
+#pragma unroll
+			for (int i = 0; i < T; ++i) {
+				const int k = c0 + i;
+				const float hh = hrow[tail ? cols - k : k]; // (the tail's H from the mirror image: H is symmetric)
+				const float pf = __int_as_float(out[i]);
+				const unsigned pm = a.need_pm && hard_mask_exact(pf, hh + FLT_EPSILON, a.thr_p) != 0.0f ? 1u : 0u;
+				const unsigned hm = a.need_hm && hard_mask_exact(hh, pf + FLT_EPSILON, a.thr_h) != 0.0f ? 1u : 0u;
+				const unsigned code = pm | (hm << 1);
+				const bool wanted = tail ? k >= cols - mid : k <= (cols >> 1);
+				if (wanted && code)
+					atomicOr(&trow[k & (tfw - 1)], code << (2 * (k >> log2tf)));
+				const int km = cols - k; // the mirror image of a bin of the lower half
+				if (!tail && k > mid && k < (cols >> 1) && code)
+					atomicOr(&trow[km & (tfw - 1)], code << (2 * (km >> log2tf)));
+			}
+		}
+		__syncthreads();
+		unsigned* dst_t = a.bits_t + (long long)blockIdx.y * a.bits_t_stream_stride + (long long)rowb * tfw;
+		int rows_here = a.n_out_rows - rowb < rpw ? a.n_out_rows - rowb : rpw;
+		rows_here = RWG - rb < rows_here ? RWG - rb : rows_here;
+		for (int k = tid; k < rows_here * tfw; k += HERM_THREADS)
+			dst_t[k] = tw[k];
+	}
+}
+
+// -------------------------------------------------------------------------------------------------
 template <int VC>
 struct VecT;
 template <>
@@ -471,6 +592,21 @@ int launch_freq(const FilterArgs& a, const RowMap& rm, hipStream_t stream, int* 
 			const size_t lds = sizeof(int) * 4 * (size_t)rpw * (lwv + twv);
 			dim3 g((unsigned)((a.n_out_rows + rpw - 1) / rpw), (unsigned)a.n_streams);
 			// mask bits instead of P (power-of-two rows of at least 16 words: every bin's place is a shift and a mask)
+			if constexpr (W == 13 || W == 11 || W == 23 || W == 21) { // both medians in one launch (FilterArgs::time_len)
+				if (bits_done && a.bits_t && a.time_len && a.nonneg && (a.cols & (a.cols - 1)) == 0 && a.cols >= 256) {
+					const int wt = a.time_len;
+					const int tt = znet::outputs_per_thread(wt), rwg = 3 * tt;
+					const size_t lds_f = lds + sizeof(unsigned) * (size_t)rpw * (a.cols >> 4) + sizeof(float) * (size_t)rwg * ((a.cols >> 1) + 8);
+					dim3 gf((unsigned)((a.n_out_rows + rwg - 1) / rwg), (unsigned)a.n_streams);
+					constexpr int WT_FOR = W == 13 ? 11 : (W == 11 ? 13 : 7); // the pairs of the BASELINE geometries (44.1 / 48 kHz)
+					if (wt == WT_FOR) {
+						hipLaunchKernelGGL((median_tf_herm_bits_kernel<WT_FOR, W>), gf, dim3(HERM_THREADS), lds_f, stream, a, rm, n_lo, n_tail, lwv, twv);
+						ZH_HIP(hipGetLastError());
+						*bits_done = 2;
+						return ZEN_HIP_OK;
+					}
+				}
+			}
 			if (bits_done && a.bits_t && a.hrows && a.nonneg && (a.cols & (a.cols - 1)) == 0 && a.cols >= 256) {
 				const size_t lds_b = lds + sizeof(unsigned) * (size_t)rpw * (a.cols >> 4);
 				hipLaunchKernelGGL((median_net_freq_herm_kernel<W, true, true>), g, dim3(HERM_THREADS), lds_b, stream, a, rm, n_lo, n_tail, lwv,
@@ -622,6 +758,22 @@ int launch_median_net(const FilterArgs& a, hipStream_t stream, bool* handled, in
 #undef X
 	default: *handled = false; return ZEN_HIP_OK;
 	}
+}
+
+// true if launch_median(a) with a.time_len = time_len, a.len = freq_len, Hermitian rows of `cols` bins and bits_t set will run
+// median_tf_herm_bits_kernel (the conditions of launch_freq above)
+bool median_tf_fused_available(int time_len, int freq_len, int cols)
+{
+	if (g_opt_no_median_tf || g_opt_median_general || cols < 256 || (cols & (cols - 1)) != 0)
+		return false;
+	const bool combo = (freq_len == 13 && time_len == 11) || (freq_len == 11 && time_len == 13)
+	                   || ((freq_len == 23 || freq_len == 21) && time_len == 7);
+	if (!combo)
+		return false;
+	const int T = znet::outputs_per_thread(freq_len), mid = freq_len / 2;
+	const int segs = (cols + 256 * T - 1) / (256 * T);
+	const int n_lo = cols / (2 * T) + 1, n_tail = (mid + T - 1) / T;
+	return segs == 1 && cols % (2 * T) == 0 && n_lo + n_tail <= HERM_THREADS && 3 * (((cols >> 1) + 4) >> 2) <= HERM_THREADS;
 }
 
 // Hermitian rows (FilterArgs::hermitian): the sorting-network kernels of this file and median47_dpp_kernel

@@ -55,7 +55,9 @@ struct SynthOut {
 };
 
 template <int LOG2N>
-__global__ __launch_bounds__(Plan<LOG2N>::THREADS) void sse_synth_kernel(SseBlockArgs b)
+// (four workgroups per CU up to nfft 2048 -- 128 registers hold the spectrum, the masks and a transform pass without
+// scratch: 0.541 -> 0.529 ms per 51 680 frames at nfft 2048; at nfft 4096 that would spill 36 bytes per lane: three there)
+__global__ __launch_bounds__(Plan<LOG2N>::THREADS, LOG2N <= 11 ? 4 : 3) void sse_synth_kernel(SseBlockArgs b)
 {
 	using PL = Plan<LOG2N>;
 	constexpr int N = PL::N, TF = PL::TF, NLO = 9; // slots 0..7 of a thread are bins below nfft/2; slot 8 of thread 0 is bin nfft/2
