@@ -246,6 +246,30 @@ def offline_rooflines(prof, steps, frames, nfft, hop, n_out1, copy_bw, freq_mask
     return roof, out
 
 
+OFFLINE_PMC_FILE = "r04_offline_batch_pmc.json"   # tools/pmc_cmd.sh _kernel python3 bench.py --workload offline_batch ... (collect_profiles.sh)
+OFFLINE_PMC_KERNELS = {"pass1.stft": "stft_kernel<14>", "pass1.freq_filter": "median_big_kernel<187", "pass1.istft": "istft_kernel<14, 3>",
+                       "pass2.stft": "stft_kernel<10>", "pass2.freq_filter": "median_tf_herm_bits_kernel<11, 13>",
+                       "pass2.istft": "istft_kernel<10, 3>"}
+
+
+def offline_valu_issue(kern, clips, clip_seconds):
+    """valu_issue_frac of the offline batch's VALU-bound kernels (SQ_INSTS_VALU per launch from the committed PMC pass of the
+    SAME workload x 2 cycles over 1024 SIMDs x 2.4 GHz x the launch time measured here); an HBM fraction is the wrong ruler
+    for the long-mask median (196 instructions per output).  Silent when the record is missing or for another batch."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", OFFLINE_PMC_FILE)))
+    except (OSError, ValueError):
+        return
+    if rec.get("clips") != clips or rec.get("clip_seconds") != clip_seconds:
+        return
+    for line, prefix in OFFLINE_PMC_KERNELS.items():
+        hit = [v for k, v in rec.get("kernels", {}).items() if k.startswith(prefix)]
+        if line in kern and hit and hit[0].get("SQ_INSTS_VALU"):
+            n = sum(h["SQ_INSTS_VALU"] for h in hit)          # per step: every matching kernel runs once per step
+            kern[line]["valu_issue_frac"] = 2.0 * n / (1024 * 2.4e9 * 1e-3 * kern[line]["ms_per_step"])
+            kern[line]["valu_instructions_per_step"] = n
+
+
 def whole_step_roofline(frames, nfft, hop, n_out, ms_per_step):
     """The whole offline step on SURVEY 8(d)'s per-frame minimum (fused_bytes_per_hop: 24*(nfft/2+1) + 8*hop for one
     output, every further output reads the spectrum again and writes its hop), both passes, over the step's wall time."""
@@ -635,6 +659,9 @@ def offline_batch_run(zen_amd, zdist, grp, rank, world, C, clip_seconds, steps, 
     if rooflines and rank == 0:
         fr, nf, hp = {"pass1": C * n1, "pass2": C * n2}, {"pass1": 4 * hop_h, "pass2": 4 * hop_p}, {"pass1": hop_h, "pass2": hop_p}
         roof, kern = offline_rooflines(prof, steps, fr, nf, hp, 3, None, {"pass1": 187, "pass2": 13})
+        offline_valu_issue(kern, C, clip_seconds)
+        if "valu_issue_frac" in kern.get(roof["kernel"], {}):
+            roof["valu_issue_frac"] = kern[roof["kernel"]]["valu_issue_frac"]
         res.update({"roofline": roof, "kernels": kern,
                     "whole_step": whole_step_roofline(fr, nf, hp, {"pass1": 3, "pass2": 1}, res["ms_per_step"])})
     first_clip = x[0].copy()

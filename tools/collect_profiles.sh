@@ -33,6 +33,15 @@ timeout 1300 tools/pmc_cmd.sh rt_fused_kernel $B --outputs HPR > $OUT/pmc_fused_
 timeout 1300 tools/pmc_cmd.sh median47_dpp_kernel $B --no-block-fused > $OUT/pmc_median47_half.json 2>> $OUT/pmc.err
 timeout 1300 tools/pmc_cmd.sh median47_dpp_kernel python3 tools/bench_median.py --suite one --rows 25840 --cols 4096 --len 47 --iters 6 > $OUT/pmc_median47_whole.json 2>> $OUT/pmc.err
 timeout 1300 tools/pmc_cmd.sh sse_synth_kernel python3 tools/sse_ab.py > $OUT/pmc_sse_synth.json 2>> $OUT/pmc.err
+# every kernel of the offline batch step (valu_issue_frac of its VALU-bound kernels: bench.py offline_valu_issue)
+timeout 1300 tools/pmc_cmd.sh _kernel python3 bench.py --workload offline_batch --steps 2 --warmup 1 --settle-ms 0 --no-cpu-baseline > $OUT/pmc_offline_batch_raw.json 2>> $OUT/pmc.err
+python3 - $OUT/pmc_offline_batch_raw.json "$REV" > $OUT/offline_batch_pmc.json <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+d.update({"build": sys.argv[2], "clips": 64, "clip_seconds": 30.0,
+          "workload": "python3 bench.py --workload offline_batch (64 x 30 s clips, HPRIOffline 4096/256 hard masks); per-dispatch means"})
+print(json.dumps(d, indent=1))
+PY
 T=$OUT/hbm_traffic.json; rm -f $T
 python3 tools/traffic_json.py $T "$REV" $OUT/pmc_fused_p.json "rt_fused_kernel<12, 47, 3, true, true, true>" $((25840*4096)) 25840 4096 "one workgroup per hop, percussive output" >> $OUT/pmc.err 2>&1
 python3 tools/traffic_json.py $T "$REV" $OUT/pmc_fused_hpr.json "rt_fused_kernel<12, 47, 3, false, true, true>" $((25840*4096)) 25840 4096 "one workgroup per hop, three outputs" >> $OUT/pmc.err 2>&1
