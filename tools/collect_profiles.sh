@@ -8,13 +8,6 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG; mkdir -p $OUT
 REV=$(cat .build_rev 2>/dev/null || echo unknown)
 echo "$REV" > $OUT/build_rev.txt
-python3 bench.py > $OUT/bench_default_line.json 2> $OUT/bench_default.err
-cp gpurun_out/bench_detail.json $OUT/bench_default.json
-python3 bench.py --workload offline_batch --detail > $OUT/bench_offline_batch.json 2>> $OUT/bench_default.err
-python3 bench.py --workload offline_long --detail > $OUT/bench_offline_long.json 2>> $OUT/bench_default.err
-python3 bench.py --workload offline_host --host-variants --detail > $OUT/bench_offline_host.json 2>> $OUT/bench_default.err
-python3 tools/bench_median.py --suite path > $OUT/median_path_shapes.jsonl 2>> $OUT/bench_default.err
-python3 tools/bench_median.py --suite path --nonneg >> $OUT/median_path_shapes.jsonl 2>> $OUT/bench_default.err
 # per-kernel durations of the default bench command, legs included (the averages must agree with bench.py's HIP events)
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-realtime > $OUT/stats_run.log 2>&1
 find $OUT/stats -name '*kernel_stats.csv' -exec cp {} $OUT/bench_default_kernel_stats.csv \;
@@ -48,6 +41,16 @@ python3 tools/traffic_json.py $T "$REV" $OUT/pmc_fused_hpr.json "rt_fused_kernel
 python3 tools/traffic_json.py $T "$REV" $OUT/pmc_median47_half.json "median47_dpp_kernel<true, 0, true>" $((25840*2072)) 25840 4096 "engine launch: bins 0..2048 and 4073..4095 of every row" >> $OUT/pmc.err 2>&1
 python3 tools/traffic_json.py $T "$REV" $OUT/pmc_median47_whole.json "median47_dpp_kernel<false, 0, false>" $((25840*4096)) 25840 4096 "whole rows through plain zen_hip_mfilt_run: the build that checks the sign bits of what it stages (BASELINE's median metric)" >> $OUT/pmc.err 2>&1
 python3 tools/traffic_json.py $T "$REV" $OUT/pmc_sse_synth.json "sse_synth_kernel<11>" $((51680*2048)) 51680 2048 "config 5: time box + frequency box + Wiener mask + inverse transform per frame" >> $OUT/pmc.err 2>&1
+# the records bench.py quotes (traffic, valu_issue_frac) are the ones just collected: put them where it looks for them, then the lines
+cp $T profiles/r04_hbm_traffic.json
+cp $OUT/offline_batch_pmc.json profiles/r04_offline_batch_pmc.json
+python3 bench.py > $OUT/bench_default_line.json 2> $OUT/bench_default.err
+cp gpurun_out/bench_detail.json $OUT/bench_default.json
+python3 bench.py --workload offline_batch --detail > $OUT/bench_offline_batch.json 2>> $OUT/bench_default.err
+python3 bench.py --workload offline_long --detail > $OUT/bench_offline_long.json 2>> $OUT/bench_default.err
+python3 bench.py --workload offline_host --host-variants --detail > $OUT/bench_offline_host.json 2>> $OUT/bench_default.err
+python3 tools/bench_median.py --suite path > $OUT/median_path_shapes.jsonl 2>> $OUT/bench_default.err
+python3 tools/bench_median.py --suite path --nonneg >> $OUT/median_path_shapes.jsonl 2>> $OUT/bench_default.err
 # micro-benchmarks the design decisions lean on
 mkdir -p /tmp/ub
 g++ -O2 -std=c++17 -I include tools/rt_latency.cpp -o /tmp/ub/rt -L zen_amd -lzen_hip -Wl,-rpath,$PWD/zen_amd && { /tmp/ub/rt 3000 --stamps; ZEN_RT_RESIDENT=100 /tmp/ub/rt 3000; } > $OUT/rt_latency.jsonl 2>&1
