@@ -192,8 +192,8 @@ int zen_hip_hpr_copy_output(zen_hip_hpr_t h, unsigned which, float* out_dev);
 int zen_hip_hpr_copy_output_async(zen_hip_hpr_t h, unsigned which, float* out_dev);
 
 /* Resident kernel for the per-hop path (an MI355X extension, off by default).  idle_ms > 0: single-hop calls of a causal
- * one-stream, one-output median-path engine whose hop sizes the fused kernel covers (hops 128..1024) no longer cost a
- * launch each: ONE workgroup is started by the first zen_hip_hpr_process_next_hop and stays on its CU, taking every
+ * one-stream, one-output engine (median path or SSE path) whose hop sizes the one-workgroup kernels cover (hops 128..1024)
+ * no longer cost a launch each: ONE workgroup is started by the first zen_hip_hpr_process_next_hop and stays on its CU, taking every
  * further hop from a mailbox in device-visible memory and publishing it behind the same sequence word
  * zen_hip_hpr_copy_output polls; it leaves by itself after idle_ms without a hop (at most 2000), when anything else is
  * asked of the engine (block calls, use_*, reset, set_stream, profile, destroy), and is started again by the next hop.
@@ -237,7 +237,7 @@ int zen_hip_hpri_set_stream(zen_hip_hpri_t h, void* stream);
 int zen_hip_hpri_use_sse_filter(zen_hip_hpri_t h); /* hps.cu:95-100 */
 int zen_hip_hpri_use_soft_mask(zen_hip_hpri_t h);  /* hps.cu:102-107 */
 /* HPRIOffline::process(std::vector<float>) (hps.cu:128-221; the call zen/offline.h:141-147 times): host buffers, n
- * samples each; any output may be NULL.  Synchronises.  Clips of 8 Mi samples and more run as a pipeline over time
+ * samples each; any output may be NULL; the buffers must not overlap (ZEN_HIP_E_BAD_ARG).  Synchronises.  Clips of 8 Mi samples and more run as a pipeline over time
  * ranges (zen_hip_hpri_process_range): the upload of range k+1 and the download of range k-1 under the kernels of range
  * k, bit-identical to the whole clip.  Buffers the runtime does not know (plain malloc / std::vector) are registered
  * with hipHostRegister for the duration of the call so that their copies are asynchronous; where that fails the copies

@@ -322,6 +322,48 @@ def _per_hop(z, rt, io, x, hop, n_hops, copy, pause_every=0, pause_s=0.0):
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("hop", [128, 256, 512, 1024])
 @pytest.mark.parametrize("flags,key", [(o.OUTPUT_PERCUSSIVE, "P"), (o.OUTPUT_HARMONIC, "H")])
+def test_resident_kernel_sse_path_vs_oracle(z, hop, flags, key):
+    """The same for the causal SSE path (use_sse_filter, hps.cu:582-652; BASELINE configs[4] hop by hop): the single-launch SSE
+    kernel's body inside the resident kernel; the history rows of the time box are ring rows the workgroup wrote during
+    the hops before.  Back to back, with idle exits, and switching to SSE in mid-stream with the kernel resident."""
+    n_hops = 60
+    x = _clip(hop * n_hops, 17 + hop)
+    ho = o.HPR(FS, hop, 2.0, flags, o.TIME_CAUSAL)
+    ho.use_sse_filter()
+    ref = ho.process_stream(x)[key]
+    io = z.IOGPU(hop)
+    rt = z.HPRRealtime(FS, hop, 2.0, flags)
+    rt.use_sse_filter()
+    copy = rt.copy_percussive if key == "P" else rt.copy_harmonic
+    eng = rt.p_impl
+    eng.set_resident(200)
+    got = _per_hop(z, rt, io, x, hop, n_hops, copy)
+    assert np.array_equal(got, ref, equal_nan=True) and np.any(np.nan_to_num(ref) != 0)
+    assert eng.resident_stats() == {"launches": 1, "hops_of_ended_launches": 0, "active": True}
+    eng.reset_buffers()
+    eng.set_resident(4)
+    got = _per_hop(z, rt, io, x, hop, n_hops, copy, pause_every=7, pause_s=0.03)
+    assert np.array_equal(got, ref, equal_nan=True)
+    assert eng.resident_stats()["launches"] >= 1 + 7
+    # median path resident, then use_sse_filter() in mid-stream (hps.h:289): the kernel goes home, the SSE one takes over
+    rt2 = z.HPRRealtime(FS, hop, 2.0, flags)
+    copy2 = rt2.copy_percussive if key == "P" else rt2.copy_harmonic
+    rt2.p_impl.set_resident(100)
+    h2 = o.HPR(FS, hop, 2.0, flags, o.TIME_CAUSAL)
+    first = 25
+    ra = h2.process_stream(x[:first * hop])[key]
+    h2.use_sse_filter()
+    rb = h2.process_stream(x[first * hop:])[key]
+    ga = _per_hop(z, rt2, io, x, hop, first, copy2)
+    rt2.use_sse_filter()
+    gb = _per_hop(z, rt2, io, x[first * hop:], hop, n_hops - first, copy2)
+    assert np.array_equal(ga, ra) and np.array_equal(gb, rb, equal_nan=True)
+    assert rt2.p_impl.resident_stats()["launches"] == 2
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("hop", [128, 256, 512, 1024])
+@pytest.mark.parametrize("flags,key", [(o.OUTPUT_PERCUSSIVE, "P"), (o.OUTPUT_HARMONIC, "H")])
 def test_resident_kernel_per_hop_calls_vs_oracle(z, hop, flags, key):
     """zen_hip_hpr_set_resident: process_next_hop + copy_* (libzen/hps.cu:334-363, the loop of zen/fakert.h:221-247)
     served by ONE workgroup that stays on the device and takes each hop from a mailbox.  Same samples as the oracle hop for
@@ -400,3 +442,20 @@ def test_time_and_frequency_median_in_one_launch(z, fs, hop, flags):
                 assert np.array_equal(got[k][s], refs[s][k]), (block, k, s)
             assert np.array_equal(got[k], old[k]), ("no_median_tf", block, k)
             assert np.any(refs[0][k] != 0)
+
+
+def test_host_process_refuses_overlapping_buffers(z):
+    """HPRIOffline::process takes its clip by value and returns new vectors (hps.cu:128-131): through the C-ABI the four host
+    buffers must be distinct -- finished ranges come down while later ranges still go up."""
+    n = 50000
+    x = _clip(n, 1)
+    g = z.HPRIOffline(FS, 1024, 256, 2.0, 2.0)
+    buf = np.zeros(2 * n, np.float32)
+    buf[:n] = x
+    with pytest.raises(z.ZenHipError):
+        g.process(buf[:n], out=(buf[n // 2:n // 2 + n], None, None))
+    with pytest.raises(z.ZenHipError):
+        g.process(x, out=(buf[:n], buf[n - 1:2 * n - 1], None))
+    h, p, r = g.process(buf[:n], out=(buf[n:], np.zeros(n, np.float32), None))   # adjacent, not overlapping
+    rh, rp, _ = o.HPRIOffline(FS, 1024, 256, 2.0, 2.0).process(x)
+    assert np.array_equal(h, rh) and np.array_equal(p, rp)

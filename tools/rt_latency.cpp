@@ -3,7 +3,7 @@
 // without an interpreter in the loop.  Prints one JSON line per hop size.
 // Arguments: [hops per configuration, default 2000] [--stamps: also print the phase stamps of one single-hop kernel
 // of every kind].  Environment: ZEN_RT_RESIDENT=<idle ms>: the per-hop calls go through the resident kernel
-// (zen_hip_hpr_set_resident; hops 256..1024 of the median path, "resident": 1 in their lines); ZEN_RT_ONLY_SSE=1 (only the SSE configurations), ZEN_RT_DIAG=<n> (sets the library's
+// (zen_hip_hpr_set_resident; hops 256..1024 of the median path and SSE hop 512, "resident": 1 in their lines); ZEN_RT_ONLY_SSE=1 (only the SSE configurations), ZEN_RT_DIAG=<n> (sets the library's
 // "rt_fused_diag" option: timing diagnostics, results not valid; 4 = agent-scope grid barriers in rt_wide.hip).
 //   g++ -O2 -std=c++17 -I include tools/rt_latency.cpp -o /tmp/rt_latency -L zen_amd -lzen_hip -Wl,-rpath,$PWD/zen_amd
 #include <chrono>
@@ -46,7 +46,7 @@ int main(int argc, char** argv)
 			if (sse)
 				CK(zen_hip_hpr_use_sse_filter(h));
 			const int resident_ms = std::getenv("ZEN_RT_RESIDENT") ? std::atoi(std::getenv("ZEN_RT_RESIDENT")) : 0;
-			const bool resident = resident_ms > 0 && !sse && hop <= 1024 && !(argc > 2);
+			const bool resident = resident_ms > 0 && hop <= 1024 && !(argc > 2); // (median path and SSE path: hops the one-workgroup kernels cover)
 			if (resident)
 				CK(zen_hip_hpr_set_resident(h, resident_ms));
 			void *hin, *din, *hout, *dout;

@@ -402,9 +402,9 @@ bool resident_eligible(const zen_hip_hpr* e)
 			++n_out;
 			o1 = o;
 		}
-	return e->res_idle_ms > 0 && e->causality == ZEN_HIP_TIME_CAUSAL && !e->use_sse && !g_opt_no_rt_fused && e->n_streams == 1
-	       && n_out == 1 && e->ready_host[o1] != nullptr && rt_fused_available(e->log2n, e->mf) && !e->prof && !e->dbg_stamps
-	       && !(e->drain[0] | e->drain[1] | e->drain[2]);
+	const bool kernel = e->use_sse ? rt_sse_available(e->log2n, e->mt, e->mf) : rt_fused_available(e->log2n, e->mf);
+	return e->res_idle_ms > 0 && e->causality == ZEN_HIP_TIME_CAUSAL && !g_opt_no_rt_fused && e->n_streams == 1 && n_out == 1
+	       && e->ready_host[o1] != nullptr && kernel && !e->prof && !e->dbg_stamps && !(e->drain[0] | e->drain[1] | e->drain[2]);
 }
 
 int resident_launch(zen_hip_hpr* e) // from res_args: the hop whose number is res_args.seq is the first the kernel will see
@@ -433,8 +433,12 @@ int resident_launch(zen_hip_hpr* e) // from res_args: the hop whose number is re
 	ZH_HIP(hipEventRecord(e->res_event, e->stream));
 	ZH_HIP(hipStreamWaitEvent(e->res_stream, e->res_event, 0));
 	const unsigned long long ticks = (unsigned long long)e->res_idle_ms * 100000ull; // s_memrealtime: 100 MHz
-	ZH_TRY(launch_rt_fused_resident(e->log2n, e->mf, e->res_args, e->res_ctl_dev, e->res_out_dev, seq_start, ticks, 0x7fffffffu,
-	                                e->res_stream));
+	if (e->use_sse) // the single-launch SSE kernel's body (rt_sse.hip); box lengths and factors as run_hop_fused passes them
+		ZH_TRY(launch_rt_sse_resident(e->log2n, e->res_args, e->mt, e->mf, (float)e->l_harm + 1.0F, (float)e->l_perc + 1.0F, e->res_ctl_dev,
+		                              e->res_out_dev, seq_start, ticks, 0x7fffffffu, e->res_stream));
+	else
+		ZH_TRY(launch_rt_fused_resident(e->log2n, e->mf, e->res_args, e->res_ctl_dev, e->res_out_dev, seq_start, ticks, 0x7fffffffu,
+		                                e->res_stream));
 	e->res_active = true;
 	++e->res_launches;
 	return ZEN_HIP_OK;

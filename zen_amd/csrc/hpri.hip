@@ -461,6 +461,15 @@ int zen_hip_hpri_process(zen_hip_hpri_t h, const float* audio_host, size_t n, fl
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_process: null argument");
 	if (h->n_clips != 1)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_process(host) needs a handle created with n_clips == 1");
+	{ // the reference takes the clip by value and returns new vectors: the four buffers are distinct.  Ranges of the clip go
+	  // up while finished ranges come down, so an output that overlaps the input (or another output) would be corrupted.
+		const char* p[4] = {(const char*)audio_host, (const char*)harm_host, (const char*)perc_host, (const char*)resid_host};
+		const size_t bytes = sizeof(float) * n;
+		for (int i = 0; i < 4; ++i)
+			for (int j = i + 1; j < 4; ++j)
+				if (p[i] && p[j] && p[i] < p[j] + bytes && p[j] < p[i] + bytes)
+					ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_process: the host buffers must not overlap");
+	}
 	const double t_start = now_ms();
 	if (n > h->stage_cap) {
 		ZH_HIP(hipStreamSynchronize(h->stream));
@@ -551,23 +560,31 @@ int zen_hip_hpri_process(zen_hip_hpri_t h, const float* audio_host, size_t n, fl
 	};
 	// the copy streams do not know the handle's stream: order them behind whatever the caller queued there (and behind an
 	// earlier call's kernels, which may still read the stage buffers)
-	ZH_HIP(hipEventRecord(h->events[2 * n_ranges], h->stream));
-	ZH_HIP(hipStreamWaitEvent(h->s_in, h->events[2 * n_ranges], 0));
-	ZH_TRY(upload_to(0));
-	for (size_t k = 0; k < n_ranges; ++k) {
-		const size_t b = k * range, e = b + range < n ? b + range : n;
-		ZH_HIP(hipStreamWaitEvent(h->stream, h->events[2 * k], 0));
-		ZH_TRY(zen_hip_hpri_process_range(h, h->stage_in, n, b, e, harm_host ? h->stage_out[0] + b : nullptr,
-		                                  perc_host ? h->stage_out[1] + b : nullptr));
-		ZH_HIP(hipEventRecord(h->events[2 * k + 1], h->stream));
-		if (k + 1 < n_ranges)
-			ZH_TRY(upload_to(k + 1));
-		ZH_TRY(download(k));
-	}
+	auto feed = [&]() -> int {
+		ZH_HIP(hipEventRecord(h->events[2 * n_ranges], h->stream));
+		ZH_HIP(hipStreamWaitEvent(h->s_in, h->events[2 * n_ranges], 0));
+		ZH_TRY(upload_to(0));
+		for (size_t k = 0; k < n_ranges; ++k) {
+			const size_t b = k * range, e = b + range < n ? b + range : n;
+			ZH_HIP(hipStreamWaitEvent(h->stream, h->events[2 * k], 0));
+			ZH_TRY(zen_hip_hpri_process_range(h, h->stage_in, n, b, e, harm_host ? h->stage_out[0] + b : nullptr,
+			                                  perc_host ? h->stage_out[1] + b : nullptr));
+			ZH_HIP(hipEventRecord(h->events[2 * k + 1], h->stream));
+			if (k + 1 < n_ranges)
+				ZH_TRY(upload_to(k + 1));
+			ZH_TRY(download(k));
+		}
+		return ZEN_HIP_OK;
+	};
+	const int rc = feed();
 	st.enqueue_ms = now_ms() - t_start - st.setup_ms;
-	ZH_HIP(hipStreamSynchronize(h->s_out));
-	ZH_HIP(hipStreamSynchronize(h->stream));
-	ZH_HIP(hipStreamSynchronize(h->s_in));
+	// Whatever happened above, nothing may still be in flight when the caller's buffers are unregistered (end of this
+	// scope) and handed back: wait for all three streams, then report the first failure.
+	const hipError_t e_out = hipStreamSynchronize(h->s_out), e_run = hipStreamSynchronize(h->stream), e_in = hipStreamSynchronize(h->s_in);
+	ZH_TRY(rc);
+	ZH_HIP(e_out);
+	ZH_HIP(e_run);
+	ZH_HIP(e_in);
 	st.total_ms = now_ms() - t_start;
 	return ZEN_HIP_OK;
 }

@@ -78,6 +78,84 @@ struct ResidentOut {
 };
 int launch_rt_fused_resident(int log2n, int freq_len, const RtFusedArgs& a, const ResidentCtl* ctl, ResidentOut* ro, unsigned seq_start,
                              unsigned long long idle_ticks, unsigned max_hops, hipStream_t stream);
+// the same for the causal SSE path (rt_sse.hip)
+int launch_rt_sse_resident(int log2n, const RtFusedArgs& a, int len_t, int len_f, float fac_h, float fac_p, const ResidentCtl* ctl,
+                           ResidentOut* ro, unsigned seq_start, unsigned long long idle_ticks, unsigned max_hops, hipStream_t stream);
+
+#if defined(__HIPCC__)
+// What changes from hop to hop of a stream: taken from the launch's arguments (HopOfArgs: one launch per call), or handed
+// in by the resident kernel, which derives it for every hop it is given (HopVar).
+struct HopOfArgs {
+	const RtFusedArgs& a;
+	__device__ __forceinline__ const float* in() const { return a.in; }
+	__device__ __forceinline__ unsigned seq() const { return a.seq; }
+	__device__ __forceinline__ long long row0() const { return a.row0; }
+	__device__ __forceinline__ const float* tail_prev() const { return a.tail_prev; }
+	__device__ __forceinline__ float* tail_next() const { return a.tail_next; }
+	__device__ __forceinline__ int prev_frames() const { return a.prev_frames; }
+};
+struct HopVar {
+	const float* in_;
+	unsigned seq_;
+	long long row0_;
+	const float* tail_prev_;
+	float* tail_next_;
+	int prev_frames_;
+	__device__ __forceinline__ const float* in() const { return in_; }
+	__device__ __forceinline__ unsigned seq() const { return seq_; }
+	__device__ __forceinline__ long long row0() const { return row0_; }
+	__device__ __forceinline__ const float* tail_prev() const { return tail_prev_; }
+	__device__ __forceinline__ float* tail_next() const { return tail_next_; }
+	__device__ __forceinline__ int prev_frames() const { return prev_frames_; }
+};
+
+// The resident kernels' wait for work (all threads call it; s_cmd: two words of LDS nobody else uses).  Thread 0 polls the
+// mailbox -- one 8-byte look per turn: the sequence word and the stop word side by side -- while the other waves sleep at
+// the barrier; returns true with *sq = the new sequence number when a hop has been posted, false when the kernel is to
+// leave (stop word, idle_ticks of the 100 MHz clock without a hop, or `leave`).  On true the caller's next loads see what
+// the host wrote before the word and what this workgroup stored during the last hop (system-scope acquire fence).
+__device__ __forceinline__ bool resident_next_hop(const ResidentCtl* ctl, unsigned last, unsigned long long idle_ticks, bool leave,
+                                                   unsigned* s_cmd, unsigned* sq_out)
+{
+	if (threadIdx.x == 0) {
+		const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+		unsigned cmd = 2, sq = last; // 1: a hop, 2: leave
+		for (;;) {
+			const unsigned long long w =
+			    __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&ctl->seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			sq = (unsigned)w;
+			if (sq != last) {
+				cmd = 1;
+				break;
+			}
+			if ((unsigned)(w >> 32) != 0u)
+				break;
+			if (__builtin_amdgcn_s_memrealtime() - t0 > idle_ticks)
+				break;
+			__builtin_amdgcn_s_sleep(1);
+		}
+		s_cmd[0] = leave ? 2u : cmd;
+		s_cmd[1] = sq;
+	}
+	__syncthreads();
+	const unsigned cmd = s_cmd[0];
+	*sq_out = s_cmd[1];
+	if (cmd != 1u)
+		return false;
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+	return true;
+}
+
+// the kernel's last act: how far it got
+__device__ __forceinline__ void resident_leave(ResidentOut* ro, unsigned last, unsigned k)
+{
+	if (threadIdx.x == 0) {
+		ro->last_seq = last;
+		ro->hops = k;
+		__hip_atomic_store(&ro->exited, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+}
+#endif
 
 bool rt_fused_available(int log2n, int freq_len);
 // true if launch_rt_fused(log2n, freq_len, a) will run the build that finishes hops itself (RtFusedArgs::out_direct)

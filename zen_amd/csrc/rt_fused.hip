@@ -265,34 +265,8 @@ __device__ __forceinline__ void publish_ready(unsigned* flag, unsigned seq, int 
 // in the first pass of the one inverse transform instead of living through a loop over outputs.
 // (the kernel's body as a device function: rt_fused_kernel runs it once per workgroup, the resident kernel of
 // rt_resident.hip once per hop it is handed; `bid` is the workgroup's place in the launch, blockIdx.x for the former)
-// What changes from hop to hop of a stream: taken from the launch's arguments (HopOfArgs: one launch per call), or handed
-// in by the resident kernel, which derives it for every hop it is given (HopVar).
-struct HopOfArgs {
-	const RtFusedArgs& a;
-	__device__ __forceinline__ const float* in() const { return a.in; }
-	__device__ __forceinline__ unsigned seq() const { return a.seq; }
-	__device__ __forceinline__ long long row0() const { return a.row0; }
-	__device__ __forceinline__ const float* tail_prev() const { return a.tail_prev; }
-	__device__ __forceinline__ float* tail_next() const { return a.tail_next; }
-	__device__ __forceinline__ int prev_frames() const { return a.prev_frames; }
-};
-struct HopVar {
-	const float* in_;
-	unsigned seq_;
-	long long row0_;
-	const float* tail_prev_;
-	float* tail_next_;
-	int prev_frames_;
-	__device__ __forceinline__ const float* in() const { return in_; }
-	__device__ __forceinline__ unsigned seq() const { return seq_; }
-	__device__ __forceinline__ long long row0() const { return row0_; }
-	__device__ __forceinline__ const float* tail_prev() const { return tail_prev_; }
-	__device__ __forceinline__ float* tail_next() const { return tail_next_; }
-	__device__ __forceinline__ int prev_frames() const { return prev_frames_; }
-};
-
 template <int LOG2N, int W, int MINB, bool SINGLE, bool LEAN = false, bool HARDP = false, class HV = HopOfArgs>
-__device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsigned bid, const HV& hv)
+__device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsigned bid, const HV& hv, const int tid)
 {
 	using PL = Plan<LOG2N>;
 	constexpr int N = PL::N, TF = PL::TF;
@@ -317,7 +291,7 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 	int* img = reinterpret_cast<int*>(lds);
 	float* Prow = LEAN ? reinterpret_cast<float*>(img + LEAN_PC_WORD) : reinterpret_cast<float*>(lds + PL::LDS_FLOAT2);
 
-	const int tf = threadIdx.x, hop = a.hop;
+	const int tf = tid, hop = a.hop; // (tid: threadIdx.x, made opaque per hop by the resident kernel)
 	// XCD-aware order.  Workgroups are dealt to the eight XCDs round-robin (workgroup b runs on XCD b % 8), each with its
 	// own L2; consecutive hops share an input hop (frame f = hops f-1, f).  Workgroup b therefore takes item
 	// (b % 8) * (total / 8) + b / 8 of the launch: the workgroups of one XCD walk through consecutive hops, and the
@@ -804,7 +778,7 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 template <int LOG2N, int W, int MINB, bool SINGLE, bool LEAN = false, bool HARDP = false>
 __global__ __launch_bounds__(Plan<LOG2N>::TF, MINB) void rt_fused_kernel(RtFusedArgs a)
 {
-	rt_fused_body<LOG2N, W, MINB, SINGLE, LEAN, HARDP>(a, blockIdx.x, HopOfArgs{a});
+	rt_fused_body<LOG2N, W, MINB, SINGLE, LEAN, HARDP>(a, blockIdx.x, HopOfArgs{a}, (int)threadIdx.x);
 }
 
 template <int LOG2N, int W, int MINB, bool SINGLE, bool LEAN = false, bool HARDP = false>
@@ -855,31 +829,9 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, 1) void rt_fused_resident_kernel(R
 	unsigned* s_cmd = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds_all) + resident_lds_bytes<LOG2N, W, LEAN>());
 	unsigned last = seq_start, k = 0;
 	for (;;) {
-		if (threadIdx.x == 0) {
-			const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-			unsigned cmd = 2, sq = last; // 1: a hop, 2: leave
-			for (;;) { // one 8-byte look per turn: the sequence word and the stop word side by side
-				const unsigned long long w =
-				    __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&ctl->seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-				sq = (unsigned)w;
-				if (sq != last) {
-					cmd = 1;
-					break;
-				}
-				if ((unsigned)(w >> 32) != 0u)
-					break;
-				if (__builtin_amdgcn_s_memrealtime() - t0 > idle_ticks)
-					break;
-				__builtin_amdgcn_s_sleep(1);
-			}
-			s_cmd[0] = k >= max_hops ? 2u : cmd;
-			s_cmd[1] = sq;
-		}
-		__syncthreads();
-		const unsigned cmd = s_cmd[0], sq = s_cmd[1];
-		if (cmd != 1u)
+		unsigned sq;
+		if (!resident_next_hop(ctl, last, idle_ticks, k >= max_hops, s_cmd, &sq))
 			break;
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); // the samples the host wrote before the word; our own rows of the last hop
 		HopVar hv; // run_hop_fused's per-call arguments, for hop k of this launch (a0 itself stays in the kernel-argument segment)
 		hv.in_ = a0.in; // (the input buffer of the launch: a caller that hands over another pointer gets another launch, hpr.hip)
 		hv.seq_ = sq;
@@ -887,16 +839,16 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, 1) void rt_fused_resident_kernel(R
 		hv.tail_prev_ = (k & 1u) ? a0.tail_next : a0.tail_prev; // the two input-tail buffers flip with every call
 		hv.tail_next_ = (k & 1u) ? const_cast<float*>(a0.tail_prev) : a0.tail_next;
 		hv.prev_frames_ = k > 0u ? 1 : a0.prev_frames;
-		rt_fused_body<LOG2N, W, 1, true, LEAN, HARDP, HopVar>(a0, 0u, hv);
+		// (The thread index is NOT made opaque per hop here, unlike in rt_sse_resident_kernel: what the compiler hoists out of
+		// the loop -- addresses, and the twiddle and window values the launch never changes -- costs registers the kernel has
+		// (one workgroup per CU, spills go to AGPRs) and saves about a microsecond per hop: 12.8-13.9 against 13.9-15.0 us at
+		// hop 1024, 9.7-10.4 against 10.9-11.5 at hop 256, same box.)
+		rt_fused_body<LOG2N, W, 1, true, LEAN, HARDP, HopVar>(a0, 0u, hv, (int)threadIdx.x);
 		__syncthreads(); // (every path of the body ends behind its last LDS access; s_cmd is rewritten next)
 		last = sq;
 		++k;
 	}
-	if (threadIdx.x == 0) {
-		ro->last_seq = last;
-		ro->hops = k;
-		__hip_atomic_store(&ro->exited, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-	}
+	resident_leave(ro, last, k);
 }
 
 template <int LOG2N, int W, bool LEAN, bool HARDP>

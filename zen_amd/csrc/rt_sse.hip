@@ -122,8 +122,11 @@ struct SseGeo {
 	static constexpr int CP = (N / 2 + NH - 1) / NH;   // samples of a hop per such thread
 };
 
-template <int LOG2N>
-__global__ __launch_bounds__(SseGeo<LOG2N>::NT) void rt_sse_kernel(RtFusedArgs a, int len_t, int len_f, float fac_h, float fac_p)
+// (the kernel's body as a device function: rt_sse_kernel runs it once per workgroup, rt_sse_resident_kernel once per hop
+// it is handed; what varies from hop to hop comes through `hv`, rt_fused.h)
+template <int LOG2N, class HV = HopOfArgs>
+__device__ __forceinline__ void rt_sse_body(const RtFusedArgs& a, int len_t, int len_f, float fac_h, float fac_p, const unsigned bid,
+                                            const HV& hv, const int tid)
 {
 	using PL = Plan<LOG2N>;
 	using GEO = SseGeo<LOG2N>;
@@ -132,9 +135,9 @@ __global__ __launch_bounds__(SseGeo<LOG2N>::NT) void rt_sse_kernel(RtFusedArgs a
 	float* pre = reinterpret_cast<float*>(lds + PL::LDS_FLOAT2);
 	float* Hrow = pre + N + 2 * SSE_HALO;
 	float* Prow = Hrow + N;
-	const int t = threadIdx.x, hop = a.hop, s = blockIdx.x;
+	const int t = tid, hop = a.hop, s = bid; // (tid: threadIdx.x, made opaque per hop by the resident kernel)
 	const bool fft_thread = t < TF;
-	const float* cur = a.in + (long long)s * a.in_stride;
+	const float* cur = hv.in() + (long long)s * a.in_stride;
 	// diagnostic (tools/rt_latency.cpp --stamps): phase times of the call, kept in registers until the end (a store
 	// to the host-mapped stamp buffer in front of a barrier would be waited for there)
 	unsigned long long stamps[5] = {0, 0, 0, 0, 0};
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(SseGeo<LOG2N>::NT) void rt_sse_kernel(RtFusedArgs a
 			stamps[k] = __builtin_amdgcn_s_memrealtime();
 	};
 	stamp(0);
-	const long long ar = a.row0; // absolute row of this frame
+	const long long ar = hv.row0(); // absolute row of this frame
 	const long long ring_base = (long long)s * a.ring_rows;
 	const int mid_t = len_t >> 1, mid_f = len_f >> 1;
 	const int ring_slot = (int)(ar % a.ring_rows);
@@ -163,13 +166,13 @@ __global__ __launch_bounds__(SseGeo<LOG2N>::NT) void rt_sse_kernel(RtFusedArgs a
 #pragma unroll
 			for (int i = 0; i < CP; ++i)
 				if (th + i * NH < hop)
-					a.tail_next[(long long)s * hop + th + i * NH] = v[i];
+					hv.tail_next()[(long long)s * hop + th + i * NH] = v[i];
 		}
-		if (a.prev_frames > 0) {
+		if (hv.prev_frames() > 0) {
 			for (int o = 0; o < 3; ++o) {
 				if (!a.carry[o])
 					continue;
-				const float* y = a.Y[o] + (long long)s * a.y_stream_stride + (long long)(a.prev_frames - 1) * (2 * hop) + hop;
+				const float* y = a.Y[o] + (long long)s * a.y_stream_stride + (long long)(hv.prev_frames() - 1) * (2 * hop) + hop;
 				float v[CP];
 #pragma unroll
 				for (int i = 0; i < CP; ++i)
@@ -221,15 +224,15 @@ __global__ __launch_bounds__(SseGeo<LOG2N>::NT) void rt_sse_kernel(RtFusedArgs a
 		for (int o = 0; o < 3; ++o) {
 			if (!a.carry[o])
 				continue;
-			const float* y = a.prev_frames > 0
-			                     ? a.Y[o] + (long long)s * a.y_stream_stride + (long long)(a.prev_frames - 1) * (2 * hop) + hop
+			const float* y = hv.prev_frames() > 0
+			                     ? a.Y[o] + (long long)s * a.y_stream_stride + (long long)(hv.prev_frames() - 1) * (2 * hop) + hop
 			                     : a.carry[o] + (long long)s * hop;
 #pragma unroll
 			for (int i = 0; i < 4; ++i)
 				cv[o][i] = y[t + i * TF];
 		}
 		SseFwdIn in;
-		in.prev = a.tail_prev + (long long)s * hop;
+		in.prev = hv.tail_prev() + (long long)s * hop;
 		in.cur = cur;
 		in.window = a.window;
 		in.hop = hop;
@@ -312,12 +315,12 @@ __global__ __launch_bounds__(SseGeo<LOG2N>::NT) void rt_sse_kernel(RtFusedArgs a
 			__threadfence_system();
 			__syncthreads();
 			if (t == 0)
-				__hip_atomic_store(reinterpret_cast<unsigned*>(ready + hop), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+				__hip_atomic_store(reinterpret_cast<unsigned*>(ready + hop), hv.seq(), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
 		__syncthreads();
 	}
 	stamp(4);
-	if (a.stamps && blockIdx.x == 0 && t == 0) {
+	if (a.stamps && bid == 0 && t == 0) {
 #pragma unroll
 		for (int k = 0; k < 5; ++k)
 			a.stamps[k] = stamps[k];
@@ -326,10 +329,54 @@ __global__ __launch_bounds__(SseGeo<LOG2N>::NT) void rt_sse_kernel(RtFusedArgs a
 }
 
 template <int LOG2N>
+__global__ __launch_bounds__(SseGeo<LOG2N>::NT) void rt_sse_kernel(RtFusedArgs a, int len_t, int len_f, float fac_h, float fac_p)
+{
+	rt_sse_body<LOG2N>(a, len_t, len_f, fac_h, fac_p, blockIdx.x, HopOfArgs{a}, (int)threadIdx.x);
+}
+
+template <int LOG2N>
+constexpr size_t sse_lds_bytes() { return sizeof(float2) * Plan<LOG2N>::LDS_FLOAT2 + sizeof(float) * (3 * Plan<LOG2N>::N + 2 * SSE_HALO); }
+
+// The same body inside a kernel that stays on its CU between the hops of a stream (rt_fused.hip rt_fused_resident_kernel:
+// mailbox, idle time-out, exit word; hpr.hip resident_*).  The history rows of the time box are the ring rows this very
+// workgroup wrote during the hops before: visible after the acquire fence of resident_next_hop.
+template <int LOG2N>
+__global__ __launch_bounds__(SseGeo<LOG2N>::NT) void rt_sse_resident_kernel(RtFusedArgs a0, int len_t, int len_f, float fac_h, float fac_p,
+                                                                            const ResidentCtl* ctl, ResidentOut* ro, unsigned seq_start,
+                                                                            unsigned long long idle_ticks, unsigned max_hops)
+{
+	extern __shared__ float2 lds_all[];
+	unsigned* s_cmd = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds_all) + sse_lds_bytes<LOG2N>());
+	unsigned last = seq_start, k = 0;
+	for (;;) {
+		unsigned sq;
+		if (!resident_next_hop(ctl, last, idle_ticks, k >= max_hops, s_cmd, &sq))
+			break;
+		HopVar hv;
+		hv.in_ = a0.in;
+		hv.seq_ = sq;
+		hv.row0_ = a0.row0 + k;
+		hv.tail_prev_ = (k & 1u) ? a0.tail_next : a0.tail_prev;
+		hv.tail_next_ = (k & 1u) ? const_cast<float*>(a0.tail_prev) : a0.tail_next;
+		hv.prev_frames_ = k > 0u ? 1 : a0.prev_frames;
+		// The thread index is made opaque per hop: otherwise every address of the body that depends on it alone is hoisted out
+		// of the loop and kept in registers (nfft 512 / 1024: 140-184 bytes of scratch per lane at the 256 registers of a
+		// 512-thread workgroup).
+		int tid_o = (int)threadIdx.x;
+		asm volatile("" : "+v"(tid_o));
+		rt_sse_body<LOG2N, HopVar>(a0, len_t, len_f, fac_h, fac_p, 0u, hv, tid_o);
+		__syncthreads();
+		last = sq;
+		++k;
+	}
+	resident_leave(ro, last, k);
+}
+
+template <int LOG2N>
 int launch_sse_t(const RtFusedArgs& a, int len_t, int len_f, float fac_h, float fac_p, hipStream_t stream)
 {
 	using PL = Plan<LOG2N>;
-	const size_t lds = sizeof(float2) * PL::LDS_FLOAT2 + sizeof(float) * (3 * PL::N + 2 * SSE_HALO);
+	const size_t lds = sse_lds_bytes<LOG2N>();
 	auto kern = rt_sse_kernel<LOG2N>;
 	if (lds > 64 * 1024)
 		ZH_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -338,7 +385,35 @@ int launch_sse_t(const RtFusedArgs& a, int len_t, int len_f, float fac_h, float 
 	return ZEN_HIP_OK;
 }
 
+template <int LOG2N>
+int launch_sse_res_t(const RtFusedArgs& a, int len_t, int len_f, float fac_h, float fac_p, const ResidentCtl* ctl, ResidentOut* ro,
+                     unsigned seq_start, unsigned long long idle_ticks, unsigned max_hops, hipStream_t stream)
+{
+	const size_t lds = sse_lds_bytes<LOG2N>() + 16;
+	auto kern = rt_sse_resident_kernel<LOG2N>;
+	if (lds > 60 * 1024)
+		ZH_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	hipLaunchKernelGGL(kern, dim3(1), dim3(SseGeo<LOG2N>::NT), lds, stream, a, len_t, len_f, fac_h, fac_p, ctl, ro, seq_start, idle_ticks,
+	                   max_hops);
+	ZH_HIP(hipGetLastError());
+	return ZEN_HIP_OK;
+}
+
 } // namespace
+
+int launch_rt_sse_resident(int log2n, const RtFusedArgs& a, int len_t, int len_f, float fac_h, float fac_p, const ResidentCtl* ctl,
+                           ResidentOut* ro, unsigned seq_start, unsigned long long idle_ticks, unsigned max_hops, hipStream_t stream)
+{
+	if (a.n_out != 1 || a.n_frames != 1 || a.n_streams != 1 || !a.publish_seq)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "resident kernel: one stream, one output, single hops, host-mapped hop buffer");
+	switch (log2n) {
+	case 9: return launch_sse_res_t<9>(a, len_t, len_f, fac_h, fac_p, ctl, ro, seq_start, idle_ticks, max_hops, stream);
+	case 10: return launch_sse_res_t<10>(a, len_t, len_f, fac_h, fac_p, ctl, ro, seq_start, idle_ticks, max_hops, stream);
+	case 11: return launch_sse_res_t<11>(a, len_t, len_f, fac_h, fac_p, ctl, ro, seq_start, idle_ticks, max_hops, stream);
+	case 12: return launch_sse_res_t<12>(a, len_t, len_f, fac_h, fac_p, ctl, ro, seq_start, idle_ticks, max_hops, stream);
+	default: ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "no resident SSE kernel for nfft 2^%d", log2n);
+	}
+}
 
 // hops 128 .. 1024 (transform sizes 512 .. 4096): one workgroup per stream
 bool rt_sse_available(int log2n, int len_t, int len_f)
