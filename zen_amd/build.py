@@ -11,9 +11,12 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "libzen_hip.so")
-OBJDIR = os.path.join(HERE, "build")
-RESOURCES = os.path.join(HERE, "kernel_resources.json")   # per-kernel registers / scratch / LDS of the last build
+# A/B builds (another set of flags beside the shipped library): ZEN_HIP_EXTRA_FLAGS="-DZEN_FFT16K_V=32" ZEN_HIP_VARIANT=v32
+# python zen_amd/build.py -> zen_amd/libzen_hip_v32.so (objects in build_v32/); run with ZEN_HIP_SO=zen_amd/libzen_hip_v32.so
+_VARIANT = os.environ.get("ZEN_HIP_VARIANT", "")
+OUT = os.path.join(HERE, "libzen_hip%s.so" % ("_" + _VARIANT if _VARIANT else ""))
+OBJDIR = os.path.join(HERE, "build" + ("_" + _VARIANT if _VARIANT else ""))
+RESOURCES = os.path.join(HERE, "kernel_resources%s.json" % ("_" + _VARIANT if _VARIANT else ""))   # per-kernel registers / scratch / LDS of the last build
 SOURCES = ["api.hip", "hpr.hip", "hpri.hip", "stft.hip", "istft.hip", "median.hip", "median_net.hip", "median47.hip", "median_big.hip", "rt_fused.hip", "rt_fused_multi.hip", "rt_fused_multi_lean.hip", "rt_sse.hip", "rt_wide.hip", "box.hip", "fft_big.hip", "sse_block.hip", "rt_resident.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 EXTRA = os.environ.get("ZEN_HIP_EXTRA_FLAGS", "").split()
@@ -120,7 +123,8 @@ def build(force=False, verbose=False):
                 usage[os.path.basename(o).replace(".o", ".hip")] = json.load(f)
     with open(RESOURCES, "w") as f:
         json.dump(usage, f, indent=1, sort_keys=True)
-    _stamp_revision()
+    if not _VARIANT:
+        _stamp_revision()
     return OUT
 
 

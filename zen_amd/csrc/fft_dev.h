@@ -36,11 +36,21 @@ struct Log2<1> {
 	static constexpr int value = 0;
 };
 
+// Complex values per thread: 16 everywhere, except that the 16384-point transform may run on 512 threads of 32 values
+// (-DZEN_FFT16K_V=32): three passes (radix 32, 32, 16) and two exchanges through LDS instead of four and three, 8
+// wavefronts per frame instead of 16 -- the same radix-2 DAG, the same values.  A/B: build.py, DESIGN.md section 8.
+#ifndef ZEN_FFT16K_V
+#define ZEN_FFT16K_V 16
+#endif
+
 template <int LOG2N>
 struct Plan {
 	static_assert(LOG2N >= 5 && LOG2N <= 14, "nfft 32..16384");
+	static_assert(ZEN_FFT16K_V == 16 || ZEN_FFT16K_V == 32, "16 or 32 values per thread");
 	static constexpr int N = 1 << LOG2N;
-	static constexpr int P = (LOG2N + 3) / 4; // passes
+	static constexpr int V = LOG2N == 14 ? ZEN_FFT16K_V : 16; // complex values per thread
+	static constexpr int LOG2V = V == 32 ? 5 : 4;
+	static constexpr int P = (LOG2N + LOG2V - 1) / LOG2V; // passes
 	static constexpr int BASE = LOG2N / P, REM = LOG2N % P;
 	static constexpr int r(int p) { return BASE + (p < REM ? 1 : 0); } // stages in pass p
 	static constexpr int s(int p) // stages completed before pass p
@@ -50,14 +60,17 @@ struct Plan {
 			a += r(i);
 		return a;
 	}
-	static constexpr int TF = N / 16;            // threads per frame: 16 complex values each
+	static constexpr int TF = N / V;             // threads per frame: V complex values each
 	// One 8-byte slot of padding per 2^PAD_SHIFT keeps the stride-R accesses of the late passes off a single bank: per
 	// 16 up to nfft 4096 (34.8 KB per 256 threads: four workgroups per CU); per 8 at nfft 8192 / 16384, where a late pass
 	// reads runs of 8 values (with one slot per 16 two such runs share banks) and a CU holds two / one frame anyway (73.7
 	// / 147 KB): synthesis -3.5 % (soft masks -10 %), analysis -2.6 % per offline batch step.  At nfft 1024 / 2048 the
 	// same padding gains 3.5 % in the analysis and loses 20 % in the soft-mask synthesis (its build then spills); at
 	// nfft 4096 it costs the fused kernel 11 % (its lean layout lives inside the image); no padding at all: +25..60 %.
-	static constexpr int PAD_SHIFT = LOG2N >= 13 ? 3 : 4;
+#ifndef ZEN_FFT16K_PAD
+#define ZEN_FFT16K_PAD 3
+#endif
+	static constexpr int PAD_SHIFT = LOG2N == 14 ? ZEN_FFT16K_PAD : (LOG2N >= 13 ? 3 : 4);
 	static constexpr int LDS_FLOAT2 = N + (N >> PAD_SHIFT); // padded frame image in LDS
 	static __device__ __forceinline__ int pad(int i) { return i + (i >> PAD_SHIFT); }
 	static constexpr int FRAMES_PER_BLOCK = (TF >= 256) ? 1 : 256 / TF;
@@ -142,13 +155,13 @@ struct TwRegs {
 	static constexpr bool PLAIN = PLAIN_;
 	static constexpr bool PACKED = false; // single-hop kernels: scalar butterflies (cmul)
 	using PL = Plan<LOG2N>;
-	static constexpr int NBMAX = 16 >> PL::BASE; // groups per thread in the pass with the fewest stages
+	static constexpr int NBMAX = PL::V >> PL::BASE; // groups per thread in the pass with the fewest stages
 	float2 w[PL::P][NBMAX][8];
 	__device__ __forceinline__ float2 get(int pass, int i, int slot, int) const { return w[pass][i][slot]; }
 	template <int PASS = 0>
 	__device__ __forceinline__ void fill(int tf, const float2* __restrict__ p)
 	{
-		constexpr int rr = PL::r(PASS), R = 1 << rr, NB = 16 / R, sL = PL::s(PASS), log2J = LOG2N - sL - rr;
+		constexpr int rr = PL::r(PASS), R = 1 << rr, NB = PL::V / R, sL = PL::s(PASS), log2J = LOG2N - sL - rr;
 #pragma unroll
 		for (int i = 0; i < NB; ++i) {
 			const int k = (tf + i * PL::TF) >> log2J;
@@ -168,7 +181,7 @@ struct TwRegs {
 	template <int PASS = 0, class F>
 	__device__ __forceinline__ void fill_with(int tf, const F& f)
 	{
-		constexpr int rr = PL::r(PASS), R = 1 << rr, NB = 16 / R, sL = PL::s(PASS), log2J = LOG2N - sL - rr;
+		constexpr int rr = PL::r(PASS), R = 1 << rr, NB = PL::V / R, sL = PL::s(PASS), log2J = LOG2N - sL - rr;
 #pragma unroll
 		for (int i = 0; i < NB; ++i) {
 			const int k = (tf + i * PL::TF) >> log2J;
@@ -300,7 +313,7 @@ struct PassRunner {
 	static __device__ __forceinline__ void run(int tf, float2* __restrict__ lds, const TW& tw, In& in, Out& out, bool active)
 	{
 		constexpr int N = PL::N, TF = PL::TF;
-		constexpr int rr = PL::r(PASS), R = 1 << rr, NB = 16 / R;
+		constexpr int rr = PL::r(PASS), R = 1 << rr, NB = PL::V / R;
 		constexpr int sL = PL::s(PASS);                    // log2 of sub-DFT size entering the pass
 		constexpr int log2J = LOG2N - sL - rr, J = 1 << log2J; // sub-sequences left after the pass
 		constexpr bool FIRST = PASS == 0, LAST = PASS == PL::P - 1;

@@ -66,12 +66,15 @@ __device__ __forceinline__ unsigned mask_code(unsigned w, int which, const MaskC
 // MODE 0: any mask (generic); 1: hard masks by comparison, any output; 2: the same for the percussive output alone
 // (the realtime default): one comparison per bin; 3: hard masks from the bits of launch_mask_bits (blocks of frames);
 // 5: soft masks (harmonic / percussive output); 7: soft masks read from the rows the median kernel left (IstftArgs::mask_rows).
-template <int MODE>
+// V: complex values per thread of the transform (fft_dev.h Plan::V).  A word of IstftArgs::bits_t holds the masks of bins
+// w + s*nfft/16, s < 16; a thread of a V = 32 plan owns bins tf + s'*nfft/32, s' < 32: its words are tf and tf + nfft/32,
+// slot s' sits in word s' & 1 at position s' >> 1.
+template <int MODE, int V = 16>
 struct IstftIn {
 	const float2* S;
 	const float* H;
 	const float* P;
-	unsigned bw;       // MODE 3: the thread's word of mask bits (IstftArgs::bits_t)
+	unsigned bw[V / 16]; // MODE 3: the thread's word(s) of mask bits (IstftArgs::bits_t)
 	MaskCfg cfg;
 	HardThr thr;
 	HardSel sel;
@@ -89,8 +92,11 @@ struct IstftIn {
 	// of the spectrum -- turned into the output's codes in the prologue it cost a trip to memory of its own in front of them
 	__device__ __forceinline__ void prepare()
 	{
-		if constexpr (MODE == 3)
-			bw = mask_code(bw, which, cfg);
+		if constexpr (MODE == 3) {
+#pragma unroll
+			for (int i = 0; i < V / 16; ++i)
+				bw[i] = mask_code(bw[i], which, cfg);
+		}
 	}
 	__device__ __forceinline__ Raw load(int idx, int) const
 	{
@@ -114,8 +120,11 @@ struct IstftIn {
 		if (idx > (n >> 1))
 			z.y = -z.y;
 		float m;
-		if constexpr (MODE == 3) // the comparisons were made once per bin (launch_mask_bits + _transpose)
-			m = (float)((int)(bw << (30 - 2 * slot)) >> 30); // two bits, sign-extended: 00 -> 0, 01 -> 1, 11 -> -1 (mask_code)
+		if constexpr (MODE == 3) { // the comparisons were made once per bin (launch_mask_bits + _transpose)
+			const unsigned w = V == 32 ? bw[slot & (V / 16 - 1)] : bw[0];
+			const int pos = V == 32 ? slot >> 1 : slot;
+			m = (float)((int)(w << (30 - 2 * pos)) >> 30); // two bits, sign-extended: 00 -> 0, 01 -> 1, 11 -> -1 (mask_code)
+		}
 		else if constexpr (MODE == 7)
 			m = r.p;
 		else if constexpr (MODE == 5) { // soft masks alone (soft_mask_functor hps.h:116-129; the residual does not exist with them)
@@ -134,28 +143,30 @@ struct IstftIn {
 	__device__ __forceinline__ float2 operator()(int idx, int slot) const { return finish(load(idx, slot), idx, slot); } // (not with MODE 3)
 };
 
-struct IstftOut {
+template <int V = 16>
+struct IstftOutV {
 	float* Y;
 	float cola;
 	float* ready;       // single-frame calls: the finished hop = carry + first half of this frame
-	const float* cv;    // the thread's four carry samples (saved by the housekeeping block of the analysis kernel of
-	int hop;            // the same call), idx = tf + slot*TF, slot < 4: loaded before the transform -- a load here
+	const float* cv;    // the thread's V/4 carry samples (saved by the housekeeping block of the analysis kernel of
+	int hop;            // the same call), idx = tf + slot*TF, slot < V/4: loaded before the transform -- a load here
 	                    // would queue behind the stores
 	__device__ __forceinline__ void operator()(int idx, float2 x, bool, int slot) const
 	{
 		const float y = x.x * cola; // the product of overlap_add_functor hps.h:68-80; the sum is in finalize ...
 		Y[idx] = y;
 		if (ready && idx < hop) // ... or here, when the call is a single hop (hps.cu:341-363 hands out [0, hop))
-			ready[idx] = cv[slot & 3] + y;
+			ready[idx] = cv[slot & (V / 4 - 1)] + y;
 	}
 };
+using IstftOut = IstftOutV<16>;
 
-// the four carry samples of thread tf (hop == 4*TF)
-template <int TF>
-__device__ __forceinline__ void load_carry(const float* carry, int tf, bool wanted, float (&cv)[4])
+// the V/4 carry samples of thread tf (hop == (V/4)*TF)
+template <int TF, int CVN>
+__device__ __forceinline__ void load_carry(const float* carry, int tf, bool wanted, float (&cv)[CVN])
 {
 #pragma unroll
-	for (int i = 0; i < 4; ++i)
+	for (int i = 0; i < CVN; ++i)
 		cv[i] = wanted ? carry[tf + i * TF] : 0.0f;
 }
 
@@ -169,8 +180,13 @@ constexpr size_t istft_lds_bytes() { return lds_bytes<LOG2N>() + (istft_tw_in_ld
 // Exactly four: the LDS image (34.8 KB per 256 threads at every size) allows no more, and a scheduler that believes in
 // six or eight waves keeps the registers low by waiting for every load right behind it (the soft-mask build at nfft 1024:
 // 76 registers, one trip to memory per element).
+// (a 512-thread frame of 32 values per thread, nfft 16384 with ZEN_FFT16K_V = 32: two waves per SIMD, 256 registers)
+template <int LOG2N>
+constexpr int istft_waves() { return Plan<LOG2N>::V == 32 ? 2 : 4; }
+
 template <int LOG2N, int MODE>
-__global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) void istft_kernel(IstftArgs a)
+__global__ __launch_bounds__(Plan<LOG2N>::THREADS, istft_waves<LOG2N>())
+    __attribute__((amdgpu_waves_per_eu(istft_waves<LOG2N>(), istft_waves<LOG2N>()))) void istft_kernel(IstftArgs a)
 {
 	using PL = Plan<LOG2N>;
 	constexpr bool TW_IN_LDS = istft_tw_in_lds(LOG2N);
@@ -195,7 +211,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) __attribute__((amdgpu_wave
 	const bool active = f_ < a.n_frames;
 	const int f = active ? f_ : a.n_frames - 1; // (an inactive slot transforms the last frame again and stores nothing)
 	const long long ring_row = ((a.crow0 + f) % a.ring_rows) + (long long)s * a.ring_rows;
-	IstftIn<MODE> in;
+	IstftIn<MODE, PL::V> in;
 	in.S = a.S + ring_row * a.s_stride;
 	in.n = PL::N;
 	in.H = a.h_is_ring ? a.H + ring_row * PL::N : a.H + (long long)s * a.h_stream_stride + (long long)f * PL::N;
@@ -205,16 +221,19 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) __attribute__((amdgpu_wave
 	in.which = a.out_id[oi];
 	in.sel = hard_sel(in.which, in.cfg);
 	in.p_mid = a.p_mid;
-	in.bw = 0;
-	if constexpr (MODE == 3)
-		in.bw = a.bits_t[(long long)s * a.bits_t_stream_stride + (long long)f * PL::TF + tf]; // (-> codes: IstftIn::prepare)
+#pragma unroll
+	for (int i = 0; i < PL::V / 16; ++i) {
+		in.bw[i] = 0;
+		if constexpr (MODE == 3) // a row is nfft/16 words (-> codes: IstftIn::prepare)
+			in.bw[i] = a.bits_t[(long long)s * a.bits_t_stream_stride + (long long)f * (PL::N / 16) + tf + i * PL::TF];
+	}
 	if constexpr (MODE == 7) // the row of this output's soft mask (percussive: where P would be; harmonic: Hm), laid out as P
 		in.H = (in.which == 0 ? a.P : a.Hm) + (long long)s * a.p_stream_stride + (long long)f * PL::N;
-	IstftOut out;
+	IstftOutV<PL::V> out;
 	out.Y = a.Y[oi] + (long long)s * a.y_stream_stride + (long long)f * (PL::N / 2);
 	out.cola = a.cola;
 	out.ready = (a.n_frames == 1 && a.ready[oi]) ? a.ready[oi] + (long long)s * a.hop : nullptr;
-	float cv[4];
+	float cv[PL::V / 4];
 	load_carry<PL::TF>(a.carry[oi] + (long long)s * a.hop, tf, out.ready != nullptr, cv);
 	out.cv = cv;
 	out.hop = a.hop;
