@@ -229,12 +229,14 @@ static void test_public_api(std::size_t extra) // hps_gpu_public.test.cu (Basic 
 // the harmonic output at hop 4096 / beta 2.5 (demos/pitch-tracking/main.cu:90-118), beat tracking the
 // percussive output at hop 256 / beta 2.5 (demos/beat-tracking/main.cu:92-127), both through IOGPU's
 // mapped buffers, one hop per call.  Only the HPR front half is in scope; it must equal the CPU path.
-static void test_demo_front_end(float fs, std::size_t hop, float beta, unsigned what, std::size_t n_hops)
+static void test_demo_front_end(float fs, std::size_t hop, float beta, unsigned what, std::size_t n_hops, int resident_ms = 0)
 {
 	auto x = generate_data_normalized(n_hops * hop);
 	zen::hps::HPRRealtime<Backend::GPU> rt(fs, hop, beta, what);
 	zen::io::IOGPU io(hop);
 	rt.warmup(io);
+	if (resident_ms > 0) // the MI355X extension: the same loop served by a resident kernel (no launch per hop)
+		rt.use_resident_kernel(resident_ms);
 	int err = 0;
 	zo_hpr* o = zo_hpr_create(fs, hop, beta, what == zen::hps::OUTPUT_HARMONIC ? ZO_OUTPUT_HARMONIC : ZO_OUTPUT_PERCUSSIVE,
 	                          ZO_TIME_CAUSAL, 1, &err);
@@ -258,6 +260,33 @@ static void test_demo_front_end(float fs, std::size_t hop, float beta, unsigned 
 	zo_hpr_destroy(o);
 }
 
+// HPRIOffline<GPU>::process on a clip long enough for the host-vector pipeline (ranges of 4 Mi samples, result vectors
+// populated by threads): equal, sample for sample, to the same call on its first part run alone wherever the two must
+// agree -- an offline output sample depends on a few hops around it -- and the residual is zeros (hps.cu:219-220, Q8).
+static void test_offline_long_clip()
+{
+	const std::size_t n = ((std::size_t)9 << 20) + 77, m = (std::size_t)1 << 20;
+	auto base = generate_data_normalized(m);
+	std::vector<float> x(n);
+	for (std::size_t i = 0; i < n; ++i)
+		x[i] = base[i % m] * (0.5F + 0.5F * (float)((i / m) & 1));
+	zen::hps::HPRIOffline<Backend::GPU> hpss(44100.0F, 4096, 256, 2.0, 2.0);
+	auto all = hpss.process(x);
+	CHECK(all[0].size() == n && all[1].size() == n && all[2].size() == n);
+	std::vector<float> head(x.begin(), x.begin() + 3 * m);
+	auto part = hpss.process(head); // under 8 Mi samples: one range, no pipeline
+	bool same = true, any = false, zeros = true;
+	for (std::size_t i = 0; i < 2 * m; ++i) { // (the last Mi samples of `head` see its end; the first two do not)
+		same = same && all[0][i] == part[0][i] && all[1][i] == part[1][i];
+		any = any || all[1][i] != 0.0F;
+	}
+	for (std::size_t i = 0; i < n; i += 997)
+		zeros = zeros && all[2][i] == 0.0F;
+	CHECK(same);
+	CHECK(any);
+	CHECK(zeros);
+}
+
 int main()
 {
 	if (zen_hip_init(0) != ZEN_HIP_OK) {
@@ -279,6 +308,9 @@ int main()
 	test_demo_front_end(44100.0F, 4096, 2.5F, zen::hps::OUTPUT_HARMONIC, 12);
 	test_demo_front_end(44100.0F, 256, 2.5F, zen::hps::OUTPUT_PERCUSSIVE, 80);  // beat-tracking front end
 	test_demo_front_end(48000.0F, 256, 2.5F, zen::hps::OUTPUT_PERCUSSIVE, 80);
+	test_demo_front_end(44100.0F, 256, 2.5F, zen::hps::OUTPUT_PERCUSSIVE, 80, 50);  // ... through the resident kernel
+	test_demo_front_end(44100.0F, 1024, 2.0F, zen::hps::OUTPUT_HARMONIC, 40, 50);
+	test_offline_long_clip();
 	std::printf("%d checks, %d failures\n", g_checks, g_fail);
 	return g_fail ? 1 : 0;
 }

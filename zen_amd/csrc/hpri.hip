@@ -424,11 +424,21 @@ void zero_host(float* dst, size_t n) // the reference's never-written residual_o
 	}
 	std::vector<std::thread> th;
 	const size_t per = (n / k + 1023) & ~(size_t)1023;
+	size_t done_to = 0; // (a thread that cannot be started -- std::system_error must not cross the C ABI -- leaves its piece to this one)
 	for (unsigned i = 0; i < k; ++i) {
 		const size_t a = (size_t)i * per, b = a + per < n ? a + per : n;
-		if (a < b)
+		if (a >= b)
+			break;
+		try {
 			th.emplace_back([=] { memset(dst + a, 0, (b - a) * sizeof(float)); });
+			done_to = b;
+		}
+		catch (...) {
+			break;
+		}
 	}
+	if (done_to < n)
+		memset(dst + done_to, 0, (n - done_to) * sizeof(float));
 	for (auto& t : th)
 		t.join();
 }
@@ -505,8 +515,14 @@ int zen_hip_hpri_process(zen_hip_hpri_t h, const float* audio_host, size_t n, fl
 	st.n_ranges = n_ranges;
 	st.range_samples = range;
 	std::thread zero_thread;
-	if (resid_host)
-		zero_thread = std::thread([=] { zero_host(resid_host, n); });
+	if (resid_host) {
+		try {
+			zero_thread = std::thread([=] { zero_host(resid_host, n); });
+		}
+		catch (...) { // no thread to be had: zeros written here, before the pipeline starts
+			zero_host(resid_host, n);
+		}
+	}
 	struct Joiner {
 		std::thread& t;
 		~Joiner()

@@ -7,6 +7,7 @@
 #include <functional>
 #include <iostream>
 #include <numeric>
+#include <system_error>
 #include <thread>
 #include <utility>
 
@@ -323,8 +324,14 @@ namespace hps {
 			std::vector<std::thread> th;
 			for (unsigned i = 0; i < k; ++i) {
 				const std::uintptr_t b0 = a + i * per, b1 = b0 + per < e ? b0 + per : e;
-				if (b0 < b1)
+				if (b0 >= b1)
+					break;
+				try {
 					th.emplace_back([=] { (void)madvise((void*)b0, b1 - b0, MADV_POPULATE_WRITE); });
+				}
+				catch (...) { // no thread: the zero fill faults those pages in itself
+					break;
+				}
 			}
 			for (auto& t : th)
 				t.join();
@@ -346,11 +353,23 @@ namespace hps {
 		static const bool trace = std::getenv("ZEN_TRACE_PROCESS") != nullptr; // stderr: where the wall time of a call goes
 		const auto t0 = std::chrono::steady_clock::now();
 		std::vector<float> harmonic_out, percussive_out, residual_out;
-		if (n >= ((std::size_t)1 << 21)) { // the three vectors at once
-			std::thread t1(fresh_zeros, std::ref(harmonic_out), n), t2(fresh_zeros, std::ref(percussive_out), n);
+		if (n >= ((std::size_t)1 << 21)) { // the three vectors at once (a thread that cannot be had: its vector is built here)
+			std::thread t1, t2;
+			try {
+				t1 = std::thread(fresh_zeros, std::ref(harmonic_out), n);
+				t2 = std::thread(fresh_zeros, std::ref(percussive_out), n);
+			}
+			catch (const std::system_error&) {
+			}
 			fresh_zeros(residual_out, n);
-			t1.join();
-			t2.join();
+			if (t1.joinable())
+				t1.join();
+			else
+				fresh_zeros(harmonic_out, n);
+			if (t2.joinable())
+				t2.join();
+			else
+				fresh_zeros(percussive_out, n);
 		}
 		else {
 			harmonic_out.resize(n);
