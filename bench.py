@@ -340,8 +340,8 @@ def realtime_leg(zen_amd, x, n_hops=400):
         os.remove(exe)
         sweep = [json.loads(ln) for ln in lines if ln.startswith("{")]
         rsweep = [json.loads(ln) for ln in res_lines if ln.startswith("{")]
-        res["resident_us_by_hop"] = {str(r["hop"]): r["us_per_hop"] for r in rsweep if r.get("resident")}
-        rat = [r for r in rsweep if r.get("resident") and r["hop"] == HOP]
+        res["resident_us_by_hop"] = {("sse_" if r["sse"] else "") + str(r["hop"]): r["us_per_hop"] for r in rsweep if r.get("resident")}
+        rat = [r for r in rsweep if r.get("resident") and r["hop"] == HOP and not r["sse"]]
         if rat:
             res["resident_us_per_hop"] = rat[0]["us_per_hop"]
             res["resident_hops_per_s"] = 1e6 / rat[0]["us_per_hop"]
