@@ -86,6 +86,7 @@ int launch_rt_sse_resident(int log2n, const RtFusedArgs& a, int len_t, int len_f
 // What changes from hop to hop of a stream: taken from the launch's arguments (HopOfArgs: one launch per call), or handed
 // in by the resident kernel, which derives it for every hop it is given (HopVar).
 struct HopOfArgs {
+	static constexpr bool KEEP = false;
 	const RtFusedArgs& a;
 	__device__ __forceinline__ const float* in() const { return a.in; }
 	__device__ __forceinline__ unsigned seq() const { return a.seq; }
@@ -95,6 +96,14 @@ struct HopOfArgs {
 	__device__ __forceinline__ int prev_frames() const { return a.prev_frames; }
 };
 struct HopVar {
+	// KEEP: between the hops of a resident launch every thread keeps, in registers, the four samples of the previous hop it
+	// will window again (keep_prev: idx = slot*TF + tf, slot < 4 of the forward transform's first pass) and the four samples
+	// of the last frame's second half it will add to the next frame's first (keep_carry: the same thread stored them as
+	// slots 4..7 of the inverse transform's last pass) -- the loads of the per-launch kernel's housekeeping, and the wait
+	// for them in front of the input loads, go away.  Memory is kept up to date all the same (tail, carry, Y row): the
+	// next launch starts from it.
+	static constexpr bool KEEP = true;
+	mutable float keep_prev[4], keep_carry[4];
 	const float* in_;
 	unsigned seq_;
 	long long row0_;

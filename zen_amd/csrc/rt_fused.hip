@@ -235,18 +235,47 @@ __device__ __forceinline__ unsigned xcc_id_of_cu()
 	asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
 	return v & 15u;
 }
-struct InvOutReg { // the single-hop build
+template <bool KEEP>
+struct InvOutRegT { // the single-hop build
 	float* Y;
 	float cola;
 	float* ready;
 	float cv[4];        // the thread's four carry samples (second half of the previous frame), idx = tf + slot*TF,
 	int hop;            // slot < 4: in registers since the housekeeping -- a load here would queue behind the stores
+	float* next;        // KEEP (resident kernel): receives the frame's second half, slots 4..7: the next hop's carries
 	__device__ __forceinline__ void operator()(int idx, float2 x, bool, int slot) const
 	{
 		const float y = x.x * cola;
 		Y[idx] = y;
 		if (ready && idx < hop)
 			ready[idx] = cv[slot & 3] + y;
+		if constexpr (KEEP) {
+			if (slot >= 4)
+				next[slot & 3] = y;
+		}
+	}
+};
+using InvOutReg = InvOutRegT<false>;
+
+// the forward transform's input with the previous hop in registers (HopVar::keep_prev) and the new hop's samples handed
+// back for the next one
+struct FwdInKeep {
+	const float* prev; // four registers: idx = slot*TF + tf, slot < 4
+	const float* cur;
+	const float* window;
+	float* next;
+	int hop;
+	__device__ __forceinline__ float2 operator()(int idx, int slot) const
+	{
+		float x;
+		if (slot < 4) {
+			x = prev[slot & 3];
+		}
+		else {
+			x = cur[idx - hop];
+			next[slot & 3] = x;
+		}
+		return make_float2(x * window[idx], 0.0f); // window_functor hps.h:24-33
 	}
 };
 
@@ -333,7 +362,17 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 	// this call is shorter, the last one) saves it first.  The tail is the call's last hop: the next call's `prev`.
 	// (hop == 4*TF: four elements per thread.)
 	float cv1[4] = {0.f, 0.f, 0.f, 0.f}; // single-hop calls with one output: the carries of this hop
-	if constexpr (MINB == 1) {
+	if constexpr (MINB == 1 && HV::KEEP) { // resident kernel: the registers hold what the loads below would fetch
+		static_assert(!HV::KEEP || SINGLE, "one output");
+		const int w0 = a.out_id[0];
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			cv1[i] = hv.keep_carry[i];
+			a.carry[w0][(long long)s * hop + tf + i * TF] = cv1[i]; // (memory stays what a per-launch hop would leave)
+		}
+		// the input tail is stored behind the forward transform, from the samples its first pass loads anyway
+	}
+	else if constexpr (MINB == 1) {
 		const bool do_carry = hv.prev_frames() > 0 && f == (hv.prev_frames() - 1 < a.n_frames - 1 ? hv.prev_frames() - 1 : a.n_frames - 1);
 		// Single-hop launches: all loads first, then the stores.  A store between two loads makes the second wait
 		// for the first (the compiler cannot know they do not alias): stored from inside the transform's input
@@ -394,7 +433,8 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 		}
 	}
 
-	using OutT = std::conditional_t<MINB == 1, InvOutReg, InvOut>;
+	using OutT = std::conditional_t<MINB == 1, InvOutRegT<HV::KEEP>, InvOut>;
+	float cnext[4] = {0.f, 0.f, 0.f, 0.f}; // KEEP: the second half of this frame, for the next hop
 	// the carries of the output being synthesised: in registers since the housekeeping (one output), or read back
 	// from the carry buffer this thread wrote there, before the transform starts (several outputs)
 	auto pick_carry = [&](int which, float (&cw)[4]) {
@@ -534,6 +574,16 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 					in.tail[(m - 4) * TF + tf] = pre.x[m];
 			}
 			zfft::fft_frame<LOG2N, false, true, false>(tf, lds, a.tw, pre, out, true);
+		}
+		else if constexpr (TWC && HV::KEEP) {
+			float nx[4];
+			FwdInKeep ink{hv.keep_prev, cur, a.window, nx, hop};
+			zfft::fft_frame<LOG2N, false, true, false>(tf, lds, twr, ink, out, true);
+#pragma unroll
+			for (int i = 0; i < 4; ++i) { // the next call's previous hop: to memory as every single-hop call leaves it, and kept
+				hv.tail_next()[(long long)s * hop + tf + i * TF] = nx[i];
+				hv.keep_prev[i] = nx[i];
+			}
 		}
 		else if constexpr (TWC)
 			zfft::fft_frame<LOG2N, false, true, false>(tf, lds, twr, in, out, true);
@@ -706,6 +756,7 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 		out.ready = (a.n_frames == 1 && a.ready[in.which]) ? a.ready[in.which] + (long long)s * hop : nullptr;
 		if constexpr (MINB == 1) {
 			pick_carry(in.which, out.cv);
+			out.next = cnext;
 		}
 		else {
 			out.carry = a.carry[in.which] + (long long)s * hop;
@@ -715,6 +766,11 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 			zfft::fft_frame<LOG2N, true, false, true, InvInLean<N, TF, mid, HARDP>, OutT, true>(tf, lds, twr, in, out, true);
 		else
 			zfft::fft_frame<LOG2N, true, false, true, InvInLean<N, TF, mid, HARDP>, OutT, true>(tf, lds, a.tw, in, out, true);
+		if constexpr (HV::KEEP) {
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+				hv.keep_carry[i] = cnext[i];
+		}
 		if (out.ready && a.publish_seq)
 			publish_ready(reinterpret_cast<unsigned*>(out.ready + hop), hv.seq(), tf);
 		if constexpr (MINB == 1) {
@@ -744,6 +800,7 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 		out.ready = (a.n_frames == 1 && a.ready[which]) ? a.ready[which] + (long long)s * hop : nullptr;
 		if constexpr (MINB == 1) {
 			pick_carry(which, out.cv);
+			out.next = cnext;
 		}
 		else {
 			out.carry = a.carry[which] + (long long)s * hop;
@@ -753,6 +810,11 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 			zfft::fft_frame<LOG2N, true, false, true>(tf, lds, twr, in, out, true);
 		else
 			zfft::fft_frame<LOG2N, true, false, true>(tf, lds, a.tw, in, out, true);
+		if constexpr (HV::KEEP) {
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+				hv.keep_carry[i] = cnext[i];
+		}
 		if (out.ready && a.publish_seq)
 			publish_ready(reinterpret_cast<unsigned*>(out.ready + hop), hv.seq(), tf);
 	};
@@ -828,11 +890,21 @@ __global__ __launch_bounds__(Plan<LOG2N>::TF, 1) void rt_fused_resident_kernel(R
 	extern __shared__ float2 lds_all[]; // (the body's image; the two command words sit behind it: no static LDS in front of the 16-byte accesses)
 	unsigned* s_cmd = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds_all) + resident_lds_bytes<LOG2N, W, LEAN>());
 	unsigned last = seq_start, k = 0;
+	HopVar hv; // run_hop_fused's per-call arguments, for hop k of this launch (a0 itself stays in the kernel-argument segment)
+	{ // what the first hop's housekeeping would load (HopVar::KEEP): the carries and the previous hop, once per launch
+		constexpr int TF = Plan<LOG2N>::TF;
+		const int w0 = a0.out_id[0];
+		const float* y0 = a0.prev_frames > 0 ? a0.Y[w0] + (long long)(a0.prev_frames - 1) * (2 * a0.hop) + a0.hop : a0.carry[w0];
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			hv.keep_carry[i] = y0[threadIdx.x + i * TF];
+			hv.keep_prev[i] = a0.tail_prev[threadIdx.x + i * TF];
+		}
+	}
 	for (;;) {
 		unsigned sq;
 		if (!resident_next_hop(ctl, last, idle_ticks, k >= max_hops, s_cmd, &sq))
 			break;
-		HopVar hv; // run_hop_fused's per-call arguments, for hop k of this launch (a0 itself stays in the kernel-argument segment)
 		hv.in_ = a0.in; // (the input buffer of the launch: a caller that hands over another pointer gets another launch, hpr.hip)
 		hv.seq_ = sq;
 		hv.row0_ = a0.row0 + k;
