@@ -247,8 +247,10 @@ struct InvOutRegT { // the single-hop build
 	{
 		const float y = x.x * cola;
 		Y[idx] = y;
+		// the finished hop goes out with system-scope (write-through) stores: publish_ready<true> then needs no write-back
+		// of the L2 (a plain store to mapped host memory may stay in the L2 until one)
 		if (ready && idx < hop)
-			ready[idx] = cv[slot & 3] + y;
+			__hip_atomic_store(ready + idx, cv[slot & 3] + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		if constexpr (KEEP) {
 			if (slot >= 4)
 				next[slot & 3] = y;
@@ -282,12 +284,28 @@ struct FwdInKeep {
 // Single-hop calls whose `ready` buffer is mapped host memory: the host does not wait for the launch to retire, it
 // polls the word behind the hop.  Every thread makes its stores visible system-wide, the workgroup meets, one
 // thread publishes the sequence number.
+// LIGHT (the single-hop builds, per launch and resident): the samples of the hop were stored with system-scope
+// (write-through) stores (InvOutRegT): they are on their way to host memory once the memory counter has counted them off, and the word
+// follows them on the same path.  The system-scope fences of the plain form write back the XCD's whole L2 -- the Y row,
+// the carries, the rings of this hop: device memory the host never reads -- twice per hop (release fence + release
+// store); here nothing else is written back, the next hop's acquire fence (resident_next_hop) is what orders this
+// workgroup's own reuse of that state.  (Plain stores to mapped host memory DO stay in the L2 until a write-back: with
+// them this form hands the host zeros.)
+template <bool LIGHT = false>
 __device__ __forceinline__ void publish_ready(unsigned* flag, unsigned seq, int tf)
 {
-	__threadfence_system();
-	__syncthreads();
-	if (tf == 0)
-		__hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	if constexpr (LIGHT) {
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		if (tf == 0)
+			__hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+	else {
+		__threadfence_system();
+		__syncthreads();
+		if (tf == 0)
+			__hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
 }
 
 // SINGLE: exactly one output is enabled (the realtime default, percussive only): the spectrum registers die
@@ -708,7 +726,7 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 			else
 				zfft::fft_frame<LOG2N, true, false, true>(tf_o, lds, tw_o, in, out, true);
 			if (out.ready && a.publish_seq)
-				publish_ready(reinterpret_cast<unsigned*>(out.ready + hop), hv.seq(), tf);
+				publish_ready<MINB == 1>(reinterpret_cast<unsigned*>(out.ready + hop), hv.seq(), tf);
 			__syncthreads(); // the frame image is reused by the next output
 		}
 		if constexpr (DIRECT) {
@@ -772,7 +790,7 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 				hv.keep_carry[i] = cnext[i];
 		}
 		if (out.ready && a.publish_seq)
-			publish_ready(reinterpret_cast<unsigned*>(out.ready + hop), hv.seq(), tf);
+			publish_ready<MINB == 1>(reinterpret_cast<unsigned*>(out.ready + hop), hv.seq(), tf);
 		if constexpr (MINB == 1) {
 			stamp(4);
 			stamp(5);
@@ -816,7 +834,7 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 				hv.keep_carry[i] = cnext[i];
 		}
 		if (out.ready && a.publish_seq)
-			publish_ready(reinterpret_cast<unsigned*>(out.ready + hop), hv.seq(), tf);
+			publish_ready<MINB == 1>(reinterpret_cast<unsigned*>(out.ready + hop), hv.seq(), tf);
 	};
 	if (a.diag == 2) { // timing diagnostic: no synthesis
 		if (tf == 0)

@@ -95,8 +95,8 @@ struct SseInvOut {
 	{
 		const float y = x.x * cola;
 		Y[idx] = y;
-		if (idx < hop)
-			ready[idx] = cv[slot & 3] + y; // hps.cu:526-528 + :341-363
+		if (idx < hop) // hps.cu:526-528 + :341-363; a system-scope (write-through) store: see the publication below
+			__hip_atomic_store(ready + idx, cv[slot & 3] + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 };
 
@@ -311,11 +311,11 @@ __device__ __forceinline__ void rt_sse_body(const RtFusedArgs& a, int len_t, int
 			out.hop = hop;
 			zfft::fft_frame<LOG2N, true, false, true>(t, lds, twr, in, out, true);
 		}
-		if (a.publish_seq) { // the host polls the word behind the finished hop (rt_fused.hip publish_ready)
-			__threadfence_system();
+		if (a.publish_seq) { // the host polls the word behind the finished hop (rt_fused.hip publish_ready<true>: the samples
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // went out write-through; no write-back of the whole L2 per hop)
 			__syncthreads();
 			if (t == 0)
-				__hip_atomic_store(reinterpret_cast<unsigned*>(ready + hop), hv.seq(), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+				__hip_atomic_store(reinterpret_cast<unsigned*>(ready + hop), hv.seq(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
 		__syncthreads();
 	}
