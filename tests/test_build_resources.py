@@ -98,3 +98,8 @@ def test_round4_kernels(usage):
     assert len(usage["rt_resident.hip"]) == 9
     for name, k in usage["rt_resident.hip"].items():
         assert k["scratch"] == 0, (name, k)
+    # pass 2 of the offline path, synthesis in runs: the next frame's spectrum row is prefetched into 32 registers -- inside
+    # the 128 of four waves per SIMD, nothing spilled
+    for n in (8, 9, 10):
+        k = kernel(usage, "istft.hip", "istft_run_kernel<%d>" % n)
+        assert k["vgprs"] <= 128 and k["scratch"] == 0 and k["occupancy"] == 4, (n, k)

@@ -459,3 +459,61 @@ def test_host_process_refuses_overlapping_buffers(z):
     h, p, r = g.process(buf[:n], out=(buf[n:], np.zeros(n, np.float32), None))   # adjacent, not overlapping
     rh, rp, _ = o.HPRIOffline(FS, 1024, 256, 2.0, 2.0).process(x)
     assert np.array_equal(h, rh) and np.array_equal(p, rp)
+
+
+# ---------------------------------------------------------------------------- pass 2 of the offline path synthesised in runs
+@pytest.mark.parametrize("hop_h,hop_p,n", [(4096, 256, 161571), (1024, 256, 70001), (2048, 128, 50000), (4096, 256, 4096 * 9 + 1),
+                                           (512, 128, 30000), (4096, 256, 2100), (256, 64, 9000)])
+@pytest.mark.parametrize("chunk,run", [(0, 0), (64, 16), (40, 7), (8, 1), (24, 64)])
+def test_offline_pass2_synthesised_in_runs(z, hop_h, hop_p, n, chunk, run):
+    """Pass 2 of HPRIOffline (hps.cu:185-205: the small hop, percussive output alone) with hard masks: a wavefront
+    synthesises a run of consecutive frames, adds the overlapping halves in registers and writes the finished hops where the
+    driver wants them (istft.hip istft_run_kernel) -- no Y rows, no overlap-add launch.  Bit-identical to the oracle and to
+    the launches it replaces ("no_istft_runs"), with the engines' chunks bounded ("offline_chunk_hops": the carry crosses
+    chunk boundaries, a run starts from the frame before it) and runs of 1 .. 64 frames; clips shorter than a chunk or a few
+    hops long; the pass falls back to the launches as a whole when one of its chunks is too short for the masks-as-bits road."""
+    x = _clip(n, 11 + n % 7)
+    rh, rp, rr = o.HPRIOffline(FS, hop_h, hop_p, 2.0, 2.0).process(x)
+    z.set_option("offline_chunk_hops", chunk)
+    z.set_option("istft_run", run)
+    try:
+        g = z.HPRIOffline(FS, hop_h, hop_p, 2.0, 2.0)
+        for rep in range(2):
+            h, p, r = g.process(x)
+            assert np.array_equal(h, rh) and np.array_equal(p, rp) and np.all(r == 0), rep
+        # the new path did run where it can (every chunk of the pass at least 8 hops): no overlap-add launch in pass 2
+        n2 = g.hop_counts(n)[1]
+        expect = n2 >= 8 and (chunk == 0 or n2 % chunk == 0 or n2 % chunk >= 8)
+        g.profile(True)
+        g.process(x)
+        prof = g.profile_get_all()
+        g.profile(False)
+        assert (prof["pass2"]["finalize"]["launches"] == 0) == expect, (n2, chunk, prof["pass2"])
+        assert prof["pass1"]["finalize"]["launches"] > 0
+        z.set_option("no_istft_runs", 1)
+        h2, p2, _ = z.HPRIOffline(FS, hop_h, hop_p, 2.0, 2.0).process(x)
+        assert np.array_equal(h2, rh) and np.array_equal(p2, rp)
+    finally:
+        z.set_option("no_istft_runs", 0)
+        z.set_option("offline_chunk_hops", 0)
+        z.set_option("istft_run", 0)
+
+
+def test_offline_batch_of_clips_synthesised_in_runs(z):
+    """The same for several clips per call (zen_hip_hpri_process_device with n_clips > 1: one stream per clip, runs never
+    cross a clip) against the per-clip oracle."""
+    n, clips = 40000, 3
+    xs = np.stack([_clip(n, 31 + c) for c in range(clips)])
+    g = z.HPRIOffline(FS, 1024, 256, 2.0, 2.0, n_clips=clips)
+    din, dh, dp = z.DeviceBuffer(clips * n), z.DeviceBuffer(clips * n), z.DeviceBuffer(clips * n)
+    din.upload(xs.reshape(-1))
+    g.profile(True)
+    g.process_device(din.ptr, n, n, harm=dh.ptr, perc=dp.ptr, out_stride=n)
+    z.synchronize()
+    assert g.profile_get_all()["pass2"]["finalize"]["launches"] == 0
+    H, P = dh.download().reshape(clips, n), dp.download().reshape(clips, n)
+    for c in range(clips):
+        rh, rp, _ = o.HPRIOffline(FS, 1024, 256, 2.0, 2.0).process(xs[c])
+        assert np.array_equal(H[c], rh) and np.array_equal(P[c], rp), c
+    for b in (din, dh, dp):
+        b.free()

@@ -28,6 +28,9 @@ opt_t g_opt_no_direct_out{0};
 opt_t g_opt_no_istft_xcd_map{0};
 opt_t g_opt_no_sse_block{0};
 opt_t g_opt_no_median_tf{0};
+opt_t g_opt_no_istft_runs{0};
+opt_t g_opt_offline_chunk_hops{0};
+opt_t g_opt_istft_run{0};
 opt_t g_opt_offline_range{0};
 opt_t g_opt_offline_no_register{0};
 std::atomic<unsigned> g_host_free_gen{0};
@@ -181,6 +184,9 @@ int zen_hip_set_option(const char* name, int value)
 	             {"no_istft_xcd_map", &g_opt_no_istft_xcd_map},
 	             {"no_sse_block", &g_opt_no_sse_block},
 	             {"no_median_tf", &g_opt_no_median_tf},
+	             {"no_istft_runs", &g_opt_no_istft_runs},
+	             {"offline_chunk_hops", &g_opt_offline_chunk_hops},
+	             {"istft_run", &g_opt_istft_run},
 	             {"offline_range", &g_opt_offline_range},
 	             {"offline_no_register", &g_opt_offline_no_register}};
 #ifndef ZEN_HIP_DIAG

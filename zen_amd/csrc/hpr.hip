@@ -109,6 +109,8 @@ void free_all(zen_hip_hpr* e)
 	(void)hipFree(e->d_Mh);
 	(void)hipFree(e->d_blk_flag);
 	(void)hipFree(e->d_blk_need);
+	(void)hipFree(e->d_run_carry[0]);
+	(void)hipFree(e->d_run_carry[1]);
 	for (int o = 0; o < 3; ++o) {
 		(void)hipFree(e->d_Y[o]);
 		(void)hipFree(e->d_carry[o]);
@@ -197,6 +199,7 @@ int reset_state(zen_hip_hpr* e)
 				ZH_HIP(hipMemsetAsync(e->d_carry[o], 0, hopb, e->stream));
 	}
 	e->tail_sel = 0;
+	e->rows_stale = false;
 	e->abs_frame = (long long)e->W - 1; // rows 0..W-2 are the all-zero history of a fresh stream
 	e->last_frames = 0;
 	e->drain[0] = e->drain[1] = e->drain[2] = 0;
@@ -519,6 +522,8 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 	if (M == 1 && in_stride == e->hop && resident_eligible(e))
 		return resident_post(e, in);
 	ZH_TRY(resident_stop(e));
+	if (e->rows_stale && !e->run_mode)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpr: the stream's last pass kept no synthesis rows (offline driver); zen_hip_hpr_reset_buffers first");
 	if (e->drain[0] | e->drain[1] | e->drain[2])
 		ZH_TRY(advance_drain(e));
 	if (e->causality == ZEN_HIP_TIME_CAUSAL && !e->use_sse && !g_opt_no_rt_fused && (M == 1 || !g_opt_no_block_fused)
@@ -547,7 +552,7 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 	if (!sse_block)
 		ZH_TRY(ensure_estimates(e, e->use_sse || !time_identity));
 	for (int o = 0; o < 3; ++o)
-		if (output_computed(e, o))
+		if (output_computed(e, o) && !e->run_mode) // (synthesis in runs: no Y rows)
 			ZH_TRY(ensure_rows(e, o));
 	const bool half = !e->use_sse && !g_opt_no_half_rows && !g_opt_median_general
 	                  && filter_supports_hermitian(e->mf, (int)N) && (time_identity || e->mt <= 63);
@@ -572,7 +577,7 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 	sa.n_streams = (int)S;
 	sa.prev_frames = (int)e->last_frames;
 	for (int o = 0; o < 3; ++o) {
-		sa.carry[o] = output_computed(e, o) ? e->d_carry[o] : nullptr;
+		sa.carry[o] = (output_computed(e, o) && !e->run_mode) ? e->d_carry[o] : nullptr;
 		sa.Y[o] = e->d_Y[o];
 	}
 	sa.y_stream_stride = (long long)(e->max_hops * e->nwin);
@@ -816,7 +821,44 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 		if (bits_done != 2)
 			ZH_TRY(launch_mask_bits_transpose((int)N, ia, e->d_bits_t, e->stream));
 	}
-	{
+	if (e->run_mode) { // synthesis in runs, finished hops straight to the pass's destination (hpr_process_spec)
+		if (!use_bits || e->run_out < 0 || !e->run_spec)
+			ZH_FAIL(ZEN_HIP_E_HIP, "hpr: synthesis in runs without mask bits (internal)");
+		const HprOutSpec& sp = *e->run_spec;
+		IstftRunArgs ra;
+		memset(&ra, 0, sizeof(ra));
+		ra.S = e->d_S;
+		ra.s_stride = (long long)e->s_stride;
+		ra.ring_rows = e->ring_rows;
+		ra.crow0 = crow0;
+		ra.tw = e->d_tw;
+		ra.bits_t = e->d_bits_t;
+		ra.bits_t_stream_stride = bits_t_stream_stride;
+		ra.n_frames = (int)M;
+		ra.n_streams = (int)S;
+		ra.hop = (int)e->hop;
+		ra.which = e->run_out;
+		ra.out_h = e->out_h ? 1 : 0;
+		ra.out_p = e->out_p ? 1 : 0;
+		ra.cola = e->cola;
+		ra.carry_prev = e->d_run_carry[e->run_sel];
+		ra.carry_next = e->d_run_carry[e->run_sel ^ 1];
+		e->run_sel ^= 1;
+		const int run = g_opt_istft_run.load(std::memory_order_relaxed);
+		ra.run = run > 0 ? run : 16;
+		ra.out = sp.dst;
+		ra.out_stride = sp.stride;
+		ra.pos0 = e->run_pos0;
+		ra.shift = sp.shift;
+		ra.len = sp.len;
+		ra.dup_from = sp.dup_from;
+		ra.dup_shift = sp.dup_shift;
+		ra.dup_len = sp.dup_len;
+		ProfScope ps(e, zen_hip_hpr::K_ISTFT);
+		ZH_TRY(launch_istft_run(e->log2n, ra, e->stream));
+		e->rows_stale = true;
+	}
+	else {
 		ProfScope ps(e, zen_hip_hpr::K_ISTFT);
 		ZH_TRY(launch_istft(e->log2n, ia, e->stream));
 	}
@@ -967,6 +1009,40 @@ int finalize_spec(zen_hip_hpr* e, int o, const HprOutSpec& sp, size_t M, long lo
 	return launch_finalize_spec(fa, e->stream);
 }
 
+// The output whose pass can be synthesised in runs (IstftRunArgs), or -1.  What it takes: a fresh stream (the pass starts
+// from reset buffers: the frame before the first is all zero), an anticausal hard-mask median engine with ONE computed
+// output, delivered plainly (no second output added to it), whose chunks all take the masks-as-bits road (>= 8 frames; the
+// median kernel or the transposition leaves IstftArgs::bits_t), at a transform a wavefront holds (istft_run_available).
+int run_pass_output(const zen_hip_hpr* e, size_t n_hops, const HprOutSpec (&spec)[3])
+{
+	if (g_opt_no_istft_runs || g_opt_no_mask_bits || g_opt_no_half_rows || g_opt_median_general)
+		return -1;
+	if (e->use_sse || e->soft || !istft_run_available(e->log2n) || e->rows_stale)
+		return -1;
+	if (e->abs_frame != (long long)e->W - 1 || e->last_frames != 0 || (e->drain[0] | e->drain[1] | e->drain[2]))
+		return -1;
+	int n = 0, o1 = -1;
+	for (int o = 0; o < 3; ++o)
+		if (output_computed(e, o)) {
+			++n;
+			o1 = o;
+		}
+	if (n != 1 || !spec[o1].dst || spec[o1].add >= 0)
+		return -1;
+	for (int o = 0; o < 3; ++o)
+		if (o != o1 && spec[o].dst)
+			return -1;
+	const size_t last = n_hops % e->max_hops;
+	if (n_hops < 8 || (last != 0 && last < 8))
+		return -1;
+	const HardThr thr = hard_mask_thresholds(e->beta, e->beta - FLT_EPSILON, false);
+	const bool time_identity = e->mt == 1;
+	if (thr.p == 0.0 || thr.h == 0.0 || !mask_bits_supported((int)e->nfft, e->mf / 2) || !filter_supports_hermitian(e->mf, (int)e->nfft)
+	    || !(time_identity || e->mt <= 63))
+		return -1;
+	return o1;
+}
+
 } // namespace
 
 namespace zen_hip_impl {
@@ -980,15 +1056,30 @@ int hpr_process_spec(zen_hip_hpr* h, const float* in_dev, size_t n_hops, size_t 
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpr_process_spec: anticausal engines only");
 	if (n_hops > h->max_hops && h->max_hops < h->max_hops_cap)
 		ZH_TRY(grow_buffers(h, n_hops < h->max_hops_cap ? n_hops : h->max_hops_cap));
-	for (size_t off = 0; off < n_hops; off += h->max_hops) {
+	const int run_out = run_pass_output(h, n_hops, spec);
+	if (run_out >= 0) { // the whole pass, or none of it: the two ways keep different state between chunks
+		const size_t hopb = sizeof(float) * h->n_streams * h->hop;
+		for (int i = 0; i < 2; ++i)
+			if (!h->d_run_carry[i])
+				ZH_HIP(hipMalloc((void**)&h->d_run_carry[i], hopb));
+		ZH_HIP(hipMemsetAsync(h->d_run_carry[h->run_sel], 0, hopb, h->stream)); // a fresh stream: nothing to add to its first hop
+		h->run_mode = true;
+		h->run_out = run_out;
+		h->run_spec = &spec[run_out];
+	}
+	int rc = ZEN_HIP_OK;
+	for (size_t off = 0; off < n_hops && rc == ZEN_HIP_OK; off += h->max_hops) {
 		const size_t M = (n_hops - off < h->max_hops) ? n_hops - off : h->max_hops;
 		const long long pos0 = (long long)(off * h->hop);
-		ZH_TRY(run_chunk(h, in_dev + off * h->hop, in_stride, M, in_valid - pos0));
-		for (int o = 0; o < 3; ++o)
-			if (spec[o].dst)
-				ZH_TRY(finalize_spec(h, o, spec[o], M, pos0));
+		h->run_pos0 = pos0;
+		rc = run_chunk(h, in_dev + off * h->hop, in_stride, M, in_valid - pos0);
+		for (int o = 0; o < 3 && rc == ZEN_HIP_OK; ++o)
+			if (spec[o].dst && o != run_out)
+				rc = finalize_spec(h, o, spec[o], M, pos0);
 	}
-	return ZEN_HIP_OK;
+	h->run_mode = false;
+	h->run_spec = nullptr;
+	return rc;
 }
 
 } // namespace zen_hip_impl

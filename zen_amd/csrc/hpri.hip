@@ -71,12 +71,15 @@ int zen_hip_hpri_create(float fs, size_t hop_h, size_t hop_p, float beta_h, floa
 	o->hop_h = hop_h;
 	o->hop_p = hop_p;
 	o->n_clips = n_clips;
+	// "offline_chunk_hops": a bound on the engines' buffers (hops per chunk, both passes) instead of the device-memory cap
+	const int chunk_opt = g_opt_offline_chunk_hops.load(std::memory_order_relaxed);
+	const size_t chunk = chunk_opt > 0 ? (size_t)chunk_opt : 0;
 	int rc = zen_hip_hpr_create(fs, hop_h, beta_h,
 	                            ZEN_HIP_OUTPUT_HARMONIC | ZEN_HIP_OUTPUT_PERCUSSIVE | ZEN_HIP_OUTPUT_RESIDUAL,
-	                            ZEN_HIP_TIME_ANTICAUSAL, !nocopybord, n_clips, 0, &o->eh);
+	                            ZEN_HIP_TIME_ANTICAUSAL, !nocopybord, n_clips, chunk, &o->eh);
 	if (rc == ZEN_HIP_OK)
 		rc = zen_hip_hpr_create(fs, hop_p, beta_p, ZEN_HIP_OUTPUT_PERCUSSIVE, ZEN_HIP_TIME_ANTICAUSAL,
-		                        !nocopybord, n_clips, 0, &o->ep);
+		                        !nocopybord, n_clips, chunk, &o->ep);
 	if (rc != ZEN_HIP_OK) {
 		zen_hip_hpr_destroy(o->eh);
 		delete o;

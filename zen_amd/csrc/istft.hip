@@ -452,6 +452,146 @@ __global__ __launch_bounds__(256) void mask_bits_transpose_kernel(IstftArgs a, u
 		dst[q] = make_uint4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Synthesis in runs (IstftRunArgs, stft.h): the small-hop pass of the offline driver (nfft <= 1024: a frame is one wavefront
+// or less), hard masks as bits, one output.  A frame here costs more to move than to transform: its Y row is 2 KB written by
+// the synthesis and 2 KB read back by the overlap-add launch for 1 KB of finished samples.  A wavefront therefore walks a
+// RUN of consecutive frames of one stream: the second half of a frame and the first half of its successor belong to the
+// same thread (idx = tf + slot*TF), so the overlap-add (hps.cu:435-449, :526-528) is four register adds per thread and the
+// finished hop goes straight to where the offline driver wants it (finalize_spec_kernel's destination arithmetic): no Y
+// rows, no overlap-add launch.  A run starts from the frame before it, synthesised once more for its second half alone
+// (1/run of redundant work; a call's first run takes the previous call's carry instead).  What made the first attempt at
+// this no faster than the two launches: gfx9 counts loads and stores in ONE in-order counter,
+// so the stores of frame f sat in front of the loads of frame f+1 that the wavefront then waited for.  Here the next
+// frame's spectrum row and its word of mask bits are fetched into registers BEFORE the current frame is transformed (32
+// registers, which the nfft-1024 build has and the nfft-16384 one of pass 1 has not).
+// (Transforming the frame again from its samples instead of loading the 4 KB row -- so that the analysis launch need not
+// store the spectrum at all -- was measured too: 0.78 ms against 0.49 for this kernel, for 0.10 saved in the analysis.)
+struct IstftRunIn {
+	const float2* S; // the frame's spectrum in registers: bin tf + slot*TF (upper half already conjugated)
+	unsigned w;      // mask_code of the thread's word of IstftArgs::bits_t
+	__device__ __forceinline__ float2 operator()(int, int slot) const
+	{
+		const float m = (float)((int)(w << (30 - 2 * slot)) >> 30); // IstftIn<3>::finish
+		const float2 z = S[slot];
+		return make_float2(z.x * m, z.y * m); // apply_mask_functor hps.h:58-66
+	}
+};
+struct IstftRunOut { // idx = tf + slot*TF, slot < 8 (HALF_OUT): the frame's nwin outputs
+	float* y;
+	float cola;
+	__device__ __forceinline__ void operator()(int, float2 x, bool, int slot) const { y[slot & 7] = x.x * cola; } // hps.h:68-80
+};
+
+template <int LOG2N>
+__global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) __attribute__((amdgpu_waves_per_eu(4, 4))) void istft_run_kernel(IstftRunArgs a)
+{
+	using PL = Plan<LOG2N>;
+	constexpr int TF = PL::TF, N = PL::N, HOP = N / 4;
+	static_assert(TF <= 64 && PL::V == 16, "a frame lives inside one wavefront: its passes synchronise there (frame_sync)");
+	extern __shared__ float2 lds[];
+	const int tid = threadIdx.x, s = blockIdx.y;
+	const int slot = tid / TF, tf = tid - slot * TF;
+	float2* twl = lds + PL::FRAMES_PER_BLOCK * PL::LDS_FLOAT2; // the twiddle table behind the frame images (istft_kernel)
+	for (int i = tid; i < N / 2; i += PL::THREADS)
+		twl[i] = a.tw[i];
+	__syncthreads();
+	const zfft::TwLds tl{twl};
+	float2* img = lds + slot * PL::LDS_FLOAT2;
+	const int i0 = (blockIdx.x * PL::FRAMES_PER_BLOCK + slot) * a.run; // the run's first frame (>= n_frames: nothing is stored)
+	const float2* S_s = a.S + (long long)s * a.ring_rows * a.s_stride;
+	const unsigned* bits_s = a.bits_t + (long long)s * a.bits_t_stream_stride;
+	float* out_s = a.out + (long long)s * a.out_stride;
+	const MaskCfg cfg{0.0f, 0.0f, 0, 0, 0, a.out_h, a.out_p};
+	// frame i of the call (one outside it: some frame of it, the result is not used): its sixteen bins tf + slot*TF -- the lower
+	// half as stored, the upper half from the mirror image (conjugated where it is used) -- and its word of mask bits
+	auto load_row = [&](int i, float2 (&z)[16]) {
+		const int r = i < 0 ? 0 : (i < a.n_frames ? i : a.n_frames - 1);
+		const float2* row = S_s + ((a.crow0 + r) % a.ring_rows) * a.s_stride;
+#pragma unroll
+		for (int sl = 0; sl < 16; ++sl) {
+			const int idx = tf + sl * TF;
+			z[sl] = row[idx > N / 2 ? N - idx : idx];
+		}
+	};
+	auto load_bits = [&](int i) {
+		const int r = i < 0 ? 0 : (i < a.n_frames ? i : a.n_frames - 1);
+		return bits_s[(long long)r * (N / 16) + tf];
+	};
+	float cprev[4], carry[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+	for (int j = 0; j < 4; ++j) // (used by the call's first run only)
+		cprev[j] = a.carry_prev[(long long)s * HOP + tf + j * TF];
+	float2 S[16];
+	load_row(i0 - 1, S);
+	unsigned bw = load_bits(i0 - 1);
+	for (int i = i0 - 1; i < i0 + a.run; ++i) {
+		float2 Sn[16];
+		load_row(i + 1, Sn); // the next frame's row and masks: in flight under this frame's transform
+		const unsigned bn = load_bits(i + 1);
+#pragma unroll
+		for (int sl = 0; sl < 16; ++sl)
+			if (tf + sl * TF > N / 2) // S[n-k] = conj(S[k]) (IstftIn)
+				S[sl].y = -S[sl].y;
+		float y[8];
+		{
+			IstftRunIn in{S, mask_code(bw, a.which, cfg)};
+			IstftRunOut out{y, a.cola};
+			// (the thread index is made opaque per transform: otherwise every LDS address and table index of the transform, all
+			// functions of tf alone, is hoisted out of the loop and kept in registers -- see istft_hard_multi_kernel)
+			int tf_o = tf;
+			asm volatile("" : "+v"(tf_o));
+			zfft::fft_frame<LOG2N, true, false, true>(tf_o, img, tl, in, out, true);
+		}
+		if (i >= i0 && i < a.n_frames) { // the finished hop of frame i (finalize_spec_kernel)
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				const float v = carry[j] + y[j];
+				const long long p0 = a.pos0 + (long long)i * HOP + tf + j * TF;
+				const long long d = p0 - a.shift;
+				if (d >= 0 && d < a.len)
+					out_s[d] = v;
+				if (p0 >= a.dup_from) {
+					const long long d2 = p0 - a.dup_shift;
+					if (d2 >= 0 && d2 < a.dup_len)
+						out_s[d2] = v;
+				}
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < 4; ++j)
+			carry[j] = (i < 0) ? cprev[j] : y[4 + j]; // (i < 0: the call's first run, the frame before the call)
+		if (i == a.n_frames - 1) {
+#pragma unroll
+			for (int j = 0; j < 4; ++j)
+				a.carry_next[(long long)s * HOP + tf + j * TF] = carry[j];
+		}
+#pragma unroll
+		for (int sl = 0; sl < 16; ++sl)
+			S[sl] = Sn[sl];
+		bw = bn;
+	}
+}
+
+template <int LOG2N>
+int launch_istft_run_t(const IstftRunArgs& a, hipStream_t stream)
+{
+	using PL = Plan<LOG2N>;
+	if constexpr (PL::TF <= 64) {
+		auto kern = istft_run_kernel<LOG2N>;
+		const size_t lds = lds_bytes<LOG2N>() + sizeof(float2) * (size_t)(PL::N / 2);
+		ZH_TRY(set_lds(kern, lds));
+		const size_t runs = ceil_div((size_t)a.n_frames, (size_t)a.run);
+		dim3 grid((unsigned)ceil_div(runs, (size_t)PL::FRAMES_PER_BLOCK), (unsigned)a.n_streams);
+		hipLaunchKernelGGL(kern, grid, dim3(PL::THREADS), lds, stream, a);
+		ZH_HIP(hipGetLastError());
+		return ZEN_HIP_OK;
+	}
+	else {
+		ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "istft runs: nfft = 2^%d", LOG2N);
+	}
+}
+
 template <int LOG2N>
 int launch_istft_t(const IstftArgs& a, hipStream_t stream)
 {
@@ -531,6 +671,23 @@ int launch_mask_bits_transpose(int nfft, const IstftArgs& a, unsigned* bits_t, h
 	                   nfft, log2tf);
 	ZH_HIP(hipGetLastError());
 	return ZEN_HIP_OK;
+}
+
+// nfft 256 .. 1024 (hop 64 .. 256): a frame is one wavefront or less, and its rows cost more than its transform
+bool istft_run_available(int log2n) { return log2n >= 8 && log2n <= 10; }
+
+int launch_istft_run(int log2n, const IstftRunArgs& a, hipStream_t stream)
+{
+	if (a.n_frames <= 0)
+		return ZEN_HIP_OK;
+	if (a.run < 1 || a.hop != (1 << log2n) / 4)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "istft runs: run = %d, hop = %d at nfft 2^%d", a.run, a.hop, log2n);
+	switch (log2n) {
+	case 8: return launch_istft_run_t<8>(a, stream);
+	case 9: return launch_istft_run_t<9>(a, stream);
+	case 10: return launch_istft_run_t<10>(a, stream);
+	default: ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "istft runs: nfft = 2^%d", log2n);
+	}
 }
 
 int launch_istft(int log2n, const IstftArgs& a, hipStream_t stream)

@@ -114,6 +114,27 @@ struct FinalizeArgs {
 	long long pos0, shift, len, dup_from, dup_shift, dup_len;
 };
 
+// Synthesis in runs (istft.hip istft_run_kernel; the offline driver's small-hop pass): hard masks from IstftArgs::bits_t,
+// one output; a wavefront walks a run of consecutive frames of a stream with the overlap-add carry in registers and writes
+// the finished hops where FinalizeArgs (second part) says: no Y rows, no overlap-add launch.
+struct IstftRunArgs {
+	const float2* S;        // the spectrum ring (IstftArgs::S, s_stride, ring_rows): frame i of the call is row crow0 + i
+	long long s_stride, ring_rows, crow0;
+	const float2* tw;
+	const unsigned* bits_t; // row i: the masks of frame i (IstftArgs::bits_t)
+	long long bits_t_stream_stride;
+	int n_frames, n_streams, hop;
+	int which, out_h, out_p; // the output (0 percussive, 1 harmonic, 2 residual) and which masks the residual reads
+	float cola;
+	const float* carry_prev; // [n_streams][hop]: second half of the frame before frame 0 (the previous call's carry_next)
+	float* carry_next;       // receives the second half of frame n_frames - 1
+	int run;                 // consecutive frames per wavefront (each run but a call's first synthesises one frame more)
+	float* out;              // destination of the finished hops, as FinalizeArgs: out, out_stride, pos0, shift, len, dup_*
+	long long out_stride, pos0, shift, len, dup_from, dup_shift, dup_len;
+};
+bool istft_run_available(int log2n);
+int launch_istft_run(int log2n, const IstftRunArgs& a, hipStream_t stream);
+
 int launch_stft(int log2n, const StftArgs& a, hipStream_t stream);
 int launch_istft(int log2n, const IstftArgs& a, hipStream_t stream);
 // fills IstftArgs::bits (passed as `bits`, writable) for the frames / streams of `a` from its H and P rows
