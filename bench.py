@@ -209,8 +209,9 @@ def offline_rooflines(prof, steps, frames, nfft, hop, n_out1, copy_bw, freq_mask
                     word of mask bits per 16 bins (nfft/4 bytes), and per output 4*nwin = 8*hop written.  Soft masks: pass 1
                     loads one mask value per bin and output (4*(nfft/2+1) each) instead of the bits, pass 2 loads H and P
                     (8*(nfft/2+1)).  (Rounds 1-3 priced it as S + H + P per OUTPUT, which the kernels no longer read.)
-      finalize    : per output 12*hop (two half frames in, one hop out); pass 2 with hard masks has none (round 4): its synthesis
-                    (istft_run_kernel) adds the halves in registers and writes 4*hop per frame instead of the 8*hop Y row"""
+      finalize    : per output 12*hop (two half frames in, one hop out); with hard masks the passes of the offline batch have none
+                    (round 4): the synthesis (istft_run_kernel / istft_run_wide_kernel) adds the halves in registers and writes
+                    4*hop per frame and destination instead of an 8*hop Y row per output"""
     out = {}
     for ps in ("pass1", "pass2"):
         N, h, F = nfft[ps], hop[ps], frames[ps]
@@ -228,9 +229,10 @@ def offline_rooflines(prof, steps, frames, nfft, hop, n_out1, copy_bw, freq_mask
             # median_tf_herm_bits_kernel: both medians in one launch.  SURVEY 8(d): "fused H+P stage (one read of abs(S), two
             # writes): 12 B per element" -- the kernel writes two mask bits per bin instead of the two rows
             per_frame["freq_filter"] = 12 * (N // 2 + 1)
-        if ps == "pass2" and not soft and prof[ps].get("istft", {}).get("launches") and not prof[ps].get("finalize", {}).get("launches"):
-            # istft_run_kernel: synthesis + overlap-add in one launch, the finished hop is all it writes (no Y rows)
-            per_frame["istft"] = 8 * (N // 2 + 1) + N // 4 + 4 * h
+        if not soft and prof[ps].get("istft", {}).get("launches") and not prof[ps].get("finalize", {}).get("launches"):
+            # istft_run_kernel / istft_run_wide_kernel: synthesis + overlap-add in one launch; all it writes is the finished hop of
+            # every destination (pass 2: P; pass 1 with three outputs: H, and P + R summed) -- no Y rows
+            per_frame["istft"] = 8 * (N // 2 + 1) + N // 4 + (1 if nout == 1 else nout - 1) * 4 * h
         for k, v in prof[ps].items():
             if not v["launches"] or k not in per_frame:
                 continue
@@ -251,7 +253,7 @@ def offline_rooflines(prof, steps, frames, nfft, hop, n_out1, copy_bw, freq_mask
 
 
 OFFLINE_PMC_FILE = "r04_offline_batch_pmc.json"   # tools/pmc_cmd.sh _kernel python3 bench.py --workload offline_batch ... (collect_profiles.sh)
-OFFLINE_PMC_KERNELS = {"pass1.stft": "stft_kernel<14>", "pass1.freq_filter": "median_big_kernel<187", "pass1.istft": "istft_kernel<14, 3>",
+OFFLINE_PMC_KERNELS = {"pass1.stft": "stft_kernel<14>", "pass1.freq_filter": "median_big_kernel<187", "pass1.istft": "istft_run_wide_kernel<14, 2>",
                        "pass2.stft": "stft_kernel<10>", "pass2.freq_filter": "median_tf_herm_bits_kernel<11, 13>",
                        "pass2.istft": "istft_run_kernel<10>"}
 

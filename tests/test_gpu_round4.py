@@ -461,35 +461,53 @@ def test_host_process_refuses_overlapping_buffers(z):
     assert np.array_equal(h, rh) and np.array_equal(p, rp)
 
 
-# ---------------------------------------------------------------------------- pass 2 of the offline path synthesised in runs
+# ---------------------------------------------------------------------------- the offline passes synthesised in runs
+def _runs_expected(n_hops, hop, chunk, groups, run):
+    """hpr.hip run_pass_groups: every chunk of the pass at least 8 hops, and a kernel for the transform and the groups.
+    None: nfft >= 2048 with the run length left to the engine -- it takes the long workgroups of istft_run_wide_kernel only
+    where they fill the device (pick_wide_run: not for one short clip)"""
+    log2n = int(np.log2(4 * hop))
+    kernel = (8 <= log2n <= 10 and groups == 1) or 11 <= log2n <= 14
+    if log2n > 10 and run == 0:
+        return None
+    return kernel and n_hops >= 8 and (chunk == 0 or n_hops % chunk == 0 or n_hops % chunk >= 8)
+
+
 @pytest.mark.parametrize("hop_h,hop_p,n", [(4096, 256, 161571), (1024, 256, 70001), (2048, 128, 50000), (4096, 256, 4096 * 9 + 1),
-                                           (512, 128, 30000), (4096, 256, 2100), (256, 64, 9000)])
+                                           (512, 128, 30000), (4096, 256, 2100), (256, 64, 9000), (4096, 1024, 120000),
+                                           (2048, 512, 77777)])
 @pytest.mark.parametrize("chunk,run", [(0, 0), (64, 16), (40, 7), (8, 1), (24, 64)])
-def test_offline_pass2_synthesised_in_runs(z, hop_h, hop_p, n, chunk, run):
-    """Pass 2 of HPRIOffline (hps.cu:185-205: the small hop, percussive output alone) with hard masks: a wavefront
-    synthesises a run of consecutive frames, adds the overlapping halves in registers and writes the finished hops where the
-    driver wants them (istft.hip istft_run_kernel) -- no Y rows, no overlap-add launch.  Bit-identical to the oracle and to
-    the launches it replaces ("no_istft_runs"), with the engines' chunks bounded ("offline_chunk_hops": the carry crosses
+def test_offline_passes_synthesised_in_runs(z, hop_h, hop_p, n, chunk, run):
+    """Both passes of HPRIOffline with hard masks (hps.cu:142-167: H, and P + R summed for pass 2; :185-205: P alone): a
+    wavefront (nfft <= 1024) or a workgroup synthesises a run of consecutive frames, adds the overlapping halves in
+    registers -- and the two outputs of a group -- and writes the finished hops where the driver wants them (istft.hip
+    istft_run_kernel / istft_run_wide_kernel): no Y rows, no overlap-add launch.  Bit-identical to the oracle and to the
+    launches it replaces ("no_istft_runs"), with the engines' chunks bounded ("offline_chunk_hops": the carry crosses
     chunk boundaries, a run starts from the frame before it) and runs of 1 .. 64 frames; clips shorter than a chunk or a few
-    hops long; the pass falls back to the launches as a whole when one of its chunks is too short for the masks-as-bits road."""
+    hops long; a pass falls back to the launches as a whole when one of its chunks is too short for the masks-as-bits road
+    or no kernel covers its transform."""
     x = _clip(n, 11 + n % 7)
     rh, rp, rr = o.HPRIOffline(FS, hop_h, hop_p, 2.0, 2.0).process(x)
     z.set_option("offline_chunk_hops", chunk)
     z.set_option("istft_run", run)
+    z.set_option("istft_run_wide", run)
     try:
         g = z.HPRIOffline(FS, hop_h, hop_p, 2.0, 2.0)
         for rep in range(2):
             h, p, r = g.process(x)
             assert np.array_equal(h, rh) and np.array_equal(p, rp) and np.all(r == 0), rep
-        # the new path did run where it can (every chunk of the pass at least 8 hops): no overlap-add launch in pass 2
-        n2 = g.hop_counts(n)[1]
-        expect = n2 >= 8 and (chunk == 0 or n2 % chunk == 0 or n2 % chunk >= 8)
+        p_only = np.full(n, np.nan, np.float32)        # the harmonic output left out: pass 1 has one group (P + R)
+        g.process(x, out=(None, p_only, None))
+        assert np.array_equal(p_only, rp)
+        # the new path did run where it can: no overlap-add launch in that pass
+        n1, n2 = g.hop_counts(n)
         g.profile(True)
         g.process(x)
         prof = g.profile_get_all()
         g.profile(False)
-        assert (prof["pass2"]["finalize"]["launches"] == 0) == expect, (n2, chunk, prof["pass2"])
-        assert prof["pass1"]["finalize"]["launches"] > 0
+        for ps, nh, hop, groups in (("pass1", n1, hop_h, 2), ("pass2", n2, hop_p, 1)):
+            exp = _runs_expected(nh, hop, chunk, groups, run)
+            assert exp is None or (prof[ps]["finalize"]["launches"] == 0) == exp, (ps, nh, chunk, prof[ps])
         z.set_option("no_istft_runs", 1)
         h2, p2, _ = z.HPRIOffline(FS, hop_h, hop_p, 2.0, 2.0).process(x)
         assert np.array_equal(h2, rh) and np.array_equal(p2, rp)
@@ -497,6 +515,7 @@ def test_offline_pass2_synthesised_in_runs(z, hop_h, hop_p, n, chunk, run):
         z.set_option("no_istft_runs", 0)
         z.set_option("offline_chunk_hops", 0)
         z.set_option("istft_run", 0)
+        z.set_option("istft_run_wide", 0)
 
 
 def test_offline_batch_of_clips_synthesised_in_runs(z):
@@ -504,16 +523,53 @@ def test_offline_batch_of_clips_synthesised_in_runs(z):
     cross a clip) against the per-clip oracle."""
     n, clips = 40000, 3
     xs = np.stack([_clip(n, 31 + c) for c in range(clips)])
-    g = z.HPRIOffline(FS, 1024, 256, 2.0, 2.0, n_clips=clips)
+    z.set_option("istft_run_wide", 5)
+    try:
+        g = z.HPRIOffline(FS, 1024, 256, 2.0, 2.0, n_clips=clips)
+        din, dh, dp = z.DeviceBuffer(clips * n), z.DeviceBuffer(clips * n), z.DeviceBuffer(clips * n)
+        din.upload(xs.reshape(-1))
+        g.profile(True)
+        g.process_device(din.ptr, n, n, harm=dh.ptr, perc=dp.ptr, out_stride=n)
+        z.synchronize()
+        prof = g.profile_get_all()
+        assert prof["pass1"]["finalize"]["launches"] == 0 and prof["pass2"]["finalize"]["launches"] == 0
+        H, P = dh.download().reshape(clips, n), dp.download().reshape(clips, n)
+        for c in range(clips):
+            rh, rp, _ = o.HPRIOffline(FS, 1024, 256, 2.0, 2.0).process(xs[c])
+            assert np.array_equal(H[c], rh) and np.array_equal(P[c], rp), c
+        for b in (din, dh, dp):
+            b.free()
+    finally:
+        z.set_option("istft_run_wide", 0)
+
+
+def test_offline_batch_config4_runs_engage_and_match_the_launches(z):
+    """BASELINE config 4's shape per GPU (64 clips x 30 s, 4096 / 256, hard masks): with the run length left to the engine
+    BOTH passes are synthesised in runs (pass 1: the long workgroups fill the device, hpr.hip pick_wide_run), and the outputs
+    are bit-identical to the synthesis + overlap-add launches ("no_istft_runs" = 1), which the full-size property test of
+    round 3 pins to the oracle."""
+    import bench as b
+    n, clips = 1323000, 64
+    x = np.stack([b.s_music(n, seed=c) for c in range(4)])
+    xs = np.concatenate([x] * (clips // 4))                      # (four different clips, repeated)
     din, dh, dp = z.DeviceBuffer(clips * n), z.DeviceBuffer(clips * n), z.DeviceBuffer(clips * n)
     din.upload(xs.reshape(-1))
-    g.profile(True)
-    g.process_device(din.ptr, n, n, harm=dh.ptr, perc=dp.ptr, out_stride=n)
-    z.synchronize()
-    assert g.profile_get_all()["pass2"]["finalize"]["launches"] == 0
-    H, P = dh.download().reshape(clips, n), dp.download().reshape(clips, n)
-    for c in range(clips):
-        rh, rp, _ = o.HPRIOffline(FS, 1024, 256, 2.0, 2.0).process(xs[c])
-        assert np.array_equal(H[c], rh) and np.array_equal(P[c], rp), c
-    for b in (din, dh, dp):
-        b.free()
+    outs = []
+    for no_runs in (0, 1):
+        z.set_option("no_istft_runs", no_runs)
+        try:
+            g = z.HPRIOffline(FS, 4096, 256, 2.0, 2.0, n_clips=clips)
+            g.profile(True)
+            g.process_device(din.ptr, n, n, harm=dh.ptr, perc=dp.ptr, out_stride=n)
+            z.synchronize()
+            prof = g.profile_get_all()
+            for ps in ("pass1", "pass2"):
+                assert (prof[ps]["finalize"]["launches"] == 0) == (no_runs == 0), (no_runs, ps, prof[ps])
+            outs.append((dh.download(), dp.download()))
+            del g
+        finally:
+            z.set_option("no_istft_runs", 0)
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][1][:n], outs[0][1][4 * n:5 * n])   # clip 4 is clip 0 again
+    for bfr in (din, dh, dp):
+        bfr.free()

@@ -31,6 +31,7 @@ opt_t g_opt_no_median_tf{0};
 opt_t g_opt_no_istft_runs{0};
 opt_t g_opt_offline_chunk_hops{0};
 opt_t g_opt_istft_run{0};
+opt_t g_opt_istft_run_wide{0};
 opt_t g_opt_offline_range{0};
 opt_t g_opt_offline_no_register{0};
 std::atomic<unsigned> g_host_free_gen{0};
@@ -187,6 +188,7 @@ int zen_hip_set_option(const char* name, int value)
 	             {"no_istft_runs", &g_opt_no_istft_runs},
 	             {"offline_chunk_hops", &g_opt_offline_chunk_hops},
 	             {"istft_run", &g_opt_istft_run},
+	             {"istft_run_wide", &g_opt_istft_run_wide},
 	             {"offline_range", &g_opt_offline_range},
 	             {"offline_no_register", &g_opt_offline_no_register}};
 #ifndef ZEN_HIP_DIAG

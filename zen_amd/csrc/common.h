@@ -30,6 +30,7 @@ extern opt_t g_opt_no_istft_xcd_map;    // "no_istft_xcd_map": several outputs: 
 extern opt_t g_opt_no_sse_block;        // "no_sse_block": blocks of frames on the SSE path through the four-launch path
 extern opt_t g_opt_offline_chunk_hops; // "offline_chunk_hops": hops per chunk of the engines of HPRIOffline handles created from now on (0: sized by the device memory cap)
 extern opt_t g_opt_no_istft_runs;      // "no_istft_runs": the offline small-hop pass writes Y rows and runs the synthesis + overlap-add launches
+extern opt_t g_opt_istft_run_wide;     // "istft_run_wide": the same for istft_run_wide_kernel (0: default 12)
 extern opt_t g_opt_istft_run;          // "istft_run": consecutive frames per wavefront of istft_run_kernel (0: default 16)
 extern opt_t g_opt_no_median_tf;        // "no_median_tf": time median and frequency median + mask bits as two launches
 extern opt_t g_opt_no_median_bits;      // "no_median_bits": the mask bits always come from mask_bits_kernel, never from a median kernel

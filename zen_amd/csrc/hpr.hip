@@ -18,6 +18,9 @@
 #include "common.h"
 #include "filters.h"
 #include "hpr_engine.h"
+
+#include <algorithm>
+#include <functional>
 #include "sse_block.h"
 #include "masks.h"
 #include "rt_fused.h"
@@ -109,8 +112,11 @@ void free_all(zen_hip_hpr* e)
 	(void)hipFree(e->d_Mh);
 	(void)hipFree(e->d_blk_flag);
 	(void)hipFree(e->d_blk_need);
-	(void)hipFree(e->d_run_carry[0]);
-	(void)hipFree(e->d_run_carry[1]);
+	(void)hipFree(e->d_run_sink);
+	for (int o = 0; o < 3; ++o) {
+		(void)hipFree(e->d_run_carry[0][o]);
+		(void)hipFree(e->d_run_carry[1][o]);
+	}
 	for (int o = 0; o < 3; ++o) {
 		(void)hipFree(e->d_Y[o]);
 		(void)hipFree(e->d_carry[o]);
@@ -516,6 +522,8 @@ int resident_post(zen_hip_hpr* e, const float* in)
 	return ZEN_HIP_OK;
 }
 
+int pick_wide_run(zen_hip_hpr* e, size_t M, size_t S, const int* group_outputs, int n_groups, int log2n, double min_eff); // below
+
 int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long long in_valid = LLONG_MAX)
 {
 	const size_t S = e->n_streams, N = e->nfft;
@@ -821,10 +829,9 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 		if (bits_done != 2)
 			ZH_TRY(launch_mask_bits_transpose((int)N, ia, e->d_bits_t, e->stream));
 	}
-	if (e->run_mode) { // synthesis in runs, finished hops straight to the pass's destination (hpr_process_spec)
-		if (!use_bits || e->run_out < 0 || !e->run_spec)
+	if (e->run_mode) { // synthesis in runs, finished hops straight to the pass's destinations (hpr_process_spec)
+		if (!use_bits || e->run_n_groups < 1)
 			ZH_FAIL(ZEN_HIP_E_HIP, "hpr: synthesis in runs without mask bits (internal)");
-		const HprOutSpec& sp = *e->run_spec;
 		IstftRunArgs ra;
 		memset(&ra, 0, sizeof(ra));
 		ra.S = e->d_S;
@@ -837,23 +844,38 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 		ra.n_frames = (int)M;
 		ra.n_streams = (int)S;
 		ra.hop = (int)e->hop;
-		ra.which = e->run_out;
 		ra.out_h = e->out_h ? 1 : 0;
 		ra.out_p = e->out_p ? 1 : 0;
 		ra.cola = e->cola;
-		ra.carry_prev = e->d_run_carry[e->run_sel];
-		ra.carry_next = e->d_run_carry[e->run_sel ^ 1];
-		e->run_sel ^= 1;
-		const int run = g_opt_istft_run.load(std::memory_order_relaxed);
+		int run = (e->log2n <= 10 ? g_opt_istft_run : g_opt_istft_run_wide).load(std::memory_order_relaxed);
+		if (run <= 0 && e->log2n > 10) { // (a chunk shorter than the pass's first: whatever fills the device best)
+			int outs[3];
+			for (int g = 0; g < e->run_n_groups; ++g)
+				outs[g] = e->run_groups[g].n_out;
+			run = pick_wide_run(e, M, S, outs, e->run_n_groups, e->log2n, 0.0);
+		}
 		ra.run = run > 0 ? run : 16;
-		ra.out = sp.dst;
-		ra.out_stride = sp.stride;
 		ra.pos0 = e->run_pos0;
-		ra.shift = sp.shift;
-		ra.len = sp.len;
-		ra.dup_from = sp.dup_from;
-		ra.dup_shift = sp.dup_shift;
-		ra.dup_len = sp.dup_len;
+		ra.n_groups = e->run_n_groups;
+		ra.sink = e->d_run_sink;
+		for (int g = 0; g < e->run_n_groups; ++g) {
+			const zen_hip_hpr::RunGroup& rg = e->run_groups[g];
+			IstftRunGroup& G = ra.g[g];
+			G.n_out = rg.n_out;
+			for (int k = 0; k < rg.n_out; ++k) {
+				G.which[k] = rg.which[k];
+				G.carry_prev[k] = e->d_run_carry[e->run_sel][rg.which[k]];
+				G.carry_next[k] = e->d_run_carry[e->run_sel ^ 1][rg.which[k]];
+			}
+			G.out = rg.spec->dst;
+			G.out_stride = rg.spec->stride;
+			G.shift = rg.spec->shift;
+			G.len = rg.spec->len;
+			G.dup_from = rg.spec->dup_from;
+			G.dup_shift = rg.spec->dup_shift;
+			G.dup_len = rg.spec->dup_len;
+		}
+		e->run_sel ^= 1;
 		ProfScope ps(e, zen_hip_hpr::K_ISTFT);
 		ZH_TRY(launch_istft_run(e->log2n, ra, e->stream));
 		e->rows_stale = true;
@@ -1009,38 +1031,115 @@ int finalize_spec(zen_hip_hpr* e, int o, const HprOutSpec& sp, size_t M, long lo
 	return launch_finalize_spec(fa, e->stream);
 }
 
-// The output whose pass can be synthesised in runs (IstftRunArgs), or -1.  What it takes: a fresh stream (the pass starts
-// from reset buffers: the frame before the first is all zero), an anticausal hard-mask median engine with ONE computed
-// output, delivered plainly (no second output added to it), whose chunks all take the masks-as-bits road (>= 8 frames; the
-// median kernel or the transposition leaves IstftArgs::bits_t), at a transform a wavefront holds (istft_run_available).
-int run_pass_output(const zen_hip_hpr* e, size_t n_hops, const HprOutSpec (&spec)[3])
+// Run length of istft_run_wide_kernel (a workgroup per run and group of outputs; nfft >= 2048).  Its workgroups are long --
+// run + 1 transforms per output, 10 us each at nfft 16384 -- and few, so how evenly they fill the device decides more than
+// the 1/run of redundant work does (pass 1 of the offline batch, 64 clips x 324 frames: runs of 54 / 41 / 81 frames take
+// 2.90 / 2.70 / 2.63 ms).  The launch is therefore simulated for every number of runs per stream: workgroups in dispatch
+// order (groups of two outputs first), each to the slot that is free first; the shortest makespan wins.  Returns 0 when
+// even that leaves the device less than `min_eff` busy with useful transforms: the caller keeps the per-frame launches,
+// whose workgroups are one transform long.
+int pick_wide_run(zen_hip_hpr* e, size_t M, size_t S, const int* group_outputs, int n_groups, int log2n, double min_eff)
 {
-	if (g_opt_no_istft_runs || g_opt_no_mask_bits || g_opt_no_half_rows || g_opt_median_general)
-		return -1;
-	if (e->use_sse || e->soft || !istft_run_available(e->log2n) || e->rows_stale)
-		return -1;
-	if (e->abs_frame != (long long)e->W - 1 || e->last_frames != 0 || (e->drain[0] | e->drain[1] | e->drain[2]))
-		return -1;
-	int n = 0, o1 = -1;
-	for (int o = 0; o < 3; ++o)
-		if (output_computed(e, o)) {
-			++n;
-			o1 = o;
+	int sig = n_groups; // (the simulation costs a millisecond: once per shape)
+	for (int g = 0; g < n_groups; ++g)
+		sig = sig * 4 + group_outputs[g];
+	if (e->run_pick_M == M && e->run_pick_sig == sig)
+		return e->run_pick_eff < min_eff ? 0 : e->run_pick;
+	e->run_pick_M = M;
+	e->run_pick_sig = sig;
+	e->run_pick = 0;
+	e->run_pick_eff = 0.0;
+	const size_t slots = 256 * (size_t)(log2n >= 14 ? 1 : (log2n == 13 ? 2 : 4)); // workgroups the device holds at once
+	size_t useful = 0;
+	for (int g = 0; g < n_groups; ++g)
+		useful += (size_t)group_outputs[g] * M * S;
+	int best = 0;
+	double best_t = 0.0;
+	std::vector<double> busy(slots);
+	for (size_t k = 1; k <= 64 && k <= M; ++k) { // runs per stream
+		const size_t run = (M + k - 1) / k, kk = (M + run - 1) / run;
+		if (run < 8)
+			break;
+		std::fill(busy.begin(), busy.end(), 0.0);
+		std::make_heap(busy.begin(), busy.end(), std::greater<double>());
+		for (int g = 0; g < n_groups; ++g)
+			for (size_t s = 0; s < S; ++s)
+				for (size_t r = 0; r < kk; ++r) {
+					const size_t len = (r + 1 == kk ? M - r * run : run) + 1;
+					std::pop_heap(busy.begin(), busy.end(), std::greater<double>());
+					busy.back() += (double)group_outputs[g] * (double)len;
+					std::push_heap(busy.begin(), busy.end(), std::greater<double>());
+				}
+		const double t = *std::max_element(busy.begin(), busy.end());
+		if (best == 0 || t < best_t * 0.995) { // (fewer, longer runs on a tie)
+			best = (int)run;
+			best_t = t;
 		}
-	if (n != 1 || !spec[o1].dst || spec[o1].add >= 0)
-		return -1;
-	for (int o = 0; o < 3; ++o)
-		if (o != o1 && spec[o].dst)
-			return -1;
+	}
+	if (best == 0)
+		return 0;
+	e->run_pick = best;
+	e->run_pick_eff = (double)useful / ((double)slots * best_t);
+	return e->run_pick_eff < min_eff ? 0 : best;
+}
+
+// Can the pass be synthesised in runs (IstftRunArgs)?  Fills e->run_groups.  What it takes: a fresh stream (the pass starts
+// from reset buffers: the frame before the first is all zero), an anticausal hard-mask median engine whose chunks all take
+// the masks-as-bits road (>= 8 frames; the median kernel or the transposition leaves IstftArgs::bits_t), every destination
+// the finished hops of one computed output or the sum of two, no output in two destinations, and a kernel for the
+// transform and the groups (istft_run_available).  Computed outputs nobody asks for are not synthesised at all.
+bool run_pass_groups(zen_hip_hpr* e, size_t n_hops, const HprOutSpec (&spec)[3])
+{
+	e->run_n_groups = 0;
+	if (g_opt_no_istft_runs == 1 || g_opt_no_mask_bits || g_opt_no_half_rows || g_opt_median_general || g_opt_no_median_bits)
+		return false;
+	if (e->use_sse || e->soft || e->rows_stale)
+		return false;
+	if (e->abs_frame != (long long)e->W - 1 || e->last_frames != 0 || (e->drain[0] | e->drain[1] | e->drain[2]))
+		return false;
+	int used[3] = {0, 0, 0}, ng = 0, max_out = 0;
+	for (int o = 0; o < 3; ++o) {
+		if (!spec[o].dst)
+			continue;
+		zen_hip_hpr::RunGroup& g = e->run_groups[ng++];
+		g.n_out = 1;
+		g.which[0] = o;
+		g.spec = &spec[o];
+		if (!output_computed(e, o))
+			return false;
+		++used[o];
+		if (spec[o].add >= 0) {
+			if (spec[o].add > 2 || !output_computed(e, spec[o].add))
+				return false; // (a partner that is not computed: the reference adds its zero accumulator -- left to finalize_spec_kernel)
+			g.which[g.n_out++] = spec[o].add;
+			++used[spec[o].add];
+		}
+		max_out = g.n_out > max_out ? g.n_out : max_out;
+	}
+	if (ng == 0 || used[0] > 1 || used[1] > 1 || used[2] > 1 || !istft_run_available(e->log2n, ng, max_out))
+		return false;
+	if (e->log2n > 10 && g_opt_no_istft_runs == 2) // ("no_istft_runs" = 2: only the transforms a wavefront holds)
+		return false;
+	if (e->log2n > 10 && g_opt_istft_run_wide <= 0) { // long workgroups: only where they fill the device (pick_wide_run)
+		int outs[3];
+		for (int g = 0; g < ng; ++g)
+			outs[g] = e->run_groups[g].n_out;
+		const size_t M0 = n_hops < e->max_hops ? n_hops : e->max_hops;
+		if (pick_wide_run(e, M0, e->n_streams, outs, ng, e->log2n, 0.92) == 0)
+			return false;
+	}
 	const size_t last = n_hops % e->max_hops;
 	if (n_hops < 8 || (last != 0 && last < 8))
-		return -1;
+		return false;
 	const HardThr thr = hard_mask_thresholds(e->beta, e->beta - FLT_EPSILON, false);
-	const bool time_identity = e->mt == 1;
 	if (thr.p == 0.0 || thr.h == 0.0 || !mask_bits_supported((int)e->nfft, e->mf / 2) || !filter_supports_hermitian(e->mf, (int)e->nfft)
-	    || !(time_identity || e->mt <= 63))
-		return -1;
-	return o1;
+	    || !(e->mt == 1 || e->mt <= 63))
+		return false;
+	for (int g = 1; g < ng; ++g) // the groups of two outputs first (istft_run_wide_kernel dispatches them first)
+		for (int k = g; k > 0 && e->run_groups[k].n_out > e->run_groups[k - 1].n_out; --k)
+			std::swap(e->run_groups[k], e->run_groups[k - 1]);
+	e->run_n_groups = ng;
+	return true;
 }
 
 } // namespace
@@ -1056,16 +1155,20 @@ int hpr_process_spec(zen_hip_hpr* h, const float* in_dev, size_t n_hops, size_t 
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpr_process_spec: anticausal engines only");
 	if (n_hops > h->max_hops && h->max_hops < h->max_hops_cap)
 		ZH_TRY(grow_buffers(h, n_hops < h->max_hops_cap ? n_hops : h->max_hops_cap));
-	const int run_out = run_pass_output(h, n_hops, spec);
-	if (run_out >= 0) { // the whole pass, or none of it: the two ways keep different state between chunks
+	const bool runs = run_pass_groups(h, n_hops, spec);
+	if (runs) { // the whole pass, or none of it: the two ways keep different state between chunks
 		const size_t hopb = sizeof(float) * h->n_streams * h->hop;
-		for (int i = 0; i < 2; ++i)
-			if (!h->d_run_carry[i])
-				ZH_HIP(hipMalloc((void**)&h->d_run_carry[i], hopb));
-		ZH_HIP(hipMemsetAsync(h->d_run_carry[h->run_sel], 0, hopb, h->stream)); // a fresh stream: nothing to add to its first hop
+		for (int g = 0; g < h->run_n_groups; ++g)
+			for (int k = 0; k < h->run_groups[g].n_out; ++k) {
+				const int o = h->run_groups[g].which[k];
+				for (int b = 0; b < 2; ++b)
+					if (!h->d_run_carry[b][o])
+						ZH_HIP(hipMalloc((void**)&h->d_run_carry[b][o], hopb));
+				ZH_HIP(hipMemsetAsync(h->d_run_carry[h->run_sel][o], 0, hopb, h->stream)); // a fresh stream: nothing to add to its first hop
+			}
+		if (!h->d_run_sink)
+			ZH_HIP(hipMalloc((void**)&h->d_run_sink, hopb));
 		h->run_mode = true;
-		h->run_out = run_out;
-		h->run_spec = &spec[run_out];
 	}
 	int rc = ZEN_HIP_OK;
 	for (size_t off = 0; off < n_hops && rc == ZEN_HIP_OK; off += h->max_hops) {
@@ -1073,12 +1176,12 @@ int hpr_process_spec(zen_hip_hpr* h, const float* in_dev, size_t n_hops, size_t 
 		const long long pos0 = (long long)(off * h->hop);
 		h->run_pos0 = pos0;
 		rc = run_chunk(h, in_dev + off * h->hop, in_stride, M, in_valid - pos0);
-		for (int o = 0; o < 3 && rc == ZEN_HIP_OK; ++o)
-			if (spec[o].dst && o != run_out)
+		for (int o = 0; o < 3 && rc == ZEN_HIP_OK && !runs; ++o)
+			if (spec[o].dst)
 				rc = finalize_spec(h, o, spec[o], M, pos0);
 	}
 	h->run_mode = false;
-	h->run_spec = nullptr;
+	h->run_n_groups = 0;
 	return rc;
 }
 

@@ -59,16 +59,24 @@ struct zen_hip_hpr {
 	long long abs_frame = 0;
 	size_t last_frames = 0;
 	// A pass of the offline driver synthesised in runs (stft.h IstftRunArgs; hpr_process_spec decides per pass): the kernel
-	// delivers the finished hops itself and keeps no Y rows.  run_*: the pass's destination, what run_chunk needs beside the
-	// chunk; d_run_carry: second half of a chunk's last frame for the next chunk (two, alternating: a launch reads one and
-	// writes the other).  rows_stale: such a pass has run since the last reset -- the Y rows and carries do not hold the
-	// stream's last frame, and the other paths refuse to continue the stream.
+	// delivers the finished hops itself and keeps no Y rows.  run_*: the pass's destinations (groups of outputs, one per
+	// HprOutSpec with a destination), what run_chunk needs beside the chunk; d_run_carry[b][o]: second half of a chunk's last
+	// frame of output o for the next chunk (b alternates: a launch reads one set and writes the other).  rows_stale: such a
+	// pass has run since the last reset -- the Y rows and carries do not hold the stream's last frame, and the other paths
+	// refuse to continue the stream.
 	bool run_mode = false, rows_stale = false;
-	int run_out = -1;
+	int run_n_groups = 0;
+	struct RunGroup {
+		int n_out, which[2];
+		const HprOutSpec* spec;
+	} run_groups[3];
 	long long run_pos0 = 0;
-	const HprOutSpec* run_spec = nullptr;
-	float* d_run_carry[2] = {nullptr, nullptr};
+	float* d_run_carry[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
 	int run_sel = 0;
+	size_t run_pick_M = 0; // pick_wide_run's last answer (hpr.hip): frames per chunk, groups signature -> run length, efficiency
+	int run_pick_sig = 0, run_pick = 0;
+	double run_pick_eff = 0.0;
+	float* d_run_sink = nullptr; // IstftRunArgs::sink
 	// An output that stops being computed (residual after use_soft_mask / use_sse_filter, hps.cu:562, :582-652)
 	// still owes the second half of its last frame: the reference's accumulator is shifted, not cleared.
 	// 0: nothing owed.  1: switched off, no hop processed since: copy_* still hands out the last finished hop(s), as

@@ -501,7 +501,8 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) __attribute__((amdgpu_wave
 	const int i0 = (blockIdx.x * PL::FRAMES_PER_BLOCK + slot) * a.run; // the run's first frame (>= n_frames: nothing is stored)
 	const float2* S_s = a.S + (long long)s * a.ring_rows * a.s_stride;
 	const unsigned* bits_s = a.bits_t + (long long)s * a.bits_t_stream_stride;
-	float* out_s = a.out + (long long)s * a.out_stride;
+	const IstftRunGroup& G = a.g[0]; // (one group of one output: launch_istft_run checks)
+	float* out_s = G.out + (long long)s * G.out_stride;
 	const MaskCfg cfg{0.0f, 0.0f, 0, 0, 0, a.out_h, a.out_p};
 	// frame i of the call (one outside it: some frame of it, the result is not used): its sixteen bins tf + slot*TF -- the lower
 	// half as stored, the upper half from the mirror image (conjugated where it is used) -- and its word of mask bits
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) __attribute__((amdgpu_wave
 	float cprev[4], carry[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
 	for (int j = 0; j < 4; ++j) // (used by the call's first run only)
-		cprev[j] = a.carry_prev[(long long)s * HOP + tf + j * TF];
+		cprev[j] = G.carry_prev[0][(long long)s * HOP + tf + j * TF];
 	float2 S[16];
 	load_row(i0 - 1, S);
 	unsigned bw = load_bits(i0 - 1);
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) __attribute__((amdgpu_wave
 				S[sl].y = -S[sl].y;
 		float y[8];
 		{
-			IstftRunIn in{S, mask_code(bw, a.which, cfg)};
+			IstftRunIn in{S, mask_code(bw, G.which[0], cfg)};
 			IstftRunOut out{y, a.cola};
 			// (the thread index is made opaque per transform: otherwise every LDS address and table index of the transform, all
 			// functions of tf alone, is hoisted out of the loop and kept in registers -- see istft_hard_multi_kernel)
@@ -548,12 +549,12 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) __attribute__((amdgpu_wave
 			for (int j = 0; j < 4; ++j) {
 				const float v = carry[j] + y[j];
 				const long long p0 = a.pos0 + (long long)i * HOP + tf + j * TF;
-				const long long d = p0 - a.shift;
-				if (d >= 0 && d < a.len)
+				const long long d = p0 - G.shift;
+				if (d >= 0 && d < G.len)
 					out_s[d] = v;
-				if (p0 >= a.dup_from) {
-					const long long d2 = p0 - a.dup_shift;
-					if (d2 >= 0 && d2 < a.dup_len)
+				if (p0 >= G.dup_from) {
+					const long long d2 = p0 - G.dup_shift;
+					if (d2 >= 0 && d2 < G.dup_len)
 						out_s[d2] = v;
 				}
 			}
@@ -564,13 +565,161 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) __attribute__((amdgpu_wave
 		if (i == a.n_frames - 1) {
 #pragma unroll
 			for (int j = 0; j < 4; ++j)
-				a.carry_next[(long long)s * HOP + tf + j * TF] = carry[j];
+				G.carry_next[0][(long long)s * HOP + tf + j * TF] = carry[j];
 		}
 #pragma unroll
 		for (int sl = 0; sl < 16; ++sl)
 			S[sl] = Sn[sl];
 		bw = bn;
 	}
+}
+
+// The same for the transforms a workgroup shares (nfft 2048 .. 16384: the large-hop pass of the offline driver, three
+// outputs in two groups -- H, and P + R summed for pass 2).  One workgroup per (run, group, stream).  No registers are left
+// for a prefetched row here (istft_kernel<14, 3> sits at 126 of the 128 that four waves per SIMD allow), so the other half
+// of the remedy is used: the finished hop of frame i waits in four registers and is stored inside the NEXT frame's
+// transform, right behind the loads of its spectrum row (the input functor's prepare(), fft_dev.h) -- the in-order memory
+// counter then lets the wavefront wait for those loads without draining the stores first.  A group of two outputs loads
+// the row again for its second transform (an L2 hit, with nothing but those old stores in front of it).
+struct IstftRunPend { // the finished hop that waits for the next frame's loads, and where it goes
+	float v[4];
+	float* base; // sample tf + j*tf_step of the hop goes to base[tf + j*tf_step]: its place in the destination, or the sink
+	int tf, tf_step;
+	// Four stores on EVERY path: behind the loads of the next frame's row the compiler can then count them and wait for the
+	// loads alone; with a conditional store there it must assume none and waits for everything (s_waitcnt vmcnt(0): the
+	// stores drained after all).  Hence the sink: a turn that has no hop to deliver (the frame before the run), or delivered
+	// it by the slow path below, stores its four values where nobody reads them.
+	__device__ __forceinline__ void flush() const
+	{
+#pragma unroll
+		for (int j = 0; j < 4; ++j)
+			base[tf + j * tf_step] = v[j];
+	}
+};
+struct IstftRunWideIn : IstftIn<3, 16> {
+	IstftRunPend* pend; // null: nothing to store behind this transform's loads
+	__device__ __forceinline__ void prepare()
+	{
+		IstftIn<3, 16>::prepare();
+		if (pend) // (compile-time after inlining: the first transform of a turn)
+			pend->flush();
+	}
+};
+
+template <int LOG2N, int NG>
+__global__ __launch_bounds__(Plan<LOG2N>::THREADS, istft_waves<LOG2N>())
+    __attribute__((amdgpu_waves_per_eu(istft_waves<LOG2N>(), istft_waves<LOG2N>()))) void istft_run_wide_kernel(IstftRunArgs a)
+{
+	using PL = Plan<LOG2N>;
+	constexpr int TF = PL::TF, N = PL::N, HOP = N / 4;
+	static_assert(PL::V == 16, "one word of mask bits per thread");
+	extern __shared__ float2 lds[];
+	// (grid: runs x streams x groups -- the groups of two outputs, twice the work per workgroup, come first in IstftRunArgs::g
+	// and are therefore dispatched first: the shorter workgroups fill the launch's tail)
+	const int tid = threadIdx.x, s = blockIdx.y;
+	const int slot = tid / TF, tf = tid - slot * TF;
+	float2* img = lds + slot * PL::LDS_FLOAT2;
+	const IstftRunGroup& G = a.g[blockIdx.z];
+	const int i0 = (blockIdx.x * PL::FRAMES_PER_BLOCK + slot) * a.run; // the run's first frame (>= n_frames: nothing is stored)
+	const float2* S_s = a.S + (long long)s * a.ring_rows * a.s_stride;
+	const unsigned* bits_s = a.bits_t + (long long)s * a.bits_t_stream_stride;
+	const MaskCfg cfg{0.0f, 0.0f, 0, 0, 0, a.out_h, a.out_p};
+	float carry[NG][4];
+#pragma unroll
+	for (int k = 0; k < NG; ++k)
+#pragma unroll
+		for (int j = 0; j < 4; ++j)
+			carry[k][j] = 0.0f;
+	float* out_s = G.out + (long long)s * G.out_stride;
+	float* sink_s = a.sink + (long long)s * HOP;
+	IstftRunPend pend;
+	pend.base = sink_s;
+	pend.tf = tf;
+	pend.tf_step = TF;
+#pragma unroll
+	for (int j = 0; j < 4; ++j)
+		pend.v[j] = 0.0f;
+	// every slot of every workgroup walks run + 1 frames (the transforms of nfft > 1024 meet at workgroup barriers): i = i0 - 1 is
+	// the frame before the run, synthesised for its second half alone -- or, for the call's first run, nothing: the previous
+	// call's carry takes its place
+	for (int i = i0 - 1; i < i0 + a.run; ++i) {
+		const int r = i < 0 ? 0 : (i < a.n_frames ? i : a.n_frames - 1);
+		const float2* row = S_s + ((a.crow0 + r) % a.ring_rows) * a.s_stride;
+		const unsigned bw = bits_s[(long long)r * (N / 16) + tf];
+		float v[4];
+#pragma unroll
+		for (int k = 0; k < NG; ++k) {
+			if (k >= G.n_out) // (workgroup-uniform: a group of one output in a call that also has a group of two)
+				break;
+			IstftRunWideIn in;
+			in.S = row;
+			in.H = in.P = nullptr;
+			in.bw[0] = bw;
+			in.cfg = cfg;
+			in.thr = HardThr{0.0, 0.0, 0, 0};
+			in.sel = HardSel{0.0f, 0.0f, 0.0f, 0.0f};
+			in.which = G.which[k];
+			in.n = N;
+			in.p_mid = 0;
+			in.pend = k == 0 ? &pend : nullptr;
+			float y[8];
+			IstftRunOut out{y, a.cola};
+			int tf_o = tf; // (opaque per transform: see istft_hard_multi_kernel)
+			const float2* tw_o = a.tw;
+			asm volatile("" : "+v"(tf_o));
+			asm volatile("" : "+s"(tw_o));
+			zfft::fft_frame<LOG2N, true, false, true>(tf_o, img, tw_o, in, out, true);
+			if (i < 0) { // (wave-uniform) the call's first run
+#pragma unroll
+				for (int j = 0; j < 4; ++j)
+					y[4 + j] = G.carry_prev[k][(long long)s * HOP + tf + j * TF];
+			}
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				const float f = carry[k][j] + y[j];
+				v[j] = k == 0 ? f : v[j] + f; // sum_vectors_functor hps.h:142-150 on the two finished hops
+				carry[k][j] = y[4 + j];
+			}
+		}
+		// (the hop before it went out inside this turn's first transform)  Where this one goes (finalize_spec_kernel's
+		// destination arithmetic): a hop that lies inside the destination as a whole -- all of them but a few at either end of
+		// a clip -- waits for the next turn; one that is cut by the destination's ends, or has a second copy to leave
+		// (FinalizeArgs::dup_*: the last hops of a clip), is stored here and now, sample by sample.
+		pend.base = sink_s;
+#pragma unroll
+		for (int j = 0; j < 4; ++j)
+			pend.v[j] = v[j];
+		if (i >= i0 && i < a.n_frames) {
+			const long long h0 = a.pos0 + (long long)i * HOP; // position of the hop's first sample (uniform)
+			const long long d0 = h0 - G.shift;
+			if (d0 >= 0 && d0 + HOP <= G.len && h0 + HOP <= G.dup_from) {
+				pend.base = out_s + d0;
+			}
+			else {
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+					const long long p0 = h0 + tf + j * TF;
+					const long long d = p0 - G.shift;
+					if (d >= 0 && d < G.len)
+						out_s[d] = v[j];
+					if (p0 >= G.dup_from) {
+						const long long d2 = p0 - G.dup_shift;
+						if (d2 >= 0 && d2 < G.dup_len)
+							out_s[d2] = v[j];
+					}
+				}
+			}
+		}
+		if (i == a.n_frames - 1) {
+#pragma unroll
+			for (int k = 0; k < NG; ++k)
+#pragma unroll
+				for (int j = 0; j < 4; ++j)
+					if (k < G.n_out)
+						G.carry_next[k][(long long)s * HOP + tf + j * TF] = carry[k][j];
+		}
+	}
+	pend.flush();
 }
 
 template <int LOG2N>
@@ -587,8 +736,20 @@ int launch_istft_run_t(const IstftRunArgs& a, hipStream_t stream)
 		ZH_HIP(hipGetLastError());
 		return ZEN_HIP_OK;
 	}
+	else if constexpr (PL::V != 16) {
+		ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "istft runs: nfft = 2^%d with %d values per thread", LOG2N, PL::V);
+	}
 	else {
-		ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "istft runs: nfft = 2^%d", LOG2N);
+		int ng = 1; // (a call with groups of one and of two outputs -- pass 1: {H}, {P, R} -- runs the build for two: a group of one
+		for (int g = 0; g < a.n_groups; ++g) // leaves the second output's turn out, a workgroup-uniform branch)
+			ng = a.g[g].n_out > ng ? a.g[g].n_out : ng;
+		auto kern = ng == 2 ? istft_run_wide_kernel<LOG2N, 2> : istft_run_wide_kernel<LOG2N, 1>;
+		ZH_TRY(set_lds(kern, lds_bytes<LOG2N>()));
+		const size_t runs = ceil_div((size_t)a.n_frames, (size_t)a.run);
+		dim3 grid((unsigned)ceil_div(runs, (size_t)PL::FRAMES_PER_BLOCK), (unsigned)a.n_streams, (unsigned)a.n_groups);
+		hipLaunchKernelGGL(kern, grid, dim3(PL::THREADS), lds_bytes<LOG2N>(), stream, a);
+		ZH_HIP(hipGetLastError());
+		return ZEN_HIP_OK;
 	}
 }
 
@@ -673,19 +834,34 @@ int launch_mask_bits_transpose(int nfft, const IstftArgs& a, unsigned* bits_t, h
 	return ZEN_HIP_OK;
 }
 
-// nfft 256 .. 1024 (hop 64 .. 256): a frame is one wavefront or less, and its rows cost more than its transform
-bool istft_run_available(int log2n) { return log2n >= 8 && log2n <= 10; }
+// nfft 256 .. 1024 (hop 64 .. 256; a frame is one wavefront or less): one group of one output, the next frame's row prefetched;
+// nfft 2048 .. 16384: up to three groups of one or two outputs (16 values per thread: not the ZEN_FFT16K_V = 32 A/B build)
+bool istft_run_available(int log2n, int n_groups, int max_outputs_per_group)
+{
+	if (log2n >= 8 && log2n <= 10)
+		return n_groups == 1 && max_outputs_per_group == 1;
+	if (log2n == 14 && zfft::Plan<14>::V != 16)
+		return false;
+	return log2n >= 11 && log2n <= 14 && n_groups >= 1 && n_groups <= 3 && max_outputs_per_group <= 2;
+}
 
 int launch_istft_run(int log2n, const IstftRunArgs& a, hipStream_t stream)
 {
-	if (a.n_frames <= 0)
+	if (a.n_frames <= 0 || a.n_groups <= 0)
 		return ZEN_HIP_OK;
-	if (a.run < 1 || a.hop != (1 << log2n) / 4)
-		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "istft runs: run = %d, hop = %d at nfft 2^%d", a.run, a.hop, log2n);
+	int ng = 0;
+	for (int g = 0; g < a.n_groups && g < 3; ++g)
+		ng = a.g[g].n_out > ng ? a.g[g].n_out : ng;
+	if (a.run < 1 || a.hop != (1 << log2n) / 4 || !istft_run_available(log2n, a.n_groups, ng))
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "istft runs: run = %d, hop = %d, %d groups of up to %d outputs at nfft 2^%d", a.run, a.hop, a.n_groups, ng, log2n);
 	switch (log2n) {
 	case 8: return launch_istft_run_t<8>(a, stream);
 	case 9: return launch_istft_run_t<9>(a, stream);
 	case 10: return launch_istft_run_t<10>(a, stream);
+	case 11: return launch_istft_run_t<11>(a, stream);
+	case 12: return launch_istft_run_t<12>(a, stream);
+	case 13: return launch_istft_run_t<13>(a, stream);
+	case 14: return launch_istft_run_t<14>(a, stream);
 	default: ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "istft runs: nfft = 2^%d", log2n);
 	}
 }

@@ -114,9 +114,19 @@ struct FinalizeArgs {
 	long long pos0, shift, len, dup_from, dup_shift, dup_len;
 };
 
-// Synthesis in runs (istft.hip istft_run_kernel; the offline driver's small-hop pass): hard masks from IstftArgs::bits_t,
-// one output; a wavefront walks a run of consecutive frames of a stream with the overlap-add carry in registers and writes
-// the finished hops where FinalizeArgs (second part) says: no Y rows, no overlap-add launch.
+// Synthesis in runs (istft.hip istft_run_kernel / istft_run_wide_kernel; the passes of the offline driver): hard masks from
+// IstftArgs::bits_t; a wavefront (nfft <= 1024) or a workgroup walks a run of consecutive frames of a stream with the
+// overlap-add carry in registers and writes the finished hops where FinalizeArgs (second part) says: no Y rows, no
+// overlap-add launch.  A GROUP is what one destination receives: the finished hops of one output, or the sum of those of
+// two (FinalizeArgs::Y2: P + R of pass 1, hps.cu:153-160).
+struct IstftRunGroup {
+	int n_out;               // 1 or 2
+	int which[2];            // output ids (0 percussive, 1 harmonic, 2 residual)
+	const float* carry_prev[2]; // [n_streams][hop]: second half of the frame before frame 0 (the previous call's carry_next)
+	float* carry_next[2];       // receives the second half of frame n_frames - 1
+	float* out;              // destination of the finished hops, as FinalizeArgs: out, out_stride, shift, len, dup_*
+	long long out_stride, shift, len, dup_from, dup_shift, dup_len;
+};
 struct IstftRunArgs {
 	const float2* S;        // the spectrum ring (IstftArgs::S, s_stride, ring_rows): frame i of the call is row crow0 + i
 	long long s_stride, ring_rows, crow0;
@@ -124,15 +134,15 @@ struct IstftRunArgs {
 	const unsigned* bits_t; // row i: the masks of frame i (IstftArgs::bits_t)
 	long long bits_t_stream_stride;
 	int n_frames, n_streams, hop;
-	int which, out_h, out_p; // the output (0 percussive, 1 harmonic, 2 residual) and which masks the residual reads
+	int out_h, out_p;        // which masks the residual reads (hps.cu:562-567)
 	float cola;
-	const float* carry_prev; // [n_streams][hop]: second half of the frame before frame 0 (the previous call's carry_next)
-	float* carry_next;       // receives the second half of frame n_frames - 1
-	int run;                 // consecutive frames per wavefront (each run but a call's first synthesises one frame more)
-	float* out;              // destination of the finished hops, as FinalizeArgs: out, out_stride, pos0, shift, len, dup_*
-	long long out_stride, pos0, shift, len, dup_from, dup_shift, dup_len;
+	int run;                 // consecutive frames per run (each run but a call's first synthesises one frame more)
+	long long pos0;          // FinalizeArgs::pos0
+	int n_groups;            // nfft <= 1024: one group of one output
+	float* sink;             // [n_streams][hop] floats nobody reads (istft_run_wide_kernel: a turn without a finished hop stores there)
+	IstftRunGroup g[3];
 };
-bool istft_run_available(int log2n);
+bool istft_run_available(int log2n, int n_groups, int max_outputs_per_group);
 int launch_istft_run(int log2n, const IstftRunArgs& a, hipStream_t stream);
 
 int launch_stft(int log2n, const StftArgs& a, hipStream_t stream);
