@@ -84,11 +84,81 @@ def run(seconds, seed):
     return n_ok, n_bad, n_skip, len(seen)
 
 
+def run_offline(seconds, seed):
+    """The two-pass offline driver (HPRIOffline::process on host vectors) on random clips, hops, sample rates and mask
+    types, with the engines' chunk size and the run lengths of the synthesis-in-runs kernels drawn at random too (0 = the
+    library's own choice).  Returns (ok, mismatches, skipped, distinct configurations)."""
+    rng = np.random.default_rng(seed)
+    zen_amd.init(0)
+    t_end = time.time() + seconds
+    n_ok = n_bad = n_skip = 0
+    seen = set()
+    opts = ("offline_chunk_hops", "istft_run", "istft_run_wide", "no_istft_runs", "offline_range")
+    while time.time() < t_end:
+        fs = float(rng.choice([8000, 16000, 22050, 32000, 44100, 48000, 96000]))
+        hop_p = int(rng.choice([32, 64, 128, 256, 512]))
+        hop_h = hop_p * int(rng.choice([1, 2, 4, 8, 16]))
+        if hop_h > 4096:
+            continue
+        beta_h, beta_p = float(rng.choice([1.5, 2.0, 3.0])), float(rng.choice([2.0, 2.5]))
+        mode = str(rng.choice(["hard", "hard", "soft", "sse"]))
+        n = int(rng.integers(1, 30)) * hop_h + int(rng.integers(0, hop_h))
+        try:
+            ro = o.HPRIOffline(fs, hop_h, hop_p, beta_h, beta_p)
+            eh = o.HPR(fs, hop_h, beta_h, 7, o.TIME_ANTICAUSAL)
+            ep = o.HPR(fs, hop_p, beta_p, 1, o.TIME_ANTICAUSAL)
+        except Exception:
+            n_skip += 1
+            continue
+        if max(eh.l_perc | 1, ep.l_perc | 1, eh.l_harm | 1, ep.l_harm | 1) > 255:
+            n_skip += 1
+            continue
+        if mode == "soft":
+            ro.use_soft_mask()
+        if mode == "sse":
+            ro.use_sse_filter()
+        x = rng.uniform(-1, 1, n).astype(np.float32)
+        x *= (rng.uniform(0, 1, n) < 0.8)
+        ref = ro.process(x)
+        cfg = {"offline_chunk_hops": int(rng.choice([0, 0, 8, 24, 100])), "istft_run": int(rng.choice([0, 0, 1, 5, 33])),
+               "istft_run_wide": int(rng.choice([0, 0, 1, 4, 9])), "no_istft_runs": int(rng.choice([0, 0, 0, 2])),
+               "offline_range": int(rng.choice([0, 0, 4 * hop_h, 9 * hop_h]))}
+        for k in opts:
+            zen_amd.set_option(k, cfg[k])
+        try:
+            g = zen_amd.HPRIOffline(fs, hop_h, hop_p, beta_h, beta_p)
+            if mode == "soft":
+                g.use_soft_mask()
+            if mode == "sse":
+                g.use_sse_filter()
+            got = g.process(x)
+            ok = all(np.array_equal(a, b, equal_nan=True) for a, b in zip(got, ref))
+        except zen_amd.ZenHipError as e:
+            print("GPU refused", fs, hop_h, hop_p, e)
+            n_skip += 1
+            continue
+        finally:
+            for k in opts:
+                zen_amd.set_option(k, 0)
+        seen.add((fs, hop_h, hop_p, mode))
+        if ok:
+            n_ok += 1
+        else:
+            n_bad += 1
+            print("MISMATCH offline", dict(fs=fs, hop_h=hop_h, hop_p=hop_p, beta_h=beta_h, beta_p=beta_p, mode=mode, n=n, **cfg), flush=True)
+    return n_ok, n_bad, n_skip, len(seen)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--offline", action="store_true", help="fuzz the two-pass offline driver instead of the streaming engine")
     args = ap.parse_args()
+    if args.offline:
+        n_ok, n_bad, n_skip, n_seen = run_offline(args.seconds, args.seed)
+        print("offline: ok %d  mismatches %d  skipped %d  distinct (fs, hop_h, hop_p, mode): %d" % (n_ok, n_bad, n_skip, n_seen))
+        return 1 if n_bad else 0
     n_ok, n_bad, n_skip, n_seen = run(args.seconds, args.seed)
     print("ok %d  mismatches %d  skipped %d  distinct (fs, hop, masks, causality, mode): %d" % (n_ok, n_bad, n_skip, n_seen))
     return 1 if n_bad else 0
