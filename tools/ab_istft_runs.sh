@@ -1,10 +1,10 @@
 #!/bin/bash
-# A/B of the offline batch step: synthesis in runs (istft_run_kernel: pass 2; istft_run_wide_kernel: pass 1) against the
-# synthesis + overlap-add launches, and the run lengths.  "no_istft_runs": 1 = neither pass, 2 = pass 2 only.
-python -m pytest tests/test_gpu_round4.py -x -q -k "synthesised_in_runs" 2>&1 | tail -3
-
-for cfg in "no_istft_runs=1" "no_istft_runs=0"; do
-  ZEN_HIP_OPTIONS=$cfg python bench.py --workload offline_batch --steps 10 --warmup 2 --detail > gpurun_out/ab_r.json 2> gpurun_out/ab_r.err
+# A/B of the offline steps: synthesis in runs (istft_run_kernel / istft_run_wide_kernel) against the synthesis + overlap-add
+# launches.  "no_istft_runs": 1 = neither pass, 2 = not for nfft >= 2048.  Usage: tools/ab_istft_runs.sh [workload] [cfg ...]
+W=${1:-offline_batch}; shift
+CFGS=("$@"); [ ${#CFGS[@]} -eq 0 ] && CFGS=("no_istft_runs=1" "no_istft_runs=2" "no_istft_runs=0")
+for cfg in "${CFGS[@]}"; do
+  ZEN_HIP_OPTIONS=$cfg python bench.py --workload $W --steps 10 --warmup 2 --detail > gpurun_out/ab_r.json 2> gpurun_out/ab_r.err
   python - "$cfg" <<EOF
 import json,sys
 d=json.loads(open("gpurun_out/ab_r.json").read().strip().splitlines()[-1])
