@@ -84,7 +84,12 @@ int zen_hip_event_destroy(void* event);
  * their own, never from the frequency-direction median kernel; "no_direct_out" = 1: the fused block kernel
  * of the headline configuration leaves the overlap-add to a launch of its own; "median47_variant" = 1 lets
  * median47_dpp_kernel store results without the LDS transpose; "offline_range" / "offline_no_register": see
- * zen_hip_hpri_process.
+ * zen_hip_hpri_process; "no_istft_runs" = 1: the passes of HPRIOffline with hard masks write synthesis rows and add the
+ * overlapping halves in a launch of its own instead of walking runs of frames with the carry in registers (2: only the
+ * large-hop pass does), "istft_run" / "istft_run_wide" = frames per run of the two kernels (0: the library's choice);
+ * "offline_chunk_hops" = n: HPRIOffline handles created from now on process at most n hops per launch in either pass
+ * (a bound on their device buffers; 0: sized by the device memory cap).  "no_sse_block", "no_median_tf",
+ * "no_istft_xcd_map": the launch-per-stage alternatives of the fused kernels of round 4.
  * Timing diagnostics whose outputs are NOT the reference's ("median47_variant" 2..4, "rt_fused_diag") and the
  * divide-based cross-check of the hard masks ("mask_divide") exist in -DZEN_HIP_DIAG builds of the library only; the
  * shipped build answers ZEN_HIP_E_UNSUPPORTED. */
