@@ -146,9 +146,9 @@ void free_all(zen_hip_hpr* e)
 // Up to eight pitched regions zeroed by one launch (reset_state: seven memsets of a few KB to MB each were 0.1 ms of
 // launch gaps per offline step, two engines reset per call).  Everything in 16-byte units: the engine's buffers are.
 struct ZeroJobs {
-	void* p[8];
-	long long pitch16[8], width16[8]; // in 16-byte units
-	int rows[8];
+	void* p[12];
+	long long pitch16[12], width16[12]; // in 16-byte units
+	int rows[12];
 	int n;
 };
 __global__ __launch_bounds__(256) void zero_regions_kernel(ZeroJobs z)
@@ -165,7 +165,7 @@ bool add_zero_job(ZeroJobs& z, void* p, size_t pitch_bytes, size_t width_bytes, 
 {
 	if (!p || width_bytes == 0 || rows == 0)
 		return true;
-	if (z.n >= 8 || ((reinterpret_cast<uintptr_t>(p) | pitch_bytes | width_bytes) & 15) != 0 || rows > 0x7fffffff)
+	if (z.n >= 12 || ((reinterpret_cast<uintptr_t>(p) | pitch_bytes | width_bytes) & 15) != 0 || rows > 0x7fffffff)
 		return false;
 	z.p[z.n] = p;
 	z.pitch16[z.n] = (long long)(pitch_bytes >> 4);
@@ -189,11 +189,13 @@ int reset_state(zen_hip_hpr* e)
 		     && add_zero_job(z, e->d_mag, mrow * e->ring_rows, mrow * (e->W - 1), S);
 	for (int o = 0; o < 3; ++o)
 		ok = ok && add_zero_job(z, e->d_carry[o], hopb, hopb, 1);
+	for (int o = 0; o < 3; ++o) // (synthesis in runs: the carry a fresh stream's first run starts from)
+		ok = ok && add_zero_job(z, e->d_run_carry[e->run_sel][o], hopb, hopb, 1);
 	if (ok && z.n > 0) {
 		hipLaunchKernelGGL(zero_regions_kernel, dim3(64, (unsigned)z.n), dim3(256), 0, e->stream, z);
 		ZH_HIP(hipGetLastError());
 	}
-	else if (!ok) { // (a hop that is not a multiple of four samples: the seven memsets)
+	else if (!ok) { // (a hop that is not a multiple of four samples: the memsets)
 		ZH_HIP(hipMemsetAsync(e->d_tail[0], 0, hopb, e->stream));
 		ZH_HIP(hipMemsetAsync(e->d_tail[1], 0, hopb, e->stream));
 		if (e->W > 1) {
@@ -203,6 +205,9 @@ int reset_state(zen_hip_hpr* e)
 		for (int o = 0; o < 3; ++o)
 			if (e->d_carry[o])
 				ZH_HIP(hipMemsetAsync(e->d_carry[o], 0, hopb, e->stream));
+		for (int o = 0; o < 3; ++o)
+			if (e->d_run_carry[e->run_sel][o])
+				ZH_HIP(hipMemsetAsync(e->d_run_carry[e->run_sel][o], 0, hopb, e->stream));
 	}
 	e->tail_sel = 0;
 	e->rows_stale = false;
@@ -1161,10 +1166,12 @@ int hpr_process_spec(zen_hip_hpr* h, const float* in_dev, size_t n_hops, size_t 
 		for (int g = 0; g < h->run_n_groups; ++g)
 			for (int k = 0; k < h->run_groups[g].n_out; ++k) {
 				const int o = h->run_groups[g].which[k];
-				for (int b = 0; b < 2; ++b)
-					if (!h->d_run_carry[b][o])
-						ZH_HIP(hipMalloc((void**)&h->d_run_carry[b][o], hopb));
-				ZH_HIP(hipMemsetAsync(h->d_run_carry[h->run_sel][o], 0, hopb, h->stream)); // a fresh stream: nothing to add to its first hop
+				if (h->d_run_carry[0][o])
+					continue; // (zeroed by the reset the pass started from: reset_state)
+				for (int b = 0; b < 2; ++b) {
+					ZH_HIP(hipMalloc((void**)&h->d_run_carry[b][o], hopb));
+					ZH_HIP(hipMemsetAsync(h->d_run_carry[b][o], 0, hopb, h->stream)); // a fresh stream: nothing to add to its first hop
+				}
 			}
 		if (!h->d_run_sink)
 			ZH_HIP(hipMalloc((void**)&h->d_run_sink, hopb));
