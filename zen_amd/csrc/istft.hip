@@ -600,9 +600,9 @@ struct IstftRunWideIn : IstftIn<3, 16> {
 	IstftRunPend* pend; // null: nothing to store behind this transform's loads
 	__device__ __forceinline__ void prepare()
 	{
-		IstftIn<3, 16>::prepare();
-		if (pend) // (compile-time after inlining: the first transform of a turn)
+		if (pend) // (compile-time after inlining: the first transform of a turn)  Before the mask codes: those wait for the word of bits
 			pend->flush();
+		IstftIn<3, 16>::prepare();
 	}
 };
 
