@@ -9,6 +9,6 @@ for cfg in "${CFGS[@]}"; do
 import json,sys
 d=json.loads(open("gpurun_out/ab_r.json").read().strip().splitlines()[-1])
 k=d.get("kernels") or {}
-print(sys.argv[1], round(d.get("ms_per_step"),4), round(d.get("x_realtime")), d.get("checksum"), {a:round(b["ms_per_step"],4) for a,b in k.items() if "istft" in a or "finalize" in a})
+print(sys.argv[1], round(d.get("ms_per_step"),4), round(d.get("x_realtime")), d.get("checksum"), {a:round(b["ms_per_step"],4) for a,b in k.items() if "istft" in a or "finalize" in a or "freq" in a})
 EOF
 done
