@@ -1060,10 +1060,15 @@ int pick_wide_run(zen_hip_hpr* e, size_t M, size_t S, const int* group_outputs, 
 		useful += (size_t)group_outputs[g] * M * S;
 	int best = 0;
 	double best_t = 0.0;
+	if (S * (size_t)n_groups >= 16 * slots) { // so many streams that any split fills the device: long runs, nothing to simulate
+		e->run_pick = (int)(M < 96 ? M : (M + (M + 95) / 96 - 1) / ((M + 95) / 96));
+		e->run_pick_eff = 1.0;
+		return e->run_pick;
+	}
 	std::vector<double> busy(slots);
 	for (size_t k = 1; k <= 64 && k <= M; ++k) { // runs per stream
 		const size_t run = (M + k - 1) / k, kk = (M + run - 1) / run;
-		if (run < 8)
+		if (run < 8 || (best != 0 && S * kk * (size_t)n_groups > 64 * slots)) // (more workgroups than that balance themselves)
 			break;
 		std::fill(busy.begin(), busy.end(), 0.0);
 		std::make_heap(busy.begin(), busy.end(), std::greater<double>());
