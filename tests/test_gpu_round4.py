@@ -470,13 +470,13 @@ def _runs_expected(n_hops, hop, chunk, groups, run):
     kernel = (8 <= log2n <= 10 and groups == 1) or 11 <= log2n <= 14
     if log2n > 10 and run == 0:
         return None
-    return kernel and n_hops >= 8 and (chunk == 0 or n_hops % chunk == 0 or n_hops % chunk >= 8)
+    return kernel and min(n_hops, chunk or n_hops) >= 8 and (chunk == 0 or n_hops % chunk == 0 or n_hops % chunk >= 8)
 
 
 @pytest.mark.parametrize("hop_h,hop_p,n", [(4096, 256, 161571), (1024, 256, 70001), (2048, 128, 50000), (4096, 256, 4096 * 9 + 1),
                                            (512, 128, 30000), (4096, 256, 2100), (256, 64, 9000), (4096, 1024, 120000),
                                            (2048, 512, 77777)])
-@pytest.mark.parametrize("chunk,run", [(0, 0), (64, 16), (40, 7), (8, 1), (24, 64)])
+@pytest.mark.parametrize("chunk,run", [(0, 0), (64, 16), (40, 7), (8, 1), (24, 64), (3, 0), (1, 5)])
 def test_offline_passes_synthesised_in_runs(z, hop_h, hop_p, n, chunk, run):
     """Both passes of HPRIOffline with hard masks (hps.cu:142-167: H, and P + R summed for pass 2; :185-205: P alone): a
     wavefront (nfft <= 1024) or a workgroup synthesises a run of consecutive frames, adds the overlapping halves in

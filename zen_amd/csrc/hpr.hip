@@ -1138,8 +1138,8 @@ bool run_pass_groups(zen_hip_hpr* e, size_t n_hops, const HprOutSpec (&spec)[3])
 		if (pick_wide_run(e, M0, e->n_streams, outs, ng, e->log2n, 0.92) == 0)
 			return false;
 	}
-	const size_t last = n_hops % e->max_hops;
-	if (n_hops < 8 || (last != 0 && last < 8))
+	const size_t last = n_hops % e->max_hops, first = n_hops < e->max_hops ? n_hops : e->max_hops;
+	if (first < 8 || (last != 0 && last < 8)) // (every chunk of the pass: run_chunk's masks-as-bits road starts at 8 frames)
 		return false;
 	const HardThr thr = hard_mask_thresholds(e->beta, e->beta - FLT_EPSILON, false);
 	if (thr.p == 0.0 || thr.h == 0.0 || !mask_bits_supported((int)e->nfft, e->mf / 2) || !filter_supports_hermitian(e->mf, (int)e->nfft)
