@@ -276,6 +276,12 @@ int zen_hip_hpri_process_range(zen_hip_hpri_t h, const float* audio_dev, size_t 
 /* profiling hooks for bench.py, as zen_hip_hpr_profile / _get_all, per pass (1: hop_h, 2: hop_p) */
 int zen_hip_hpri_profile(zen_hip_hpri_t h, int enable);
 int zen_hip_hpri_profile_get_all(zen_hip_hpri_t h, int pass, double ms[6], unsigned long long launches[6]);
+/* How a pass of `frames` frames per stream at transform size nfft (2048..16384) would be synthesised in runs (no
+ * reference counterpart; host arithmetic only, no device needed): group_outputs[g] = 1 or 2 outputs summed into destination
+ * g (pass 1 of HPRIOffline with hard masks: {2, 1} = P + R, H).  *run = frames per run, or 0 where the long workgroups
+ * of such runs would leave the device less than 92 % busy and the pass keeps one launch per frame; *busy (may be NULL) =
+ * the simulated share of the device's workgroup slots doing useful transforms. */
+int zen_hip_run_plan(size_t frames, size_t streams, size_t nfft, const int* group_outputs, int n_groups, int* run, double* busy);
 /* hops the two passes run for an n-sample clip (hps.cu:109-126), for throughput accounting */
 int zen_hip_hpri_hop_counts(zen_hip_hpri_t h, size_t n, size_t* n_hops_h, size_t* n_hops_p);
 

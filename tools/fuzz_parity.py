@@ -117,24 +117,45 @@ def run_offline(seconds, seed):
             ro.use_soft_mask()
         if mode == "sse":
             ro.use_sse_filter()
-        x = rng.uniform(-1, 1, n).astype(np.float32)
-        x *= (rng.uniform(0, 1, n) < 0.8)
+        clips = int(rng.choice([1, 1, 1, 2, 5]))      # > 1: zen_hip_hpri_process_device, one stream per clip
+        xs = rng.uniform(-1, 1, (clips, n)).astype(np.float32)
+        xs *= (rng.uniform(0, 1, xs.shape) < 0.8)
+        x = xs[0]
         ref = ro.process(x)
+        refs = [ref]
+        for c in range(1, clips):
+            rc = o.HPRIOffline(fs, hop_h, hop_p, beta_h, beta_p)
+            if mode == "soft":
+                rc.use_soft_mask()
+            if mode == "sse":
+                rc.use_sse_filter()
+            refs.append(rc.process(xs[c]))
         cfg = {"offline_chunk_hops": int(rng.choice([0, 0, 1, 3, 8, 24, 100])), "istft_run": int(rng.choice([0, 0, 1, 5, 33])),
                "istft_run_wide": int(rng.choice([0, 0, 1, 4, 9])), "no_istft_runs": int(rng.choice([0, 0, 0, 2])),
                "offline_range": int(rng.choice([0, 0, 4 * hop_h, 9 * hop_h]))}
         for k in opts:
             zen_amd.set_option(k, cfg[k])
         try:
-            g = zen_amd.HPRIOffline(fs, hop_h, hop_p, beta_h, beta_p)
+            g = zen_amd.HPRIOffline(fs, hop_h, hop_p, beta_h, beta_p, n_clips=clips)
             if mode == "soft":
                 g.use_soft_mask()
             if mode == "sse":
                 g.use_sse_filter()
-            got = g.process(x)
-            ok = all(np.array_equal(a, b, equal_nan=True) for a, b in zip(got, ref))
+            if clips == 1:
+                got = g.process(x)
+                ok = all(np.array_equal(a, b, equal_nan=True) for a, b in zip(got, ref))
+            else:
+                din, dh, dp, dr = (zen_amd.DeviceBuffer(clips * n) for _ in range(4))
+                din.upload(xs.reshape(-1))
+                g.process_device(din.ptr, n, n, harm=dh.ptr, perc=dp.ptr, resid=dr.ptr, out_stride=n)
+                zen_amd.synchronize()
+                H, P, R = (b.download().reshape(clips, n) for b in (dh, dp, dr))
+                ok = all(np.array_equal(H[c], refs[c][0], equal_nan=True) and np.array_equal(P[c], refs[c][1], equal_nan=True)
+                         and np.array_equal(R[c], refs[c][2], equal_nan=True) for c in range(clips))
+                for b in (din, dh, dp, dr):
+                    b.free()
         except zen_amd.ZenHipError as e:      # the oracle accepted the configuration: a refusal is a failure
-            print("GPU refused", dict(fs=fs, hop_h=hop_h, hop_p=hop_p, mode=mode, n=n, **cfg), e, flush=True)
+            print("GPU refused", dict(fs=fs, hop_h=hop_h, hop_p=hop_p, mode=mode, n=n, clips=clips, **cfg), e, flush=True)
             ok = False
         finally:
             for k in opts:
@@ -144,7 +165,7 @@ def run_offline(seconds, seed):
             n_ok += 1
         else:
             n_bad += 1
-            print("MISMATCH offline", dict(fs=fs, hop_h=hop_h, hop_p=hop_p, beta_h=beta_h, beta_p=beta_p, mode=mode, n=n, **cfg), flush=True)
+            print("MISMATCH offline", dict(fs=fs, hop_h=hop_h, hop_p=hop_p, beta_h=beta_h, beta_p=beta_p, mode=mode, n=n, clips=clips, **cfg), flush=True)
     return n_ok, n_bad, n_skip, len(seen)
 
 

@@ -1043,28 +1043,22 @@ int finalize_spec(zen_hip_hpr* e, int o, const HprOutSpec& sp, size_t M, long lo
 // order (groups of two outputs first), each to the slot that is free first; the shortest makespan wins.  Returns 0 when
 // even that leaves the device less than `min_eff` busy with useful transforms: the caller keeps the per-frame launches,
 // whose workgroups are one transform long.
-int pick_wide_run(zen_hip_hpr* e, size_t M, size_t S, const int* group_outputs, int n_groups, int log2n, double min_eff)
+// (plan_wide_run: the simulation itself, zen_hip_run_plan's body; pick_wide_run: the engine's cached question)
+int plan_wide_run(size_t M, size_t S, const int* group_outputs, int n_groups, int log2n, double* eff)
 {
-	int sig = n_groups; // (the simulation costs a millisecond: once per shape)
-	for (int g = 0; g < n_groups; ++g)
-		sig = sig * 4 + group_outputs[g];
-	if (e->run_pick_M == M && e->run_pick_sig == sig)
-		return e->run_pick_eff < min_eff ? 0 : e->run_pick;
-	e->run_pick_M = M;
-	e->run_pick_sig = sig;
-	e->run_pick = 0;
-	e->run_pick_eff = 0.0;
 	const size_t slots = 256 * (size_t)(log2n >= 14 ? 1 : (log2n == 13 ? 2 : 4)); // workgroups the device holds at once
 	size_t useful = 0;
 	for (int g = 0; g < n_groups; ++g)
 		useful += (size_t)group_outputs[g] * M * S;
+	*eff = 0.0;
+	if (M == 0 || S == 0 || n_groups <= 0)
+		return 0;
+	if (S * (size_t)n_groups >= 16 * slots) { // so many streams that any split fills the device: long runs, nothing to simulate
+		*eff = 1.0;
+		return (int)(M < 96 ? M : (M + (M + 95) / 96 - 1) / ((M + 95) / 96));
+	}
 	int best = 0;
 	double best_t = 0.0;
-	if (S * (size_t)n_groups >= 16 * slots) { // so many streams that any split fills the device: long runs, nothing to simulate
-		e->run_pick = (int)(M < 96 ? M : (M + (M + 95) / 96 - 1) / ((M + 95) / 96));
-		e->run_pick_eff = 1.0;
-		return e->run_pick;
-	}
 	std::vector<double> busy(slots);
 	for (size_t k = 1; k <= 64 && k <= M; ++k) { // runs per stream
 		const size_t run = (M + k - 1) / k, kk = (M + run - 1) / run;
@@ -1086,11 +1080,22 @@ int pick_wide_run(zen_hip_hpr* e, size_t M, size_t S, const int* group_outputs, 
 			best_t = t;
 		}
 	}
-	if (best == 0)
-		return 0;
-	e->run_pick = best;
-	e->run_pick_eff = (double)useful / ((double)slots * best_t);
-	return e->run_pick_eff < min_eff ? 0 : best;
+	if (best != 0)
+		*eff = (double)useful / ((double)slots * best_t);
+	return best;
+}
+
+int pick_wide_run(zen_hip_hpr* e, size_t M, size_t S, const int* group_outputs, int n_groups, int log2n, double min_eff)
+{
+	int sig = n_groups; // (the simulation costs up to a millisecond: once per shape)
+	for (int g = 0; g < n_groups; ++g)
+		sig = sig * 4 + group_outputs[g];
+	if (!(e->run_pick_M == M && e->run_pick_sig == sig)) {
+		e->run_pick_M = M;
+		e->run_pick_sig = sig;
+		e->run_pick = plan_wide_run(M, S, group_outputs, n_groups, log2n, &e->run_pick_eff);
+	}
+	return e->run_pick_eff < min_eff ? 0 : e->run_pick;
 }
 
 // Can the pass be synthesised in runs (IstftRunArgs)?  Fills e->run_groups.  What it takes: a fresh stream (the pass starts
@@ -1403,6 +1408,21 @@ int zen_hip_hpr_resident_stats(zen_hip_hpr_t h, unsigned long long* launches, un
 		*hops = h->res_hops; // (of the launches that have ended)
 	if (active)
 		*active = h->res_active ? 1 : 0;
+	return ZEN_HIP_OK;
+}
+
+int zen_hip_run_plan(size_t frames, size_t streams, size_t nfft, const int* group_outputs, int n_groups, int* run, double* busy)
+{
+	if (!group_outputs || n_groups < 1 || n_groups > 3 || !run || !is_pow2(nfft) || nfft < 2048 || nfft > 16384)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "zen_hip_run_plan: 1..3 groups of 1 or 2 outputs, nfft 2048..16384");
+	for (int g = 0; g < n_groups; ++g)
+		if (group_outputs[g] < 1 || group_outputs[g] > 2)
+			ZH_FAIL(ZEN_HIP_E_BAD_ARG, "zen_hip_run_plan: a group has 1 or 2 outputs");
+	double eff = 0.0;
+	const int r = plan_wide_run(frames, streams, group_outputs, n_groups, ilog2(nfft), &eff);
+	*run = eff < 0.92 ? 0 : r; // (run_pass_groups' threshold)
+	if (busy)
+		*busy = eff;
 	return ZEN_HIP_OK;
 }
 

@@ -108,6 +108,7 @@ SYMBOLS = [
     ("zen_hip_hpri_range_halo", _i, [_vp, _sz, _sz, _sz, C.POINTER(_sz), C.POINTER(_sz)]),
     ("zen_hip_hpri_process_range", _i, [_vp, _vp, _sz, _sz, _sz, _vp, _vp]),
     ("zen_hip_hpri_hop_counts", _i, [_vp, _sz, C.POINTER(_sz), C.POINTER(_sz)]),
+    ("zen_hip_run_plan", _i, [_sz, _sz, _sz, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     ("zen_hip_hpri_profile", _i, [_vp, _i]),
     ("zen_hip_hpri_profile_get_all", _i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong)]),
 ]
@@ -170,6 +171,14 @@ class Event:
 
 def synchronize(stream=None):
     _ck(load().zen_hip_synchronize(stream))
+
+
+def run_plan(frames, streams, nfft, group_outputs=(2, 1)):
+    """zen_hip_run_plan: (frames per run or 0, simulated busy share) for a pass synthesised in runs; host arithmetic only."""
+    g = (C.c_int * len(group_outputs))(*group_outputs)
+    run, busy = C.c_int(), C.c_double()
+    _ck(load().zen_hip_run_plan(frames, streams, nfft, g, len(group_outputs), C.byref(run), C.byref(busy)))
+    return run.value, busy.value
 
 
 def set_option(name, value):
