@@ -573,3 +573,47 @@ def test_offline_batch_config4_runs_engage_and_match_the_launches(z):
     assert np.array_equal(outs[0][1][:n], outs[0][1][4 * n:5 * n])   # clip 4 is clip 0 again
     for bfr in (din, dh, dp):
         bfr.free()
+
+
+def test_ten_minute_clip_runs_across_the_engines_own_chunks(z):
+    """One 10-minute mono clip with hard masks, resident in HBM: pass 2 has 103 000 hops, more than the 65 536 an engine takes
+    per launch, so the carry of the synthesis in runs crosses a chunk boundary at the engine's own chunk size (the small
+    cases above bound the chunks with an option).  Bit-identical to the synthesis + overlap-add launches, and to the oracle
+    on windows at the start, around the chunk boundary and at the end (an oracle started warm-up frames early reaches the
+    serial state: tests/test_gpu_round3.py)."""
+    import bench as b
+    n = 26460000
+    x = b.s_music(n, seed=5)
+    din, dh, dp = z.DeviceBuffer(n), z.DeviceBuffer(n), z.DeviceBuffer(n)
+    din.upload(x)
+    outs = []
+    for no_runs in (0, 1):
+        z.set_option("no_istft_runs", no_runs)
+        try:
+            g = z.HPRIOffline(FS, 4096, 256, 2.0, 2.0)
+            g.profile(True)
+            g.process_device(din.ptr, n, n, harm=dh.ptr, perc=dp.ptr, out_stride=n)
+            z.synchronize()
+            prof = g.profile_get_all()
+            assert (prof["pass2"]["finalize"]["launches"] == 0) == (no_runs == 0), prof["pass2"]
+            if no_runs == 0:
+                assert prof["pass2"]["istft"]["launches"] >= 2          # two chunks
+            outs.append((dh.download(), dp.download()))
+            del g
+        finally:
+            z.set_option("no_istft_runs", 0)
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    # oracle windows (the pattern of tests/test_gpu_round3.py): a slice that starts 12 pass-1 hops early, on a pass-1 hop
+    # boundary, reaches the serial state before the window; an output sample depends on a few hops of input beyond it
+    H, P = outs[0]
+    hop_h, lead, m = 4096, 12 * 4096, int(2 * FS)
+    rh, rp, _ = o.HPRIOffline(FS, 4096, 256, 2.0, 2.0).process(x[:int(4 * FS)])
+    assert np.array_equal(H[:m], rh[:m]) and np.array_equal(P[:m], rp[:m])
+    b0 = 65536 * 256 - (m // 2 // hop_h) * hop_h                 # the window straddles pass 2's chunk boundary
+    rh, rp, _ = o.HPRIOffline(FS, 4096, 256, 2.0, 2.0).process(x[b0 - lead:b0 + m + 8 * hop_h])
+    assert np.array_equal(H[b0:b0 + m], rh[lead:lead + m]) and np.array_equal(P[b0:b0 + m], rp[lead:lead + m])
+    e0 = ((n - m) // hop_h) * hop_h                              # the clip's end, padding and all
+    rh, rp, _ = o.HPRIOffline(FS, 4096, 256, 2.0, 2.0).process(x[e0 - lead:])
+    assert np.array_equal(H[e0:], rh[lead:]) and np.array_equal(P[e0:], rp[lead:])
+    for bfr in (din, dh, dp):
+        bfr.free()
