@@ -87,6 +87,34 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, LOG2N <= 11 ? 4 : 3) void sse
 			z[i] = S[idx > N / 2 ? N - idx : idx];
 		}
 	}
+	// the time box's rows, four per turn: their loads (tap_load), then their sums (tap_sum)
+	auto tap_load = [&](int j0, float (&m)[4][NLO], int (&d)[4]) {
+#pragma unroll
+		for (int jj = 0; jj < 4; ++jj) {
+			const int j = j0 + jj < b.len_t ? j0 + jj : b.len_t - 1;
+			long long r = ar - mid_t + j;
+			r = r < b.clamp_lo ? b.clamp_lo : (r > b.clamp_hi ? b.clamp_hi : r);
+			if (b.causal_self && r > ar)
+				r = ar;
+			d[jj] = (int)(r - ar); // |d| < ring_rows: the ring slot without a 64-bit remainder per row
+			int rs = base_slot + d[jj];
+			rs = rs < 0 ? rs + (int)a.ring_rows : (rs >= (int)a.ring_rows ? rs - (int)a.ring_rows : rs);
+			const float* mrow = b.mag + (ring_base + rs) * N;
+			if (d[jj] != 0) { // (frame-uniform.  The consumed row itself -- every tap past it of a causal engine -- is at hand: `own`)
+#pragma unroll
+				for (int i = 0; i < NLO; ++i)
+					m[jj][i] = mrow[i < 8 ? tf + i * TF : N / 2];
+			}
+			else {
+#pragma unroll
+				for (int i = 0; i < NLO; ++i)
+					m[jj][i] = 0.0f;
+			}
+		}
+	};
+	float m0[4][NLO]; // the first four rows of the time box: in flight together with the frame's own rows (one round trip
+	int d0[4];        // to memory less per frame: 0.522 -> 0.511 ms per 51 680 frames)
+	tap_load(0, m0, d0);
 	// ---- 1/|S|^2 of the frame's own row (lower half computed, both halves stored)
 	float own[NLO];
 	{
@@ -106,44 +134,34 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, LOG2N <= 11 ? 4 : 3) void sse
 			}
 		}
 	}
-	// ---- time box: rows ar - mid_t .. ar + mid_t in ascending order (box_time_kernel: clamped rows, causal_self)
-	{
-		float acc[NLO];
-		for (int j0 = 0; j0 < b.len_t; j0 += 4) {
-			float m[4][NLO];
-			int d[4];
+	auto tap_sum = [&](int j0, const float (&m)[4][NLO], const int (&d)[4], float (&acc)[NLO]) {
 #pragma unroll
-			for (int jj = 0; jj < 4; ++jj) {
-				const int j = j0 + jj < b.len_t ? j0 + jj : b.len_t - 1;
-				long long r = ar - mid_t + j;
-				r = r < b.clamp_lo ? b.clamp_lo : (r > b.clamp_hi ? b.clamp_hi : r);
-				if (b.causal_self && r > ar)
-					r = ar;
-				d[jj] = (int)(r - ar); // |d| < ring_rows: the ring slot without a 64-bit remainder per row
-				int rs = base_slot + d[jj];
-				rs = rs < 0 ? rs + (int)a.ring_rows : (rs >= (int)a.ring_rows ? rs - (int)a.ring_rows : rs);
-				const float* mrow = b.mag + (ring_base + rs) * N;
+		for (int jj = 0; jj < 4; ++jj) {
+			if (j0 + jj < b.len_t) {
+				if (d[jj] == 0) { // the consumed row itself: its 1/|S|^2 is at hand
 #pragma unroll
-				for (int i = 0; i < NLO; ++i)
-					m[jj][i] = mrow[i < 8 ? tf + i * TF : N / 2];
-			}
+					for (int i = 0; i < NLO; ++i)
+						acc[i] = (j0 + jj) == 0 ? own[i] : acc[i] + own[i];
+				}
+				else {
 #pragma unroll
-			for (int jj = 0; jj < 4; ++jj) {
-				if (j0 + jj < b.len_t) {
-					if (d[jj] == 0) { // the consumed row itself: its 1/|S|^2 is at hand
-#pragma unroll
-						for (int i = 0; i < NLO; ++i)
-							acc[i] = (j0 + jj) == 0 ? own[i] : acc[i] + own[i];
-					}
-					else {
-#pragma unroll
-						for (int i = 0; i < NLO; ++i) {
-							const float v = (1.0f / (m[jj][i] * m[jj][i])) * 1.0F;
-							acc[i] = (j0 + jj) == 0 ? v : acc[i] + v;
-						}
+					for (int i = 0; i < NLO; ++i) {
+						const float v = (1.0f / (m[jj][i] * m[jj][i])) * 1.0F;
+						acc[i] = (j0 + jj) == 0 ? v : acc[i] + v;
 					}
 				}
 			}
+		}
+	};
+	// ---- time box: rows ar - mid_t .. ar + mid_t in ascending order (box_time_kernel: clamped rows, causal_self)
+	{
+		float acc[NLO];
+		tap_sum(0, m0, d0, acc);
+		for (int j0 = 4; j0 < b.len_t; j0 += 4) {
+			float m[4][NLO];
+			int d[4];
+			tap_load(j0, m, d);
+			tap_sum(j0, m, d, acc);
 		}
 		const float flen_t = (float)b.len_t;
 #pragma unroll
