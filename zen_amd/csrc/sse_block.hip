@@ -190,9 +190,17 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, LOG2N <= 11 ? 4 : 3) void sse
 		for (int i = 0; i < 16; ++i)
 			accf[i] = p0[i * TF];
 		for (int j = 1; j < b.len_f; ++j) {
+			// sixteen reads in flight, then the sixteen sums: left to itself the scheduler pairs every two reads with their wait
+			// (two taps of one bin at a time: 190 trips to the LDS per frame and thread, one after the other)
+			float t[16];
 #pragma unroll
 			for (int i = 0; i < 16; ++i)
-				accf[i] = accf[i] + p0[i * TF + j];
+				t[i] = p0[i * TF + j];
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for (int i = 0; i < 16; ++i)
+				accf[i] = accf[i] + t[i];
+			__builtin_amdgcn_sched_barrier(0);
 		}
 		const float flen_f = (float)b.len_f;
 #pragma unroll
