@@ -59,15 +59,30 @@ __global__ __launch_bounds__(256) void box_freq_kernel(FilterArgs a, int segs_pe
 	}
 	__syncthreads();
 	const float flen = (float)len;
+	// the thread's four outputs tap by tap (ascending order each): four reads in flight, then the four sums -- one output
+	// after the other was one dependent LDS round trip per tap.  (Lanes read consecutive words: no bank conflicts; an output
+	// past the row reads inside the tile and is not stored.)
+	constexpr int K = FREQ_OUTS / 256;
+	float acc[K];
 #pragma unroll
-	for (int k = 0; k < FREQ_OUTS / 256; ++k) {
-		const int o = tid + 256 * k; // lanes read consecutive words: no bank conflicts
-		if (col0 + o >= cols)
-			break;
-		float acc = tile[o];
-		for (int j = 1; j < len; ++j)
-			acc = acc + tile[o + j];
-		drow[col0 + o] = post_of(acc, flen, a.sse_post, a.post_factor);
+	for (int k = 0; k < K; ++k)
+		acc[k] = tile[tid + 256 * k];
+	for (int j = 1; j < len; ++j) {
+		float t[K];
+#pragma unroll
+		for (int k = 0; k < K; ++k)
+			t[k] = tile[tid + 256 * k + j];
+		__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+		for (int k = 0; k < K; ++k)
+			acc[k] = acc[k] + t[k];
+		__builtin_amdgcn_sched_barrier(0);
+	}
+#pragma unroll
+	for (int k = 0; k < K; ++k) {
+		const int o = tid + 256 * k;
+		if (col0 + o < cols)
+			drow[col0 + o] = post_of(acc[k], flen, a.sse_post, a.post_factor);
 	}
 }
 
@@ -112,11 +127,31 @@ __global__ __launch_bounds__(256) void box_time_kernel(FilterArgs a, int rows_pe
 	const float flen = (float)len;
 	// causal_self: taps beyond the output's own row are that row again (hps.h:265-268): tile row q + mid
 	const int jmax = a.causal_self ? mid : len - 1;
-	for (int q = rl; q < nq; q += 4) {
-		float acc = tile[q * TIME_COLS + lane_col];
-		for (int j = 1; j < len; ++j)
-			acc = acc + tile[(q + (j < jmax ? j : jmax)) * TIME_COLS + lane_col];
-		dst[(long long)(q0 + q) * cols + col] = post_of(acc, flen, a.sse_post, a.post_factor);
+	// four output rows of the thread at a time, tap by tap (ascending order each): four reads in flight, then the four sums
+	for (int qb = rl; qb < nq; qb += 16) {
+		int q[4];
+		float acc[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			q[u] = qb + 4 * u < nq ? qb + 4 * u : nq - 1; // (a row past the block: the last one again, not stored)
+			acc[u] = tile[q[u] * TIME_COLS + lane_col];
+		}
+		for (int j = 1; j < len; ++j) {
+			const int jj = j < jmax ? j : jmax;
+			float t[4];
+#pragma unroll
+			for (int u = 0; u < 4; ++u)
+				t[u] = tile[(q[u] + jj) * TIME_COLS + lane_col];
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for (int u = 0; u < 4; ++u)
+				acc[u] = acc[u] + t[u];
+			__builtin_amdgcn_sched_barrier(0);
+		}
+#pragma unroll
+		for (int u = 0; u < 4; ++u)
+			if (qb + 4 * u < nq)
+				dst[(long long)(q0 + q[u]) * cols + col] = post_of(acc[u], flen, a.sse_post, a.post_factor);
 	}
 }
 

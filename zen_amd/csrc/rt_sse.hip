@@ -269,9 +269,15 @@ __device__ __forceinline__ void rt_sse_body(const RtFusedArgs& a, int len_t, int
 			acct[i] = mid_t == 0 ? own[i] : hist[i] + own[i]; // the history sum, then the frame itself ...
 		}
 		for (int j = 1; j < len_f; ++j) { // frequency box: taps idx-mid_f .. idx+mid_f in ascending order (box_freq_kernel)
+			float t[BH]; // (the reads of a tap in flight together, then the sums: sse_block.hip)
 #pragma unroll
 			for (int i = 0; i < BH; ++i)
-				accf[i] = accf[i] + pre[SSE_HALO + idx[i] - mid_f + j];
+				t[i] = pre[SSE_HALO + idx[i] - mid_f + j];
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for (int i = 0; i < BH; ++i)
+				accf[i] = accf[i] + t[i];
+			__builtin_amdgcn_sched_barrier(0);
 		}
 		for (int j = mid_t + 1; j < len_t; ++j) { // ... for the remaining len_t - mid_t taps of the time box
 #pragma unroll
