@@ -362,6 +362,8 @@ __global__ __launch_bounds__(HERM_THREADS) void median_tf_herm_bits_kernel(Filte
 				e[2][q] = __float_as_int(x.z);
 				e[3][q] = __float_as_int(x.w);
 			}
+			__builtin_amdgcn_sched_barrier(0); // all NET loads before the first comparator: the scheduler had woven the networks into
+			                                   // the loads, eight dependent trips to the L2 per thread
 			int out[4][TT];
 #pragma unroll
 			for (int v = 0; v < 4; ++v)
@@ -414,10 +416,15 @@ __global__ __launch_bounds__(HERM_THREADS) void median_tf_herm_bits_kernel(Filte
 			const int c0 = tail ? c_t0 + T * (j - n_lo) : T * j; // first bin of the chunk
 			const float* hrow = Hs + (rb + rr) * hs;
 			unsigned* trow = tw + rr * tfw;
+			float hv[T]; // (the T harmonic estimates read together, not one in front of every comparison)
+#pragma unroll
+			for (int i = 0; i < T; ++i)
+				hv[i] = hrow[tail ? cols - (c0 + i) : c0 + i]; // (the tail's H from the mirror image: H is symmetric)
+			__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
 			for (int i = 0; i < T; ++i) {
 				const int k = c0 + i;
-				const float hh = hrow[tail ? cols - k : k]; // (the tail's H from the mirror image: H is symmetric)
+				const float hh = hv[i];
 				const float pf = __int_as_float(out[i]);
 				const unsigned pm = a.need_pm && hard_mask_exact(pf, hh + FLT_EPSILON, a.thr_p) != 0.0f ? 1u : 0u;
 				const unsigned hm = a.need_hm && hard_mask_exact(hh, pf + FLT_EPSILON, a.thr_h) != 0.0f ? 1u : 0u;
@@ -535,6 +542,7 @@ __global__ __launch_bounds__(256) void median_net_time_kernel(FilterArgs a, RowM
 			for (int v = 0; v < VC; ++v)
 				e[v][W - 1 + i] = k[v];
 		}
+		__builtin_amdgcn_sched_barrier(0); // (the T new rows requested together, before the first comparator)
 		int out[VC][T];
 #pragma unroll
 		for (int v = 0; v < VC; ++v)
