@@ -140,6 +140,45 @@ struct TwGlobal {
 	__device__ __forceinline__ float2 get(int, int, int, int idx) const { return p[idx]; }
 };
 
+// The table in global memory, every twiddle of a pass requested at the TOP of the pass (PassRunner), before the pass reads
+// its inputs from LDS: left to the scheduler the loads of a stage sit in front of that stage, each waited for on the spot --
+// up to five dependent trips to the L2 per pass in the kernels whose transform sits in a loop (istft_run_wide_kernel).
+struct TwGlobalPre {
+	static constexpr bool PLAIN = true;
+	static constexpr bool PACKED = true;
+	static constexpr bool PRELOAD = true;
+	const float2* __restrict__ p;
+	__device__ __forceinline__ float2 get(int, int, int, int idx) const { return p[idx]; }
+};
+// one pass's twiddles in registers (TwRegs for a single pass; the slots butterfly() never asks for are never loaded)
+template <int LOG2N, int PASS, bool PACKED_>
+struct TwPassRegs {
+	static constexpr bool PLAIN = true;
+	static constexpr bool PACKED = PACKED_;
+	using PL = Plan<LOG2N>;
+	static constexpr int rr = PL::r(PASS), R = 1 << rr, NB = PL::V / R, sL = PL::s(PASS), log2J = LOG2N - sL - rr;
+	float2 w[NB][8];
+	__device__ __forceinline__ float2 get(int, int i, int slot, int) const { return w[i][slot]; }
+	__device__ __forceinline__ void fill(int tf, const float2* __restrict__ p)
+	{
+#pragma unroll
+		for (int i = 0; i < NB; ++i) {
+			const int k = (tf + i * PL::TF) >> log2J;
+#pragma unroll
+			for (int q = 1; q <= rr; ++q) {
+				const int nload = q == 1 ? 1 : (1 << (q - 2));
+#pragma unroll
+				for (int c = 0; c < nload; ++c)
+					w[i][(q == 1 ? 0 : (1 << (q - 2))) + c] = p[(k << (LOG2N - sL - q)) + (c << (LOG2N - q))];
+			}
+		}
+	}
+};
+template <class T, class = void>
+struct tw_preloads : std::false_type {};
+template <class T>
+struct tw_preloads<T, std::enable_if_t<T::PRELOAD>> : std::true_type {};
+
 // the table staged in LDS by the kernel (synthesis at nfft <= 2048: a table read costs the LDS a cycle, not the vector
 // memory path 8 bytes per lane -- per frame the three passes ask it for 12 KB of twiddles, more than the spectrum)
 struct TwLds {
@@ -292,7 +331,14 @@ __device__ __forceinline__ void frame_sync()
 		__builtin_amdgcn_wave_barrier();
 	}
 	else {
+#ifdef ZEN_FFT_LDS_BARRIER
+		// the frame's threads exchange through LDS only: its counter drained, then the barrier.  __syncthreads() is a fence as
+		// well, which on gfx950 also waits for every global load and store in flight (s_waitcnt vmcnt(0)): the twiddles a pass
+		// has asked for, the hop a run kernel stores in the background
+		asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
 		__syncthreads();
+#endif
 	}
 }
 
@@ -318,6 +364,10 @@ struct PassRunner {
 		constexpr int log2J = LOG2N - sL - rr, J = 1 << log2J; // sub-sequences left after the pass
 		constexpr bool FIRST = PASS == 0, LAST = PASS == PL::P - 1;
 		constexpr bool ZUP = ZU && FIRST;
+		constexpr bool PRE = tw_preloads<TW>::value;
+		TwPassRegs<LOG2N, PASS, TW::PACKED> twp;
+		if constexpr (PRE)
+			twp.fill(tf, tw.p);
 
 		float2 v[NB][R];
 		if constexpr (FIRST && !ZUP && has_split_input<In>::value) {
@@ -360,7 +410,10 @@ struct PassRunner {
 		for (int i = 0; i < NB; ++i) {
 			const int b = tf + i * TF;
 			const int k = b >> log2J;
-			butterfly<R, INV, ZUP, (FIRST && TW::PLAIN)>(v[i], k, sL, LOG2N, tw, PASS, i);
+			if constexpr (PRE)
+				butterfly<R, INV, ZUP, (FIRST && TW::PLAIN)>(v[i], k, sL, LOG2N, twp, PASS, i);
+			else
+				butterfly<R, INV, ZUP, (FIRST && TW::PLAIN)>(v[i], k, sL, LOG2N, tw, PASS, i);
 #pragma unroll
 			for (int c = 0; c < R; ++c) {
 				const int idx = b + c * (N / R);
@@ -396,6 +449,12 @@ __device__ __forceinline__ void fft_frame(int tf, float2* __restrict__ lds, cons
 {
 	const TwGlobal g{tw};
 	PassRunner<LOG2N, 0, INV, ZU, HALF_OUT, In, Out, SYNC_FIRST, TwGlobal>::run(tf, lds, g, in, out, active);
+}
+// the same with every pass's twiddles requested at its top (TwGlobalPre)
+template <int LOG2N, bool INV, bool ZU, bool HALF_OUT, class In, class Out, bool SYNC_FIRST = false>
+__device__ __forceinline__ void fft_frame(int tf, float2* __restrict__ lds, const TwGlobalPre& tw, In& in, Out& out, bool active)
+{
+	PassRunner<LOG2N, 0, INV, ZU, HALF_OUT, In, Out, SYNC_FIRST, TwGlobalPre>::run(tf, lds, tw, in, out, active);
 }
 // the same with the table in LDS (TwLds)
 template <int LOG2N, bool INV, bool ZU, bool HALF_OUT, class In, class Out, bool SYNC_FIRST = false>

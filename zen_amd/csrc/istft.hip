@@ -336,9 +336,10 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void istft_hard_multi_kernel(
 		// twiddle index of the transform (all functions of tf alone) is hoisted out of this loop and kept
 		// in registers (226 VGPRs instead of 90 at nfft 4096, 128 spilled at nfft 16384).
 		int tf_o = tf;
-		const float2* tw_o = a.tw;
+		int tw_off = 0; // (an opaque offset, not an opaque pointer: istft_run_wide_kernel)
 		asm volatile("" : "+v"(tf_o));
-		asm volatile("" : "+s"(tw_o));
+		asm volatile("" : "+s"(tw_off));
+		const float2* tw_o = a.tw + tw_off;
 		zfft::fft_frame<LOG2N, true, false, true>(tf_o, lds + slot * PL::LDS_FLOAT2, tw_o, in, out, active);
 		if (a.n_frames == 1 && a.publish_seq && a.ready[oi]) {
 			__threadfence_system();
@@ -665,10 +666,12 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, istft_waves<LOG2N>())
 			float y[8];
 			IstftRunOut out{y, a.cola};
 			int tf_o = tf; // (opaque per transform: see istft_hard_multi_kernel)
-			const float2* tw_o = a.tw;
-			asm volatile("" : "+v"(tf_o));
-			asm volatile("" : "+s"(tw_o));
-			zfft::fft_frame<LOG2N, true, false, true>(tf_o, img, tw_o, in, out, true);
+			int tw_off = 0; // (the table pointer through an opaque OFFSET: made opaque itself it loses its address space, and every
+			asm volatile("" : "+v"(tf_o)); // twiddle becomes a flat load waited for on the spot, stage by stage)
+			asm volatile("" : "+s"(tw_off));
+			const float2* tw_o = a.tw + tw_off;
+			const zfft::TwGlobalPre twp{tw_o};
+			zfft::fft_frame<LOG2N, true, false, true>(tf_o, img, twp, in, out, true);
 			if (i < 0) { // (wave-uniform) the call's first run
 #pragma unroll
 				for (int j = 0; j < 4; ++j)

@@ -231,9 +231,10 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, LOG2N <= 11 ? 4 : 3) void sse
 			SynthIn in{z, mk[oi]};
 			SynthOut out{a.Y[oi] + (long long)s * a.y_stream_stride + (long long)f * (N / 2), a.cola};
 			int tf_o = tf; // (opaque per output: otherwise every LDS address of the transform is hoisted out of the loop, istft.hip)
-			const float2* tw_o = a.tw;
+			int tw_off = 0; // (an opaque offset, not an opaque pointer: the table keeps its address space, istft.hip)
 			asm volatile("" : "+v"(tf_o));
-			asm volatile("" : "+s"(tw_o));
+			asm volatile("" : "+s"(tw_off));
+			const float2* tw_o = a.tw + tw_off;
 			zfft::fft_frame<LOG2N, true, false, true>(tf_o, img, tw_o, in, out, active);
 			if (oi + 1 < a.n_out)
 				zfft::frame_sync<TF>(); // the image is reused by the next output
