@@ -718,9 +718,10 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 			// opaque per output (see istft_hard_multi_kernel): otherwise every LDS address and twiddle index of the
 			// transform, all functions of tf alone, is hoisted out of this loop and kept in registers
 			int tf_o = tf;
-			const float2* tw_o = a.tw;
+			int tw_off = 0; // (an opaque offset, not an opaque pointer: the table keeps its address space, istft.hip)
 			asm volatile("" : "+v"(tf_o));
-			asm volatile("" : "+s"(tw_o));
+			asm volatile("" : "+s"(tw_off));
+			const float2* tw_o = a.tw + tw_off;
 			if constexpr (TWC)
 				zfft::fft_frame<LOG2N, true, false, true>(tf_o, lds, twr, in, out, true);
 			else

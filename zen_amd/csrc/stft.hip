@@ -112,7 +112,13 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void stft_kernel(StftArgs a)
 	out.mag = a.mag + row * PL::N;
 	out.n = PL::N;
 	out.full = f >= a.mag_full_from;
-	zfft::fft_frame<LOG2N, false, true, false>(tf, lds + slot * PL::LDS_FLOAT2, a.tw, in, out, active);
+	if constexpr (LOG2N == 10) { // (every pass's twiddles requested at its top: 0.65 -> 0.61 ms per 331 456 frames at nfft 1024; the
+		const zfft::TwGlobalPre twp{a.tw}; // other sizes lose with it -- nfft 16384: 0.94 -> 1.02 ms -- and keep the scheduler's placement)
+		zfft::fft_frame<LOG2N, false, true, false>(tf, lds + slot * PL::LDS_FLOAT2, twp, in, out, active);
+	}
+	else {
+		zfft::fft_frame<LOG2N, false, true, false>(tf, lds + slot * PL::LDS_FLOAT2, a.tw, in, out, active);
+	}
 }
 
 // streaming 16-byte accesses (aligned): the Y rows are read once, the outputs written once
