@@ -90,10 +90,37 @@ int zen_hip_event_destroy(void* event);
  * "offline_chunk_hops" = n: HPRIOffline handles created from now on process at most n hops per launch in either pass
  * (a bound on their device buffers; 0: sized by the device memory cap).  "no_sse_block", "no_median_tf",
  * "no_istft_xcd_map": the launch-per-stage alternatives of the fused kernels of round 4.
+ * "publish_release" = 1 (default: the environment variable ZEN_HIP_PUBLISH_RELEASE, else 0): the single-hop kernels
+ * publish a finished hop to its host-mapped buffer with a system-scope release fence + release store instead of
+ * write-through sample stores followed by a relaxed flag store.  The default form relies on gfx950's write-through
+ * system-scope stores and on posted writes reaching host memory in order; set this on a host where either is in doubt
+ * (PCIe relaxed ordering).  Costs about a microsecond per hop.
  * Timing diagnostics whose outputs are NOT the reference's ("median47_variant" 2..4, "rt_fused_diag") and the
  * divide-based cross-check of the hard masks ("mask_divide") exist in -DZEN_HIP_DIAG builds of the library only; the
  * shipped build answers ZEN_HIP_E_UNSUPPORTED. */
 int zen_hip_set_option(const char* name, int value);
+
+/* Memory checking (no reference counterpart in the API: the reference runs its tests under cuda-memcheck,
+ * libzen/CMakeLists.txt:56-73).  With ZEN_HIP_REDZONE=<bytes> in the environment before the first allocation, every
+ * device and mapped-host allocation of the library (zen_hip_malloc and zen_hip_host_alloc_mapped included) carries that
+ * many bytes of NaN-patterned red zone on either side (ZEN_HIP_POISON=1: its interior starts as NaNs too);
+ * zen_hip_memcheck synchronises the device, compares the zones of every live allocation and returns the cumulative
+ * findings (every free checks as well).  In -DZEN_HIP_BOUNDS builds of the library the kernels additionally look up
+ * every instrumented load / store in a table of the live allocations: `bounds_violations` counts the misses
+ * (ZEN_HIP_BOUNDS_TRAP=1: the offending wavefront traps).  Without either, the call reports zeros. */
+typedef struct zen_hip_memcheck_report {
+	unsigned long long redzone_bytes;       /* 0: red zones are off */
+	unsigned long long allocations;         /* allocations made so far */
+	unsigned long long live_allocations;    /* tracked allocations alive now */
+	unsigned long long corrupt_words;       /* 4-byte words of red zone found overwritten, cumulative */
+	unsigned long long corrupt_allocations; /* zone sides they belonged to */
+	unsigned long long bounds_violations;   /* out-of-bounds accesses the bounds build recorded, cumulative */
+	int bounds_build;                       /* 1: this library was built with -DZEN_HIP_BOUNDS */
+	char first_message[256];                /* the first finding, as text */
+} zen_hip_memcheck_report;
+int zen_hip_memcheck(zen_hip_memcheck_report* out);
+/* test hook: one thread stores `value` at dev + byte_offset (through the instrumented store path) and the call synchronises */
+int zen_hip_debug_poke(void* dev, long long byte_offset, unsigned value);
 
 /* device memory + copies: what thrust::device_vector / thrust::copy are to the reference
  * (core.h:26-27; used by every wrapper and test). */

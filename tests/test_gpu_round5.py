@@ -1,0 +1,181 @@
+"""GPU parity tests added in round 5.  Every call goes through the C-ABI (libzen_hip.so via ctypes) and is compared
+BIT-EXACTLY (tolerance 0) with the CPU oracle."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import oracle as o
+
+pytestmark = pytest.mark.gpu
+ALL = o.OUTPUT_HARMONIC | o.OUTPUT_PERCUSSIVE | o.OUTPUT_RESIDUAL
+FS = 44100.0
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def z():
+    import zen_amd
+    zen_amd.init(0)
+    return zen_amd
+
+
+def _clip(n, seed):
+    from tests.test_gpu_parity import music
+    return music(n, seed)
+
+
+# ---------------------------------------------------------------------------- memory checking (memguard)
+def test_red_zones_are_on_and_clean(z):
+    r = z.memcheck()
+    assert r["redzone_bytes"] >= 4096, "tests/conftest.py switches the red zones on before the library's first allocation"
+    assert r["corrupt_words"] == 0, r["first_message"]
+
+
+@pytest.mark.memcheck_expected
+@pytest.mark.parametrize("where", ["behind", "in_front"])
+def test_deliberately_broken_store_is_caught(z, where):
+    """A store one word outside an allocation (zen_hip_debug_poke: a one-thread kernel) must show up in zen_hip_memcheck:
+    as overwritten red-zone words in any build, and as a recorded out-of-bounds access in a -DZEN_HIP_BOUNDS build."""
+    buf = z.DeviceBuffer(1000)
+    before = z.memcheck()
+    z.debug_poke(buf.ptr, 4 * 1000 + 256 if where == "behind" else -4, 0x12345678)   # (behind: past the 256-byte alignment slack)
+    after = z.memcheck()
+    assert after["corrupt_words"] == before["corrupt_words"] + 1, after
+    assert "red zone" in after["first_message"] or after["bounds_violations"] > 0
+    if after["bounds_build"]:
+        assert after["bounds_violations"] == before["bounds_violations"] + 1
+    again = z.memcheck()                             # reported once: the zone is repaired
+    assert again["corrupt_words"] == after["corrupt_words"]
+    z.debug_poke(buf.ptr, 4 * 999, 0)                # the last word of the allocation itself: fine
+    assert z.memcheck()["corrupt_words"] == after["corrupt_words"]
+    assert z.memcheck()["bounds_violations"] == after["bounds_violations"]
+
+
+def test_child_process_with_a_broken_store_exits_86(z):
+    """Child processes of the tier (C++ host tests, CLI) run with the same red zones: one that overwrote a zone does not
+    exit with status 0 whatever it thinks of itself (memguard's exit handler)."""
+    code = ("import zen_amd\n"
+            "zen_amd.init(0)\n"
+            "b = zen_amd.DeviceBuffer(64)\n"
+            "zen_amd.debug_poke(b.ptr, -8, 1)\n"
+            "b.free()\n")
+    env = dict(os.environ, ZEN_HIP_REDZONE="4096", ZEN_HIP_BOUNDS_TRAP="0")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       universal_newlines=True, timeout=300)
+    assert r.returncode == 86, (r.returncode, r.stderr[-2000:])
+    assert "red zone" in r.stderr
+
+
+def test_copy_into_interior_leaves_the_neighbouring_slots_alone(z):
+    """copy_* into the middle slot of a mapped buffer of three (zen/fakert.h:221-247 hands out IOGPU::device_out; a host may
+    well keep several hops in one allocation): the slot written is the oracle's hop, the slots on either side keep their
+    fill pattern -- checked for every hop, with the percussive and the harmonic output."""
+    hop, n_hops = 512, 10
+    x = _clip(hop * n_hops, 3)
+    ref = o.HPR(FS, hop, 2.0, ALL, o.TIME_CAUSAL).process_stream(x)
+    rt = z.HPRRealtime(FS, hop, 2.0, ALL)
+    io = z.IOGPU(3 * hop)
+    for i in range(n_hops):
+        io.host_in[:hop] = x[i * hop:(i + 1) * hop]
+        rt.process_next_hop(io.device_in)
+        for copy, key in ((rt.copy_percussive, "P"), (rt.copy_harmonic, "H"), (rt.copy_residual, "R")):
+            io.host_out[:] = -7.0
+            copy(io.device_out + 4 * hop)
+            assert np.array_equal(io.host_out[hop:2 * hop], ref[key][i * hop:(i + 1) * hop]), (i, key)
+            assert np.all(io.host_out[:hop] == -7.0) and np.all(io.host_out[2 * hop:] == -7.0), (i, key)
+
+
+# ---------------------------------------------------------------------------- ADVICE round 4
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("hop", [256, 1024])
+def test_one_hop_block_calls_with_the_resident_kernel_enabled(z, hop):
+    """zen_hip_hpr_process with n_hops == 1 while set_resident is on: the block call queues its overlap-add on the engine's
+    own stream, so it must not hand the hop to the resident kernel (which works asynchronously on another stream) -- a race
+    that returned stale samples.  One-hop block calls, per-hop calls through the mailbox and longer blocks interleaved;
+    every hop against the oracle."""
+    n_hops = 48
+    x = _clip(hop * n_hops, 23 + hop)
+    ref = o.HPR(FS, hop, 2.0, o.OUTPUT_PERCUSSIVE, o.TIME_CAUSAL).process_stream(x)["P"]
+    io = z.IOGPU(hop)
+    rt = z.HPRRealtime(FS, hop, 2.0, z.OUTPUT_PERCUSSIVE)
+    eng = rt.p_impl
+    eng.set_resident(200)
+    got = np.zeros_like(x)
+    i = 0
+    pattern = ["hop", "hop", "block1", "block1", "hop", "block3", "block1", "hop"]
+    k = 0
+    while i < n_hops:
+        kind = pattern[k % len(pattern)]
+        k += 1
+        if kind == "hop":
+            io.host_in[:] = x[i * hop:(i + 1) * hop]
+            rt.process_next_hop(io.device_in)
+            rt.copy_percussive(io.device_out)
+            got[i * hop:(i + 1) * hop] = io.host_out
+            i += 1
+        else:
+            m = min(int(kind[5:]), n_hops - i)
+            got[i * hop:(i + m) * hop] = eng.process_stream_host(x[i * hop:(i + m) * hop])["P"]
+            i += m
+    assert np.array_equal(got, ref) and np.any(ref != 0)
+    assert eng.resident_stats()["launches"] >= 3     # every block call sent the kernel home
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("release", [0, 1])
+@pytest.mark.parametrize("mode,hop", [("median", 1024), ("median", 256), ("sse", 512)])
+@pytest.mark.parametrize("resident", [False, True])
+def test_publication_of_a_hop_host_poll_stress(z, release, mode, hop, resident):
+    """The host polls the sequence word behind a finished hop and copies the hop from mapped memory (hpr.hip copy_output).
+    Both publication forms -- write-through sample stores + relaxed flag (default) and system-scope release fence + release
+    store ("publish_release", ZEN_HIP_PUBLISH_RELEASE) -- over several thousand hops, per launch and resident, EVERY sample
+    against the oracle: a hop handed over before its samples arrived shows up as a mismatch."""
+    n_hops = 3000 if hop <= 512 else 2000
+    rng = np.random.default_rng(hop + release)
+    x = rng.uniform(-1, 1, hop * n_hops).astype(np.float32)          # every hop different from the one before
+    ho = o.HPR(FS, hop, 2.0, o.OUTPUT_PERCUSSIVE, o.TIME_CAUSAL)
+    if mode == "sse":
+        ho.use_sse_filter()
+    ref = ho.process_stream(x)["P"]
+    z.set_option("publish_release", release)
+    try:
+        io = z.IOGPU(hop)
+        rt = z.HPRRealtime(FS, hop, 2.0, z.OUTPUT_PERCUSSIVE)
+        if mode == "sse":
+            rt.use_sse_filter()
+        if resident:
+            rt.p_impl.set_resident(100)
+        got = np.zeros_like(x)
+        for i in range(n_hops):
+            io.host_in[:] = x[i * hop:(i + 1) * hop]
+            rt.process_next_hop(io.device_in)
+            rt.copy_percussive(io.device_out)
+            got[i * hop:(i + 1) * hop] = io.host_out
+        bad = np.flatnonzero(~((got == ref) | (np.isnan(got) & np.isnan(ref))))
+        assert bad.size == 0, ("first mismatch in hop", int(bad[0]) // hop, "of", n_hops, bad.size, "samples differ")
+    finally:
+        z.set_option("publish_release", 0)
+
+
+def test_pipeline_buffers_are_sized_before_the_first_range(z):
+    """zen_hip_hpri_process as a pipeline: range 0 has no warm-up halo, so sized by it the buffers grew again at range 1 (a
+    device-wide synchronisation in the middle of the pipeline).  Sized for the largest range up front, the FIRST call on a
+    handle and the second one give the oracle's samples (and the second allocates nothing)."""
+    n = 4096 * 40 + 123
+    x = _clip(n, 9)
+    rh, rp, rr = o.HPRIOffline(FS, 1024, 256, 2.0, 2.0).process(x)
+    z.set_option("offline_range", 8192 * 4)
+    try:
+        h = z.HPRIOffline(FS, 1024, 256, 2.0, 2.0)
+        for call in range(2):
+            a0 = z.memcheck()["allocations"]
+            gh, gp, gr = h.process(x)
+            assert h.host_stats()["n_ranges"] >= 4
+            assert np.array_equal(gh, rh) and np.array_equal(gp, rp) and np.array_equal(gr, rr), call
+            if call == 1:
+                assert z.memcheck()["allocations"] == a0
+    finally:
+        z.set_option("offline_range", 0)

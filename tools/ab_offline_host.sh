@@ -1,7 +1,8 @@
 #!/bin/bash
 # kernels-alone and wall time of the one-hour host-vector pipeline with / without the synthesis in runs for its pass 1
-for cfg in "${@:-no_istft_runs=2 no_istft_runs=0}"; do :; done
-for cfg in "$@"; do
+CFGS=("$@")
+[ ${#CFGS[@]} -eq 0 ] && CFGS=(no_istft_runs=2 no_istft_runs=0)
+for cfg in "${CFGS[@]}"; do
   ZEN_HIP_OPTIONS=$cfg python bench.py --workload offline_host --steps 4 --warmup 1 --no-cpu-baseline > gpurun_out/ab_h.json 2> gpurun_out/ab_h.err
   python - "$cfg" <<EOF
 import json,sys

@@ -8,5 +8,5 @@ library is missing or no GPU is present the calls raise.
 from .lib import (  # noqa: F401
     FREQUENCY, OUTPUT_HARMONIC, OUTPUT_PERCUSSIVE, OUTPUT_RESIDUAL, TIME_ANTICAUSAL, TIME_CAUSAL,
     BoxFilterGPU, DeviceBuffer, Event, FFTC2CWrapperGPU, HPR, HPRIOffline, HPRRealtime, IOGPU, MedianFilterGPU,
-    ZenHipError, ZgException, device_name, init, load, run_plan, set_option, synchronize,
+    ZenHipError, ZgException, debug_poke, device_name, init, load, memcheck, run_plan, set_option, synchronize,
 )

@@ -1,6 +1,7 @@
 // api.hip -- runtime, memory and wrapper-level entry points of the C-ABI (include/zen_hip.h):
 // zen_hip_init, device/mapped memory, FFTC2CWrapperGPU, MedianFilterGPU, BoxFilterGPU.
 #include "common.h"
+#include "memguard.h"
 #include "filters.h"
 #include "stft.h"
 
@@ -34,6 +35,9 @@ opt_t g_opt_istft_run{0};
 opt_t g_opt_istft_run_wide{0};
 opt_t g_opt_offline_range{0};
 opt_t g_opt_offline_no_register{0};
+// (the environment decides the default: a host whose PCIe root complex relaxes the order of posted writes, or whose
+// mapped host memory is not write-through for the device, sets ZEN_HIP_PUBLISH_RELEASE=1 without touching the caller)
+opt_t g_opt_publish_release{[] { const char* v = getenv("ZEN_HIP_PUBLISH_RELEASE"); return (v && *v && *v != '0') ? 1 : 0; }()};
 std::atomic<unsigned> g_host_free_gen{0};
 
 void set_error(const char* fmt, ...)
@@ -190,7 +194,8 @@ int zen_hip_set_option(const char* name, int value)
 	             {"istft_run", &g_opt_istft_run},
 	             {"istft_run_wide", &g_opt_istft_run_wide},
 	             {"offline_range", &g_opt_offline_range},
-	             {"offline_no_register", &g_opt_offline_no_register}};
+	             {"offline_no_register", &g_opt_offline_no_register},
+	             {"publish_release", &g_opt_publish_release}};
 #ifndef ZEN_HIP_DIAG
 	if (name && (!strcmp(name, "rt_fused_diag") || !strcmp(name, "mask_divide") || (!strcmp(name, "median47_variant") && value > 1)))
 		ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "zen_hip_set_option: '%s' = %d is a diagnostic of -DZEN_HIP_DIAG builds", name, value);
@@ -269,13 +274,13 @@ int zen_hip_event_destroy(void* event)
 
 int zen_hip_malloc(void** dev, size_t bytes)
 {
-	ZH_HIP(hipMalloc(dev, bytes ? bytes : 1));
+	ZH_HIP(zh_malloc(dev, bytes ? bytes : 1));
 	return ZEN_HIP_OK;
 }
 int zen_hip_free(void* dev)
 {
 	if (dev)
-		ZH_HIP(hipFree(dev));
+		ZH_HIP(zh_free(dev));
 	return ZEN_HIP_OK;
 }
 int zen_hip_memset(void* dev, int value, size_t bytes, void* stream)
@@ -331,7 +336,7 @@ int zen_hip_host_alloc_mapped(size_t bytes, int write_combined, void** host, voi
 		if (hipGetDevice(&devid) == hipSuccess
 		    && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, devid) == hipSuccess && large_bar) {
 			void* p = nullptr;
-			if (hipExtMallocWithFlags(&p, bytes ? bytes : 1, hipDeviceMallocFinegrained) == hipSuccess) {
+			if (zh_ext_malloc(&p, bytes ? bytes : 1, hipDeviceMallocFinegrained) == hipSuccess) {
 				std::lock_guard<std::mutex> lk(g_bar_mu);
 				g_bar_bufs.push_back(p);
 				*host = p;
@@ -344,8 +349,8 @@ int zen_hip_host_alloc_mapped(size_t bytes, int write_combined, void** host, voi
 	unsigned flags = hipHostMallocMapped | hipHostMallocPortable;
 	if (write_combined)
 		flags |= hipHostMallocWriteCombined;
-	ZH_HIP(hipHostMalloc(host, bytes ? bytes : 1, flags));
-	ZH_HIP(hipHostGetDevicePointer(dev, *host, 0));
+	ZH_HIP(zh_host_malloc(host, bytes ? bytes : 1, flags));
+	ZH_HIP(zh_host_device_pointer(dev, *host));
 	return ZEN_HIP_OK;
 }
 int zen_hip_host_free(void* host)
@@ -358,12 +363,12 @@ int zen_hip_host_free(void* host)
 		for (size_t i = 0; i < g_bar_bufs.size(); ++i) {
 			if (g_bar_bufs[i] == host) {
 				g_bar_bufs.erase(g_bar_bufs.begin() + (long)i);
-				ZH_HIP(hipFree(host));
+				ZH_HIP(zh_free(host));
 				return ZEN_HIP_OK;
 			}
 		}
 	}
-	ZH_HIP(hipHostFree(host));
+	ZH_HIP(zh_host_free(host));
 	return ZEN_HIP_OK;
 }
 
@@ -382,9 +387,9 @@ int zen_hip_fft_create(size_t nfft, zen_hip_fft_t* h)
 	f->tw = nullptr;
 	std::vector<float> tw(nfft);
 	make_twiddles(tw.data(), nfft);
-	if (hipMalloc((void**)&f->tw, sizeof(float) * nfft) != hipSuccess
+	if (zh_malloc((void**)&f->tw, sizeof(float) * nfft) != hipSuccess
 	    || hipMemcpy(f->tw, tw.data(), sizeof(float) * nfft, hipMemcpyHostToDevice) != hipSuccess) {
-		(void)hipFree(f->tw);
+		(void)zh_free(f->tw);
 		(void)hipGetLastError();
 		delete f;
 		ZH_FAIL(ZEN_HIP_E_HIP, "fft_create: device allocation failed");
@@ -402,10 +407,10 @@ int zen_hip_fft_exec_batched(zen_hip_fft_t h, float* inout_dev, size_t batch, in
 			// the buffer may still be in use by an earlier call on ANOTHER stream: wait for the device, not for `stream`
 			// (a 32768-point handle has one scratch buffer: its calls must not overlap across streams, zen_hip.h)
 			ZH_HIP(hipDeviceSynchronize());
-			(void)hipFree(h->xch);
+			(void)zh_free(h->xch);
 			h->xch = nullptr;
 			h->xch_batch = 0;
-			ZH_HIP(hipMalloc((void**)&h->xch, sizeof(float2) * h->nfft * batch));
+			ZH_HIP(zh_malloc((void**)&h->xch, sizeof(float2) * h->nfft * batch));
 			h->xch_batch = batch;
 		}
 		return launch_fft_big(h->log2n, (float2*)inout_dev, h->xch, h->tw, batch, inverse, (hipStream_t)stream);
@@ -421,8 +426,8 @@ int zen_hip_fft_exec(zen_hip_fft_t h, float* inout_dev, int inverse, void* strea
 int zen_hip_fft_destroy(zen_hip_fft_t h)
 {
 	if (h) {
-		(void)hipFree(h->tw);
-		(void)hipFree(h->xch);
+		(void)zh_free(h->tw);
+		(void)zh_free(h->xch);
 		delete h;
 	}
 	return ZEN_HIP_OK;

@@ -16,6 +16,7 @@
 // second half of the last synthesised frame (`*_out[hop:]`).  Rows live in a ring addressed by an
 // absolute frame counter, so nothing is ever shifted (the reference moves (W-1)*nfft complex per hop).
 #include "common.h"
+#include "memguard.h"
 #include "filters.h"
 #include "hpr_engine.h"
 
@@ -94,45 +95,45 @@ void free_all(zen_hip_hpr* e)
 {
 	if (e->res_ctl) {
 		(void)zen_hip_host_free(e->res_ctl);
-		(void)hipHostFree(e->res_out);
+		(void)zh_host_free(e->res_out);
 		(void)hipStreamDestroy(e->res_stream);
 		(void)hipEventDestroy(e->res_event);
 		e->res_ctl = nullptr;
 	}
-	(void)hipFree(e->d_window);
-	(void)hipFree(e->d_tw);
-	(void)hipFree(e->d_tail[0]);
-	(void)hipFree(e->d_tail[1]);
-	(void)hipFree(e->d_S);
-	(void)hipFree(e->d_mag);
-	(void)hipFree(e->d_H);
-	(void)hipFree(e->d_P);
-	(void)hipFree(e->d_bits);
-	(void)hipFree(e->d_bits_t);
-	(void)hipFree(e->d_Mh);
-	(void)hipFree(e->d_blk_flag);
-	(void)hipFree(e->d_blk_need);
-	(void)hipFree(e->d_run_sink);
+	(void)zh_free(e->d_window);
+	(void)zh_free(e->d_tw);
+	(void)zh_free(e->d_tail[0]);
+	(void)zh_free(e->d_tail[1]);
+	(void)zh_free(e->d_S);
+	(void)zh_free(e->d_mag);
+	(void)zh_free(e->d_H);
+	(void)zh_free(e->d_P);
+	(void)zh_free(e->d_bits);
+	(void)zh_free(e->d_bits_t);
+	(void)zh_free(e->d_Mh);
+	(void)zh_free(e->d_blk_flag);
+	(void)zh_free(e->d_blk_need);
+	(void)zh_free(e->d_run_sink);
 	for (int o = 0; o < 3; ++o) {
-		(void)hipFree(e->d_run_carry[0][o]);
-		(void)hipFree(e->d_run_carry[1][o]);
+		(void)zh_free(e->d_run_carry[0][o]);
+		(void)zh_free(e->d_run_carry[1][o]);
 	}
 	for (int o = 0; o < 3; ++o) {
-		(void)hipFree(e->d_Y[o]);
-		(void)hipFree(e->d_carry[o]);
+		(void)zh_free(e->d_Y[o]);
+		(void)zh_free(e->d_carry[o]);
 		if (e->ready_host[o])
-			(void)hipHostFree(e->ready_host[o]);
+			(void)zh_host_free(e->ready_host[o]);
 		else
-			(void)hipFree(e->ready_dev[o]);
+			(void)zh_free(e->ready_dev[o]);
 	}
 	if (e->dbg_stamps_host)
-		(void)hipHostFree(e->dbg_stamps_host);
+		(void)zh_host_free(e->dbg_stamps_host);
 	if (e->d_wide_xch)
-		(void)hipFree(e->d_wide_xch);
+		(void)zh_free(e->d_wide_xch);
 	if (e->d_wide_bar)
-		(void)hipFree(e->d_wide_bar);
+		(void)zh_free(e->d_wide_bar);
 	if (e->wide_fail_host)
-		(void)hipHostFree(e->wide_fail_host);
+		(void)zh_host_free(e->wide_fail_host);
 	for (auto& p : e->prof_pending) {
 		(void)hipEventDestroy(p.e0);
 		(void)hipEventDestroy(p.e1);
@@ -230,11 +231,11 @@ int ensure_estimates(zen_hip_hpr* e, bool need_h)
 {
 	const size_t bytes = sizeof(float) * e->n_streams * e->max_hops * e->nfft;
 	if (!e->d_P) { // zeroed like the Y rows: the half-row filters leave the bins nobody reads untouched
-		ZH_HIP(hipMalloc((void**)&e->d_P, bytes));
+		ZH_HIP(zh_malloc((void**)&e->d_P, bytes));
 		ZH_HIP(hipMemsetAsync(e->d_P, 0, bytes, e->stream));
 	}
 	if (need_h && !e->d_H) {
-		ZH_HIP(hipMalloc((void**)&e->d_H, bytes));
+		ZH_HIP(zh_malloc((void**)&e->d_H, bytes));
 		ZH_HIP(hipMemsetAsync(e->d_H, 0, bytes, e->stream));
 	}
 	return ZEN_HIP_OK;
@@ -245,7 +246,7 @@ int ensure_rows(zen_hip_hpr* e, int o)
 	if (e->d_Y[o])
 		return ZEN_HIP_OK;
 	const size_t bytes = sizeof(float) * e->n_streams * e->max_hops * e->nwin;
-	ZH_HIP(hipMalloc((void**)&e->d_Y[o], bytes));
+	ZH_HIP(zh_malloc((void**)&e->d_Y[o], bytes));
 	ZH_HIP(hipMemsetAsync(e->d_Y[o], 0, bytes, e->stream));
 	return ZEN_HIP_OK;
 }
@@ -286,7 +287,7 @@ void fused_args(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, RtF
 	}
 	if (M == 1)
 		a.seq = ++e->hop_seq;
-	a.publish_seq = e->ready_host[0] != nullptr;
+	a.publish_seq = e->ready_host[0] != nullptr ? (g_opt_publish_release ? 2 : 1) : 0; // rt_fused.hip publish_ready
 	a.beta = e->beta;
 	a.beta_h = e->beta - FLT_EPSILON;
 	a.cola = e->cola;
@@ -311,15 +312,15 @@ int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, H
 	if (kind == HOP_WIDE) {
 		ZH_TRY(ensure_estimates(e, false));
 		if (!e->d_wide_xch) {
-			ZH_HIP(hipMalloc((void**)&e->d_wide_xch, sizeof(float2) * e->n_streams * e->nfft));
-			ZH_HIP(hipMalloc((void**)&e->d_wide_bar, sizeof(unsigned) * 4 * e->n_streams));
+			ZH_HIP(zh_malloc((void**)&e->d_wide_xch, sizeof(float2) * e->n_streams * e->nfft));
+			ZH_HIP(zh_malloc((void**)&e->d_wide_bar, sizeof(unsigned) * 4 * e->n_streams));
 			ZH_HIP(hipMemsetAsync(e->d_wide_bar, 0, sizeof(unsigned) * 4 * e->n_streams, e->stream));
 			e->wide_arrivals = 0;
 			e->wide_calls = 0;
 			void* dev = nullptr;
-			ZH_HIP(hipHostMalloc((void**)&e->wide_fail_host, 64, hipHostMallocMapped | hipHostMallocPortable));
+			ZH_HIP(zh_host_malloc((void**)&e->wide_fail_host, 64, hipHostMallocMapped | hipHostMallocPortable));
 			*e->wide_fail_host = 0;
-			ZH_HIP(hipHostGetDevicePointer(&dev, e->wide_fail_host, 0));
+			ZH_HIP(zh_host_device_pointer(&dev, e->wide_fail_host));
 			e->wide_fail_dev = (unsigned*)dev;
 		}
 		a.wide_fail = e->wide_fail_dev;
@@ -342,8 +343,8 @@ int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, H
 		direct_o = a.out_id[0];
 		if (!e->d_blk_flag) {
 			const size_t bytes = sizeof(unsigned) * e->n_streams * e->max_hops;
-			ZH_HIP(hipMalloc((void**)&e->d_blk_flag, bytes));
-			ZH_HIP(hipMalloc((void**)&e->d_blk_need, bytes));
+			ZH_HIP(zh_malloc((void**)&e->d_blk_flag, bytes));
+			ZH_HIP(zh_malloc((void**)&e->d_blk_need, bytes));
 			ZH_HIP(hipMemsetAsync(e->d_blk_flag, 0, bytes, e->stream));
 			ZH_HIP(hipMemsetAsync(e->d_blk_need, 0, bytes, e->stream));
 			e->blk_seq = 0;
@@ -428,8 +429,8 @@ int resident_launch(zen_hip_hpr* e) // from res_args: the hop whose number is re
 		ZH_TRY(zen_hip_host_alloc_mapped(sizeof(ResidentCtl), 1, &h, &d)); // device memory behind the BAR where there is one
 		e->res_ctl = (ResidentCtl*)h;
 		e->res_ctl_dev = (ResidentCtl*)d;
-		ZH_HIP(hipHostMalloc((void**)&e->res_out, sizeof(ResidentOut), hipHostMallocMapped | hipHostMallocPortable));
-		ZH_HIP(hipHostGetDevicePointer(&d, e->res_out, 0));
+		ZH_HIP(zh_host_malloc((void**)&e->res_out, sizeof(ResidentOut), hipHostMallocMapped | hipHostMallocPortable));
+		ZH_HIP(zh_host_device_pointer(&d, e->res_out));
 		e->res_out_dev = (ResidentOut*)d;
 		ZH_HIP(hipStreamCreateWithFlags(&e->res_stream, hipStreamNonBlocking));
 		ZH_HIP(hipEventCreateWithFlags(&e->res_event, hipEventDisableTiming));
@@ -529,10 +530,13 @@ int resident_post(zen_hip_hpr* e, const float* in)
 
 int pick_wide_run(zen_hip_hpr* e, size_t M, size_t S, const int* group_outputs, int n_groups, int log2n, double min_eff); // below
 
-int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long long in_valid = LLONG_MAX)
+// may_post: the call is zen_hip_hpr_process_next_hop -- the only entry point whose result is collected through copy_* /
+// resident_wait.  A block call of one hop (zen_hip_hpr_process, n_hops == 1) queues its overlap-add on the engine's own
+// stream right behind this: it must not hand the hop to a kernel that works asynchronously on another stream.
+int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long long in_valid = LLONG_MAX, bool may_post = false)
 {
 	const size_t S = e->n_streams, N = e->nfft;
-	if (M == 1 && in_stride == e->hop && resident_eligible(e))
+	if (may_post && M == 1 && in_stride == e->hop && resident_eligible(e))
 		return resident_post(e, in);
 	ZH_TRY(resident_stop(e));
 	if (e->rows_stale && !e->run_mode)
@@ -673,8 +677,8 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 	const long long bits_stream_stride = (long long)e->max_hops * bits_row_words;
 	const long long bits_t_stream_stride = (long long)e->max_hops * (long long)(N / 16);
 	if (use_bits && !e->d_bits) {
-		ZH_HIP(hipMalloc((void**)&e->d_bits, sizeof(unsigned) * S * (size_t)bits_stream_stride));
-		ZH_HIP(hipMalloc((void**)&e->d_bits_t, sizeof(unsigned) * S * (size_t)bits_t_stream_stride));
+		ZH_HIP(zh_malloc((void**)&e->d_bits, sizeof(unsigned) * S * (size_t)bits_stream_stride));
+		ZH_HIP(zh_malloc((void**)&e->d_bits_t, sizeof(unsigned) * S * (size_t)bits_t_stream_stride));
 	}
 	int bits_done = 0; // 1: the frequency-direction kernel wrote IstftArgs::bits, 2: ::bits_t
 	// the masks an enabled output reads: its own, and for the residual those of hps.cu:562-567
@@ -749,7 +753,7 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 		ff.need_hm = need_hm;
 		if (need_hm) {
 			if (!e->d_Mh)
-				ZH_HIP(hipMalloc((void**)&e->d_Mh, sizeof(float) * S * e->max_hops * N));
+				ZH_HIP(zh_malloc((void**)&e->d_Mh, sizeof(float) * S * e->max_hops * N));
 			ff.mh_dst = e->d_Mh;
 			ff.mh_stream_stride = (long long)(e->max_hops * N);
 		}
@@ -803,7 +807,7 @@ int run_chunk(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, long 
 	}
 	if (M == 1)
 		ia.seq = ++e->hop_seq;
-	ia.publish_seq = e->ready_host[0] != nullptr;
+	ia.publish_seq = e->ready_host[0] != nullptr ? (g_opt_publish_release ? 2 : 1) : 0;
 	ia.beta = e->beta;
 	ia.beta_h = beta_h;
 	ia.soft = e->soft ? 1 : 0;
@@ -947,15 +951,15 @@ int grow_buffers(zen_hip_hpr* e, size_t new_hops)
 	float2* nS = nullptr;
 	float* nmag = nullptr;
 	float* nY[3] = {nullptr, nullptr, nullptr};
-	bool ok = hipMalloc((void**)&nS, srow * S * new_rows) == hipSuccess && hipMalloc((void**)&nmag, mrow * S * new_rows) == hipSuccess;
+	bool ok = zh_malloc((void**)&nS, srow * S * new_rows) == hipSuccess && zh_malloc((void**)&nmag, mrow * S * new_rows) == hipSuccess;
 	for (int o = 0; o < 3 && ok; ++o)
 		if (e->d_Y[o])
-			ok = hipMalloc((void**)&nY[o], sizeof(float) * S * new_hops * e->nwin) == hipSuccess;
+			ok = zh_malloc((void**)&nY[o], sizeof(float) * S * new_hops * e->nwin) == hipSuccess;
 	if (!ok) {
-		(void)hipFree(nS);
-		(void)hipFree(nmag);
+		(void)zh_free(nS);
+		(void)zh_free(nmag);
 		for (int o = 0; o < 3; ++o)
-			(void)hipFree(nY[o]);
+			(void)zh_free(nY[o]);
 		(void)hipGetLastError();
 		ZH_FAIL(ZEN_HIP_E_HIP, "hpr_process: growing the engine to %zu hops per chunk failed (nfft %zu, streams %zu)", new_hops, N, S);
 	}
@@ -976,24 +980,24 @@ int grow_buffers(zen_hip_hpr* e, size_t new_hops)
 			                        sizeof(float) * e->last_frames * e->nwin, S, hipMemcpyDeviceToDevice, e->stream));
 	}
 	ZH_HIP(hipStreamSynchronize(e->stream));
-	(void)hipFree(e->d_S);
-	(void)hipFree(e->d_mag);
-	(void)hipFree(e->d_H);
-	(void)hipFree(e->d_P);
-	(void)hipFree(e->d_bits);
-	(void)hipFree(e->d_bits_t);
-	(void)hipFree(e->d_Mh);
+	(void)zh_free(e->d_S);
+	(void)zh_free(e->d_mag);
+	(void)zh_free(e->d_H);
+	(void)zh_free(e->d_P);
+	(void)zh_free(e->d_bits);
+	(void)zh_free(e->d_bits_t);
+	(void)zh_free(e->d_Mh);
 	e->d_Mh = nullptr;
 	e->d_S = nS;
 	e->d_mag = nmag;
 	e->d_H = e->d_P = nullptr; // ensure_estimates
 	e->d_bits = e->d_bits_t = nullptr; // run_chunk
-	(void)hipFree(e->d_blk_flag);
-	(void)hipFree(e->d_blk_need);
+	(void)zh_free(e->d_blk_flag);
+	(void)zh_free(e->d_blk_need);
 	e->d_blk_flag = e->d_blk_need = nullptr; // run_hop_fused
 	for (int o = 0; o < 3; ++o) {
 		if (e->d_Y[o]) {
-			(void)hipFree(e->d_Y[o]);
+			(void)zh_free(e->d_Y[o]);
 			e->d_Y[o] = nY[o];
 		}
 	}
@@ -1161,6 +1165,13 @@ bool run_pass_groups(zen_hip_hpr* e, size_t n_hops, const HprOutSpec (&spec)[3])
 
 namespace zen_hip_impl {
 
+int hpr_reserve_hops(zen_hip_hpr* h, size_t n_hops) // the growth a call of n_hops hops would start with, ahead of time
+{
+	if (n_hops > h->max_hops && h->max_hops < h->max_hops_cap)
+		ZH_TRY(grow_buffers(h, n_hops < h->max_hops_cap ? n_hops : h->max_hops_cap));
+	return ZEN_HIP_OK;
+}
+
 int hpr_process_spec(zen_hip_hpr* h, const float* in_dev, size_t n_hops, size_t in_stride, long long in_valid,
                      const HprOutSpec (&spec)[3])
 {
@@ -1179,12 +1190,12 @@ int hpr_process_spec(zen_hip_hpr* h, const float* in_dev, size_t n_hops, size_t 
 				if (h->d_run_carry[0][o])
 					continue; // (zeroed by the reset the pass started from: reset_state)
 				for (int b = 0; b < 2; ++b) {
-					ZH_HIP(hipMalloc((void**)&h->d_run_carry[b][o], hopb));
+					ZH_HIP(zh_malloc((void**)&h->d_run_carry[b][o], hopb));
 					ZH_HIP(hipMemsetAsync(h->d_run_carry[b][o], 0, hopb, h->stream)); // a fresh stream: nothing to add to its first hop
 				}
 			}
 		if (!h->d_run_sink)
-			ZH_HIP(hipMalloc((void**)&h->d_run_sink, hopb));
+			ZH_HIP(zh_malloc((void**)&h->d_run_sink, hopb));
 		h->run_mode = true;
 	}
 	int rc = ZEN_HIP_OK;
@@ -1282,26 +1293,26 @@ int zen_hip_hpr_create(float fs, size_t hop, float beta, unsigned output_flags, 
 	e->cola = (float)nfft / cola;
 
 	const size_t S = n_streams, MH = e->max_hops;
-	bool ok = hipMalloc((void**)&e->d_window, sizeof(float) * nwin) == hipSuccess
-	          && hipMalloc((void**)&e->d_tw, sizeof(float) * nfft) == hipSuccess
-	          && hipMalloc((void**)&e->d_tail[0], sizeof(float) * S * hop) == hipSuccess
-	          && hipMalloc((void**)&e->d_tail[1], sizeof(float) * S * hop) == hipSuccess
-	          && hipMalloc((void**)&e->d_S, sizeof(float2) * S * e->ring_rows * e->s_stride) == hipSuccess
-	          && hipMalloc((void**)&e->d_mag, sizeof(float) * S * e->ring_rows * nfft) == hipSuccess;
+	bool ok = zh_malloc((void**)&e->d_window, sizeof(float) * nwin) == hipSuccess
+	          && zh_malloc((void**)&e->d_tw, sizeof(float) * nfft) == hipSuccess
+	          && zh_malloc((void**)&e->d_tail[0], sizeof(float) * S * hop) == hipSuccess
+	          && zh_malloc((void**)&e->d_tail[1], sizeof(float) * S * hop) == hipSuccess
+	          && zh_malloc((void**)&e->d_S, sizeof(float2) * S * e->ring_rows * e->s_stride) == hipSuccess
+	          && zh_malloc((void**)&e->d_mag, sizeof(float) * S * e->ring_rows * nfft) == hipSuccess;
 	// d_H, d_P and d_Y[] are allocated by the first call that needs them (ensure_estimates / ensure_rows)
 	for (int o = 0; o < 3 && ok; ++o)
-		ok = hipMalloc((void**)&e->d_carry[o], sizeof(float) * S * hop) == hipSuccess;
+		ok = zh_malloc((void**)&e->d_carry[o], sizeof(float) * S * hop) == hipSuccess;
 	for (int o = 0; o < 3 && ok; ++o) {
 		if (S == 1) { // io.h:24-66 style: pinned, mapped; the kernel writes it over the host link
 			void* dev = nullptr;
-			ok = hipHostMalloc((void**)&e->ready_host[o], sizeof(float) * (hop + 16), hipHostMallocMapped | hipHostMallocPortable) == hipSuccess
-			     && hipHostGetDevicePointer(&dev, e->ready_host[o], 0) == hipSuccess;
+			ok = zh_host_malloc((void**)&e->ready_host[o], sizeof(float) * (hop + 16), hipHostMallocMapped | hipHostMallocPortable) == hipSuccess
+			     && zh_host_device_pointer(&dev, e->ready_host[o]) == hipSuccess;
 			e->ready_dev[o] = (float*)dev;
 			if (ok)
 				memset(e->ready_host[o], 0, sizeof(float) * (hop + 16)); // [hop] = sequence word
 		}
 		else {
-			ok = hipMalloc((void**)&e->ready_dev[o], sizeof(float) * S * hop) == hipSuccess;
+			ok = zh_malloc((void**)&e->ready_dev[o], sizeof(float) * S * hop) == hipSuccess;
 		}
 	}
 	if (ok)
@@ -1479,7 +1490,7 @@ int zen_hip_hpr_process_next_hop(zen_hip_hpr_t h, const float* in_dev)
 {
 	if (!h || !in_dev)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpr_process_next_hop: null argument");
-	return run_chunk(h, in_dev, h->hop, 1);
+	return run_chunk(h, in_dev, h->hop, 1, LLONG_MAX, /*may_post=*/true);
 }
 
 // host address of a copy_* destination if it is (mapped) host memory, else null; one lookup per distinct pointer
@@ -1601,8 +1612,8 @@ int zen_hip_hpr_debug_stamps(zen_hip_hpr_t h, unsigned long long** host_stamps)
 	ZH_TRY(resident_stop(h));
 	if (!h->dbg_stamps_host) {
 		void* dev = nullptr;
-		ZH_HIP(hipHostMalloc((void**)&h->dbg_stamps_host, 16 * sizeof(unsigned long long), hipHostMallocMapped));
-		ZH_HIP(hipHostGetDevicePointer(&dev, h->dbg_stamps_host, 0));
+		ZH_HIP(zh_host_malloc((void**)&h->dbg_stamps_host, 16 * sizeof(unsigned long long), hipHostMallocMapped));
+		ZH_HIP(zh_host_device_pointer(&dev, h->dbg_stamps_host));
 		h->dbg_stamps = (unsigned long long*)dev;
 		memset(h->dbg_stamps_host, 0, 16 * sizeof(unsigned long long));
 	}

@@ -139,4 +139,5 @@ namespace zen_hip_impl {
 // 1 harmonic, 2 residual).  The engine must be an anticausal one (the two passes of HPRIOffline).
 int hpr_process_spec(zen_hip_hpr* h, const float* in_dev, size_t n_hops, size_t in_stride, long long in_valid,
                      const HprOutSpec (&spec)[3]);
+int hpr_reserve_hops(zen_hip_hpr* h, size_t n_hops); // grows the engine's buffers for calls of n_hops hops (up to its cap)
 } // namespace zen_hip_impl

@@ -7,8 +7,10 @@
 //                    block calls on the engine.  Also: a batch of equal-length clips per call, and any time
 //                    range of one clip from its own warm-up halo.
 #include "common.h"
+#include "memguard.h"
 #include "hpr_engine.h"
 
+#include <algorithm>
 #include <cfloat>
 #include <climits>
 #include <cmath>
@@ -51,7 +53,7 @@ int chunk_padder(size_t audio_size, size_t hop, size_t lag, size_t* padded)
 
 void hpri_free_scratch(zen_hip_hpri* o)
 {
-	(void)hipFree(o->in2);
+	(void)zh_free(o->in2);
 	o->in2 = nullptr;
 	o->cap2 = 0;
 }
@@ -95,9 +97,9 @@ int zen_hip_hpri_destroy(zen_hip_hpri_t h)
 		zen_hip_hpr_destroy(h->eh);
 		zen_hip_hpr_destroy(h->ep);
 		hpri_free_scratch(h);
-		(void)hipFree(h->stage_in);
+		(void)zh_free(h->stage_in);
 		for (int i = 0; i < 2; ++i)
-			(void)hipFree(h->stage_out[i]);
+			(void)zh_free(h->stage_out[i]);
 		for (hipEvent_t e : h->events)
 			(void)hipEventDestroy(e);
 		if (h->s_in)
@@ -174,7 +176,7 @@ int zen_hip_hpri_process_device(zen_hip_hpri_t h, const float* audio_dev, size_t
 	if (padded2 > h->cap2) {
 		ZH_HIP(hipStreamSynchronize(h->stream));
 		hpri_free_scratch(h);
-		ZH_HIP(hipMalloc((void**)&h->in2, sizeof(float) * C * padded2));
+		ZH_HIP(zh_malloc((void**)&h->in2, sizeof(float) * C * padded2));
 		h->cap2 = padded2;
 	}
 	ZH_TRY(zen_hip_hpr_reset_buffers(h->eh)); // each process() call is a fresh pair of HPR objects' state
@@ -304,7 +306,7 @@ int zen_hip_hpri_process_range(zen_hip_hpri_t h, const float* audio_dev, size_t 
 	if (c2 > h->cap2) {
 		ZH_HIP(hipStreamSynchronize(h->stream));
 		hpri_free_scratch(h);
-		ZH_HIP(hipMalloc((void**)&h->in2, sizeof(float) * (c2 ? c2 : 1)));
+		ZH_HIP(zh_malloc((void**)&h->in2, sizeof(float) * (c2 ? c2 : 1)));
 		h->cap2 = c2;
 	}
 	ZH_TRY(zen_hip_hpr_reset_buffers(h->eh));
@@ -486,20 +488,20 @@ int zen_hip_hpri_process(zen_hip_hpri_t h, const float* audio_host, size_t n, fl
 	const double t_start = now_ms();
 	if (n > h->stage_cap) {
 		ZH_HIP(hipStreamSynchronize(h->stream));
-		(void)hipFree(h->stage_in);
+		(void)zh_free(h->stage_in);
 		h->stage_in = nullptr; // a failed allocation below must not leave freed pointers behind a stale capacity
 		for (int i = 0; i < 2; ++i) {
-			(void)hipFree(h->stage_out[i]);
+			(void)zh_free(h->stage_out[i]);
 			h->stage_out[i] = nullptr;
 		}
 		h->stage_cap = 0;
-		ZH_HIP(hipMalloc((void**)&h->stage_in, sizeof(float) * n));
+		ZH_HIP(zh_malloc((void**)&h->stage_in, sizeof(float) * n));
 		for (int i = 0; i < 2; ++i)
-			ZH_HIP(hipMalloc((void**)&h->stage_out[i], sizeof(float) * n));
+			ZH_HIP(zh_malloc((void**)&h->stage_out[i], sizeof(float) * n));
 		h->stage_cap = n;
 	}
 	float* hosts[2] = {harm_host, perc_host};
-	// ranges of the pipeline: equal lengths (the first is never the shortest: the engines' buffers grow once), a multiple of hop_h
+	// ranges of the pipeline: equal lengths, a multiple of hop_h (the buffers are sized for the largest one up front, below)
 	size_t want = (size_t)g_opt_offline_range.load(std::memory_order_relaxed);
 	if (want == 0) {
 		// 8 Mi samples (32 MB up, 64 MB down, ~0.6 + ~1.1 ms on the link, ~0.8 ms of kernels), 4 Mi for clips that would
@@ -546,6 +548,27 @@ int zen_hip_hpri_process(zen_hip_hpri_t h, const float* audio_host, size_t n, fl
 		return ZEN_HIP_OK;
 	}
 	ZH_TRY(ensure_copy_streams(h, 2 * n_ranges + 1));
+	{ // Range 0 is the cheapest one (no warm-up halo in front of it): sized by it, pass 2's input buffer and the engines would
+	  // grow again at range 1 -- a device-wide synchronisation, hipFree and hipMalloc in the middle of the pipeline.  Size
+	  // everything for the largest range before the first copy is queued.
+		size_t c2_max = 0, hops1 = 0, hops2 = 0;
+		for (size_t k = 0; k < n_ranges; ++k) {
+			const size_t b = k * range, e = b + range < n ? b + range : n;
+			RangePlan p;
+			ZH_TRY(plan_range(h, n, b, e, &p));
+			c2_max = std::max(c2_max, (p.m1 - p.q2) * h->hop_p);
+			hops1 = std::max(hops1, p.k1 - p.q1);
+			hops2 = std::max(hops2, p.m1 - p.q2);
+		}
+		if (c2_max > h->cap2) {
+			ZH_HIP(hipStreamSynchronize(h->stream));
+			hpri_free_scratch(h);
+			ZH_HIP(zh_malloc((void**)&h->in2, sizeof(float) * c2_max));
+			h->cap2 = c2_max;
+		}
+		ZH_TRY(hpr_reserve_hops(h->eh, hops1));
+		ZH_TRY(hpr_reserve_hops(h->ep, hops2));
+	}
 	const bool try_register = g_opt_offline_no_register.load(std::memory_order_relaxed) == 0;
 	Registered reg_in, reg_out[2];
 	reg_in.take(audio_host, sizeof(float) * n, try_register);

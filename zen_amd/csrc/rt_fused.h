@@ -27,7 +27,8 @@ struct RtFusedArgs {
 	long long y_stream_stride;
 	float* ready[3];        // indexed by output id; single-hop calls: receives carry + first half of the new frame
 	unsigned seq;           // single-hop calls: written to ready[o][hop] (as an integer) once ready[o] is complete,
-	int publish_seq;        // when publish_seq != 0 (ready is host-mapped: the host polls it instead of synchronising)
+	int publish_seq;        // when publish_seq != 0 (ready is host-mapped: the host polls it instead of synchronising);
+	                        // 2: with the system-scope release form (option "publish_release"), see publish_ready
 	int n_out;              // enabled outputs
 	int out_id[3];
 	float beta, beta_h, cola;

@@ -291,11 +291,17 @@ struct FwdInKeep {
 // store); here nothing else is written back, the next hop's acquire fence (resident_next_hop) is what orders this
 // workgroup's own reuse of that state.  (Plain stores to mapped host memory DO stay in the L2 until a write-back: with
 // them this form hands the host zeros.)
+// What the light form leans on beyond the memory model: write-through system-scope stores of gfx950 and the order of
+// posted writes on the way to host memory.  Where either does not hold (relaxed-ordering PCIe, another MTYPE for mapped
+// host memory) `release` -- RtFusedArgs::publish_seq == 2, option "publish_release" / ZEN_HIP_PUBLISH_RELEASE=1 -- selects
+// the plain form at run time (a workgroup-uniform branch); tests/test_gpu_round5.py polls from the host over many
+// thousand hops in both forms and compares every sample.
 template <bool LIGHT = false>
-__device__ __forceinline__ void publish_ready(unsigned* flag, unsigned seq, int tf)
+__device__ __forceinline__ void publish_ready(unsigned* flag, unsigned seq, int tf, bool release = false)
 {
-	if constexpr (LIGHT) {
+	if (LIGHT && !release) {
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // (the compiler may not sink a sample store below the barrier)
 		__syncthreads();
 		if (tf == 0)
 			__hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -727,7 +733,7 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 			else
 				zfft::fft_frame<LOG2N, true, false, true>(tf_o, lds, tw_o, in, out, true);
 			if (out.ready && a.publish_seq)
-				publish_ready<MINB == 1>(reinterpret_cast<unsigned*>(out.ready + hop), hv.seq(), tf);
+				publish_ready<MINB == 1>(reinterpret_cast<unsigned*>(out.ready + hop), hv.seq(), tf, a.publish_seq == 2);
 			__syncthreads(); // the frame image is reused by the next output
 		}
 		if constexpr (DIRECT) {
@@ -791,7 +797,7 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 				hv.keep_carry[i] = cnext[i];
 		}
 		if (out.ready && a.publish_seq)
-			publish_ready<MINB == 1>(reinterpret_cast<unsigned*>(out.ready + hop), hv.seq(), tf);
+			publish_ready<MINB == 1>(reinterpret_cast<unsigned*>(out.ready + hop), hv.seq(), tf, a.publish_seq == 2);
 		if constexpr (MINB == 1) {
 			stamp(4);
 			stamp(5);
@@ -835,7 +841,7 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 				hv.keep_carry[i] = cnext[i];
 		}
 		if (out.ready && a.publish_seq)
-			publish_ready<MINB == 1>(reinterpret_cast<unsigned*>(out.ready + hop), hv.seq(), tf);
+			publish_ready<MINB == 1>(reinterpret_cast<unsigned*>(out.ready + hop), hv.seq(), tf, a.publish_seq == 2);
 	};
 	if (a.diag == 2) { // timing diagnostic: no synthesis
 		if (tf == 0)

@@ -318,10 +318,20 @@ __device__ __forceinline__ void rt_sse_body(const RtFusedArgs& a, int len_t, int
 			zfft::fft_frame<LOG2N, true, false, true>(t, lds, twr, in, out, true);
 		}
 		if (a.publish_seq) { // the host polls the word behind the finished hop (rt_fused.hip publish_ready<true>: the samples
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // went out write-through; no write-back of the whole L2 per hop)
-			__syncthreads();
-			if (t == 0)
-				__hip_atomic_store(reinterpret_cast<unsigned*>(ready + hop), hv.seq(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			// went out write-through; no write-back of the whole L2 per hop; publish_seq == 2: the release form instead)
+			if (a.publish_seq == 2) {
+				__threadfence_system();
+				__syncthreads();
+				if (t == 0)
+					__hip_atomic_store(reinterpret_cast<unsigned*>(ready + hop), hv.seq(), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+			}
+			else {
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+				__syncthreads();
+				if (t == 0)
+					__hip_atomic_store(reinterpret_cast<unsigned*>(ready + hop), hv.seq(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			}
 		}
 		__syncthreads();
 	}

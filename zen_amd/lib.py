@@ -35,6 +35,12 @@ class _Params(C.Structure):
                 ("n_streams", C.c_size_t), ("max_hops_per_chunk", C.c_size_t)]
 
 
+class _MemcheckReport(C.Structure):
+    _fields_ = [("redzone_bytes", C.c_ulonglong), ("allocations", C.c_ulonglong), ("live_allocations", C.c_ulonglong),
+                ("corrupt_words", C.c_ulonglong), ("corrupt_allocations", C.c_ulonglong),
+                ("bounds_violations", C.c_ulonglong), ("bounds_build", C.c_int), ("first_message", C.c_char * 256)]
+
+
 class _HostStats(C.Structure):
     _fields_ = [("n_ranges", C.c_size_t), ("range_samples", C.c_size_t), ("input_pinned", C.c_int),
                 ("outputs_pinned", C.c_int), ("setup_ms", C.c_double), ("enqueue_ms", C.c_double),
@@ -58,6 +64,8 @@ SYMBOLS = [
     ("zen_hip_event_elapsed_ms", _i, [_vp, _vp, C.POINTER(C.c_float)]),
     ("zen_hip_event_destroy", _i, [_vp]),
     ("zen_hip_set_option", _i, [C.c_char_p, _i]),
+    ("zen_hip_memcheck", _i, [C.POINTER(_MemcheckReport)]),
+    ("zen_hip_debug_poke", _i, [_vp, C.c_longlong, _u]),
     ("zen_hip_malloc", _i, [_pvp, _sz]),
     ("zen_hip_free", _i, [_vp]),
     ("zen_hip_memset", _i, [_vp, _i, _sz, _vp]),
@@ -179,6 +187,20 @@ def run_plan(frames, streams, nfft, group_outputs=(2, 1)):
     run, busy = C.c_int(), C.c_double()
     _ck(load().zen_hip_run_plan(frames, streams, nfft, g, len(group_outputs), C.byref(run), C.byref(busy)))
     return run.value, busy.value
+
+
+def memcheck():
+    """zen_hip_memcheck: red zones of every live allocation verified (ZEN_HIP_REDZONE=<bytes> in the environment before the
+    library's first allocation), plus what a -DZEN_HIP_BOUNDS build recorded.  Cumulative counters."""
+    r = _MemcheckReport()
+    _ck(load().zen_hip_memcheck(C.byref(r)))
+    d = {k: getattr(r, k) for k, _ in _MemcheckReport._fields_}
+    d["first_message"] = d["first_message"].decode(errors="replace")
+    return d
+
+
+def debug_poke(dev_ptr, byte_offset, value):
+    _ck(load().zen_hip_debug_poke(dev_ptr, int(byte_offset), int(value) & 0xFFFFFFFF))
 
 
 def set_option(name, value):

@@ -8,6 +8,7 @@
 #include <iostream>
 #include <numeric>
 #include <system_error>
+#include <exception>
 #include <thread>
 #include <utility>
 
@@ -354,22 +355,45 @@ namespace hps {
 		const auto t0 = std::chrono::steady_clock::now();
 		std::vector<float> harmonic_out, percussive_out, residual_out;
 		if (n >= ((std::size_t)1 << 21)) { // the three vectors at once (a thread that cannot be had: its vector is built here)
-			std::thread t1, t2;
-			try {
-				t1 = std::thread(fresh_zeros, std::ref(harmonic_out), n);
-				t2 = std::thread(fresh_zeros, std::ref(percussive_out), n);
-			}
-			catch (const std::system_error&) {
-			}
+			// A worker's std::bad_alloc is carried back to this thread and thrown after both have been joined; the joiner also
+			// covers an exception out of this thread's own fresh_zeros (a joinable std::thread destroyed during unwinding would
+			// call std::terminate, where a plain vector construction gives the caller something to catch).
+			struct Worker {
+				std::thread t;
+				std::exception_ptr err;
+				~Worker()
+				{
+					if (t.joinable())
+						t.join();
+				}
+			} w1, w2;
+			auto start = [n](Worker& w, std::vector<float>& v) {
+				try {
+					w.t = std::thread([&w, &v, n] {
+						try {
+							fresh_zeros(v, n);
+						}
+						catch (...) {
+							w.err = std::current_exception();
+						}
+					});
+				}
+				catch (const std::system_error&) {
+				}
+			};
+			start(w1, harmonic_out);
+			start(w2, percussive_out);
 			fresh_zeros(residual_out, n);
-			if (t1.joinable())
-				t1.join();
-			else
-				fresh_zeros(harmonic_out, n);
-			if (t2.joinable())
-				t2.join();
-			else
-				fresh_zeros(percussive_out, n);
+			for (Worker* w : {&w1, &w2}) {
+				std::vector<float>& v = w == &w1 ? harmonic_out : percussive_out;
+				if (w->t.joinable())
+					w->t.join();
+				else
+					fresh_zeros(v, n);
+			}
+			for (Worker* w : {&w1, &w2})
+				if (w->err)
+					std::rethrow_exception(w->err);
 		}
 		else {
 			harmonic_out.resize(n);
