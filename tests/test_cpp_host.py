@@ -214,6 +214,23 @@ def test_median_networks_on_the_host(tmp_path):
     assert r.returncode == 0 and "passed" in r.stdout, r.stdout[-2000:]
 
 
+def test_real_input_transform_on_the_host(tmp_path, oracle):
+    """zen_amd/csrc/rfft_dev.h compiled for the CPU (tests/cpp/test_rfft_host.cpp; the image's host clang++, scalar
+    butterflies): the Hermitian half of the radix-2 DAG on real frames, the N/32 threads of a frame run one after the other,
+    bit-identical to the oracle's complex transform (fftw.h:51-129; the analysis of hps.cu:456-465) for nfft 32..16384,
+    zero-padded and not, every bin 0..nfft/2 delivered exactly once."""
+    clang = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(clang):
+        pytest.skip("no host clang++ (the header uses clang vector extensions)")
+    exe = str(tmp_path / "test_rfft_host")
+    odir = os.path.join(ROOT, "oracle")
+    subprocess.check_call([clang, "-std=c++17", "-O1", "-ffp-contract=off", "-Wno-everything", "-I/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "cpp", "test_rfft_host.cpp"), "-o", exe, "-L", odir, "-lzen_oracle",
+                           "-Wl,-rpath," + odir])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "bit-identical" in r.stdout, r.stdout[-2000:]
+
+
 @pytest.mark.gpu
 def test_cli_batch_over_two_processes_matches_one(tmp_path):
     """`zen batch --gpus 2` (SURVEY 8(e), configs[3]): the parent starts two copies of itself before anything has

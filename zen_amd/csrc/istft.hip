@@ -6,6 +6,7 @@
 // Its own translation unit because it is compiled with the max-ILP scheduling strategy (build.py), which
 // helps these kernels (-4 %); since the loads of a frame are in flight together it helps stft.hip's as well.
 #include "common.h"
+#include "bounds.h"
 #include "fft_dev.h"
 #include "fft_launch.h"
 #include "masks.h"
@@ -103,12 +104,16 @@ struct IstftIn {
 		const bool mirror = idx > (n >> 1); // upper half: S[n-k] = conj(S[k])
 		const int lo = mirror ? n - idx : idx;
 		Raw r;
+		ZH_CHK(S + lo, 1);
 		r.z = S[lo];
 		r.h = r.p = 0.0f;
 		if constexpr (MODE == 7) { // the output's soft mask, computed by the median kernel: one value per bin (H: that row)
+			ZH_CHK(H + ((mirror && idx >= n - p_mid) ? idx : lo), 1);
 			r.p = H[(mirror && idx >= n - p_mid) ? idx : lo];
 		}
 		else if constexpr (MODE != 3) { // (MODE 3: the masks are in the thread's word of bits)
+			ZH_CHK(H + lo, 1);
+			ZH_CHK(P + ((mirror && idx >= n - p_mid) ? idx : lo), 1);
 			r.h = H[lo];
 			r.p = P[(mirror && idx >= n - p_mid) ? idx : lo];
 		}
@@ -154,9 +159,12 @@ struct IstftOutV {
 	__device__ __forceinline__ void operator()(int idx, float2 x, bool, int slot) const
 	{
 		const float y = x.x * cola; // the product of overlap_add_functor hps.h:68-80; the sum is in finalize ...
+		ZH_CHK(Y + idx, 1);
 		Y[idx] = y;
-		if (ready && idx < hop) // ... or here, when the call is a single hop (hps.cu:341-363 hands out [0, hop))
+		if (ready && idx < hop) { // ... or here, when the call is a single hop (hps.cu:341-363 hands out [0, hop))
+			ZH_CHK(ready + idx, 1);
 			ready[idx] = cv[slot & (V / 4 - 1)] + y;
+		}
 	}
 };
 using IstftOut = IstftOutV<16>;
@@ -166,8 +174,11 @@ template <int TF, int CVN>
 __device__ __forceinline__ void load_carry(const float* carry, int tf, bool wanted, float (&cv)[CVN])
 {
 #pragma unroll
-	for (int i = 0; i < CVN; ++i)
+	for (int i = 0; i < CVN; ++i) {
+		if (wanted)
+			ZH_CHK(carry + tf + i * TF, 1);
 		cv[i] = wanted ? carry[tf + i * TF] : 0.0f;
+	}
 }
 
 // nfft 512 .. 2048: the twiddle table lives in LDS (4 / 8 KB behind the 34.8 KB of frame images: still four workgroups per CU)
@@ -224,8 +235,10 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, istft_waves<LOG2N>())
 #pragma unroll
 	for (int i = 0; i < PL::V / 16; ++i) {
 		in.bw[i] = 0;
-		if constexpr (MODE == 3) // a row is nfft/16 words (-> codes: IstftIn::prepare)
+		if constexpr (MODE == 3) { // a row is nfft/16 words (-> codes: IstftIn::prepare)
+			ZH_CHK(a.bits_t + ((long long)s * a.bits_t_stream_stride + (long long)f * (PL::N / 16) + tf + i * PL::TF), 1);
 			in.bw[i] = a.bits_t[(long long)s * a.bits_t_stream_stride + (long long)f * (PL::N / 16) + tf + i * PL::TF];
+		}
 	}
 	if constexpr (MODE == 7) // the row of this output's soft mask (percussive: where P would be; harmonic: Hm), laid out as P
 		in.H = (in.which == 0 ? a.P : a.Hm) + (long long)s * a.p_stream_stride + (long long)f * PL::N;
@@ -277,10 +290,13 @@ struct IstftHardIn {
 	{
 		const bool mirror = idx > (n >> 1);
 		const int lo = mirror ? n - idx : idx;
+		ZH_CHK(S + lo, 1);
 		float2 z = S[lo];
 		if (mirror)
 			z.y = -z.y;
 		if (first) {
+			ZH_CHK(H + lo, 1);
+			ZH_CHK(P + ((mirror && idx >= n - p_mid) ? idx : lo), 1);
 			const float h = H[lo], p = P[(mirror && idx >= n - p_mid) ? idx : lo]; // see IstftIn
 			unsigned pm, hm;
 			if (cmp_only) { // wave-uniform; both thresholds valid: no divide behind it
@@ -373,6 +389,8 @@ __global__ __launch_bounds__(256) void mask_bits_kernel(IstftArgs a, unsigned* b
 		const int e0 = 4 * q, half = n >> 1;
 		float h[4], p[4];
 		if (e0 + 3 <= half) {
+			ZH_CHK(H + e0, 4);
+			ZH_CHK(P + e0, 4);
 			const float4 hv = *reinterpret_cast<const float4*>(H + e0), pv = *reinterpret_cast<const float4*>(P + e0);
 			h[0] = hv.x, h[1] = hv.y, h[2] = hv.z, h[3] = hv.w;
 			p[0] = pv.x, p[1] = pv.y, p[2] = pv.z, p[3] = pv.w;
@@ -383,6 +401,10 @@ __global__ __launch_bounds__(256) void mask_bits_kernel(IstftArgs a, unsigned* b
 				const int e = e0 + i;
 				const int idx = e <= half ? e : n - a.p_mid + (e - half - 1); // the bin; past the last entry: >= n
 				const bool ok = idx < n;
+				if (ok) {
+					ZH_CHK(H + (idx <= half ? idx : n - idx), 1);
+					ZH_CHK(P + idx, 1);
+				}
 				h[i] = ok ? H[idx <= half ? idx : n - idx] : 0.0f;
 				p[i] = ok ? P[idx] : 0.0f; // (past the last entry: 0 against 0, no bit set; nobody reads those)
 			}
@@ -397,8 +419,10 @@ __global__ __launch_bounds__(256) void mask_bits_kernel(IstftArgs a, unsigned* b
 	unsigned w = byte << (8 * (threadIdx.x & 3));
 	w |= __shfl_xor(w, 1);
 	w |= __shfl_xor(w, 2);
-	if (live && (threadIdx.x & 3) == 0)
+	if (live && (threadIdx.x & 3) == 0) {
+		ZH_CHK(bits + ((long long)s * a.bits_stream_stride + (long long)f * a.bits_row_words + (q >> 2)), 1);
 		bits[(long long)s * a.bits_stream_stride + (long long)f * a.bits_row_words + (q >> 2)] = w;
+	}
 }
 
 // natural order -> the synthesis threads' order (IstftArgs::bits_t); the mirrored half and the tail are expanded here.
@@ -420,8 +444,10 @@ __global__ __launch_bounds__(256) void mask_bits_transpose_kernel(IstftArgs a, u
 	unsigned lo[8], m0[8], m1[8];
 #pragma unroll
 	for (int sl = 0; sl < 8; ++sl) {
-		lo[sl] = nat[g + sl * wstep];
 		const int w0 = (8 - sl) * wstep - g; // word of entry E0 = (16 - (8 + sl)) * TF - tf0
+		ZH_CHK(nat + g + sl * wstep, 1);
+		ZH_CHK(nat + w0 - 1, 2);
+		lo[sl] = nat[g + sl * wstep];
 		m0[sl] = nat[w0];
 		m1[sl] = nat[w0 - 1];
 	}
@@ -443,14 +469,17 @@ __global__ __launch_bounds__(256) void mask_bits_transpose_kernel(IstftArgs a, u
 			const int idx = tf0 + t + (15 << log2tf);
 			if (idx >= tail0) {
 				const int e = half + 1 + idx - tail0;
+				ZH_CHK(nat + (e >> 4), 1);
 				out[t] = (out[t] & 0x3fffffffu) | (((nat[e >> 4] >> (2 * (e & 15))) & 3u) << 30);
 			}
 		}
 	}
 	uint4* dst = reinterpret_cast<uint4*>(bits_t + (long long)s * a.bits_t_stream_stride + ((long long)f << log2tf) + tf0);
 #pragma unroll
-	for (int q = 0; q < 4; ++q)
+	for (int q = 0; q < 4; ++q) {
+		ZH_CHK(dst + q, 1);
 		dst[q] = make_uint4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+	}
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -513,17 +542,21 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) __attribute__((amdgpu_wave
 #pragma unroll
 		for (int sl = 0; sl < 16; ++sl) {
 			const int idx = tf + sl * TF;
+			ZH_CHK(row + (idx > N / 2 ? N - idx : idx), 1);
 			z[sl] = row[idx > N / 2 ? N - idx : idx];
 		}
 	};
 	auto load_bits = [&](int i) {
 		const int r = i < 0 ? 0 : (i < a.n_frames ? i : a.n_frames - 1);
+		ZH_CHK(bits_s + ((long long)r * (N / 16) + tf), 1);
 		return bits_s[(long long)r * (N / 16) + tf];
 	};
 	float cprev[4], carry[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-	for (int j = 0; j < 4; ++j) // (used by the call's first run only)
+	for (int j = 0; j < 4; ++j) { // (used by the call's first run only)
+		ZH_CHK(G.carry_prev[0] + ((long long)s * HOP + tf + j * TF), 1);
 		cprev[j] = G.carry_prev[0][(long long)s * HOP + tf + j * TF];
+	}
 	float2 S[16];
 	load_row(i0 - 1, S);
 	unsigned bw = load_bits(i0 - 1);
@@ -551,12 +584,16 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) __attribute__((amdgpu_wave
 				const float v = carry[j] + y[j];
 				const long long p0 = a.pos0 + (long long)i * HOP + tf + j * TF;
 				const long long d = p0 - G.shift;
-				if (d >= 0 && d < G.len)
+				if (d >= 0 && d < G.len) {
+					ZH_CHK(out_s + d, 1);
 					out_s[d] = v;
+				}
 				if (p0 >= G.dup_from) {
 					const long long d2 = p0 - G.dup_shift;
-					if (d2 >= 0 && d2 < G.dup_len)
+					if (d2 >= 0 && d2 < G.dup_len) {
+						ZH_CHK(out_s + d2, 1);
 						out_s[d2] = v;
+					}
 				}
 			}
 		}
@@ -565,8 +602,10 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, 4) __attribute__((amdgpu_wave
 			carry[j] = (i < 0) ? cprev[j] : y[4 + j]; // (i < 0: the call's first run, the frame before the call)
 		if (i == a.n_frames - 1) {
 #pragma unroll
-			for (int j = 0; j < 4; ++j)
+			for (int j = 0; j < 4; ++j) {
+				ZH_CHK(G.carry_next[0] + ((long long)s * HOP + tf + j * TF), 1);
 				G.carry_next[0][(long long)s * HOP + tf + j * TF] = carry[j];
+			}
 		}
 #pragma unroll
 		for (int sl = 0; sl < 16; ++sl)
@@ -593,8 +632,10 @@ struct IstftRunPend { // the finished hop that waits for the next frame's loads,
 	__device__ __forceinline__ void flush() const
 	{
 #pragma unroll
-		for (int j = 0; j < 4; ++j)
+		for (int j = 0; j < 4; ++j) {
+			ZH_CHK(base + tf + j * tf_step, 1);
 			base[tf + j * tf_step] = v[j];
+		}
 	}
 };
 struct IstftRunWideIn : IstftIn<3, 16> {
@@ -646,6 +687,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, istft_waves<LOG2N>())
 	for (int i = i0 - 1; i < i0 + a.run; ++i) {
 		const int r = i < 0 ? 0 : (i < a.n_frames ? i : a.n_frames - 1);
 		const float2* row = S_s + ((a.crow0 + r) % a.ring_rows) * a.s_stride;
+		ZH_CHK(bits_s + ((long long)r * (N / 16) + tf), 1);
 		const unsigned bw = bits_s[(long long)r * (N / 16) + tf];
 		float v[4];
 #pragma unroll
@@ -674,8 +716,10 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, istft_waves<LOG2N>())
 			zfft::fft_frame<LOG2N, true, false, true>(tf_o, img, twp, in, out, true);
 			if (i < 0) { // (wave-uniform) the call's first run
 #pragma unroll
-				for (int j = 0; j < 4; ++j)
+				for (int j = 0; j < 4; ++j) {
+					ZH_CHK(G.carry_prev[k] + ((long long)s * HOP + tf + j * TF), 1);
 					y[4 + j] = G.carry_prev[k][(long long)s * HOP + tf + j * TF];
+				}
 			}
 #pragma unroll
 			for (int j = 0; j < 4; ++j) {
@@ -703,12 +747,16 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, istft_waves<LOG2N>())
 				for (int j = 0; j < 4; ++j) {
 					const long long p0 = h0 + tf + j * TF;
 					const long long d = p0 - G.shift;
-					if (d >= 0 && d < G.len)
+					if (d >= 0 && d < G.len) {
+						ZH_CHK(out_s + d, 1);
 						out_s[d] = v[j];
+					}
 					if (p0 >= G.dup_from) {
 						const long long d2 = p0 - G.dup_shift;
-						if (d2 >= 0 && d2 < G.dup_len)
+						if (d2 >= 0 && d2 < G.dup_len) {
+							ZH_CHK(out_s + d2, 1);
 							out_s[d2] = v[j];
+						}
 					}
 				}
 			}
@@ -718,8 +766,10 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, istft_waves<LOG2N>())
 			for (int k = 0; k < NG; ++k)
 #pragma unroll
 				for (int j = 0; j < 4; ++j)
-					if (k < G.n_out)
+					if (k < G.n_out) {
+						ZH_CHK(G.carry_next[k] + ((long long)s * HOP + tf + j * TF), 1);
 						G.carry_next[k][(long long)s * HOP + tf + j * TF] = carry[k][j];
+					}
 		}
 	}
 	pend.flush();

@@ -8,8 +8,10 @@
 //   finalize_kernel: overlap-add of neighbouring frames + copy-out (hps.cu:435-449, :526-528, :341-363).
 //   fft_kernel    : the plain FFTC2CWrapperGPU transform (fftw.h:35-43).
 #include "common.h"
+#include "bounds.h"
 #include "fft_dev.h"
 #include "fft_launch.h"
+#include "rfft_dev.h"
 #include "masks.h"
 #include "stft.h"
 
@@ -119,6 +121,98 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void stft_kernel(StftArgs a)
 	else {
 		zfft::fft_frame<LOG2N, false, true, false>(tf, lds + slot * PL::LDS_FLOAT2, a.tw, in, out, active);
 	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same analysis through the real-input transform of rfft_dev.h: the frame is real (window_functor, hps.h:24-33; the
+// imaginary parts are zeroed, hps.cu:456-465), so every sub-transform of the radix-2 DAG is exactly Hermitian and only
+// its lower half is computed -- half the butterflies, half the LDS image, N/32 threads per frame, the oracle's bits.
+struct StftInR {
+	const float* prev;
+	const float* cur;
+	const float* window;
+	int hop;
+	int nv_prev, nv_cur;
+	__device__ __forceinline__ float operator()(int idx) const
+	{
+		const bool first = idx < hop;
+		const int k = first ? idx : idx - hop;
+		const bool ok = k < (first ? nv_prev : nv_cur);
+		const float* p = ok ? (first ? prev : cur) + k : window; // (one unconditional load from a selected address: StftIn)
+		ZH_CHK(p, 1);
+		const float v = *p;
+		const float x = ok ? v : 0.0f;
+		return x * window[idx];
+	}
+};
+struct StftOutR {
+	float2* S;
+	float* mag;
+	int n;
+	bool full;
+	__device__ __forceinline__ void operator()(int bin, float2 X) const
+	{
+		ZH_CHK(S + bin, 1);
+		ZH_CHK(mag + bin, 1);
+		S[bin] = X;
+		const float m = zfft::cabs_exact(X.x, X.y); // complex_abs_functor hps.h:82-89
+		mag[bin] = m;
+		if (full && bin != 0 && bin != (n >> 1)) {
+			ZH_CHK(mag + (n - bin), 1);
+			mag[n - bin] = m;
+		}
+	}
+};
+
+// (four waves per SIMD: two 512-thread workgroups per CU at nfft 16384, whose 74 KB images now both fit the LDS)
+template <int LOG2N>
+__global__ __launch_bounds__(zfft::RPlan<LOG2N>::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void stft_real_kernel(StftArgs a)
+{
+	using RP = zfft::RPlan<LOG2N>;
+	extern __shared__ float2 lds[];
+	const int tid = threadIdx.x, s = blockIdx.y, hop = a.hop;
+	if (blockIdx.x == gridDim.x - 1) { // housekeeping block
+		const float* last = a.in + (long long)s * a.in_stride + (long long)(a.n_frames - 1) * hop;
+		const int nv = valid_in_hop(a.in_valid, a.n_frames - 1, hop);
+		for (int i = tid; i < hop; i += RP::THREADS)
+			a.tail_next[(long long)s * hop + i] = i < nv ? last[i] : 0.0f;
+		if (a.prev_frames > 0) {
+			for (int o = 0; o < 3; ++o) {
+				if (!a.carry[o])
+					continue;
+				const float* y = a.Y[o] + (long long)s * a.y_stream_stride + (long long)(a.prev_frames - 1) * (2 * hop) + hop;
+				for (int i = tid; i < hop; i += RP::THREADS)
+					a.carry[o][(long long)s * hop + i] = y[i];
+			}
+		}
+		return;
+	}
+	const int slot = tid / RP::TF, tf = tid - slot * RP::TF;
+	const int f_ = blockIdx.x * RP::FRAMES_PER_BLOCK + slot;
+	const bool active = f_ < a.n_frames;
+	const int f = active ? f_ : a.n_frames - 1; // (an inactive slot transforms the last frame again and stores nothing)
+	const float* in_s = a.in + (long long)s * a.in_stride;
+	StftInR in;
+	in.prev = (f == 0) ? a.tail_prev + (long long)s * hop : in_s + (long long)(f - 1) * hop;
+	in.cur = in_s + (long long)f * hop;
+	in.window = a.window;
+	in.hop = hop;
+	in.nv_prev = f == 0 ? hop : valid_in_hop(a.in_valid, f - 1, hop);
+	in.nv_cur = valid_in_hop(a.in_valid, f, hop);
+	const long long row = ((a.row0 + f) % a.ring_rows) + (long long)s * a.ring_rows;
+	StftOutR out;
+	out.S = a.S + row * a.s_stride;
+	out.mag = a.mag + row * RP::N;
+	out.n = RP::N;
+	out.full = f >= a.mag_full_from;
+	const zfft::TwGlobal tw{a.tw};
+	zfft::rfft_frame<LOG2N, true>(tf, lds + slot * RP::LDS_FLOAT2, tw, in, out, active);
+}
+
+template <int LOG2N>
+constexpr size_t rlds_bytes()
+{
+	return sizeof(float2) * (size_t)zfft::RPlan<LOG2N>::LDS_FLOAT2 * zfft::RPlan<LOG2N>::FRAMES_PER_BLOCK;
 }
 
 // streaming 16-byte accesses (aligned): the Y rows are read once, the outputs written once
@@ -262,6 +356,15 @@ template <int LOG2N>
 int launch_stft_t(const StftArgs& a, hipStream_t stream)
 {
 	using PL = Plan<LOG2N>;
+	if (!g_opt_no_rfft) {
+		using RP = zfft::RPlan<LOG2N>;
+		auto kern = stft_real_kernel<LOG2N>;
+		ZH_TRY(set_lds(kern, rlds_bytes<LOG2N>()));
+		dim3 grid((unsigned)ceil_div((size_t)a.n_frames, (size_t)RP::FRAMES_PER_BLOCK) + 1, (unsigned)a.n_streams);
+		hipLaunchKernelGGL(kern, grid, dim3(RP::THREADS), rlds_bytes<LOG2N>(), stream, a);
+		ZH_HIP(hipGetLastError());
+		return ZEN_HIP_OK;
+	}
 	auto kern = stft_kernel<LOG2N>;
 	ZH_TRY(set_lds(kern, lds_bytes<LOG2N>()));
 	dim3 grid((unsigned)ceil_div((size_t)a.n_frames, (size_t)PL::FRAMES_PER_BLOCK) + 1, (unsigned)a.n_streams);
