@@ -40,6 +40,8 @@ struct StftIn {
 		const int k = first ? idx : idx - hop;
 		const bool ok = k < (first ? nv_prev : nv_cur);
 		const float* p = ok ? (first ? prev : cur) + k : window;
+		ZH_CHK(p, 1);
+		ZH_CHK(window + idx, 1);
 		const float v = *p;
 		const float x = ok ? v : 0.0f;
 		return make_float2(x * window[idx], 0.0f); // window_functor hps.h:24-33
@@ -64,11 +66,15 @@ struct StftOut {
 	__device__ __forceinline__ void operator()(int idx, float2 X, bool lower, int) const
 	{
 		if (lower || idx == (n >> 1)) {
+			ZH_CHK(S + idx, 1);
+			ZH_CHK(mag + idx, 1);
 			S[idx] = X;
 			const float m = zfft::cabs_exact(X.x, X.y); // complex_abs_functor hps.h:82-89
 			mag[idx] = m;
-			if (full && idx != 0 && idx != (n >> 1))
+			if (full && idx != 0 && idx != (n >> 1)) {
+				ZH_CHK(mag + (n - idx), 1);
 				mag[n - idx] = m;
+			}
 		}
 	}
 };
@@ -82,16 +88,23 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void stft_kernel(StftArgs a)
 	if (blockIdx.x == gridDim.x - 1) { // housekeeping block
 		const float* last = a.in + (long long)s * a.in_stride + (long long)(a.n_frames - 1) * hop;
 		const int nv = valid_in_hop(a.in_valid, a.n_frames - 1, hop);
-		for (int i = tid; i < hop; i += PL::THREADS)
+		for (int i = tid; i < hop; i += PL::THREADS) {
+			ZH_CHK(a.tail_next + ((long long)s * hop + i), 1);
+			if (i < nv)
+				ZH_CHK(last + i, 1);
 			a.tail_next[(long long)s * hop + i] = i < nv ? last[i] : 0.0f;
+		}
 		if (a.prev_frames > 0) {
 			for (int o = 0; o < 3; ++o) {
 				if (!a.carry[o])
 					continue;
 				const float* y = a.Y[o] + (long long)s * a.y_stream_stride
 				                 + (long long)(a.prev_frames - 1) * (2 * hop) + hop;
-				for (int i = tid; i < hop; i += PL::THREADS)
+				for (int i = tid; i < hop; i += PL::THREADS) {
+					ZH_CHK(a.carry[o] + ((long long)s * hop + i), 1);
+					ZH_CHK(y + i, 1);
 					a.carry[o][(long long)s * hop + i] = y[i];
+				}
 			}
 		}
 		return;
@@ -140,6 +153,7 @@ struct StftInR {
 		const bool ok = k < (first ? nv_prev : nv_cur);
 		const float* p = ok ? (first ? prev : cur) + k : window; // (one unconditional load from a selected address: StftIn)
 		ZH_CHK(p, 1);
+		ZH_CHK(window + idx, 1);
 		const float v = *p;
 		const float x = ok ? v : 0.0f;
 		return x * window[idx];
@@ -174,15 +188,22 @@ __global__ __launch_bounds__(zfft::RPlan<LOG2N>::THREADS) __attribute__((amdgpu_
 	if (blockIdx.x == gridDim.x - 1) { // housekeeping block
 		const float* last = a.in + (long long)s * a.in_stride + (long long)(a.n_frames - 1) * hop;
 		const int nv = valid_in_hop(a.in_valid, a.n_frames - 1, hop);
-		for (int i = tid; i < hop; i += RP::THREADS)
+		for (int i = tid; i < hop; i += RP::THREADS) {
+			ZH_CHK(a.tail_next + ((long long)s * hop + i), 1);
+			if (i < nv)
+				ZH_CHK(last + i, 1);
 			a.tail_next[(long long)s * hop + i] = i < nv ? last[i] : 0.0f;
+		}
 		if (a.prev_frames > 0) {
 			for (int o = 0; o < 3; ++o) {
 				if (!a.carry[o])
 					continue;
 				const float* y = a.Y[o] + (long long)s * a.y_stream_stride + (long long)(a.prev_frames - 1) * (2 * hop) + hop;
-				for (int i = tid; i < hop; i += RP::THREADS)
+				for (int i = tid; i < hop; i += RP::THREADS) {
+					ZH_CHK(a.carry[o] + ((long long)s * hop + i), 1);
+					ZH_CHK(y + i, 1);
 					a.carry[o][(long long)s * hop + i] = y[i];
+				}
 			}
 		}
 		return;
@@ -219,12 +240,14 @@ constexpr size_t rlds_bytes()
 __device__ __forceinline__ float4 load4_nt(const float* p)
 {
 	const float* q = reinterpret_cast<const float*>(__builtin_assume_aligned(p, 16));
+	ZH_CHK(q, 4);
 	return make_float4(__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1), __builtin_nontemporal_load(q + 2),
 	                   __builtin_nontemporal_load(q + 3));
 }
 __device__ __forceinline__ void store4_nt(float* p, float4 v)
 {
 	float* q = reinterpret_cast<float*>(__builtin_assume_aligned(p, 16));
+	ZH_CHK(q, 4);
 	__builtin_nontemporal_store(v.x, q);
 	__builtin_nontemporal_store(v.y, q + 1);
 	__builtin_nontemporal_store(v.z, q + 2);
@@ -255,6 +278,9 @@ __global__ __launch_bounds__(256) void finalize_kernel(FinalizeArgs a)
 			store4_nt(out + i * hop + k, make_float4(p.x + c.x, p.y + c.y, p.z + c.z, p.w + c.w));
 		}
 		else {
+			ZH_CHK(prev, 1);
+			ZH_CHK(cur, 1);
+			ZH_CHK(out + (i * hop + k), 1);
 			out[i * hop + k] = prev[0] + cur[0];
 		}
 	}
@@ -286,6 +312,8 @@ __global__ __launch_bounds__(256) void finalize_spec_kernel(FinalizeArgs a)
 				v[0] = p.x + c.x, v[1] = p.y + c.y, v[2] = p.z + c.z, v[3] = p.w + c.w;
 			}
 			else {
+				ZH_CHK(prev, 1);
+				ZH_CHK(cur, 1);
 				v[0] = prev[0] + cur[0];
 			}
 		}
@@ -297,6 +325,8 @@ __global__ __launch_bounds__(256) void finalize_spec_kernel(FinalizeArgs a)
 				v[0] = v[0] + (p.x + c.x), v[1] = v[1] + (p.y + c.y), v[2] = v[2] + (p.z + c.z), v[3] = v[3] + (p.w + c.w);
 			}
 			else {
+				ZH_CHK(prev, 1);
+				ZH_CHK(cur, 1);
 				v[0] = v[0] + (prev[0] + cur[0]);
 			}
 		}
@@ -313,15 +343,19 @@ __global__ __launch_bounds__(256) void finalize_spec_kernel(FinalizeArgs a)
 		else {
 #pragma unroll
 			for (int q = 0; q < V; ++q)
-				if (j + q >= 0 && j + q < a.len)
+				if (j + q >= 0 && j + q < a.len) {
+					ZH_CHK(out + (j + q), 1);
 					out[j + q] = v[q];
+				}
 		}
 		if (p0 + V > a.dup_from) {
 #pragma unroll
 			for (int q = 0; q < V; ++q) {
 				const long long j2 = p0 + q - a.dup_shift;
-				if (p0 + q >= a.dup_from && j2 >= 0 && j2 < a.dup_len)
+				if (p0 + q >= a.dup_from && j2 >= 0 && j2 < a.dup_len) {
+					ZH_CHK(out + j2, 1);
 					out[j2] = v[q];
+				}
 			}
 		}
 	}
@@ -330,11 +364,19 @@ __global__ __launch_bounds__(256) void finalize_spec_kernel(FinalizeArgs a)
 // ------------------------------------------------------------------------------------------------
 struct PlainIn {
 	const float2* d;
-	__device__ __forceinline__ float2 operator()(int idx, int) const { return d[idx]; }
+	__device__ __forceinline__ float2 operator()(int idx, int) const
+	{
+		ZH_CHK(d + idx, 1);
+		return d[idx];
+	}
 };
 struct PlainOut {
 	float2* d;
-	__device__ __forceinline__ void operator()(int idx, float2 X, bool, int) const { d[idx] = X; }
+	__device__ __forceinline__ void operator()(int idx, float2 X, bool, int) const
+	{
+		ZH_CHK(d + idx, 1);
+		d[idx] = X;
+	}
 };
 
 template <int LOG2N, bool INV>
