@@ -30,6 +30,9 @@ struct TwScalar { // the table in memory, scalar butterflies (the packed ones ar
 	const float2* p;
 	float2 get(int, int, int, int idx) const { return p[idx]; }
 };
+struct TwScalarPre : TwScalar { // every pass's twiddles requested at its top (RPass::TwP)
+	static constexpr bool PRELOAD = true;
+};
 struct In {
 	const float* x;
 	float operator()(int idx) const { return x[idx]; }
@@ -44,23 +47,23 @@ struct Out {
 	}
 };
 
-template <int LOG2N, int PASS, bool ZU>
-static void run_passes(float2* lds, const TwScalar& tw, In& in, Out& out)
+template <int LOG2N, int PASS, bool ZU, class TW>
+static void run_passes(float2* lds, const TW& tw, In& in, Out& out)
 {
 	using RP = zfft::RPlan<LOG2N>;
-	using PS = zfft::RPass<LOG2N, PASS, ZU, TwScalar>;
+	using PS = zfft::RPass<LOG2N, PASS, ZU, TW>;
 	std::vector<typename PS::Regs> regs(RP::TF);
 	for (int tf = 0; tf < RP::TF; ++tf)
-		PS::load(tf, lds, in, regs[tf]);
+		PS::load(tf, lds, in, regs[tf], tw.p);
 	for (int tf = 0; tf < RP::TF; ++tf)
 		PS::compute(tf, lds, tw, out, true, regs[tf]);
 	if constexpr (PASS + 1 < RP::P)
-		run_passes<LOG2N, PASS + 1, ZU>(lds, tw, in, out);
+		run_passes<LOG2N, PASS + 1, ZU, TW>(lds, tw, in, out);
 }
 
 static bool same(float a, float b) { return a == b || (std::isnan(a) && std::isnan(b)); } // (+0 == -0)
 
-template <int LOG2N, bool ZU>
+template <int LOG2N, bool ZU, class TW = TwScalar>
 static void check(unsigned seed)
 {
 	using RP = zfft::RPlan<LOG2N>;
@@ -80,10 +83,11 @@ static void check(unsigned seed)
 	std::vector<float2> lds(RP::LDS_FLOAT2, make_float2(NAN, NAN));
 	std::vector<float2> X(N / 2 + 1, make_float2(NAN, NAN));
 	std::vector<int> hits(N / 2 + 1, 0);
-	TwScalar t{reinterpret_cast<const float2*>(tw.data())};
+	TW t;
+	t.p = reinterpret_cast<const float2*>(tw.data());
 	In in{x.data()};
 	Out out{X.data(), hits.data()};
-	run_passes<LOG2N, 0, ZU>(lds.data(), t, in, out);
+	run_passes<LOG2N, 0, ZU, TW>(lds.data(), t, in, out);
 	int bad = 0;
 	for (int k = 0; k <= N / 2; ++k) {
 		if (hits[k] != 1 || !same(X[k].x, ref[2 * k]) || !same(X[k].y, ref[2 * k + 1])) {
@@ -109,6 +113,7 @@ static void check_size()
 		check<L, true>(s * 977 + L);
 		check<L, false>(s * 131 + L);
 	}
+	check<L, true, TwScalarPre>(4242 + L);
 	if constexpr (L < 14)
 		check_size<L + 1>();
 }

@@ -34,24 +34,42 @@ def test_red_zones_are_on_and_clean(z):
     assert r["corrupt_words"] == 0, r["first_message"]
 
 
-@pytest.mark.memcheck_expected
+_POKE_CHILD = """
+import json, sys
+import zen_amd
+zen_amd.init(0)
+where = sys.argv[1]
+buf = zen_amd.DeviceBuffer(1000)
+rep = [zen_amd.memcheck()]
+zen_amd.debug_poke(buf.ptr, 4 * 1000 + 256 if where == "behind" else -4, 0x12345678)   # (behind: past the 256-byte alignment slack)
+rep.append(zen_amd.memcheck())
+rep.append(zen_amd.memcheck())                   # reported once: the zone is repaired
+zen_amd.debug_poke(buf.ptr, 4 * 999, 0)          # the last word of the allocation itself: fine
+rep.append(zen_amd.memcheck())
+print("REPORTS " + json.dumps(rep))
+"""
+
+
 @pytest.mark.parametrize("where", ["behind", "in_front"])
 def test_deliberately_broken_store_is_caught(z, where):
     """A store one word outside an allocation (zen_hip_debug_poke: a one-thread kernel) must show up in zen_hip_memcheck:
-    as overwritten red-zone words in any build, and as a recorded out-of-bounds access in a -DZEN_HIP_BOUNDS build."""
-    buf = z.DeviceBuffer(1000)
-    before = z.memcheck()
-    z.debug_poke(buf.ptr, 4 * 1000 + 256 if where == "behind" else -4, 0x12345678)   # (behind: past the 256-byte alignment slack)
-    after = z.memcheck()
-    assert after["corrupt_words"] == before["corrupt_words"] + 1, after
+    as overwritten red-zone words in any build, and as a recorded out-of-bounds access in a -DZEN_HIP_BOUNDS build.  In a
+    child process: a process that found a zone overwritten exits with status 86 (next test), and this one must not."""
+    import json
+    env = dict(os.environ, ZEN_HIP_REDZONE="4096", ZEN_HIP_BOUNDS_TRAP="0")
+    r = subprocess.run([sys.executable, "-c", _POKE_CHILD, where], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       universal_newlines=True, timeout=300)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("REPORTS ")]
+    assert line, (r.returncode, r.stdout[-1000:], r.stderr[-2000:])
+    before, after, again, last = json.loads(line[0][8:])
+    assert before["redzone_bytes"] >= 4096 and before["corrupt_words"] == 0
+    assert after["corrupt_words"] == 1, after
     assert "red zone" in after["first_message"] or after["bounds_violations"] > 0
     if after["bounds_build"]:
         assert after["bounds_violations"] == before["bounds_violations"] + 1
-    again = z.memcheck()                             # reported once: the zone is repaired
-    assert again["corrupt_words"] == after["corrupt_words"]
-    z.debug_poke(buf.ptr, 4 * 999, 0)                # the last word of the allocation itself: fine
-    assert z.memcheck()["corrupt_words"] == after["corrupt_words"]
-    assert z.memcheck()["bounds_violations"] == after["bounds_violations"]
+    assert again["corrupt_words"] == 1
+    assert last["corrupt_words"] == 1 and last["bounds_violations"] == after["bounds_violations"]
+    assert r.returncode == 86
 
 
 def test_child_process_with_a_broken_store_exits_86(z):

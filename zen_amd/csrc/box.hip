@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void box_freq_kernel(FilterArgs a, int segs_pe
 		for (int u = 0; u < NT; ++u) {
 			int c = col0 - mid + tid + 256 * u;
 			c = c < 0 ? 0 : (c > cols - 1 ? cols - 1 : c); // replicate border (ippBorderRepl); past the span: not stored
+			ZH_CHK(srow + c, 1);
 			v[u] = srow[c];
 		}
 #pragma unroll
@@ -81,8 +82,10 @@ __global__ __launch_bounds__(256) void box_freq_kernel(FilterArgs a, int segs_pe
 #pragma unroll
 	for (int k = 0; k < K; ++k) {
 		const int o = tid + 256 * k;
-		if (col0 + o < cols)
+		if (col0 + o < cols) {
+			ZH_CHK(drow + col0 + o, 1);
 			drow[col0 + o] = post_of(acc[k], flen, a.sse_post, a.post_factor);
+		}
 	}
 }
 
@@ -113,6 +116,7 @@ __global__ __launch_bounds__(256) void box_time_kernel(FilterArgs a, int rows_pe
 				const int i = i0 + 4 * u < nrows ? i0 + 4 * u : nrows - 1;
 				long long r = ar0 - mid + i;
 				r = r < a.clamp_lo ? a.clamp_lo : (r > a.clamp_hi ? a.clamp_hi : r);
+				ZH_CHK(src + ((r % a.ring_rows) * cols + col), 1);
 				v[u] = src[(r % a.ring_rows) * cols + col];
 			}
 #pragma unroll
@@ -150,8 +154,10 @@ __global__ __launch_bounds__(256) void box_time_kernel(FilterArgs a, int rows_pe
 		}
 #pragma unroll
 		for (int u = 0; u < 4; ++u)
-			if (qb + 4 * u < nq)
+			if (qb + 4 * u < nq) {
+				ZH_CHK(dst + ((long long)(q0 + q[u]) * cols + col), 1);
 				dst[(long long)(q0 + q[u]) * cols + col] = post_of(acc[u], flen, a.sse_post, a.post_factor);
+			}
 	}
 }
 
@@ -175,6 +181,7 @@ __global__ __launch_bounds__(256) void box_direct_kernel(FilterArgs a)
 			if (DIR == 0) {
 				int c = col - mid + j;
 				c = c < 0 ? 0 : (c > cols - 1 ? cols - 1 : c);
+				ZH_CHK(src + ((ar % a.ring_rows) * cols + c), 1);
 				v = src[(ar % a.ring_rows) * cols + c];
 			}
 			else {
@@ -182,11 +189,13 @@ __global__ __launch_bounds__(256) void box_direct_kernel(FilterArgs a)
 				r = r < a.clamp_lo ? a.clamp_lo : (r > a.clamp_hi ? a.clamp_hi : r);
 				if (a.causal_self && r > ar)
 					r = ar;
+				ZH_CHK(src + ((r % a.ring_rows) * cols + col), 1);
 				v = src[(r % a.ring_rows) * cols + col];
 			}
 			v = pre_of(v, a.sse_pre);
 			acc = (j == 0) ? v : acc + v;
 		}
+		ZH_CHK(dst + i, 1);
 		dst[i] = post_of(acc, flen, a.sse_post, a.post_factor);
 	}
 }

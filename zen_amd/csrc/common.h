@@ -8,6 +8,7 @@
 #include <cstring>
 
 #include "../../include/zen_hip.h"
+#include "bounds.h" // ZH_CHK: the bounds checks of -DZEN_HIP_BOUNDS builds (nothing otherwise)
 
 namespace zen_hip_impl {
 

@@ -137,6 +137,7 @@ __global__ __launch_bounds__(256) void median_wave_kernel(FilterArgs a)
 				int col = seg * SEG - mid + u;
 				col = col < 0 ? 0 : (col > cols - 1 ? cols - 1 : col);
 				const long long srow = (a.first_row + row) % a.ring_rows;
+				ZH_CHK(src + (srow * cols + col), 1);
 				tin[line * pin + u] = f2key(src[srow * cols + col]);
 			}
 		}
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(256) void median_wave_kernel(FilterArgs a)
 			const int col = c0 + line;
 			if (col < cols) {
 				long long ar = clampll(a.first_row + t0 - mid + u, a.clamp_lo, a.clamp_hi);
+				ZH_CHK(src + ((ar % a.ring_rows) * cols + col), 1);
 				tin[line * pin + u] = f2key(src[(ar % a.ring_rows) * cols + col]);
 			}
 		}
@@ -197,8 +199,10 @@ __global__ __launch_bounds__(256) void median_wave_kernel(FilterArgs a)
 				const long long row = L / segs_per_row;
 				const int seg = (int)(L - row * segs_per_row);
 				const int col = seg * SEG + o;
-				if (col < cols)
+				if (col < cols) {
+					ZH_CHK(dst + (row * cols + col), 1);
 					dst[row * cols + col] = key2f(tout[line * pout + o]);
+				}
 			}
 		}
 	}
@@ -206,8 +210,10 @@ __global__ __launch_bounds__(256) void median_wave_kernel(FilterArgs a)
 		for (int e = tid; e < NL * SEG; e += 256) {
 			const int line = e & (NL - 1), o = e / NL;
 			const int col = c0 + line, row = t0 + o;
-			if (col < cols && row < a.n_out_rows)
+			if (col < cols && row < a.n_out_rows) {
+				ZH_CHK(dst + ((long long)row * cols + col), 1);
 				dst[(long long)row * cols + col] = key2f(tout[line * pout + o]);
+			}
 		}
 	}
 }
@@ -222,6 +228,8 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(FilterArgs a)
 	     i += (long long)gridDim.x * blockDim.x) {
 		const long long row = i / a.cols;
 		const int col = (int)(i - row * a.cols);
+		ZH_CHK(dst + i, 1);
+		ZH_CHK(src + (((a.first_row + row) % a.ring_rows) * a.cols + col), 1);
 		dst[i] = src[((a.first_row + row) % a.ring_rows) * a.cols + col];
 	}
 }

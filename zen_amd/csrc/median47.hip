@@ -28,6 +28,7 @@
 // prologue without integer division, clamps or branches (whole rows only; other geometries use the generic
 // kernel).  HBM traffic is unchanged: 4 B read + 4 B written per element.
 #include "common.h"
+#include "bounds.h"
 #include "filters.h"
 #include "median47_core.h"
 
@@ -56,11 +57,13 @@ struct M47Args {
 // (profiles/r02_ubench_copy.txt).
 __device__ __forceinline__ float4 load_nt(const float* p)
 {
+	ZH_CHK(p, 4);
 	return make_float4(__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1), __builtin_nontemporal_load(p + 2),
 	                   __builtin_nontemporal_load(p + 3));
 }
 __device__ __forceinline__ void store_nt(float* p, float4 v)
 {
+	ZH_CHK(p, 4);
 	__builtin_nontemporal_store(v.x, p);
 	__builtin_nontemporal_store(v.y, p + 1);
 	__builtin_nontemporal_store(v.z, p + 2);
@@ -104,10 +107,12 @@ __global__ __launch_bounds__(256) void median47_dpp_kernel(M47Args p)
 		for (int i = 0; i < 4; ++i) {
 			if (HERM && i >= 2) { // columns 2048 + ...: the mirror image of the stored half, back to front
 				const int mc = COLS - (4 * tid + 1024 * i); // columns mc, mc-1, mc-2, mc-3
+				ZH_CHK(srow + mc - 4, 5);
 				const float4 v = *reinterpret_cast<const float4*>(srow + mc - 4);
 				x[i] = make_float4(srow[mc], v.w, v.z, v.y);
 			}
 			else {
+				ZH_CHK(srow + 4 * tid + 1024 * i, 4);
 				x[i] = NT ? load_nt(srow + 4 * tid + 1024 * i) : *reinterpret_cast<const float4*>(srow + 4 * tid + 1024 * i);
 			}
 		}
@@ -334,6 +339,7 @@ __global__ __launch_bounds__(256) void median47_dpp_kernel(M47Args p)
 		{
 			int4 k = make_int4(out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]);
 			unkey4(k);
+			ZH_CHK(drow + 16 * tid + 4 * v, 4);
 			*reinterpret_cast<float4*>(drow + 16 * tid + 4 * v) =
 			    make_float4(__int_as_float(k.x), __int_as_float(k.y), __int_as_float(k.z), __int_as_float(k.w));
 		}
@@ -354,6 +360,7 @@ __global__ __launch_bounds__(256) void median47_dpp_kernel(M47Args p)
 			int4 k = *reinterpret_cast<const int4*>(rd + i * 64 * RSTR);
 			unkey4(k);
 			const float4 r = make_float4(__int_as_float(k.x), __int_as_float(k.y), __int_as_float(k.z), __int_as_float(k.w));
+			ZH_CHK(drow + 4 * tid + 1024 * i, 4);
 			if (NT)
 				store_nt(drow + 4 * tid + 1024 * i, r);
 			else

@@ -124,6 +124,7 @@ __global__ __launch_bounds__(256, ZEN_BIG_MINB) void median_big_kernel(FilterArg
 		if (wanted) {
 			int h[16];
 			znet::lds_load<16>(&raw[(tid + G::a + 2) * RSTR], h); // the thread's own block
+			ZH_CHK(a.bits + ((long long)st * a.bits_stream_stride + (long long)row * a.bits_row_words + (col0 >> 4) + tid), 1);
 			a.bits[(long long)st * a.bits_stream_stride + (long long)row * a.bits_row_words + (col0 >> 4) + tid] =
 			    mask_word16(out, h, a.thr_p, a.thr_h, a.need_pm, a.need_hm);
 		}
@@ -157,12 +158,14 @@ __global__ __launch_bounds__(256, ZEN_BIG_MINB) void median_big_kernel(FilterArg
 		const int c = col0 + g;
 		if (c < cols && (c >> 4) < nblk_main) {
 			const int4 k = *reinterpret_cast<const int4*>(&raw[(g >> 4) * RSTR + (g & 15)]);
+			ZH_CHK(drow + c, 4);
 			*reinterpret_cast<float4*>(drow + c) =
 			    make_float4(from_key<NONNEG>(k.x), from_key<NONNEG>(k.y), from_key<NONNEG>(k.z), from_key<NONNEG>(k.w));
 			if constexpr (SOFT) {
 				if (a.mh_dst) {
 					const int4 m = *reinterpret_cast<const int4*>(&srt[(g >> 4) * RSTR + (g & 15)]);
 					float* mrow = a.mh_dst + (long long)st * a.mh_stream_stride + (long long)row * cols;
+					ZH_CHK(mrow + c, 4);
 					*reinterpret_cast<float4*>(mrow + c) =
 					    make_float4(__int_as_float(m.x), __int_as_float(m.y), __int_as_float(m.z), __int_as_float(m.w));
 				}
@@ -265,6 +268,7 @@ __global__ __launch_bounds__(64) void median_big_tail_kernel(FilterArgs a, int r
 		const int nw = a.bits_row_words - blkA; // words behind the main kernel's (the row's padding included)
 		for (int k = lane; k < rows_here * nw; k += 64) {
 			const int r2 = k / nw, w2 = k - r2 * nw;
+			ZH_CHK(a.bits + ((long long)st * a.bits_stream_stride + (long long)(row0 + r2) * a.bits_row_words + blkA + w2), 1);
 			a.bits[(long long)st * a.bits_stream_stride + (long long)(row0 + r2) * a.bits_row_words + blkA + w2] = tb[r2 * TBW + w2];
 		}
 		return;
@@ -277,16 +281,20 @@ __global__ __launch_bounds__(64) void median_big_tail_kernel(FilterArgs a, int r
 		if (a.mh_dst) {
 			float* mrow = a.mh_dst + (long long)st * a.mh_stream_stride + (long long)(row0 + rr) * cols + c;
 #pragma unroll
-			for (int v = 0; v < 4; ++v)
+			for (int v = 0; v < 4; ++v) {
+				ZH_CHK(mrow + 4 * v, 4);
 				*reinterpret_cast<float4*>(mrow + 4 * v) = make_float4(mh[4 * v], mh[4 * v + 1], mh[4 * v + 2], mh[4 * v + 3]);
+			}
 		}
 	}
 	float* drow = a.dst + (long long)st * a.dst_stream_stride + (long long)(row0 + rr) * cols;
 #pragma unroll
-	for (int v = 0; v < 4; ++v)
+	for (int v = 0; v < 4; ++v) {
+		ZH_CHK(drow + c + 4 * v, 4);
 		*reinterpret_cast<float4*>(drow + c + 4 * v) =
 		    make_float4(from_key<NONNEG>(out[4 * v]), from_key<NONNEG>(out[4 * v + 1]), from_key<NONNEG>(out[4 * v + 2]),
 		                from_key<NONNEG>(out[4 * v + 3]));
+	}
 }
 
 template <int W>

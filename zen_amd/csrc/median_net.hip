@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowM
 		for (int g = tid; g < SPANV * 4; g += 256) {
 			int c = c_lo + g;
 			c = c < 0 ? 0 : (c > cols - 1 ? cols - 1 : c);
+			ZH_CHK(srow + c, 1);
 			tile[IM::addr(g)] = to_key<NONNEG>(srow[c]);
 		}
 	}
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowM
 			if (c < cols && (!herm || c <= (cols >> 1) || c + 4 > cols - mid)) {
 				const int4 k = *reinterpret_cast<const int4*>(&tile[IM::addr(g)]);
 				float* dq = reinterpret_cast<float*>(__builtin_assume_aligned(drow + c, 16)); // streaming store
+				ZH_CHK(dq, 4);
 				__builtin_nontemporal_store(from_key<NONNEG>(k.x), dq);
 				__builtin_nontemporal_store(from_key<NONNEG>(k.y), dq + 1);
 				__builtin_nontemporal_store(from_key<NONNEG>(k.z), dq + 2);
@@ -203,8 +205,10 @@ __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowM
 	else {
 		for (int g = tid; g < OUTS; g += 256) {
 			const int c = col0 + g;
-			if (c < cols)
+			if (c < cols) {
+				ZH_CHK(drow + c, 1);
 				drow[c] = from_key<NONNEG>(tile[IM::addr(g)]);
+			}
 		}
 	}
 }
@@ -279,8 +283,10 @@ __global__ __launch_bounds__(HERM_THREADS) void median_net_freq_herm_kernel(Filt
 			const float* hrow = a.hrows + (long long)blockIdx.y * a.h_stream_stride + (long long)(row0 + rr) * cols;
 			float h[T]; // H of the bins (the tail's from the mirror image: H is symmetric, only its lower half is stored)
 #pragma unroll
-			for (int i = 0; i < T; ++i)
+			for (int i = 0; i < T; ++i) {
+				ZH_CHK(hrow + (tail ? cols - (c0 + i) : c0 + i), 1);
 				h[i] = hrow[tail ? cols - (c0 + i) : c0 + i];
+			}
 			int log2tf = 0;
 			while ((1 << log2tf) < tfw)
 				++log2tf;
@@ -303,8 +309,10 @@ __global__ __launch_bounds__(HERM_THREADS) void median_net_freq_herm_kernel(Filt
 		__syncthreads();
 		unsigned* dst_t = a.bits_t + (long long)blockIdx.y * a.bits_t_stream_stride + (long long)row0 * tfw;
 		const int rows_here = a.n_out_rows - row0 < rpw ? a.n_out_rows - row0 : rpw;
-		for (int k = tid; k < rows_here * tfw; k += HERM_THREADS)
+		for (int k = tid; k < rows_here * tfw; k += HERM_THREADS) {
+			ZH_CHK(dst_t + k, 1);
 			dst_t[k] = tw[k];
+		}
 		return;
 	}
 	znet::medians<W, T, W + T - 1>(e, out);
@@ -312,6 +320,7 @@ __global__ __launch_bounds__(HERM_THREADS) void median_net_freq_herm_kernel(Filt
 #pragma unroll
 	for (int v = 0; v < T / 4; ++v) {
 		float* dq = reinterpret_cast<float*>(__builtin_assume_aligned(d + 4 * v, 16)); // streaming store
+		ZH_CHK(dq, 4);
 #pragma unroll
 		for (int i = 0; i < 4; ++i)
 			__builtin_nontemporal_store(from_key<NONNEG>(out[4 * v + i]), dq + i);
@@ -356,6 +365,7 @@ __global__ __launch_bounds__(HERM_THREADS) void median_tf_herm_bits_kernel(Filte
 			int e[4][NET];
 #pragma unroll
 			for (int q = 0; q < NET; ++q) { // taps r0 - midT .. r0 + midT + TT - 1 (replicate border: map_row clamps)
+				ZH_CHK(src + ((long long)map_row(rm, r0 - midT + q) * cols + c), 4);
 				const float4 x = *reinterpret_cast<const float4*>(src + (long long)map_row(rm, r0 - midT + q) * cols + c);
 				e[0][q] = __float_as_int(x.x); // |S| >= +0: the bits are the ordering key
 				e[1][q] = __float_as_int(x.y);
@@ -441,8 +451,10 @@ __global__ __launch_bounds__(HERM_THREADS) void median_tf_herm_bits_kernel(Filte
 		unsigned* dst_t = a.bits_t + (long long)blockIdx.y * a.bits_t_stream_stride + (long long)rowb * tfw;
 		int rows_here = a.n_out_rows - rowb < rpw ? a.n_out_rows - rowb : rpw;
 		rows_here = RWG - rb < rows_here ? RWG - rb : rows_here;
-		for (int k = tid; k < rows_here * tfw; k += HERM_THREADS)
+		for (int k = tid; k < rows_here * tfw; k += HERM_THREADS) {
+			ZH_CHK(dst_t + k, 1);
 			dst_t[k] = tw[k];
+		}
 	}
 }
 
@@ -465,6 +477,7 @@ struct VecT<4> {
 template <int VC>
 __device__ __forceinline__ void load_keys(const float* p, int (&k)[VC])
 {
+	ZH_CHK(p, VC);
 	if constexpr (VC == 1) {
 		k[0] = f2key(*p);
 	}
@@ -485,6 +498,7 @@ __device__ __forceinline__ void load_keys(const float* p, int (&k)[VC])
 template <int VC>
 __device__ __forceinline__ void store_keys(float* p, const int (&k)[VC])
 {
+	ZH_CHK(p, VC);
 	if constexpr (VC == 4) { // streaming store
 #pragma unroll
 		for (int i = 0; i < 4; ++i)

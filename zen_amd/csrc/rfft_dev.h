@@ -156,13 +156,23 @@ struct RPass {
 	static constexpr int log2J = LOG2N - sL - rr, J = 1 << log2J;
 	static constexpr bool FIRST = PASS == 0, LAST = PASS == RP::P - 1;
 	static constexpr int NI = FIRST ? 32 / R : 16 / R; // items per thread
+	static constexpr bool PRE = tw_preloads<TW>::value && !FIRST;
+	// the twiddles of the pass's general items in registers (TwPassRegs with this plan's thread count), requested by load()
+	// in front of the reads of the image: left to the scheduler they sit in front of their stage, each waited for on the spot
+	struct TwP {
+		static constexpr bool PLAIN = true;
+		static constexpr bool PACKED = TW::PACKED;
+		float2 w[PRE ? NI : 1][8];
+		__device__ __forceinline__ float2 get(int, int i, int slot, int) const { return w[i][slot]; }
+	};
 	struct Regs {
 		float x[FIRST ? NI : 1][FIRST ? R : 1];    // pass 0: real samples
 		float2 v[FIRST ? 1 : NI][FIRST ? 1 : R];   // later passes: slots
+		TwP tw;
 	};
 
 	template <class In>
-	static __device__ __forceinline__ void load(int tf, const float2* __restrict__ lds, In& in, Regs& g)
+	static __device__ __forceinline__ void load(int tf, const float2* __restrict__ lds, In& in, Regs& g, const float2* __restrict__ tw_p = nullptr)
 	{
 		if constexpr (FIRST) {
 #pragma unroll
@@ -172,6 +182,19 @@ struct RPass {
 					g.x[i][m] = (ZU && m >= R / 2) ? 0.0f : in(tf + i * TF + m * J);
 		}
 		else {
+			if constexpr (PRE) {
+#pragma unroll
+				for (int i = 0; i < NI; ++i) {
+					const int k = (tf + i * TF) >> log2J;
+#pragma unroll
+					for (int q = 1; q <= rr; ++q) {
+						const int nload = q == 1 ? 1 : (1 << (q - 2));
+#pragma unroll
+						for (int c = 0; c < nload; ++c)
+							g.tw.w[i][(q == 1 ? 0 : (1 << (q - 2))) + c] = tw_p[(k << (LOG2N - sL - q)) + (c << (LOG2N - q))];
+					}
+				}
+			}
 #pragma unroll
 			for (int i = 0; i < NI; ++i) {
 				const int b = tf + i * TF, k = b >> log2J, j = b & (J - 1);
@@ -246,7 +269,10 @@ struct RPass {
 						emit(lds, out, active, (1 << (sL - 1)) + (c << sL), j, yh[c]);
 				}
 				else {
-					butterfly<R, false, false, false>(g.v[i], k, sL, LOG2N, tw, PASS, i);
+					if constexpr (PRE)
+						butterfly<R, false, false, false>(g.v[i], k, sL, LOG2N, g.tw, PASS, i);
+					else
+						butterfly<R, false, false, false>(g.v[i], k, sL, LOG2N, tw, PASS, i);
 #pragma unroll
 					for (int c = 0; c < R / 2; ++c)
 						emit(lds, out, active, k + (c << sL), j, g.v[i][c]);
@@ -266,7 +292,7 @@ struct RPassRunner {
 	{
 		using PS = RPass<LOG2N, PASS, ZU, TW>;
 		typename PS::Regs g;
-		PS::load(tf, lds, in, g);
+		PS::load(tf, lds, in, g, tw.p);
 		if constexpr (PASS != 0)
 			frame_sync<RP::TF>(); // every thread has its inputs in registers: the image may be overwritten
 		PS::compute(tf, lds, tw, out, active, g);

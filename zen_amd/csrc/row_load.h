@@ -1,5 +1,6 @@
 // row_load.h -- staging loads shared by the frequency-direction median kernels (median_net.hip, median_big.hip).
 #pragma once
+#include "bounds.h"
 #include "median_net.h"
 
 namespace zen_hip_impl {
@@ -23,6 +24,7 @@ __device__ __forceinline__ int4 row_vec_keys(const float* __restrict__ srow, int
 	const int va = up ? (mir ? mc - 3 : 0) : vcl;
 	// (streaming: every sample is staged by one workgroup and its halo by the next; nothing gains from staying in a cache)
 	const float* q = srow + va;
+	ZH_CHK(q, 4);
 	const float x0 = __builtin_nontemporal_load(q), x1 = __builtin_nontemporal_load(q + 1), x2 = __builtin_nontemporal_load(q + 2),
 	            x3 = __builtin_nontemporal_load(q + 3);
 	const int k0 = to_key<NONNEG>(x0), k1 = to_key<NONNEG>(x1), k2 = to_key<NONNEG>(x2), k3 = to_key<NONNEG>(x3);

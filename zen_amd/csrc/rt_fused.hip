@@ -57,9 +57,13 @@ struct FwdIn {
 	int hop;
 	__device__ __forceinline__ float2 operator()(int idx, int) const
 	{
+		ZH_CHK(idx < hop ? prev + idx : cur + (idx - hop), 1);
+		ZH_CHK(window + idx, 1);
 		const float x = idx < hop ? prev[idx] : cur[idx - hop];
-		if (tail && idx >= hop) // (a store between two loads: the second waits for the first.  One workgroup of a
+		if (tail && idx >= hop) { // (a store between two loads: the second waits for the first.  One workgroup of a
+			ZH_CHK(tail + (idx - hop), 1);
 			tail[idx - hop] = x; // block call can afford that; the single-hop call copies the tail below instead)
+		}
 		return make_float2(x * window[idx], 0.0f); // window_functor hps.h:24-33
 	}
 };
@@ -90,9 +94,13 @@ struct FwdOut {
 			const int mir = (idx == 0 || idx == (n >> 1)) ? idx : n - idx;
 			img[RtImage<T>::addr(idx + mid_al)] = key;
 			img[RtImage<T>::addr(mir + mid_al)] = key;
-			if (S) // the spectrum ring is only kept for single-hop calls
+			if (S) { // the spectrum ring is only kept for single-hop calls
+				ZH_CHK(S + idx, 1);
 				S[idx] = X;
+			}
 			if (mag) { // the magnitude ring: single-hop calls and the last stft_width-1 frames of a block
+				ZH_CHK(mag + idx, 1);
+				ZH_CHK(mag + mir, 1);
 				mag[idx] = m;
 				mag[mir] = m;
 			}
@@ -224,9 +232,13 @@ struct InvOut { // block builds
 	__device__ __forceinline__ void operator()(int idx, float2 x, bool, int) const
 	{
 		const float y = x.x * cola;
+		ZH_CHK(Y + idx, 1);
 		Y[idx] = y;
-		if (ready && idx < hop)
+		if (ready && idx < hop) {
+			ZH_CHK(ready + idx, 1);
+			ZH_CHK(carry + idx, 1);
 			ready[idx] = carry[idx] + y;
+		}
 	}
 };
 __device__ __forceinline__ unsigned xcc_id_of_cu()
@@ -246,11 +258,14 @@ struct InvOutRegT { // the single-hop build
 	__device__ __forceinline__ void operator()(int idx, float2 x, bool, int slot) const
 	{
 		const float y = x.x * cola;
+		ZH_CHK(Y + idx, 1);
 		Y[idx] = y;
 		// the finished hop goes out with system-scope (write-through) stores: publish_ready<true> then needs no write-back
 		// of the L2 (a plain store to mapped host memory may stay in the L2 until one)
-		if (ready && idx < hop)
+		if (ready && idx < hop) {
+			ZH_CHK(ready + idx, 1);
 			__hip_atomic_store(ready + idx, cv[slot & 3] + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
 		if constexpr (KEEP) {
 			if (slot >= 4)
 				next[slot & 3] = y;
@@ -274,9 +289,11 @@ struct FwdInKeep {
 			x = prev[slot & 3];
 		}
 		else {
+			ZH_CHK(cur + (idx - hop), 1);
 			x = cur[idx - hop];
 			next[slot & 3] = x;
 		}
+		ZH_CHK(window + idx, 1);
 		return make_float2(x * window[idx], 0.0f); // window_functor hps.h:24-33
 	}
 };
@@ -299,6 +316,7 @@ struct FwdInKeep {
 template <bool LIGHT = false>
 __device__ __forceinline__ void publish_ready(unsigned* flag, unsigned seq, int tf, bool release = false)
 {
+	ZH_CHK(flag, 1);
 	if (LIGHT && !release) {
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // (the compiler may not sink a sample store below the barrier)
@@ -392,6 +410,7 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
 			cv1[i] = hv.keep_carry[i];
+			ZH_CHK(a.carry[w0] + ((long long)s * hop + tf + i * TF), 1);
 			a.carry[w0][(long long)s * hop + tf + i * TF] = cv1[i]; // (memory stays what a per-launch hop would leave)
 		}
 		// the input tail is stored behind the forward transform, from the samples its first pass loads anyway
@@ -409,8 +428,10 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 					continue;
 				const float* y = a.Y[o] + (long long)s * a.y_stream_stride + (long long)(hv.prev_frames() - 1) * (2 * hop) + hop;
 #pragma unroll
-				for (int i = 0; i < 4; ++i)
+				for (int i = 0; i < 4; ++i) {
+					ZH_CHK(y + tf + i * TF, 1);
 					sv[o][i] = y[tf + i * TF];
+				}
 			}
 		}
 		if constexpr (SINGLE) { // the carries the synthesis will add: from the previous call's Y row or the carry buffer
@@ -418,13 +439,17 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 			const float* y = do_carry ? a.Y[w0] + (long long)s * a.y_stream_stride + (long long)(hv.prev_frames() - 1) * (2 * hop) + hop
 			                          : a.carry[w0] + (long long)s * hop;
 #pragma unroll
-			for (int i = 0; i < 4; ++i)
+			for (int i = 0; i < 4; ++i) {
+				ZH_CHK(y + tf + i * TF, 1);
 				cv1[i] = y[tf + i * TF];
+			}
 		}
 		if (f == a.n_frames - 1) {
 #pragma unroll
-			for (int i = 0; i < 4; ++i)
+			for (int i = 0; i < 4; ++i) {
+				ZH_CHK(cur + tf + i * TF, 1);
 				tv[i] = cur[tf + i * TF];
+			}
 		}
 		if (do_carry) {
 #pragma unroll
@@ -432,14 +457,18 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 				if (!a.carry[o])
 					continue;
 #pragma unroll
-				for (int i = 0; i < 4; ++i)
+				for (int i = 0; i < 4; ++i) {
+					ZH_CHK(a.carry[o] + ((long long)s * hop + tf + i * TF), 1);
 					a.carry[o][(long long)s * hop + tf + i * TF] = sv[o][i];
+				}
 			}
 		}
 		if (f == a.n_frames - 1) {
 #pragma unroll
-			for (int i = 0; i < 4; ++i)
+			for (int i = 0; i < 4; ++i) {
+				ZH_CHK(hv.tail_next() + ((long long)s * hop + tf + i * TF), 1);
 				hv.tail_next()[(long long)s * hop + tf + i * TF] = tv[i];
+			}
 		}
 	}
 	else if (hv.prev_frames() > 0 && f == (hv.prev_frames() - 1 < a.n_frames - 1 ? hv.prev_frames() - 1 : a.n_frames - 1)) {
@@ -449,11 +478,15 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 			const float* y = a.Y[o] + (long long)s * a.y_stream_stride + (long long)(hv.prev_frames() - 1) * (2 * hop) + hop;
 			float v[4];
 #pragma unroll
-			for (int i = 0; i < 4; ++i)
+			for (int i = 0; i < 4; ++i) {
+				ZH_CHK(y + tf + i * TF, 1);
 				v[i] = y[tf + i * TF];
+			}
 #pragma unroll
-			for (int i = 0; i < 4; ++i)
+			for (int i = 0; i < 4; ++i) {
+				ZH_CHK(a.carry[o] + ((long long)s * hop + tf + i * TF), 1);
 				a.carry[o][(long long)s * hop + tf + i * TF] = v[i];
+			}
 		}
 	}
 
@@ -465,6 +498,8 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 #pragma unroll
 		for (int i = 0; i < 4; ++i)
 			cw[i] = SINGLE ? cv1[i] : a.carry[which][(long long)s * hop + tf + i * TF];
+			if (!SINGLE)
+				ZH_CHK(a.carry[which] + ((long long)s * hop + tf + i * TF), 1);
 	};
 	stamp(1);
 	// ---- block build that finishes hops itself (RtFusedArgs::out_direct), first part.  Output hop h = second half of
@@ -499,6 +534,8 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 #pragma unroll
 		for (int m = 0; m < 8; ++m) {
 			const int idx = m * TF + tf;
+			ZH_CHK(m < 4 ? pv + idx : cur + (idx - hop), 1);
+			ZH_CHK(a.window + idx, 1);
 			pre.x[m] = m < 4 ? pv[idx] : cur[idx - hop];
 			pre.w[m] = a.window[idx];
 		}
@@ -507,13 +544,16 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 	if constexpr (DIRECT) {
 		if (a.direct_on) {
 			const int xi = bid >> 3, xcount = xq + (xcd < xr ? 1 : 0);
-			if (xi + DIRECT_BACK >= xcount && tf == 0)
+			if (xi + DIRECT_BACK >= xcount && tf == 0) {
+				ZH_CHK(a.blk_need + item, 1);
 				a.blk_need[item] = 1u; // nobody comes DIRECT_BACK items after this one
+			}
 			if (xi >= DIRECT_BACK) {
 				dh = item - DIRECT_BACK;
 				const int hs = dh / a.n_frames, hf = dh - hs * a.n_frames;
 				unsigned v0 = 0, v1 = 0;
 				if (hf > 0) {
+					ZH_CHK(a.blk_flag + dh - 1, 2);
 					v0 = __hip_atomic_load(a.blk_flag + dh - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 					v1 = __hip_atomic_load(a.blk_flag + dh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				}
@@ -528,6 +568,8 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 					                                                        + (long long)hf * (2 * hop));
 #pragma unroll
 					for (int i = 0; i < 4; ++i) {
+						ZH_CHK(row - hop + tf + i * TF, 1);
+						ZH_CHK(row + tf + i * TF, 1);
 						dv[i] = __hip_atomic_load(row - hop + tf + i * TF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // frame h-1, second half
 						dv[4 + i] = __hip_atomic_load(row + tf + i * TF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // frame h, first half
 					}
@@ -541,6 +583,8 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 							                                                        + (long long)hf * (2 * hop));
 #pragma unroll
 							for (int i = 0; i < 4; ++i) {
+								ZH_CHK(row - hop + tf + i * TF, 1);
+								ZH_CHK(row + tf + i * TF, 1);
 								dm[oi][i] = __hip_atomic_load(row - hop + tf + i * TF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 								dm[oi][4 + i] = __hip_atomic_load(row + tf + i * TF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 							}
@@ -551,12 +595,15 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 						if (oi < a.n_out) {
 							float* o = a.out_direct[a.out_id[oi]] + (long long)hs * a.out_direct_stride + (long long)hf * hop;
 #pragma unroll
-							for (int i = 0; i < 4; ++i)
+							for (int i = 0; i < 4; ++i) {
+								ZH_CHK(o + tf + i * TF, 1);
 								o[tf + i * TF] = __uint_as_float(dm[oi][i]) + __uint_as_float(dm[oi][4 + i]);
+							}
 						}
 					}
 				}
 				else {
+					ZH_CHK(a.blk_need + dh, 1);
 					a.blk_need[dh] = 1u; // (every thread that does not add its four samples says so: the decision is per thread)
 				}
 			}
@@ -594,8 +641,10 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 				preload_inputs();
 			if (in.tail) { // the call's last frame hands its new hop to the next call
 #pragma unroll
-				for (int m = 4; m < 8; ++m)
+				for (int m = 4; m < 8; ++m) {
+					ZH_CHK(in.tail + ((m - 4) * TF + tf), 1);
 					in.tail[(m - 4) * TF + tf] = pre.x[m];
+				}
 			}
 			zfft::fft_frame<LOG2N, false, true, false>(tf, lds, a.tw, pre, out, true);
 		}
@@ -605,6 +654,7 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 			zfft::fft_frame<LOG2N, false, true, false>(tf, lds, twr, ink, out, true);
 #pragma unroll
 			for (int i = 0; i < 4; ++i) { // the next call's previous hop: to memory as every single-hop call leaves it, and kept
+				ZH_CHK(hv.tail_next() + ((long long)s * hop + tf + i * TF), 1);
 				hv.tail_next()[(long long)s * hop + tf + i * TF] = nx[i];
 				hv.keep_prev[i] = nx[i];
 			}
@@ -620,8 +670,10 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 			const int hs = dh / a.n_frames, hf = dh - hs * a.n_frames;
 			float* o = a.out_direct[a.out_id[0]] + (long long)hs * a.out_direct_stride + (long long)hf * hop;
 #pragma unroll
-			for (int i = 0; i < 4; ++i)
+			for (int i = 0; i < 4; ++i) {
+				ZH_CHK(o + tf + i * TF, 1);
 				o[tf + i * TF] = __uint_as_float(dv[i]) + __uint_as_float(dv[4 + i]);
+			}
 		}
 	}
 	stamp(2);
@@ -1070,6 +1122,8 @@ __global__ __launch_bounds__(256) void rt_fused_fixup_kernel(RtFusedArgs a)
 	// workgroup that walked through its items one after the other would serialise them)
 	const int hop = a.hop, total = a.n_streams * a.n_frames;
 	const int item = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	if (item < total)
+		ZH_CHK(a.blk_need + item, 1);
 	if (item >= total || !a.blk_need[item])
 		return;
 	const int s = item / a.n_frames, f = item - s * a.n_frames;
@@ -1078,8 +1132,12 @@ __global__ __launch_bounds__(256) void rt_fused_fixup_kernel(RtFusedArgs a)
 		const float* Y = a.Y[which] + (long long)s * a.y_stream_stride + (long long)f * (2 * hop);
 		const float* prev = f == 0 ? a.carry[which] + (long long)s * hop : Y - hop;
 		float* o = a.out_direct[which] + (long long)s * a.out_direct_stride + (long long)f * hop;
-		for (int k = lane; k < hop; k += 64)
+		for (int k = lane; k < hop; k += 64) {
+			ZH_CHK(o + k, 1);
+			ZH_CHK(prev + k, 1);
+			ZH_CHK(Y + k, 1);
 			o[k] = prev[k] + Y[k];
+		}
 	}
 	if (lane == 0)
 		a.blk_need[item] = 0u;

@@ -50,6 +50,7 @@ struct SynthOut {
 	float cola;
 	__device__ __forceinline__ void operator()(int idx, float2 x, bool, int) const
 	{
+		ZH_CHK(Y + idx, 1);
 		Y[idx] = x.x * cola; // the product of overlap_add_functor hps.h:68-80; the sum is in finalize_kernel
 	}
 };
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, LOG2N <= 11 ? 4 : 3) void sse
 #pragma unroll
 		for (int i = 0; i < 16; ++i) {
 			const int idx = tf + i * TF;
+			ZH_CHK(S + (idx > N / 2 ? N - idx : idx), 1);
 			z[i] = S[idx > N / 2 ? N - idx : idx];
 		}
 	}
@@ -102,8 +104,10 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, LOG2N <= 11 ? 4 : 3) void sse
 			const float* mrow = b.mag + (ring_base + rs) * N;
 			if (d[jj] != 0) { // (frame-uniform.  The consumed row itself -- every tap past it of a causal engine -- is at hand: `own`)
 #pragma unroll
-				for (int i = 0; i < NLO; ++i)
+				for (int i = 0; i < NLO; ++i) {
+					ZH_CHK(mrow + (i < 8 ? tf + i * TF : N / 2), 1);
 					m[jj][i] = mrow[i < 8 ? tf + i * TF : N / 2];
+				}
 			}
 			else {
 #pragma unroll
@@ -121,8 +125,10 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, LOG2N <= 11 ? 4 : 3) void sse
 		const float* mrow = b.mag + (ring_base + base_slot) * N;
 		float m[NLO];
 #pragma unroll
-		for (int i = 0; i < NLO; ++i)
+		for (int i = 0; i < NLO; ++i) {
+			ZH_CHK(mrow + (i < 8 ? tf + i * TF : N / 2), 1);
 			m[i] = mrow[i < 8 ? tf + i * TF : N / 2]; // (slot 8: every thread reads bin nfft/2, thread 0 uses it)
+		}
 #pragma unroll
 		for (int i = 0; i < NLO; ++i) {
 			own[i] = (1.0f / (m[i] * m[i])) * 1.0F;

@@ -226,8 +226,17 @@ __global__ __launch_bounds__(zfft::RPlan<LOG2N>::THREADS) __attribute__((amdgpu_
 	out.mag = a.mag + row * RP::N;
 	out.n = RP::N;
 	out.full = f >= a.mag_full_from;
-	const zfft::TwGlobal tw{a.tw};
-	zfft::rfft_frame<LOG2N, true>(tf, lds + slot * RP::LDS_FLOAT2, tw, in, out, active);
+#ifndef ZEN_RFFT_TWPRE_MASK
+#define ZEN_RFFT_TWPRE_MASK 0
+#endif
+	if constexpr (((ZEN_RFFT_TWPRE_MASK) >> LOG2N) & 1) { // (the passes' twiddles requested at the top of each pass: A/B per size)
+		const zfft::TwGlobalPre tw{a.tw};
+		zfft::rfft_frame<LOG2N, true>(tf, lds + slot * RP::LDS_FLOAT2, tw, in, out, active);
+	}
+	else {
+		const zfft::TwGlobal tw{a.tw};
+		zfft::rfft_frame<LOG2N, true>(tf, lds + slot * RP::LDS_FLOAT2, tw, in, out, active);
+	}
 }
 
 template <int LOG2N>
