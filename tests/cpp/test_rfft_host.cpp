@@ -40,8 +40,10 @@ struct In {
 struct Out {
 	float2* X;
 	int* hits;
-	void operator()(int bin, float2 v)
+	void operator()(int bin, float2 v, int slot)
 	{
+		if (slot < 0 || slot > 16)
+			++fails;
 		X[bin] = v;
 		++hits[bin];
 	}

@@ -20,6 +20,10 @@ RESOURCES = os.path.join(HERE, "kernel_resources%s.json" % ("_" + _VARIANT if _V
 SOURCES = ["api.hip", "hpr.hip", "hpri.hip", "stft.hip", "istft.hip", "median.hip", "median_net.hip", "median47.hip", "median_big.hip", "rt_fused.hip", "rt_fused_multi.hip", "rt_fused_multi_lean.hip", "rt_sse.hip", "rt_wide.hip", "box.hip", "fft_big.hip", "sse_block.hip", "rt_resident.hip", "memguard.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 EXTRA = os.environ.get("ZEN_HIP_EXTRA_FLAGS", "").split()
+# A/B builds that differ in a few files only: ZEN_HIP_VARIANT_FILES="stft.hip,istft.hip" compiles just those with the extra
+# flags (into build_<variant>/) and links them with the shipped build's other objects (zen_amd/build/, brought up to date first)
+_VARIANT_FILES = [f for f in os.environ.get("ZEN_HIP_VARIANT_FILES", "").split(",") if f]
+BASE_OBJDIR = os.path.join(HERE, "build")
 FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]
 
@@ -57,13 +61,19 @@ def _deps():
 
 
 def _compile(src):
-    obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+    if _VARIANT and _VARIANT_FILES and src not in _VARIANT_FILES:
+        return _compile_in(src, BASE_OBJDIR, FLAGS[len(EXTRA):])
+    return _compile_in(src, OBJDIR, FLAGS)
+
+
+def _compile_in(src, objdir, flags):
+    obj = os.path.join(objdir, src.replace(".hip", ".o"))
     srcp = os.path.join(CSRC, src)
     extra = [os.path.join(CSRC, "rt_fused.hip")] if src.startswith(("rt_fused_multi", "rt_resident")) else []   # they include that file
     newest = max(os.path.getmtime(p) for p in [srcp] + extra + _deps())
     if os.path.exists(obj) and os.path.getmtime(obj) >= newest:
         return obj, False
-    cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(src, []) + ["-Rpass-analysis=kernel-resource-usage", "-c", srcp, "-o", obj]
+    cmd = [HIPCC] + flags + FILE_FLAGS.get(src, []) + ["-Rpass-analysis=kernel-resource-usage", "-c", srcp, "-o", obj]
     r = subprocess.run(cmd, stderr=subprocess.PIPE, universal_newlines=True)
     if r.returncode != 0:
         sys.stderr.write(r.stderr)
@@ -106,6 +116,7 @@ def _parse_usage(remarks):
 
 def build(force=False, verbose=False):
     os.makedirs(OBJDIR, exist_ok=True)
+    os.makedirs(BASE_OBJDIR, exist_ok=True)
     if force:
         for f in os.listdir(OBJDIR):
             os.remove(os.path.join(OBJDIR, f))

@@ -53,25 +53,41 @@ template <int LOG2J>
 struct AIn {
 	const float2* x;
 	int j;
-	__device__ __forceinline__ float2 operator()(int n, int) const { return x[j + (n << LOG2J)]; }
+	__device__ __forceinline__ float2 operator()(int n, int) const
+	{
+		ZH_CHK(x + (j + (n << LOG2J)), 1);
+		return x[j + (n << LOG2J)];
+	}
 };
 template <int LOG2J>
 struct AOut { // Y_7[j][k] -> T[k][j]: step B reads a column contiguously
 	float2* T;
 	int j;
-	__device__ __forceinline__ void operator()(int k, float2 X, bool, int) const { T[(k << LOG2J) + j] = X; }
+	__device__ __forceinline__ void operator()(int k, float2 X, bool, int) const
+	{
+		ZH_CHK(T + ((k << LOG2J) + j), 1);
+		T[(k << LOG2J) + j] = X;
+	}
 };
 template <int LOG2J>
 struct BIn {
 	const float2* T;
 	int kappa;
-	__device__ __forceinline__ float2 operator()(int jj, int) const { return T[(kappa << LOG2J) + jj]; }
+	__device__ __forceinline__ float2 operator()(int jj, int) const
+	{
+		ZH_CHK(T + ((kappa << LOG2J) + jj), 1);
+		return T[(kappa << LOG2J) + jj];
+	}
 };
 template <int LOG2M>
 struct BOut {
 	float2* x;
 	int kappa;
-	__device__ __forceinline__ void operator()(int q, float2 X, bool, int) const { x[kappa + (q << LOG2M)] = X; }
+	__device__ __forceinline__ void operator()(int q, float2 X, bool, int) const
+	{
+		ZH_CHK(x + (kappa + (q << LOG2M)), 1);
+		x[kappa + (q << LOG2M)] = X;
+	}
 };
 
 template <int LOG2N, bool INV>

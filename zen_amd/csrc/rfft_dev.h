@@ -142,11 +142,19 @@ __device__ __forceinline__ void real_dagh(const float (&x)[R], float2 (&y)[R / 2
 		y[c] = a[c];
 }
 
+// An input functor may take over the whole first-pass load of a thread: x[i][m] = sample tf + i*TF + m*J (m < R/2 when ZU, the
+// rest zeros), e.g. to choose between two forms of ALL its loads with one wave-uniform branch.
+template <class T, class = void>
+struct has_first_pass : std::false_type {};
+template <class T>
+struct has_first_pass<T, std::void_t<decltype(T::HAS_FIRST_PASS)>> : std::true_type {};
+
 // One pass of the real transform, split in two so that the caller places the synchronisation (and a host test can run the
 // threads of a frame one after the other): load() brings the thread's inputs into registers, compute() runs the stages and
 // stores to the LDS image of the next level or, in the last pass, hands bins 0..N/2 to out(bin, value).
 //   In : float in(int idx) -> x[idx] (only idx < N/2 when ZU)
-//   Out: void out(int bin, float2 X)
+//   Out: void out(int bin, float2 X, int slot): slot < 16 numbers the thread's outputs (a constant after unrolling); the
+//        thread that holds bin 0 hands over bin N/2 as slot 16
 template <int LOG2N, int PASS, bool ZU, class TW>
 struct RPass {
 	using RP = RPlan<LOG2N>;
@@ -174,7 +182,10 @@ struct RPass {
 	template <class In>
 	static __device__ __forceinline__ void load(int tf, const float2* __restrict__ lds, In& in, Regs& g, const float2* __restrict__ tw_p = nullptr)
 	{
-		if constexpr (FIRST) {
+		if constexpr (FIRST && has_first_pass<In>::value) {
+			in.template first_pass<NI, R, J, TF, ZU>(tf, g.x); // (a functor that wants to see all of a thread's loads at once)
+		}
+		else if constexpr (FIRST) {
 #pragma unroll
 			for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -205,29 +216,17 @@ struct RPass {
 		}
 	}
 
+	// slot: the thread's sixteen outputs numbered i * R + c (compile-time after unrolling); in the last pass the thread that
+	// holds the two real bins hands bin N/2 over as a seventeenth (slot 16)
 	template <class Out>
-	static __device__ __forceinline__ void emit(float2* __restrict__ lds, Out& out, bool active, int bin, int j, float2 X)
+	static __device__ __forceinline__ void emit(float2* __restrict__ lds, Out& out, bool active, int bin, int j, float2 X, int slot)
 	{
 		if constexpr (LAST) {
 			if (active)
-				out(bin, X);
+				out(bin, X, slot);
 		}
 		else {
 			lds[RP::pad(bin * J + j)] = X;
-		}
-	}
-	// the two real bins of a sub-transform: one slot in the image, two bins of the spectrum
-	template <class Out>
-	static __device__ __forceinline__ void emit_real_pair(float2* __restrict__ lds, Out& out, bool active, int j, float y0, float yh)
-	{
-		if constexpr (LAST) {
-			if (active) {
-				out(0, make_float2(y0, 0.0f));
-				out(N / 2, make_float2(yh, 0.0f));
-			}
-		}
-		else {
-			lds[RP::pad(j)] = make_float2(y0, yh);
 		}
 	}
 
@@ -240,45 +239,85 @@ struct RPass {
 				const int j = tf + i * TF;
 				float2 y[R / 2 + 1];
 				real_dag0<R, ZU, TW::PACKED>(g.x[i], y, tw.p, LOG2N);
-				emit_real_pair(lds, out, active, j, y[0].x, y[R / 2].x);
+				static_assert(!LAST, "a transform has at least two passes");
+				emit(lds, out, active, 0, j, make_float2(y[0].x, y[R / 2].x), i * (R / 2)); // the two real bins: one slot
 #pragma unroll
 				for (int c = 1; c < R / 2; ++c)
-					emit(lds, out, active, c, j, y[c]); // bin c 2^0
+					emit(lds, out, active, c, j, y[c], i * (R / 2) + c); // bin c 2^0
 			}
 		}
 		else {
+			static_assert(J <= TF, "only a thread's first item can be the one with k == 0");
 #pragma unroll
 			for (int i = 0; i < NI; ++i) {
 				const int b = tf + i * TF, k = b >> log2J, j = b & (J - 1);
-				if (i == 0 && tf < J) { // k == 0: the packed real bins 0 and h of J sub-sequences (J <= TF: only ever item 0)
-					float x0[R], xh[R];
-#pragma unroll
-					for (int m = 0; m < R; ++m) {
-						x0[m] = g.v[i][m].x;
-						xh[m] = g.v[i][m].y;
-					}
-					float2 y0[R / 2 + 1], yh[R / 2];
-					real_dag0<R, false, TW::PACKED>(x0, y0, tw.p, LOG2N);
-					real_dagh<R, TW::PACKED>(xh, yh, tw.p, LOG2N);
-					emit_real_pair(lds, out, active, j, y0[0].x, y0[R / 2].x);
-#pragma unroll
-					for (int c = 1; c < R / 2; ++c)
-						emit(lds, out, active, c << sL, j, y0[c]);
-#pragma unroll
-					for (int c = 0; c < R / 2; ++c)
-						emit(lds, out, active, (1 << (sL - 1)) + (c << sL), j, yh[c]);
-				}
-				else {
+				// The item's R results and their bins, then ONE sequence of stores for all lanes.  (Written as two branches that each
+				// stored their own results, every wavefront with a k == 0 lane -- all of them at nfft <= 2048 -- ran the output
+				// functor's code twice: the magnitudes' double-precision square roots, the address arithmetic, the stores.)
+				float2 o[R];
+				int ob[R];
+				float nyq = 0.0f;
+				const bool sp = i == 0 && tf < J; // k == 0: the packed real bins 0 and h of J sub-sequences
+				auto general = [&]() {
 					if constexpr (PRE)
 						butterfly<R, false, false, false>(g.v[i], k, sL, LOG2N, g.tw, PASS, i);
 					else
 						butterfly<R, false, false, false>(g.v[i], k, sL, LOG2N, tw, PASS, i);
 #pragma unroll
-					for (int c = 0; c < R / 2; ++c)
-						emit(lds, out, active, k + (c << sL), j, g.v[i][c]);
+					for (int c = 0; c < R / 2; ++c) {
+						o[c] = g.v[i][c];
+						ob[c] = k + (c << sL);
+					}
 #pragma unroll
-					for (int c = R / 2; c < R; ++c)
-						emit(lds, out, active, ((R - c) << sL) - k, j, make_float2(g.v[i][c].x, -g.v[i][c].y));
+					for (int c = R / 2; c < R; ++c) {
+						o[c] = make_float2(g.v[i][c].x, -g.v[i][c].y);
+						ob[c] = ((R - c) << sL) - k;
+					}
+				};
+				float x0[R], xh[R]; // (the packed real values, before the general stages run over the registers)
+#pragma unroll
+				for (int m = 0; m < R; ++m) {
+					x0[m] = g.v[i][m].x;
+					xh[m] = g.v[i][m].y;
+				}
+				auto special = [&]() {
+					float2 y0[R / 2 + 1], yh[R / 2];
+					real_dag0<R, false, TW::PACKED>(x0, y0, tw.p, LOG2N);
+					real_dagh<R, TW::PACKED>(xh, yh, tw.p, LOG2N);
+					o[0] = make_float2(y0[0].x, LAST ? 0.0f : y0[R / 2].x); // one slot of the image; two bins of the spectrum (nyq)
+					ob[0] = 0;
+					nyq = y0[R / 2].x;
+#pragma unroll
+					for (int c = 1; c < R / 2; ++c) {
+						o[c] = y0[c];
+						ob[c] = c << sL;
+					}
+#pragma unroll
+					for (int c = 0; c < R / 2; ++c) {
+						o[R / 2 + c] = yh[c];
+						ob[R / 2 + c] = (1 << (sL - 1)) + (c << sL);
+					}
+				};
+				if (i != 0) {
+					general();
+				}
+				else if (J >= 64) { // whole wavefronts of k == 0 items: one or the other
+					if (sp)
+						special();
+					else
+						general();
+				}
+				else { // a few lanes of a wavefront: the general stages for everybody (on those lanes: of values nobody uses), then
+					general(); // the real sub-DAGs over them
+					if (sp)
+						special();
+				}
+#pragma unroll
+				for (int c = 0; c < R; ++c)
+					emit(lds, out, active, ob[c], j, o[c], i * R + c);
+				if constexpr (LAST) {
+					if (sp && active) // (one lane per frame)
+						out(N / 2, make_float2(nyq, 0.0f), 16);
 				}
 			}
 		}

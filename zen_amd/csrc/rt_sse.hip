@@ -44,6 +44,8 @@ struct SseFwdIn {
 	int hop;
 	__device__ __forceinline__ float2 operator()(int idx, int) const
 	{
+		ZH_CHK(idx < hop ? prev + idx : cur + (idx - hop), 1);
+		ZH_CHK(window + idx, 1);
 		const float x = idx < hop ? prev[idx] : cur[idx - hop];
 		return make_float2(x * window[idx], 0.0f); // window_functor hps.h:24-33
 	}
@@ -62,6 +64,9 @@ struct SseFwdOut {
 			const float m = zfft::cabs_exact(X.x, X.y);
 			const float p = (1.0f / (m * m)) * 1.0F;
 			const int mir = (idx == 0 || idx == (n >> 1)) ? idx : n - idx;
+			ZH_CHK(S + idx, 1);
+			ZH_CHK(mag + idx, 1);
+			ZH_CHK(mag + mir, 1);
 			S[idx] = X;
 			mag[idx] = m;
 			mag[mir] = m;
@@ -94,9 +99,12 @@ struct SseInvOut {
 	__device__ __forceinline__ void operator()(int idx, float2 x, bool, int slot) const
 	{
 		const float y = x.x * cola;
+		ZH_CHK(Y + idx, 1);
 		Y[idx] = y;
-		if (idx < hop) // hps.cu:526-528 + :341-363; a system-scope (write-through) store: see the publication below
+		if (idx < hop) { // hps.cu:526-528 + :341-363; a system-scope (write-through) store: see the publication below
+			ZH_CHK(ready + idx, 1);
 			__hip_atomic_store(ready + idx, cv[slot & 3] + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
 	}
 };
 
@@ -161,12 +169,16 @@ __device__ __forceinline__ void rt_sse_body(const RtFusedArgs& a, int len_t, int
 		{
 			float v[CP];
 #pragma unroll
-			for (int i = 0; i < CP; ++i)
+			for (int i = 0; i < CP; ++i) {
+				ZH_CHK(cur + (th + i * NH < hop ? th + i * NH : hop - 1), 1);
 				v[i] = cur[th + i * NH < hop ? th + i * NH : hop - 1];
+			}
 #pragma unroll
 			for (int i = 0; i < CP; ++i)
-				if (th + i * NH < hop)
+				if (th + i * NH < hop) {
+					ZH_CHK(hv.tail_next() + ((long long)s * hop + th + i * NH), 1);
 					hv.tail_next()[(long long)s * hop + th + i * NH] = v[i];
+				}
 		}
 		if (hv.prev_frames() > 0) {
 			for (int o = 0; o < 3; ++o) {
@@ -175,12 +187,16 @@ __device__ __forceinline__ void rt_sse_body(const RtFusedArgs& a, int len_t, int
 				const float* y = a.Y[o] + (long long)s * a.y_stream_stride + (long long)(hv.prev_frames() - 1) * (2 * hop) + hop;
 				float v[CP];
 #pragma unroll
-				for (int i = 0; i < CP; ++i)
+				for (int i = 0; i < CP; ++i) {
+					ZH_CHK(y + (th + i * NH < hop ? th + i * NH : hop - 1), 1);
 					v[i] = y[th + i * NH < hop ? th + i * NH : hop - 1];
+				}
 #pragma unroll
 				for (int i = 0; i < CP; ++i)
-					if (th + i * NH < hop)
+					if (th + i * NH < hop) {
+						ZH_CHK(a.carry[o] + ((long long)s * hop + th + i * NH), 1);
 						a.carry[o][(long long)s * hop + th + i * NH] = v[i];
+					}
 			}
 		}
 		// time box, history part: rows ar-mid_t .. ar-1 (clamped below at row 0, box_time_kernel), summed in
@@ -198,6 +214,7 @@ __device__ __forceinline__ void rt_sse_body(const RtFusedArgs& a, int len_t, int
 #pragma unroll
 				for (int i = 0; i < BH; ++i) {
 					const int idx = th + i * NH;
+					ZH_CHK(mrow + (idx < N ? idx : N - 1), 1);
 					m[jj][i] = mrow[idx < N ? idx : N - 1];
 				}
 			}
@@ -228,8 +245,10 @@ __device__ __forceinline__ void rt_sse_body(const RtFusedArgs& a, int len_t, int
 			                     ? a.Y[o] + (long long)s * a.y_stream_stride + (long long)(hv.prev_frames() - 1) * (2 * hop) + hop
 			                     : a.carry[o] + (long long)s * hop;
 #pragma unroll
-			for (int i = 0; i < 4; ++i)
+			for (int i = 0; i < 4; ++i) {
+				ZH_CHK(y + t + i * TF, 1);
 				cv[o][i] = y[t + i * TF];
+			}
 		}
 		SseFwdIn in;
 		in.prev = hv.tail_prev() + (long long)s * hop;

@@ -177,6 +177,8 @@ struct FwdAIn { // x[j + n*J] of the windowed, zero-padded frame (only n < M/2 i
 	__device__ __forceinline__ float2 operator()(int n, int) const
 	{
 		const int idx = j + (n << LOG2J);
+		ZH_CHK(idx < hop ? prev + idx : cur + (idx - hop), 1);
+		ZH_CHK(window + idx, 1);
 		const float x = idx < hop ? prev[idx] : cur[idx - hop];
 		return make_float2(x * window[idx], 0.0f); // window_functor hps.h:24-33
 	}
@@ -185,13 +187,21 @@ template <int LOG2J>
 struct XchOut { // Y_7[j][k] -> exchange buffer, laid out [k][j]: step B reads a column contiguously
 	float2* T;
 	int j;
-	__device__ __forceinline__ void operator()(int k, float2 X, bool, int) const { T[(k << LOG2J) + j] = X; }
+	__device__ __forceinline__ void operator()(int k, float2 X, bool, int) const
+	{
+		ZH_CHK(T + ((k << LOG2J) + j), 1);
+		T[(k << LOG2J) + j] = X;
+	}
 };
 template <int LOG2J>
 struct XchIn {
 	const float2* T;
 	int kappa;
-	__device__ __forceinline__ float2 operator()(int jj, int) const { return T[(kappa << LOG2J) + jj]; }
+	__device__ __forceinline__ float2 operator()(int jj, int) const
+	{
+		ZH_CHK(T + ((kappa << LOG2J) + jj), 1);
+		return T[(kappa << LOG2J) + jj];
+	}
 };
 template <int LOG2M>
 struct FwdBOut { // X[kappa + M*q]: spectrum ring row (bins 0..N/2) and the whole magnitude row (StftOut of stft.hip)
@@ -202,11 +212,15 @@ struct FwdBOut { // X[kappa + M*q]: spectrum ring row (bins 0..N/2) and the whol
 	{
 		const int k = kappa + (q << LOG2M);
 		if (k <= (n >> 1)) {
+			ZH_CHK(S + k, 1);
+			ZH_CHK(mag + k, 1);
 			S[k] = X;
 			const float m = zfft::cabs_exact(X.x, X.y); // complex_abs_functor hps.h:82-89
 			mag[k] = m;
-			if (k != 0 && k != (n >> 1))
+			if (k != 0 && k != (n >> 1)) {
+				ZH_CHK(mag + (n - k), 1);
 				mag[n - k] = m; // |S[n-k]| == |S[k]| bit for bit
+			}
 		}
 	}
 };
@@ -223,10 +237,13 @@ struct InvAIn { // (S * mask)[j + n*J] (IstftIn of istft.hip): the upper half of
 		const int idx = j + (nn << LOG2J);
 		const bool mirror = idx > (n >> 1);
 		const int lo = mirror ? n - idx : idx;
+		ZH_CHK(S + lo, 1);
 		float2 z = S[lo];
 		if (mirror)
 			z.y = -z.y;
 		const int pi = (mirror && idx >= n - p_mid) ? idx : lo;
+		ZH_CHK(H + lo, 1);
+		ZH_CHK(P + pi, 1);
 		const float m = mask_value_thr(which, H[lo], P[pi], cfg, thr);
 		return make_float2(z.x * m, z.y * m); // apply_mask_functor hps.h:58-66
 	}
@@ -242,9 +259,13 @@ struct InvBOut { // x[kappa + M*q], q < J/2 (HALF_OUT): the nwin real outputs th
 	{
 		const int idx = kappa + (q << LOG2M);
 		const float y = x.x * cola; // overlap_add_functor hps.h:68-80
+		ZH_CHK(Y + idx, 1);
 		Y[idx] = y;
-		if (idx < hop)
+		if (idx < hop) {
+			ZH_CHK(ready + idx, 1);
+			ZH_CHK(carry + idx, 1);
 			ready[idx] = carry[idx] + y; // hps.cu:526-528 + :341-363
+		}
 	}
 };
 

@@ -140,16 +140,19 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS) void stft_kernel(StftArgs a)
 // The same analysis through the real-input transform of rfft_dev.h: the frame is real (window_functor, hps.h:24-33; the
 // imaginary parts are zeroed, hps.cu:456-465), so every sub-transform of the radix-2 DAG is exactly Hermitian and only
 // its lower half is computed -- half the butterflies, half the LDS image, N/32 threads per frame, the oracle's bits.
+template <int LOG2N>
 struct StftInR {
+	static constexpr bool HAS_FIRST_PASS = true;
+	static constexpr int HOP = (1 << LOG2N) / 4; // hps.h:224-225: nwin = 2 hop, nfft = 4 hop (launch_stft checks)
 	const float* prev;
 	const float* cur;
 	const float* window;
-	int hop;
 	int nv_prev, nv_cur;
+	bool contiguous; // wave-uniform: every frame of this wavefront has all its samples, prev hop and hop next to each other
 	__device__ __forceinline__ float operator()(int idx) const
 	{
-		const bool first = idx < hop;
-		const int k = first ? idx : idx - hop;
+		const bool first = idx < HOP;
+		const int k = first ? idx : idx - HOP;
 		const bool ok = k < (first ? nv_prev : nv_cur);
 		const float* p = ok ? (first ? prev : cur) + k : window; // (one unconditional load from a selected address: StftIn)
 		ZH_CHK(p, 1);
@@ -158,22 +161,62 @@ struct StftInR {
 		const float x = ok ? v : 0.0f;
 		return x * window[idx];
 	}
+	// All of a thread's loads in one of two forms, chosen by ONE wave-uniform branch.  The usual frame -- not a chunk's first
+	// (whose previous hop is the saved tail), every sample there -- is 2 * hop consecutive samples: plain loads from one base.
+	// The general form selects an address and a value per sample (five VALU instructions each).
+	template <int NI, int R, int J, int TF, bool ZU>
+	__device__ __forceinline__ void first_pass(int tf, float (&x)[NI][R]) const
+	{
+		static_assert(ZU, "the analysis frame is zero-padded");
+		if (contiguous) {
+			const float* base = cur - HOP;
+			float v[NI][R / 2], w[NI][R / 2];
+#pragma unroll
+			for (int i = 0; i < NI; ++i)
+#pragma unroll
+				for (int m = 0; m < R / 2; ++m) {
+					const int idx = tf + i * TF + m * J;
+					ZH_CHK(base + idx, 1);
+					ZH_CHK(window + idx, 1);
+					v[i][m] = base[idx];
+					w[i][m] = window[idx];
+				}
+#pragma unroll
+			for (int i = 0; i < NI; ++i)
+#pragma unroll
+				for (int m = 0; m < R; ++m)
+					x[i][m] = m < R / 2 ? v[i][m < R / 2 ? m : 0] * w[i][m < R / 2 ? m : 0] : 0.0f; // window_functor hps.h:24-33
+		}
+		else {
+#pragma unroll
+			for (int i = 0; i < NI; ++i)
+#pragma unroll
+				for (int m = 0; m < R; ++m)
+					x[i][m] = m < R / 2 ? (*this)(tf + i * TF + m * J) : 0.0f;
+		}
+	}
 };
+// FULL rows (StftArgs::mag_full_from: the last W - 1 frames of a chunk) also get the mirrored upper half of the magnitudes;
+// `any_full` is wave-uniform, so the usual frame pays a scalar branch per bin for it and nothing else.
 struct StftOutR {
 	float2* S;
 	float* mag;
 	int n;
-	bool full;
-	__device__ __forceinline__ void operator()(int bin, float2 X) const
+	bool full, any_full;
+	__device__ __forceinline__ void operator()(int bin, float2 X, int slot) const
 	{
 		ZH_CHK(S + bin, 1);
 		ZH_CHK(mag + bin, 1);
 		S[bin] = X;
-		const float m = zfft::cabs_exact(X.x, X.y); // complex_abs_functor hps.h:82-89
+		// complex_abs_functor hps.h:82-89; the two real bins (slot 0 of the thread that holds them, and its slot 16): sqrt of an
+		// exact square
+		const float m = slot == 16 ? __builtin_fabsf(X.x) : zfft::cabs_exact(X.x, X.y);
 		mag[bin] = m;
-		if (full && bin != 0 && bin != (n >> 1)) {
-			ZH_CHK(mag + (n - bin), 1);
-			mag[n - bin] = m;
+		if (any_full) {
+			if (full && bin != 0 && bin != (n >> 1)) {
+				ZH_CHK(mag + (n - bin), 1);
+				mag[n - bin] = m;
+			}
 		}
 	}
 };
@@ -209,33 +252,36 @@ __global__ __launch_bounds__(zfft::RPlan<LOG2N>::THREADS) __attribute__((amdgpu_
 		return;
 	}
 	const int slot = tid / RP::TF, tf = tid - slot * RP::TF;
+	__builtin_assume(tf >= 0 && tf < RP::TF);
 	const int f_ = blockIdx.x * RP::FRAMES_PER_BLOCK + slot;
-	const bool active = f_ < a.n_frames;
-	const int f = active ? f_ : a.n_frames - 1; // (an inactive slot transforms the last frame again and stores nothing)
+	// A slot past the last frame transforms the last frame again AND stores it again: the same values to the same places as the
+	// slot that owns that frame (a benign duplicate), instead of a test around every store of every thread.
+	const int f = f_ < a.n_frames ? f_ : a.n_frames - 1;
 	const float* in_s = a.in + (long long)s * a.in_stride;
-	StftInR in;
+	StftInR<LOG2N> in;
 	in.prev = (f == 0) ? a.tail_prev + (long long)s * hop : in_s + (long long)(f - 1) * hop;
 	in.cur = in_s + (long long)f * hop;
 	in.window = a.window;
-	in.hop = hop;
 	in.nv_prev = f == 0 ? hop : valid_in_hop(a.in_valid, f - 1, hop);
 	in.nv_cur = valid_in_hop(a.in_valid, f, hop);
+	in.contiguous = __builtin_amdgcn_ballot_w64(!(f > 0 && in.nv_prev == hop && in.nv_cur == hop)) == 0ull;
 	const long long row = ((a.row0 + f) % a.ring_rows) + (long long)s * a.ring_rows;
 	StftOutR out;
 	out.S = a.S + row * a.s_stride;
 	out.mag = a.mag + row * RP::N;
 	out.n = RP::N;
 	out.full = f >= a.mag_full_from;
+	out.any_full = __builtin_amdgcn_ballot_w64(out.full) != 0ull;
 #ifndef ZEN_RFFT_TWPRE_MASK
-#define ZEN_RFFT_TWPRE_MASK 0
+#define ZEN_RFFT_TWPRE_MASK 0xFFFF
 #endif
-	if constexpr (((ZEN_RFFT_TWPRE_MASK) >> LOG2N) & 1) { // (the passes' twiddles requested at the top of each pass: A/B per size)
-		const zfft::TwGlobalPre tw{a.tw};
-		zfft::rfft_frame<LOG2N, true>(tf, lds + slot * RP::LDS_FLOAT2, tw, in, out, active);
+	if constexpr (((ZEN_RFFT_TWPRE_MASK) >> LOG2N) & 1) { // (the passes' twiddles requested at the top of each pass: -4 % at nfft 1024
+		const zfft::TwGlobalPre tw{a.tw};                 // and 16384, A/B per size)
+		zfft::rfft_frame<LOG2N, true>(tf, lds + slot * RP::LDS_FLOAT2, tw, in, out, true);
 	}
 	else {
 		const zfft::TwGlobal tw{a.tw};
-		zfft::rfft_frame<LOG2N, true>(tf, lds + slot * RP::LDS_FLOAT2, tw, in, out, active);
+		zfft::rfft_frame<LOG2N, true>(tf, lds + slot * RP::LDS_FLOAT2, tw, in, out, true);
 	}
 }
 
@@ -407,7 +453,7 @@ template <int LOG2N>
 int launch_stft_t(const StftArgs& a, hipStream_t stream)
 {
 	using PL = Plan<LOG2N>;
-	if (!g_opt_no_rfft) {
+	if (!g_opt_no_rfft && a.hop * 4 == PL::N) { // (StftInR::HOP; the engine never asks for anything else, hps.h:224-225)
 		using RP = zfft::RPlan<LOG2N>;
 		auto kern = stft_real_kernel<LOG2N>;
 		ZH_TRY(set_lds(kern, rlds_bytes<LOG2N>()));
