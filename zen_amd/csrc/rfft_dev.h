@@ -44,9 +44,85 @@ struct RPlan {
 	static constexpr int PAD_SHIFT = LOG2N >= 14 ? ZEN_RFFT_PAD16K : 4; // (the image of a 2^L-point real frame is that of a 2^(L-1)-point complex one)
 	static constexpr int LDS_FLOAT2 = SLOTS + (SLOTS >> PAD_SHIFT);
 	static __device__ __forceinline__ int pad(int i) { return i + (i >> PAD_SHIFT); }
+	// pad(base + off) for an offset that is a multiple of 2^PAD_SHIFT (or a base that is zero): the offset's share is a
+	// compile-time constant of the access (base may be negative as long as the sum is not: the shift is arithmetic)
+	static __device__ __forceinline__ int pad_off(int base, int off)
+	{
+		return (off & ((1 << PAD_SHIFT) - 1)) == 0 ? pad(base) + off + (off >> PAD_SHIFT) : pad(base + off);
+	}
 	static constexpr int FRAMES_PER_BLOCK = (TF >= 256) ? 1 : 256 / TF;
 	static constexpr int THREADS = TF * FRAMES_PER_BLOCK;
 };
+
+// (-i w) * b: the product with a twiddle a quarter turn on (tw[i + N/4] == -i tw[i] bit for bit) without forming that twiddle.
+// fft_dev.h's butterfly() builds w' = (w.y, -w.x) and multiplies: tr = w'.x b.x - w'.y b.y, ti = w'.x b.y + w'.y b.x.  Here the
+// same four products (a negated factor negates the rounded product exactly) meet in one packed add with the signs as
+// modifiers: (w.y b.x + w.x b.y, w.y b.y - w.x b.x) -- the same bits, one packed negation per derived twiddle less.
+template <bool PK>
+__device__ __forceinline__ float2 cmul_negi(float2 w, float2 b)
+{
+	if constexpr (PK) {
+		const v2f t1 = (v2f){w.y, w.y} * (v2f){b.x, b.y};
+		const v2f t2 = (v2f){w.x, w.x} * (v2f){b.y, b.x};
+		v2f r;
+		asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,0] neg_hi:[0,1]" : "=v"(r) : "v"(t1), "v"(t2));
+		return make_float2(r.x, r.y);
+	}
+	else {
+		return make_float2(w.y * b.x + w.x * b.y, w.y * b.y - w.x * b.x);
+	}
+}
+// conj(a - b) = (a.x - b.x, b.y - a.y) as one packed add (x - y == -(y - x) exactly): the conjugated outputs of a pass cost
+// no sign flips of their own
+template <bool PK>
+__device__ __forceinline__ float2 csub_conj(float2 a, float2 b)
+{
+	if constexpr (PK) {
+		const v2f av = (v2f){a.x, a.y}, bv = (v2f){b.x, b.y};
+		v2f r;
+		asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(av), "v"(bv));
+		return make_float2(r.x, r.y);
+	}
+	else {
+		return make_float2(a.x - b.x, b.y - a.y);
+	}
+}
+
+// fft_dev.h's butterfly() for the general items of the real transform: forward, no known-value shortcuts, and the upper half
+// of the results -- which the real transform keeps as conjugates, see RPass -- comes out conjugated:
+//   in : a[m] = Y_s[j + m*J][k], m < R
+//   out: a[c] = Y_{s+r}[j][k + c 2^s], c < R/2;   a[c] = conj(Y_{s+r}[j][k + c 2^s]), c >= R/2
+template <int R, class TW>
+__device__ __forceinline__ void rbutterfly(float2 (&a)[R], int k, int log2L, int log2N, const TW& tw, int pass, int grp)
+{
+	constexpr int r = Log2<R>::value;
+	constexpr bool PK = TW::PACKED;
+	float2 b[R];
+#pragma unroll
+	for (int q = 1; q <= r; ++q) {
+		const int half = R >> q;     // sub-sequences left after this stage
+		const int nc = 1 << (q - 1); // frequency groups entering this stage
+		float2 w[(R / 4) > 0 ? (R / 4) : 1]; // the loaded twiddles: groups c < max(1, nc/2); group c + nc/2 is a quarter turn on
+#pragma unroll
+		for (int c = 0; c < (nc >= 2 ? nc / 2 : 1); ++c) {
+			const int idx = (k << (log2N - log2L - q)) + (c << (log2N - q));
+			w[c] = tw.get(pass, grp, (q == 1 ? 0 : (1 << (q - 2))) + c, idx);
+		}
+#pragma unroll
+		for (int c = 0; c < nc; ++c) {
+#pragma unroll
+			for (int m = 0; m < half; ++m) {
+				const float2 A = a[c * 2 * half + m], B = a[c * 2 * half + m + half];
+				const float2 t = (q >= 2 && c >= (nc >> 1)) ? cmul_negi<PK>(w[c - (nc >> 1)], B) : cmul<PK>(w[c], B);
+				b[c * half + m] = cadd<PK>(A, t);
+				b[(c + nc) * half + m] = q == r ? csub_conj<PK>(A, t) : csub<PK>(A, t);
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < R; ++i)
+			a[i] = b[i];
+	}
+}
 
 // R-point sub-DAG of r = log2 R stages on REAL inputs at k = 0 (any level s: the twiddles of frequency group c at the
 // pass's stage q are tw[c N/2^q], whatever s is).
@@ -93,8 +169,7 @@ __device__ __forceinline__ void real_dag0(const float (&x)[R], float2 (&y)[R / 2
 					const float2 w = tw[c << (log2N - q - 1)];
 					const float2 t = cmul<PK>(w, B);
 					b[c * half + m] = cadd<PK>(A, t);
-					const float2 u = csub<PK>(A, t);
-					b[(2 * H - c) * half + m] = make_float2(u.x, -u.y);
+					b[(2 * H - c) * half + m] = csub_conj<PK>(A, t);
 				}
 			}
 		}
@@ -129,8 +204,7 @@ __device__ __forceinline__ void real_dagh(const float (&x)[R], float2 (&y)[R / 2
 				const float2 A = a[c * cnt + m], B = a[c * cnt + m + half];
 				const float2 t = cmul<PK>(w, B);
 				b[c * half + m] = cadd<PK>(A, t);
-				const float2 u = csub<PK>(A, t);
-				b[(2 * G - 1 - c) * half + m] = make_float2(u.x, -u.y);
+				b[(2 * G - 1 - c) * half + m] = csub_conj<PK>(A, t);
 			}
 		}
 #pragma unroll
@@ -251,52 +325,46 @@ struct RPass {
 #pragma unroll
 			for (int i = 0; i < NI; ++i) {
 				const int b = tf + i * TF, k = b >> log2J, j = b & (J - 1);
-				// The item's R results and their bins, then ONE sequence of stores for all lanes.  (Written as two branches that each
-				// stored their own results, every wavefront with a k == 0 lane -- all of them at nfft <= 2048 -- ran the output
-				// functor's code twice: the magnitudes' double-precision square roots, the address arithmetic, the stores.)
+				// The item's R results, then ONE sequence of stores for all lanes.  (Written as two branches that each stored their
+				// own results, every wavefront with a k == 0 lane -- all of them at nfft <= 2048 -- ran the output functor's code
+				// twice: the magnitudes' double-precision square roots, the address arithmetic, the stores.)
+				// Where they go: result c < R/2 is bin k1 + c 2^s, result c >= R/2 is bin (R - c) 2^s - k2, with k1 = k2 = k for a
+				// general item.  The k == 0 item fits the same two formulas with k1 = 0, k2 = h = 2^(s-1): its sub-DAG at bin 0
+				// yields bins c 2^s (c < R/2; the two real ones share c = 0), the one at bin h yields h + c' 2^s = (c' + 1) 2^s - h,
+				// the place of result R - 1 - c'.  So the addresses of all lanes are two bases plus compile-time offsets.
 				float2 o[R];
-				int ob[R];
 				float nyq = 0.0f;
+				int k1 = k, k2 = k;
 				const bool sp = i == 0 && tf < J; // k == 0: the packed real bins 0 and h of J sub-sequences
-				auto general = [&]() {
-					if constexpr (PRE)
-						butterfly<R, false, false, false>(g.v[i], k, sL, LOG2N, g.tw, PASS, i);
-					else
-						butterfly<R, false, false, false>(g.v[i], k, sL, LOG2N, tw, PASS, i);
-#pragma unroll
-					for (int c = 0; c < R / 2; ++c) {
-						o[c] = g.v[i][c];
-						ob[c] = k + (c << sL);
-					}
-#pragma unroll
-					for (int c = R / 2; c < R; ++c) {
-						o[c] = make_float2(g.v[i][c].x, -g.v[i][c].y);
-						ob[c] = ((R - c) << sL) - k;
-					}
-				};
 				float x0[R], xh[R]; // (the packed real values, before the general stages run over the registers)
 #pragma unroll
 				for (int m = 0; m < R; ++m) {
 					x0[m] = g.v[i][m].x;
 					xh[m] = g.v[i][m].y;
 				}
+				auto general = [&]() {
+					if constexpr (PRE)
+						rbutterfly<R>(g.v[i], k, sL, LOG2N, g.tw, PASS, i);
+					else
+						rbutterfly<R>(g.v[i], k, sL, LOG2N, tw, PASS, i);
+#pragma unroll
+					for (int c = 0; c < R; ++c)
+						o[c] = g.v[i][c]; // (the upper half comes out conjugated)
+				};
 				auto special = [&]() {
 					float2 y0[R / 2 + 1], yh[R / 2];
 					real_dag0<R, false, TW::PACKED>(x0, y0, tw.p, LOG2N);
 					real_dagh<R, TW::PACKED>(xh, yh, tw.p, LOG2N);
 					o[0] = make_float2(y0[0].x, LAST ? 0.0f : y0[R / 2].x); // one slot of the image; two bins of the spectrum (nyq)
-					ob[0] = 0;
 					nyq = y0[R / 2].x;
 #pragma unroll
-					for (int c = 1; c < R / 2; ++c) {
+					for (int c = 1; c < R / 2; ++c)
 						o[c] = y0[c];
-						ob[c] = c << sL;
-					}
 #pragma unroll
-					for (int c = 0; c < R / 2; ++c) {
-						o[R / 2 + c] = yh[c];
-						ob[R / 2 + c] = (1 << (sL - 1)) + (c << sL);
-					}
+					for (int c = 0; c < R / 2; ++c)
+						o[R - 1 - c] = yh[c];
+					k1 = 0;
+					k2 = 1 << (sL - 1);
 				};
 				if (i != 0) {
 					general();
@@ -312,9 +380,14 @@ struct RPass {
 					if (sp)
 						special();
 				}
+				const int a1 = k1 * J + j, a2 = j - k2 * J; // (the image: bin * J + j)
 #pragma unroll
-				for (int c = 0; c < R; ++c)
-					emit(lds, out, active, ob[c], j, o[c], i * R + c);
+				for (int c = 0; c < R; ++c) {
+					if constexpr (LAST)
+						emit(lds, out, active, c < R / 2 ? k1 + (c << sL) : ((R - c) << sL) - k2, 0, o[c], i * R + c);
+					else
+						lds[RP::pad_off(c < R / 2 ? a1 : a2, (c < R / 2 ? c : R - c) * (N / R))] = o[c];
+				}
 				if constexpr (LAST) {
 					if (sp && active) // (one lane per frame)
 						out(N / 2, make_float2(nyq, 0.0f), 16);
