@@ -40,8 +40,9 @@ struct In {
 struct Out {
 	float2* X;
 	int* hits;
-	void operator()(int bin, float2 v, int slot)
+	void operator()(int base, int off, float2 v, int slot)
 	{
+		const int bin = base + off;
 		if (slot < 0 || slot > 16)
 			++fails;
 		X[bin] = v;

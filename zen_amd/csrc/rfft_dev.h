@@ -227,8 +227,9 @@ struct has_first_pass<T, std::void_t<decltype(T::HAS_FIRST_PASS)>> : std::true_t
 // threads of a frame one after the other): load() brings the thread's inputs into registers, compute() runs the stages and
 // stores to the LDS image of the next level or, in the last pass, hands bins 0..N/2 to out(bin, value).
 //   In : float in(int idx) -> x[idx] (only idx < N/2 when ZU)
-//   Out: void out(int bin, float2 X, int slot): slot < 16 numbers the thread's outputs (a constant after unrolling); the
-//        thread that holds bin 0 hands over bin N/2 as slot 16
+//   Out: void out(int base, int off, float2 X, int slot): bin base + off, off and slot constants after unrolling (a thread's
+//        sixteen results use two values of base per item); slot < 16 numbers the thread's outputs, the thread that holds bin 0
+//        hands over bin N/2 as slot 16
 template <int LOG2N, int PASS, bool ZU, class TW>
 struct RPass {
 	using RP = RPlan<LOG2N>;
@@ -285,7 +286,7 @@ struct RPass {
 				const int b = tf + i * TF, k = b >> log2J, j = b & (J - 1);
 #pragma unroll
 				for (int m = 0; m < R; ++m)
-					g.v[i][m] = lds[RP::pad((k * R + m) * J + j)];
+					g.v[i][m] = lds[RP::pad_off(k * R * J + j, m * J)]; // (one address per item, the rest immediates)
 			}
 		}
 	}
@@ -295,13 +296,9 @@ struct RPass {
 	template <class Out>
 	static __device__ __forceinline__ void emit(float2* __restrict__ lds, Out& out, bool active, int bin, int j, float2 X, int slot)
 	{
-		if constexpr (LAST) {
-			if (active)
-				out(bin, X, slot);
-		}
-		else {
-			lds[RP::pad(bin * J + j)] = X;
-		}
+		static_assert(!LAST, "the last pass calls the output functor itself");
+		(void)out, (void)active, (void)slot;
+		lds[RP::pad_off(j, bin * J)] = X;
 	}
 
 	template <class Out>
@@ -343,6 +340,15 @@ struct RPass {
 					xh[m] = g.v[i][m].y;
 				}
 				auto general = [&]() {
+#ifdef ZEN_RFFT_OLD_BFLY
+					if constexpr (PRE)
+						butterfly<R, false, false, false>(g.v[i], k, sL, LOG2N, g.tw, PASS, i);
+					else
+						butterfly<R, false, false, false>(g.v[i], k, sL, LOG2N, tw, PASS, i);
+#pragma unroll
+					for (int c = 0; c < R; ++c)
+						o[c] = c < R / 2 ? g.v[i][c] : make_float2(g.v[i][c].x, -g.v[i][c].y);
+#else
 					if constexpr (PRE)
 						rbutterfly<R>(g.v[i], k, sL, LOG2N, g.tw, PASS, i);
 					else
@@ -350,6 +356,7 @@ struct RPass {
 #pragma unroll
 					for (int c = 0; c < R; ++c)
 						o[c] = g.v[i][c]; // (the upper half comes out conjugated)
+#endif
 				};
 				auto special = [&]() {
 					float2 y0[R / 2 + 1], yh[R / 2];
@@ -383,14 +390,16 @@ struct RPass {
 				const int a1 = k1 * J + j, a2 = j - k2 * J; // (the image: bin * J + j)
 #pragma unroll
 				for (int c = 0; c < R; ++c) {
-					if constexpr (LAST)
-						emit(lds, out, active, c < R / 2 ? k1 + (c << sL) : ((R - c) << sL) - k2, 0, o[c], i * R + c);
+					if constexpr (LAST) { // bin = base + a compile-time offset: the functor forms two addresses per item, not sixteen
+						if (active)
+							out(c < R / 2 ? k1 : -k2, c < R / 2 ? (c << sL) : ((R - c) << sL), o[c], i * R + c);
+					}
 					else
 						lds[RP::pad_off(c < R / 2 ? a1 : a2, (c < R / 2 ? c : R - c) * (N / R))] = o[c];
 				}
 				if constexpr (LAST) {
 					if (sp && active) // (one lane per frame)
-						out(N / 2, make_float2(nyq, 0.0f), 16);
+						out(0, N / 2, make_float2(nyq, 0.0f), 16);
 				}
 			}
 		}

@@ -203,19 +203,24 @@ struct StftOutR {
 	float* mag;
 	int n;
 	bool full, any_full;
-	__device__ __forceinline__ void operator()(int bin, float2 X, int slot) const
+	// bin = base + off, off a compile-time constant: S + base and mag + base are formed once per value of base (two per item),
+	// the stores take their offsets as immediates
+	__device__ __forceinline__ void operator()(int base, int off, float2 X, int slot) const
 	{
-		ZH_CHK(S + bin, 1);
-		ZH_CHK(mag + bin, 1);
-		S[bin] = X;
-		// complex_abs_functor hps.h:82-89; the two real bins (slot 0 of the thread that holds them, and its slot 16): sqrt of an
-		// exact square
+		float2* Sb = S + base;
+		float* mb = mag + base;
+		ZH_CHK(Sb + off, 1);
+		ZH_CHK(mb + off, 1);
+		Sb[off] = X;
+		// complex_abs_functor hps.h:82-89; bin nfft/2 (slot 16) is real: the root of an exact square
 		const float m = slot == 16 ? __builtin_fabsf(X.x) : zfft::cabs_exact(X.x, X.y);
-		mag[bin] = m;
+		mb[off] = m;
 		if (any_full) {
+			const int bin = base + off;
 			if (full && bin != 0 && bin != (n >> 1)) {
-				ZH_CHK(mag + (n - bin), 1);
-				mag[n - bin] = m;
+				float* mm = mag + (n - base);
+				ZH_CHK(mm - off, 1);
+				mm[-off] = m;
 			}
 		}
 	}
@@ -265,7 +270,11 @@ __global__ __launch_bounds__(zfft::RPlan<LOG2N>::THREADS) __attribute__((amdgpu_
 	in.nv_prev = f == 0 ? hop : valid_in_hop(a.in_valid, f - 1, hop);
 	in.nv_cur = valid_in_hop(a.in_valid, f, hop);
 	in.contiguous = __builtin_amdgcn_ballot_w64(!(f > 0 && in.nv_prev == hop && in.nv_cur == hop)) == 0ull;
-	const long long row = ((a.row0 + f) % a.ring_rows) + (long long)s * a.ring_rows;
+	// (launch_stft_t hands over row0 already reduced modulo ring_rows, and n_frames <= ring_rows: one conditional subtraction
+	// instead of a 64-bit remainder per thread -- fifty VALU instructions)
+	long long rr = a.row0 + f;
+	rr = rr >= a.ring_rows ? rr - a.ring_rows : rr;
+	const long long row = rr + (long long)s * a.ring_rows;
 	StftOutR out;
 	out.S = a.S + row * a.s_stride;
 	out.mag = a.mag + row * RP::N;
@@ -453,12 +462,14 @@ template <int LOG2N>
 int launch_stft_t(const StftArgs& a, hipStream_t stream)
 {
 	using PL = Plan<LOG2N>;
-	if (!g_opt_no_rfft && a.hop * 4 == PL::N) { // (StftInR::HOP; the engine never asks for anything else, hps.h:224-225)
+	if (!g_opt_no_rfft && a.hop * 4 == PL::N && a.n_frames <= a.ring_rows && a.row0 >= 0) { // (StftInR::HOP; the engine never asks for anything else, hps.h:224-225)
 		using RP = zfft::RPlan<LOG2N>;
 		auto kern = stft_real_kernel<LOG2N>;
 		ZH_TRY(set_lds(kern, rlds_bytes<LOG2N>()));
 		dim3 grid((unsigned)ceil_div((size_t)a.n_frames, (size_t)RP::FRAMES_PER_BLOCK) + 1, (unsigned)a.n_streams);
-		hipLaunchKernelGGL(kern, grid, dim3(RP::THREADS), rlds_bytes<LOG2N>(), stream, a);
+		StftArgs ar = a;
+		ar.row0 = a.row0 % a.ring_rows; // (see the kernel)
+		hipLaunchKernelGGL(kern, grid, dim3(RP::THREADS), rlds_bytes<LOG2N>(), stream, ar);
 		ZH_HIP(hipGetLastError());
 		return ZEN_HIP_OK;
 	}
