@@ -50,7 +50,10 @@ struct RPlan {
 	{
 		return (off & ((1 << PAD_SHIFT) - 1)) == 0 ? pad(base) + off + (off >> PAD_SHIFT) : pad(base + off);
 	}
-	static constexpr int FRAMES_PER_BLOCK = (TF >= 256) ? 1 : 256 / TF;
+#ifndef ZEN_RFFT_BLOCK_THREADS
+#define ZEN_RFFT_BLOCK_THREADS 256
+#endif
+	static constexpr int FRAMES_PER_BLOCK = (TF >= ZEN_RFFT_BLOCK_THREADS) ? 1 : ZEN_RFFT_BLOCK_THREADS / TF;
 	static constexpr int THREADS = TF * FRAMES_PER_BLOCK;
 };
 

@@ -496,10 +496,11 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 	// from the carry buffer this thread wrote there, before the transform starts (several outputs)
 	auto pick_carry = [&](int which, float (&cw)[4]) {
 #pragma unroll
-		for (int i = 0; i < 4; ++i)
-			cw[i] = SINGLE ? cv1[i] : a.carry[which][(long long)s * hop + tf + i * TF];
+		for (int i = 0; i < 4; ++i) {
 			if (!SINGLE)
 				ZH_CHK(a.carry[which] + ((long long)s * hop + tf + i * TF), 1);
+			cw[i] = SINGLE ? cv1[i] : a.carry[which][(long long)s * hop + tf + i * TF];
+		}
 	};
 	stamp(1);
 	// ---- block build that finishes hops itself (RtFusedArgs::out_direct), first part.  Output hop h = second half of

@@ -16,6 +16,7 @@
 #include "stft.h"
 
 #include <cfloat>
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -226,9 +227,93 @@ struct StftOutR {
 	}
 };
 
+// The same results by way of the frame's LDS image, so that they leave in 16-byte stores of consecutive bins.  The last pass
+// hands thread k bins k + c 2^s and d 2^s - k: stored from there, a wave instruction writes 8 bytes per lane for the spectrum
+// and 4 for the magnitudes -- and that store pattern ALONE, in a kernel with no arithmetic and no loads, takes as long as the
+// whole analysis kernel (tools/ubench_rowwrite.hip, nfft 1024: 0.56 ms per 331 456 frames; the same bytes as 16-byte stores
+// 0.41).  The image is free once the last pass has its inputs in registers: the spectrum goes there in natural order and
+// is copied out four floats per lane; then the magnitudes (kept in registers meanwhile) take the same road.
+template <int LOG2N>
+struct StftOutLds {
+	float2* nat; // the frame's image, bin b at nat[b]
+	float m[17];
+	int bin[17];
+	__device__ __forceinline__ void operator()(int base, int off, float2 X, int slot)
+	{
+		nat[base + off] = X;
+		m[slot] = slot == 16 ? __builtin_fabsf(X.x) : zfft::cabs_exact(X.x, X.y); // complex_abs_functor hps.h:82-89 (StftOutR)
+		bin[slot] = base + off;
+	}
+};
+template <int LOG2N>
+__device__ __forceinline__ void stft_store_rows(int tf, StftOutLds<LOG2N>& o, float2* __restrict__ S, float* __restrict__ mag, bool full,
+                                                bool any_full)
+{
+	using RP = zfft::RPlan<LOG2N>;
+	constexpr int N = RP::N, TF = RP::TF;
+	static_assert((N / 2 + 1) * 8 <= RP::LDS_FLOAT2 * 8, "the spectrum's half fits the image");
+	zfft::frame_sync<TF>();
+	{
+		const float4* n4 = reinterpret_cast<const float4*>(o.nat);
+		float4* g4 = reinterpret_cast<float4*>(__builtin_assume_aligned(S, 16));
+		float4 v[N / 4 / TF];
+#pragma unroll
+		for (int i = 0; i < N / 4 / TF; ++i)
+			v[i] = n4[tf + i * TF];
+#pragma unroll
+		for (int i = 0; i < N / 4 / TF; ++i) {
+			ZH_CHK(g4 + tf + i * TF, 1);
+			g4[tf + i * TF] = v[i];
+		}
+		if (tf == 0) {
+			ZH_CHK(S + N / 2, 1);
+			S[N / 2] = o.nat[N / 2];
+		}
+	}
+	zfft::frame_sync<TF>(); // the spectrum has been read: the magnitudes take its place
+	float* natm = reinterpret_cast<float*>(o.nat);
+#pragma unroll
+	for (int sl = 0; sl < 16; ++sl)
+		natm[o.bin[sl]] = o.m[sl];
+	if (o.bin[16] >= 0)
+		natm[o.bin[16]] = o.m[16];
+	zfft::frame_sync<TF>();
+	{
+		const float4* n4 = reinterpret_cast<const float4*>(natm);
+		float4* g4 = reinterpret_cast<float4*>(__builtin_assume_aligned(mag, 16));
+		float4 v[N / 8 / TF];
+#pragma unroll
+		for (int i = 0; i < N / 8 / TF; ++i)
+			v[i] = n4[tf + i * TF];
+#pragma unroll
+		for (int i = 0; i < N / 8 / TF; ++i) {
+			ZH_CHK(g4 + tf + i * TF, 1);
+			g4[tf + i * TF] = v[i];
+		}
+		if (tf == 0) {
+			ZH_CHK(mag + N / 2, 1);
+			mag[N / 2] = natm[N / 2];
+		}
+	}
+	if (any_full) { // (wave-uniform; the last W - 1 frames of a chunk) the mirrored upper half: |S[n-k]| == |S[k]| bit for bit
+		if (full) {
+			for (int b = 1 + tf; b < N / 2; b += TF) {
+				ZH_CHK(mag + (N - b), 1);
+				mag[N - b] = natm[b];
+			}
+		}
+	}
+}
+#ifndef ZEN_RFFT_WIDE_MASK
+#define ZEN_RFFT_WIDE_MASK 0x0FC0 // nfft 64 .. 2048: a frame inside one wavefront
+#endif
+
 // (four waves per SIMD: two 512-thread workgroups per CU at nfft 16384, whose 74 KB images now both fit the LDS)
 template <int LOG2N>
-__global__ __launch_bounds__(zfft::RPlan<LOG2N>::THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void stft_real_kernel(StftArgs a)
+#ifndef ZEN_RFFT_WAVES
+#define ZEN_RFFT_WAVES 4
+#endif
+__global__ __launch_bounds__(zfft::RPlan<LOG2N>::THREADS) __attribute__((amdgpu_waves_per_eu(ZEN_RFFT_WAVES, ZEN_RFFT_WAVES))) void stft_real_kernel(StftArgs a)
 {
 	using RP = zfft::RPlan<LOG2N>;
 	extern __shared__ float2 lds[];
@@ -275,23 +360,34 @@ __global__ __launch_bounds__(zfft::RPlan<LOG2N>::THREADS) __attribute__((amdgpu_
 	long long rr = a.row0 + f;
 	rr = rr >= a.ring_rows ? rr - a.ring_rows : rr;
 	const long long row = rr + (long long)s * a.ring_rows;
-	StftOutR out;
-	out.S = a.S + row * a.s_stride;
-	out.mag = a.mag + row * RP::N;
-	out.n = RP::N;
-	out.full = f >= a.mag_full_from;
-	out.any_full = __builtin_amdgcn_ballot_w64(out.full) != 0ull;
+	const bool full = f >= a.mag_full_from;
+	const bool any_full = __builtin_amdgcn_ballot_w64(full) != 0ull;
+	float2* S_row = a.S + row * a.s_stride;
+	float* mag_row = a.mag + row * RP::N;
 #ifndef ZEN_RFFT_TWPRE_MASK
 #define ZEN_RFFT_TWPRE_MASK 0xFFFF
 #endif
-	if constexpr (((ZEN_RFFT_TWPRE_MASK) >> LOG2N) & 1) { // (the passes' twiddles requested at the top of each pass: -4 % at nfft 1024
-		const zfft::TwGlobalPre tw{a.tw};                 // and 16384, A/B per size)
-		zfft::rfft_frame<LOG2N, true>(tf, lds + slot * RP::LDS_FLOAT2, tw, in, out, true);
+	constexpr bool TWPRE = ((ZEN_RFFT_TWPRE_MASK) >> LOG2N) & 1; // (the passes' twiddles requested at the top of each pass: -4 % at
+	using TWT = std::conditional_t<TWPRE, zfft::TwGlobalPre, zfft::TwGlobal>; // nfft 1024 and 16384, A/B per size)
+	const TWT tw{a.tw};
+	if constexpr ((((ZEN_RFFT_WIDE_MASK) >> LOG2N) & 1) != 0) {
+		if (a.s_stride % 2 == 0) { // (16-byte aligned rows: the engine's are; workgroup-uniform)
+			StftOutLds<LOG2N> out;
+			out.nat = lds + slot * RP::LDS_FLOAT2;
+			out.bin[16] = -1;
+			out.m[16] = 0.0f;
+			zfft::rfft_frame<LOG2N, true>(tf, lds + slot * RP::LDS_FLOAT2, tw, in, out, true);
+			stft_store_rows<LOG2N>(tf, out, S_row, mag_row, full, any_full);
+			return;
+		}
 	}
-	else {
-		const zfft::TwGlobal tw{a.tw};
-		zfft::rfft_frame<LOG2N, true>(tf, lds + slot * RP::LDS_FLOAT2, tw, in, out, true);
-	}
+	StftOutR out;
+	out.S = S_row;
+	out.mag = mag_row;
+	out.n = RP::N;
+	out.full = full;
+	out.any_full = any_full;
+	zfft::rfft_frame<LOG2N, true>(tf, lds + slot * RP::LDS_FLOAT2, tw, in, out, true);
 }
 
 template <int LOG2N>
