@@ -286,9 +286,36 @@ def whole_step_roofline(frames, nfft, hop, n_out, ms_per_step):
             "note": "SURVEY 8(d) per-frame minimum of the batched pipeline x frames of both passes / wall time of the step"}
 
 
+COPY_DETAIL = {}        # what device_copy_bandwidth measured, for the detail record
+
+
+def tuned_copy_record():
+    """tools/ubench_copy --json: the best streaming copy KERNEL of this box (4 x 16 B per thread, nontemporal loads and stores)
+    over the median kernel's working set and over 1 GiB, next to hipMemcpy device-to-device.  The binary is built by
+    __graft_entry__.build() (tools/bin/, travels with the tree); compiled here with hipcc if it is missing."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "tools", "bin", "ubench_copy")
+    tmp = None
+    try:
+        if not os.path.exists(exe):
+            tmp = exe = os.path.join(tempfile.gettempdir(), "zen_ubench_copy_%d" % os.getpid())
+            subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3",
+                                   os.path.join(ROOT, "tools", "ubench_copy.hip"), "-o", exe], stderr=subprocess.DEVNULL, timeout=300)
+        txt = subprocess.run([exe, "--json"], capture_output=True, text=True, timeout=120).stdout
+        return next(json.loads(ln) for ln in txt.splitlines() if ln.startswith("{"))
+    except Exception as exc:
+        return {"error": str(exc)[:200]}
+    finally:
+        if tmp and os.path.exists(tmp):
+            os.remove(tmp)
+
+
 def device_copy_bandwidth(zen_amd, n_floats=1 << 28, iters=10):
-    """Device-to-device copy of 1 GiB (read + write bytes per second): the practical HBM roof of this box,
-    quoted next to the nominal 8 TB/s (roofline denominators)."""
+    """The practical HBM roof of this box (read + write bytes per second), quoted next to the nominal 8 TB/s (BASELINE.md,
+    roofline denominators): the TUNED copy kernel over the median kernel's working set -- a kernel that streams at
+    0.72 of 8 TB/s is measured against the best a copy kernel does here, not against hipMemcpy, which it beats.  hipMemcpy
+    device-to-device of 1 GiB is kept beside it (`hipMemcpy_d2d_GBps`); it is the fallback if the tool cannot run."""
     import ctypes as C
     a, b = zen_amd.DeviceBuffer(n_floats), zen_amd.DeviceBuffer(n_floats)
     a.zero()
@@ -307,7 +334,14 @@ def device_copy_bandwidth(zen_amd, n_floats=1 << 28, iters=10):
     dt = (time.perf_counter() - t0) / iters
     a.free()
     b.free()
-    return 8.0 * n_floats / dt / 1e9
+    memcpy_bw = 8.0 * n_floats / dt / 1e9
+    rec = tuned_copy_record()
+    COPY_DETAIL.clear()
+    COPY_DETAIL.update(rec)
+    COPY_DETAIL["hipMemcpy_d2d_GBps"] = memcpy_bw
+    tuned = max(rec.get("tuned_copy_median_shape_GBps", 0.0), rec.get("tuned_copy_1GiB_GBps", 0.0))
+    COPY_DETAIL["device_copy_GBps_is"] = "tuned copy kernel" if tuned > 0 else "hipMemcpy device-to-device (the tuned copy tool did not run)"
+    return tuned if tuned > 0 else memcpy_bw
 
 
 def realtime_leg(zen_amd, x, n_hops=400):
@@ -599,7 +633,35 @@ def median_rooflines(zen_amd, run, S, M, copy_bw):
         "traffic": tr, "traffic_source": tsrc,
         "kernel": K_MEDIAN_WHOLE + " (frequency direction, 47 taps, whole 4096-bin rows; rows without a set sign bit keep raw-bit keys)",
         "elements_per_launch": el, "rows": rows, "cols": cols, "algorithmic_bytes_per_element": 8}
+    roof["long_masks"] = long_mask_shapes(zen_amd)
+    roof["device_copy"] = dict(COPY_DETAIL)
     return roof, three
+
+
+def long_mask_shapes(zen_amd, iters=30):
+    """The long frequency masks through the plain wrapper, so that every instantiation of median_big_kernel a user can reach has
+    a number in the line: 93 taps on 8192-bin rows (hop 2048 at 44.1 kHz), 187 taps on 16384-bin rows (hop 4096: pass 1 of the
+    offline path) and 255 taps -- the longest mask the API accepts, 1.1 KB of scratch per lane (kernel_resources.json)."""
+    out = []
+    for rows, cols, flen in ((12920, 8192, 93), (6460, 16384, 187), (6460, 16384, 255)):
+        rng = np.random.default_rng(flen)
+        src = zen_amd.DeviceBuffer.from_host(rng.random((rows, cols), dtype=np.float32))
+        dst = zen_amd.DeviceBuffer(rows * cols)
+        f = zen_amd.MedianFilterGPU(rows, cols, flen, zen_amd.FREQUENCY)
+        for _ in range(3):
+            f.filter(src, dst)
+        zen_amd.synchronize()
+        e0, e1 = zen_amd.Event(), zen_amd.Event()
+        e0.record()
+        for _ in range(iters):
+            f.filter(src, dst)
+        e1.record()
+        ms = e0.elapsed_ms(e1) / iters
+        gb = 8.0 * rows * cols / (1e-3 * ms) / 1e9
+        out.append({"rows": rows, "cols": cols, "taps": flen, "ms": ms, "GBps": gb, "frac": gb / 8000.0, "launches": iters})
+        src.free()
+        dst.free()
+    return out
 
 
 def sse_rooflines(prof, steps, frames, nfft, hop):
@@ -777,6 +839,40 @@ def link_roof(zen_amd, n, reps=5):
     return res
 
 
+def offline_host_sharded_run(zen_amd, grp, rank, world, seconds, barrier, numa_cpus, reps=3):
+    """N ranks, each with its own pageable host clip of `seconds` (mono S-music, another seed per rank), all calling
+    HPRIOffline<GPU>::process (zen_hip_hpri_process: upload, both passes, two downloads, pipelined) at the same time: what
+    `zen batch --gpus N` does to the host.  Per rank the wall time of its own call; for the job the audio of all ranks over the
+    slowest rank's time, and the bytes that crossed the host links in that time (12 per sample and rank) -- on one node the
+    ranks share the host's DRAM bandwidth, so this curve, not the HBM-resident one, is what a user's batch scales like."""
+    n = int(seconds * FS)
+    base = s_music(int(30 * FS), seed=7000 + rank)
+    x = np.tile(base, -(-n // base.size))[:n].copy()
+    outs = [np.zeros(n, np.float32) for _ in range(3)]
+    eng = zen_amd.HPRIOffline(FS, 4096, 256, BETA, BETA)
+    eng.process(x, out=tuple(outs))                                    # warm-up: staging buffers, engine growth, registration
+    walls = []
+    for _ in range(reps):
+        barrier()
+        t0 = time.perf_counter()
+        eng.process(x, out=tuple(outs))
+        walls.append(time.perf_counter() - t0)
+    mine = min(walls)
+    slowest = grp.max(mine)
+    one_hot = [0.0] * world
+    one_hot[rank] = 1e3 * mine
+    per_rank = grp.sum(one_hot)
+    chk, ranks = grp.sum([float(np.abs(outs[1][:4096]).sum()), 1.0])
+    return {"metric": "x real time, N ranks x HPRIOffline<GPU>::process on host vectors at the same time", "unit": "x_realtime",
+            "value": world * seconds / slowest, "per_rank_wall_ms": per_rank, "slowest_rank_wall_ms": 1e3 * slowest,
+            "per_rank_x_realtime_min": seconds / slowest, "clip_seconds_per_rank": seconds, "ranks_reported": int(round(ranks)),
+            "host_link_GBps_aggregate": 12e-9 * n * world / slowest, "bytes_per_sample": 12, "checksum": chk,
+            "numa_cpus_rank0": (numa_cpus[:4] + ["..."] + numa_cpus[-1:]) if numa_cpus and len(numa_cpus) > 6 else numa_cpus,
+            "host_stats_rank0": eng.host_stats(),
+            "config": {"workload": "%d ranks, each: HPRIOffline<GPU>(44100, 4096, 256, 2.0, 2.0).process on its own %.0f s mono "
+                                   "clip in pageable host memory, concurrently; no exchange between ranks" % (world, seconds)}}
+
+
 def cpp_process_ms(seconds, reps=3):
     """HPRIOffline<GPU>::process(std::vector<float>) through the C++ host mirror (zen_amd/libzen), timed like
     zen/offline.h:141-147 by tools/offline_host.cpp: the by-value copy of the clip and the three result vectors included."""
@@ -912,12 +1008,22 @@ def compact_line(full):
             cfg[name + "_x_realtime"] = leg.get("x_realtime")
             legs[name] = {"x_realtime": leg.get("x_realtime"), "ms_per_step": leg.get("ms_per_step"), "hops_per_s": leg.get("value"),
                           "whole_step_frac_of_hbm_roof": leg.get("whole_step", {}).get("frac")}
+            if name == "offline_batch_sharded" and full.get("offline_host_sharded"):
+                hs = full["offline_host_sharded"]
+                cfg["offline_host_sharded_x_realtime"] = hs.get("value")
+                cfg["offline_host_sharded_link_GBps"] = hs.get("host_link_GBps_aggregate")
+                legs["offline_host_sharded"] = {k: hs.get(k) for k in ("value", "per_rank_wall_ms", "slowest_rank_wall_ms", "ranks_reported",
+                                                                       "host_link_GBps_aggregate", "clip_seconds_per_rank", "numa_cpus_rank0")}
             if name == "offline_batch_sharded":
                 cfg["offline_batch_sharded_ranks_reported"] = leg.get("ranks_reported")
                 cfg["offline_batch_sharded_clips_total"] = leg.get("config", {}).get("clips_total")
     oh = full.get("offline_host")
     if oh:
         cfg["offline_host_x_realtime"] = oh.get("value")
+        # what a `zen offline` user sees: the reference's literal C++ signature process(std::vector<float>) (by-value clip, three
+        # new result vectors), by copy and from a caller that moves its clip in
+        cfg["offline_host_cpp_x_realtime"] = oh.get("cpp_process", {}).get("x_realtime")
+        cfg["offline_host_cpp_moved_x_realtime"] = oh.get("cpp_process", {}).get("moved_x_realtime")
         legs["offline_host"] = {"x_realtime": oh.get("value"), "wall_ms": oh.get("wall_ms"), "clip_seconds": oh.get("clip_seconds"),
                                 "frac_of_link_roof": oh.get("roofline", {}).get("frac"),
                                 "link_roof_ms": oh.get("roofline", {}).get("roof_ms"), "kernels_alone_ms": oh.get("compute_ms"),
@@ -949,7 +1055,11 @@ def compact_line(full):
                                               "launches": m["sustained"]["launches"], "seconds": m["sustained"]["seconds"]},
                                 "burst_frac": m["burst"]["frac"], "cold_frac": m["cold"]["frac"],
                                 "traffic": m.get("traffic"), "frac_of_device_copy": m.get("frac_of_device_copy"),
-                                "through": "plain zen_hip_mfilt_run, no option, no promise"}
+                                "through": "plain zen_hip_mfilt_run, no option, no promise",
+                                "long_masks_frac": {"%d taps / %d bins" % (x["taps"], x["cols"]): round(x["frac"], 4)
+                                                    for x in m.get("long_masks", [])}}
+            roof["device_copy_is"] = m.get("device_copy", {}).get("device_copy_GBps_is")
+            roof["hipMemcpy_d2d_GBps"] = m.get("device_copy", {}).get("hipMemcpy_d2d_GBps")
         line["roofline"] = roof
     if "cpu_baseline" in full:
         c = full["cpu_baseline"]
@@ -1014,6 +1124,14 @@ def dry_main(args, zdist):
         tot_clips, ranks2 = grp.sum([len(mine), 1])
         line["offline_batch_sharded"] = {"dry": True, "clips_total": int(tot_clips), "clips_rank0": len(mine),
                                          "ranks_reported": int(ranks2)}
+        # the host-clip leg's aggregation: per-rank wall times gathered as a one-hot sum, the slowest rank, the rank count
+        mine_ms = 1.0 + rank
+        one_hot = [0.0] * world
+        one_hot[rank] = mine_ms
+        per_rank = grp.sum(one_hot)
+        line["offline_host_sharded"] = {"dry": True, "per_rank_wall_ms": per_rank, "slowest_rank_wall_ms": grp.max(mine_ms),
+                                        "ranks_reported": int(grp.sum([1])[0]),
+                                        "numa_bound": zdist.gpu_numa_cpus(rank) is not None}
     if rank == 0:
         print(json.dumps(line))
     grp.close()
@@ -1028,6 +1146,7 @@ def main():
     ap.add_argument("--workload", default="realtime_block", choices=["realtime_block", "offline_batch", "offline_long", "offline_host"])
     ap.add_argument("--host-seconds", type=float, default=3600.0, help="offline_host: length of the clip")
     ap.add_argument("--host-variants", action="store_true", help="offline_host: also time range lengths / unregistered / pinned buffers")
+    ap.add_argument("--host-shard-seconds", type=float, default=600.0, help="N > 1: length of every rank's host clip in the offline_host_sharded leg")
     ap.add_argument("--hops", type=int, default=25840, help="hops per step per stream (25840 = 10 min)")
     ap.add_argument("--streams", type=int, default=1, help="independent streams per GPU")
     ap.add_argument("--clips", type=int, default=64, help="offline_batch: clips per GPU")
@@ -1062,6 +1181,7 @@ def main():
         # HIP library or touched a GPU; the ranks are fresh interpreters (one per GPU), rank 0's line is relayed.
         sys.exit(zdist.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
     rank, local_rank, world = zdist.env_world()
+    numa_cpus = zdist.bind_to_gpu_numa(local_rank) if world > 1 else None   # before torch / HIP: the ranks' host buffers stay local
     if world != args.gpus and rank == 0:
         print("bench.py: --gpus %d but WORLD_SIZE=%d from the launcher; using WORLD_SIZE" % (args.gpus, world),
               file=sys.stderr)
@@ -1206,6 +1326,11 @@ def main():
                                              barrier, rooflines=False)
                 if rank == 0:
                     out["offline_batch_sharded"] = ob
+                # -- and the path a user runs (`zen batch --gpus N`): every rank separates its own HOST clip through
+                #    HPRIOffline::process at the same time -- N x 12 bytes per sample over the host links
+                oh = offline_host_sharded_run(zen_amd, grp, rank, world, args.host_shard_seconds, barrier, numa_cpus)
+                if rank == 0:
+                    out["offline_host_sharded"] = oh
     elif args.workload == "offline_batch":
         res, clip0, (n1, n2) = offline_batch_run(zen_amd, zdist, grp, rank, world, args.clips, args.clip_seconds, args.steps,
                                                  args.warmup, args.settle_ms, barrier)

@@ -44,6 +44,9 @@ def test_plain_launch_time_shards_and_replicas():
     # the default N > 1 line also carries the path that shards: the offline batch, clips dealt to the ranks
     sh = j["offline_batch_sharded"]
     assert sh["ranks_reported"] == 3 and sh["clips_total"] == 3 * 64 and sh["clips_rank0"] == 64
+    # ... and the host-clip leg (every rank HPRIOffline::process on its own host vectors at once): per-rank times gathered
+    hs = j["offline_host_sharded"]
+    assert hs["ranks_reported"] == 3 and hs["per_rank_wall_ms"] == [1.0, 2.0, 3.0] and hs["slowest_rank_wall_ms"] == 3.0
 
 
 def test_torchrun_launch_is_not_respawned():
@@ -115,7 +118,7 @@ def test_default_line_at_two_ranks_carries_the_sharded_offline_batch():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--hops", "300", "--steps", "2", "--warmup", "1",
-                        "--settle-ms", "0", "--leg-clips", "2", "--clip-seconds", "2", "--leg-steps", "2"],
+                        "--settle-ms", "0", "--leg-clips", "2", "--clip-seconds", "2", "--leg-steps", "2", "--host-shard-seconds", "20"],
                        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     j = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][0])
@@ -125,4 +128,9 @@ def test_default_line_at_two_ranks_carries_the_sharded_offline_batch():
     cfg, sh = j["config"], j["legs"]["offline_batch_sharded"]
     assert cfg["offline_batch_sharded_ranks_reported"] == 2 and cfg["offline_batch_sharded_clips_total"] == 4
     assert cfg["offline_batch_sharded_x_realtime"] > 0 and sh["hops_per_s"] > 0 and sh["x_realtime"] == cfg["offline_batch_sharded_x_realtime"]
+    # the path a user runs: both ranks separate their own HOST clip at the same time (zen/offline.h:141-147's timed region)
+    hs = j["legs"]["offline_host_sharded"]
+    assert hs["ranks_reported"] == 2 and len(hs["per_rank_wall_ms"]) == 2 and min(hs["per_rank_wall_ms"]) > 0
+    assert hs["slowest_rank_wall_ms"] >= max(hs["per_rank_wall_ms"]) - 1e-6
+    assert cfg["offline_host_sharded_x_realtime"] == hs["value"] > 0 and cfg["offline_host_sharded_link_GBps"] > 0
     assert "cpu_baseline" not in j and "per_hop_api_us" not in cfg   # rank 0 at N = 1 only

@@ -96,3 +96,44 @@ def test_time_shards_cover_the_clip():
         for (b0, e0), (b1, e1) in zip(sh, sh[1:]):
             assert e0 == b1 and b0 <= e0
         assert all(b % align == 0 for b, _ in sh)
+
+
+def _fake_sysfs(root, gpus):
+    """gpus: [(kfd node id, render minor, numa node, cpulist)]; node 0 is a CPU-only KFD node, as on a real box."""
+    def put(path, text):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            f.write(text)
+    put(os.path.join(root, "class/kfd/kfd/topology/nodes/0/properties"), "cpu_cores_count 64\nsimd_count 0\ndrm_render_minor -1\n")
+    for node, minor, numa, cpus in gpus:
+        put(os.path.join(root, "class/kfd/kfd/topology/nodes/%d/properties" % node),
+            "cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor %d\n" % minor)
+        put(os.path.join(root, "class/drm/renderD%d/device/numa_node" % minor), "%d\n" % numa)
+        put(os.path.join(root, "class/drm/renderD%d/device/local_cpulist" % minor), cpus + "\n")
+
+
+def test_gpu_numa_cpus_from_a_sysfs_tree(tmp_path, monkeypatch):
+    """The ranks of `bench.py --gpus N` (and the children of `zen batch --gpus N`) pin themselves to the CPUs next to their
+    GPU before their first GPU call; the topology comes from sysfs alone (KFD nodes -> render minor -> local_cpulist)."""
+    for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "ZEN_NO_NUMA_BIND"):
+        monkeypatch.delenv(v, raising=False)
+    root = str(tmp_path)
+    _fake_sysfs(root, [(2, 128, 0, "0-3,64-67"), (3, 129, 1, "4-7"), (10, 136, -1, "0-127")])
+    assert zdist.gpu_numa_cpus(0, root) == [0, 1, 2, 3, 64, 65, 66, 67]
+    assert zdist.gpu_numa_cpus(1, root) == [4, 5, 6, 7]
+    assert zdist.gpu_numa_cpus(2, root) is None          # numa_node -1: the box does not say
+    assert zdist.gpu_numa_cpus(3, root) is None          # no such GPU
+    assert zdist.gpu_numa_cpus(0, str(tmp_path / "nothing")) is None
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1,0")     # remapped: device 0 is the second GPU
+    assert zdist.gpu_numa_cpus(0, root) == [4, 5, 6, 7]
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    # binding: only CPUs this process may use anyway; restored afterwards
+    before = os.sched_getaffinity(0)
+    try:
+        first = sorted(before)[0]
+        _fake_sysfs(root, [(2, 128, 0, "%d" % first)])
+        assert zdist.bind_to_gpu_numa(0, root) == [first] and os.sched_getaffinity(0) == {first}
+        monkeypatch.setenv("ZEN_NO_NUMA_BIND", "1")
+        assert zdist.bind_to_gpu_numa(0, root) is None
+    finally:
+        os.sched_setaffinity(0, before)

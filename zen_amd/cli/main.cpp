@@ -5,14 +5,19 @@
 // the GPU drop-in; the CPU restatement lives under oracle/ as test infrastructure only.
 #include <algorithm>
 #include <array>
+#include <cctype>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <dirent.h>
+#include <fstream>
 #include <iostream>
+#include <sstream>
 #include <map>
 #include <string>
 #include <vector>
 
+#include <sched.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -165,6 +170,79 @@ BatchRank batch_rank_from_env()
 	return b;
 }
 
+// CPUs next to GPU `index` (the order HIP enumerates: the GPU nodes of the KFD topology), from sysfs alone -- no HIP call:
+// node N of /sys/class/kfd/kfd/topology/nodes is a GPU when its simd_count > 0, its drm_render_minor M names
+// /sys/class/drm/renderD<M>/device, whose local_cpulist is the answer (zen_amd/dist.py gpu_numa_cpus: the same walk).
+// Empty when the box does not say, when ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES remap the devices, or ZEN_NO_NUMA_BIND is set.
+std::vector<int> gpu_numa_cpus(int index)
+{
+	std::vector<int> cpus;
+	if (std::getenv("ZEN_NO_NUMA_BIND") || std::getenv("ROCR_VISIBLE_DEVICES") || std::getenv("HIP_VISIBLE_DEVICES"))
+		return cpus;
+	const char* env_root = std::getenv("ZEN_SYSFS_ROOT"); // (tests)
+	const std::string sysfs = env_root ? env_root : "/sys";
+	const std::string root = sysfs + "/class/kfd/kfd/topology/nodes";
+	std::vector<int> nodes;
+	if (DIR* d = opendir(root.c_str())) {
+		while (dirent* e = readdir(d))
+			if (std::isdigit((unsigned char)e->d_name[0]))
+				nodes.push_back(std::atoi(e->d_name));
+		closedir(d);
+	}
+	std::sort(nodes.begin(), nodes.end());
+	int seen = 0, minor = -1;
+	for (int nd : nodes) {
+		std::ifstream f(root + "/" + std::to_string(nd) + "/properties");
+		std::string k;
+		long long v, simd = 0, rm = -1;
+		while (f >> k >> v) {
+			if (k == "simd_count")
+				simd = v;
+			if (k == "drm_render_minor")
+				rm = v;
+		}
+		if (simd > 0 && seen++ == index)
+			minor = (int)rm;
+	}
+	if (minor < 0)
+		return cpus;
+	const std::string dev = sysfs + "/class/drm/renderD" + std::to_string(minor) + "/device/";
+	int node = -1;
+	std::ifstream(dev + "numa_node") >> node;
+	if (node < 0)
+		return cpus;
+	std::ifstream lf(dev + "local_cpulist");
+	std::string list;
+	std::getline(lf, list);
+	std::stringstream ss(list);
+	std::string part;
+	while (std::getline(ss, part, ',')) {
+		int lo = 0, hi = 0;
+		if (std::sscanf(part.c_str(), "%d-%d", &lo, &hi) == 2)
+			for (int c = lo; c <= hi; ++c)
+				cpus.push_back(c);
+		else if (std::sscanf(part.c_str(), "%d", &lo) == 1)
+			cpus.push_back(lo);
+	}
+	return cpus;
+}
+
+// Pin the calling process to the CPUs next to its GPU, before its first GPU call: the offline path moves 12 bytes per sample
+// between pageable host vectors and the device (zen/offline.h:141-147); a child whose buffers sit on the other socket pays the
+// inter-socket link for every one of them.
+void bind_to_gpu_numa(int index)
+{
+	const std::vector<int> cpus = gpu_numa_cpus(index);
+	if (cpus.empty())
+		return;
+	cpu_set_t set;
+	CPU_ZERO(&set);
+	for (int c : cpus)
+		if (c >= 0 && c < CPU_SETSIZE)
+			CPU_SET(c, &set);
+	(void)sched_setaffinity(0, sizeof(set), &set);
+}
+
 // `zen batch --gpus N` (BASELINE configs[3]): clips are independent units, so the parent only
 // starts N copies of itself -- one per GPU, before anything in this process has touched a GPU -- and adds
 // up what they report through a pipe.  Child r separates files r, r+N, r+2N, ... of the sorted directory
@@ -189,6 +267,7 @@ int run_batch_multi(int gpus, char* argv[])
 			setenv("ZEN_BATCH_RANK", std::to_string(r).c_str(), 1);
 			setenv("ZEN_BATCH_WORLD", std::to_string(gpus).c_str(), 1);
 			setenv("ZEN_BATCH_REPORT_FD", std::to_string(fds[1]).c_str(), 1);
+			bind_to_gpu_numa(r); // (inherited across the exec: the child's threads and first-touched pages stay next to GPU r)
 			execv("/proc/self/exe", argv);
 			_exit(127);
 		}

@@ -30,6 +30,75 @@ def _free_port():
     return port
 
 
+def _parse_cpulist(text):
+    """'0-31,64-95' -> [0..31, 64..95] (the kernel's cpulist format)."""
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_cpus(index, sysfs="/sys"):
+    """CPUs local to GPU `index` (the order HIP enumerates: the GPU nodes of the KFD topology, filtered by ROCR_VISIBLE_DEVICES /
+    HIP_VISIBLE_DEVICES when those hold plain indices), from sysfs alone -- no HIP call, so it can run before anything touches
+    a GPU: node N of /sys/class/kfd/kfd/topology/nodes is a GPU when its simd_count > 0; its drm_render_minor M names
+    /sys/class/drm/renderD<M>/device, whose local_cpulist is the answer.  None when the box does not say (no KFD, numa_node -1,
+    an unreadable file): the caller then leaves the affinity alone."""
+    try:
+        root = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
+        gpus = []
+        for name in sorted(os.listdir(root), key=lambda v: int(v) if v.isdigit() else 1 << 30):
+            props = {}
+            with open(os.path.join(root, name, "properties")) as f:
+                for ln in f:
+                    k, _, v = ln.strip().partition(" ")
+                    props[k] = v
+            if int(props.get("simd_count", "0")) > 0:
+                gpus.append(int(props.get("drm_render_minor", "-1")))
+        for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):
+            vis = os.environ.get(var)
+            if vis:
+                ids = [v.strip() for v in vis.split(",") if v.strip()]
+                if not all(v.isdigit() for v in ids):
+                    return None                        # UUIDs: not resolved here
+                gpus = [gpus[int(v)] for v in ids if int(v) < len(gpus)]
+        if not (0 <= index < len(gpus)) or gpus[index] < 0:
+            return None
+        dev = os.path.join(sysfs, "class", "drm", "renderD%d" % gpus[index], "device")
+        with open(os.path.join(dev, "numa_node")) as f:
+            if int(f.read().strip()) < 0:
+                return None
+        with open(os.path.join(dev, "local_cpulist")) as f:
+            cpus = _parse_cpulist(f.read())
+        return cpus or None
+    except (OSError, ValueError, IndexError):
+        return None
+
+
+def bind_to_gpu_numa(index, sysfs="/sys"):
+    """Pin this process (and the threads it will start: the runtime's, the host-vector pipeline's) to the CPUs next to GPU
+    `index`, BEFORE its first GPU call.  The offline path moves 12 bytes per sample over the host link from / to pageable host
+    memory (zen/offline.h:141-147): a rank whose buffers sit on the other socket pays the inter-socket link for every one of
+    them.  Returns the CPU list, or None (nothing changed) when the topology is unknown or ZEN_NO_NUMA_BIND is set."""
+    if os.environ.get("ZEN_NO_NUMA_BIND"):
+        return None
+    cpus = gpu_numa_cpus(index, sysfs)
+    if not cpus:
+        return None
+    try:
+        allowed = os.sched_getaffinity(0)
+        want = set(cpus) & allowed
+        if not want:
+            return None
+        os.sched_setaffinity(0, want)
+        return sorted(want)
+    except (AttributeError, OSError):
+        return None
+
+
 def spawn_ranks(argv, n, timeout=None, env_extra=None):
     """Run `argv` as n fresh child processes, one per GPU of this node (RANK = LOCAL_RANK = 0..n-1,
     WORLD_SIZE = n, MASTER_ADDR = 127.0.0.1, a free MASTER_PORT), the same environment torch.distributed.run
@@ -53,6 +122,8 @@ def spawn_ranks(argv, n, timeout=None, env_extra=None):
             env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
             if env_extra:
                 env.update(env_extra)
+            # (the child binds itself to its GPU's NUMA node first thing -- bench.py main(), zen_amd.dist.bind_to_gpu_numa -- as a
+            # rank started by torch.distributed.run has to)
             procs.append(subprocess.Popen(argv, env=env, stdout=out0 if r == 0 else subprocess.DEVNULL))
         deadline = None if timeout is None else time.monotonic() + timeout
         try:
