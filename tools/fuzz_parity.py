@@ -73,6 +73,8 @@ def run(seconds, seed):
                 a = got[k][s] if streams > 1 else got[k]
                 if not np.array_equal(a, refs[s][k], equal_nan=True):
                     ok = False
+        if zen_amd.memcheck()["corrupt_words"]:
+            ok = False
         key = (fs, hop, time_len, freq_len, causal, mode)
         seen.add(key)
         if ok:
@@ -160,6 +162,8 @@ def run_offline(seconds, seed):
         finally:
             for k in opts:
                 zen_amd.set_option(k, 0)
+        if zen_amd.memcheck()["corrupt_words"]:
+            ok = False
         seen.add((fs, hop_h, hop_p, mode))
         if ok:
             n_ok += 1
@@ -167,6 +171,16 @@ def run_offline(seconds, seed):
             n_bad += 1
             print("MISMATCH offline", dict(fs=fs, hop_h=hop_h, hop_p=hop_p, beta_h=beta_h, beta_p=beta_p, mode=mode, n=n, clips=clips, **cfg), flush=True)
     return n_ok, n_bad, n_skip, len(seen)
+
+
+def memcheck_line():
+    """Red zones (ZEN_HIP_REDZONE, set by tools/fuzz_final.sh) of everything still alive, plus what the frees found."""
+    r = zen_amd.memcheck()
+    if not r["redzone_bytes"]:
+        return "memcheck off (no ZEN_HIP_REDZONE)", 0
+    bad = r["corrupt_words"] + r["bounds_violations"]
+    return ("memcheck clean (%d allocations, %d-byte red zones)" % (r["allocations"], r["redzone_bytes"]) if not bad
+            else "MEMCHECK: " + r["first_message"]), bad
 
 
 def main():
@@ -177,11 +191,13 @@ def main():
     args = ap.parse_args()
     if args.offline:
         n_ok, n_bad, n_skip, n_seen = run_offline(args.seconds, args.seed)
-        print("offline: ok %d  mismatches %d  skipped %d  distinct (fs, hop_h, hop_p, mode): %d" % (n_ok, n_bad, n_skip, n_seen))
-        return 1 if n_bad else 0
+        mc, bad = memcheck_line()
+        print("offline: ok %d  mismatches %d  skipped %d  distinct (fs, hop_h, hop_p, mode): %d  %s" % (n_ok, n_bad, n_skip, n_seen, mc))
+        return 1 if n_bad or bad else 0
     n_ok, n_bad, n_skip, n_seen = run(args.seconds, args.seed)
-    print("ok %d  mismatches %d  skipped %d  distinct (fs, hop, masks, causality, mode): %d" % (n_ok, n_bad, n_skip, n_seen))
-    return 1 if n_bad else 0
+    mc, bad = memcheck_line()
+    print("ok %d  mismatches %d  skipped %d  distinct (fs, hop, masks, causality, mode): %d  %s" % (n_ok, n_bad, n_skip, n_seen, mc))
+    return 1 if n_bad or bad else 0
 
 
 if __name__ == "__main__":

@@ -139,6 +139,9 @@ def build(force=False, verbose=False):
     return OUT
 
 
+KERNEL_PATHS = ("--", "zen_amd/csrc", "include", "zen_amd/build.py")   # git pathspec of the library's sources
+
+
 def _stamp_revision():
     """.build_rev (git-ignored, travels to the GPU box with the built library): the commit the library was built from, with
     a mark when the kernel sources differ from it.  tools/collect_profiles.sh labels every record it writes with this; the
@@ -152,6 +155,12 @@ def _stamp_revision():
         n = len([d for d in dirty if d.strip()])
         with open(os.path.join(root, ".build_rev"), "w") as f:
             f.write(rev + ("+%d-uncommitted-source-files" % n if n else "") + "\n")
+        # the last commit that touched what the library is made of: what a fuzz summary must name (tools/fuzz_final.sh refuses
+        # to write one for a build with uncommitted kernel sources; tests/test_profiles.py compares the name with the tree)
+        krev = subprocess.run(["git", "log", "-1", "--format=%h"] + list(KERNEL_PATHS), cwd=root, stdout=subprocess.PIPE,
+                              stderr=subprocess.DEVNULL, universal_newlines=True, check=True).stdout.strip()
+        with open(os.path.join(root, ".build_kernel_rev"), "w") as f:
+            f.write(krev + ("+%d-uncommitted-source-files" % n if n else "") + "\n")
     except (OSError, subprocess.CalledProcessError):
         pass          # no git here (the GPU box): the stamp written where the library was built stays
 
