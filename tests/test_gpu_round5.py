@@ -72,6 +72,39 @@ def test_deliberately_broken_store_is_caught(z, where):
     assert r.returncode == 86
 
 
+_SHORT_DST_CHILD = """
+import json
+import numpy as np
+import zen_amd
+zen_amd.init(0)
+rows, cols = 64, 4096
+src = zen_amd.DeviceBuffer.from_host(np.random.default_rng(0).random((rows, cols), dtype=np.float32))
+dst = zen_amd.DeviceBuffer(rows * cols - 1000)            # 1000 floats short: the last row's stores run 4000 bytes past the end
+f = zen_amd.MedianFilterGPU(rows, cols, 47, zen_amd.FREQUENCY)
+f.filter(src, dst)
+zen_amd.synchronize()
+print("REPORT " + json.dumps(zen_amd.memcheck()))
+"""
+
+
+def test_a_product_kernel_writing_past_its_destination_is_caught(z):
+    """The same through a PRODUCT kernel of another translation unit (median47_dpp_kernel via zen_hip_mfilt_run) handed a
+    destination that is 1000 floats too short -- a caller's bug, here on purpose: the red zone behind the buffer takes the
+    stores (any build), and a -DZEN_HIP_BOUNDS build records every one of them with the source line of the store."""
+    import json
+    env = dict(os.environ, ZEN_HIP_REDZONE="4096", ZEN_HIP_BOUNDS_TRAP="0")
+    r = subprocess.run([sys.executable, "-c", _SHORT_DST_CHILD], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       universal_newlines=True, timeout=300)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("REPORT ")]
+    assert line, (r.returncode, r.stdout[-1000:], r.stderr[-2000:])
+    rep = json.loads(line[0][7:])
+    assert rep["corrupt_words"] >= 900, rep                 # (1000 floats minus the 256-byte alignment slack behind the buffer)
+    assert "back red zone" in rep["first_message"] or rep["bounds_violations"] > 0
+    if rep["bounds_build"]:
+        assert rep["bounds_violations"] > 0 and "median47" in rep["first_message"]
+    assert r.returncode == 86
+
+
 def test_child_process_with_a_broken_store_exits_86(z):
     """Child processes of the tier (C++ host tests, CLI) run with the same red zones: one that overwrote a zone does not
     exit with status 0 whatever it thinks of itself (memguard's exit handler)."""
