@@ -116,7 +116,8 @@ typedef struct zen_hip_memcheck_report {
 	unsigned long long corrupt_allocations; /* zone sides they belonged to */
 	unsigned long long bounds_violations;   /* out-of-bounds accesses the bounds build recorded, cumulative */
 	int bounds_build;                       /* 1: this library was built with -DZEN_HIP_BOUNDS */
-	char first_message[256];                /* the first finding, as text */
+	char first_message[256];                /* the first red-zone finding (else the first bounds violation), as text */
+	char first_violation[160];              /* bounds build: the first out-of-bounds access: bytes, address, source file and line */
 } zen_hip_memcheck_report;
 int zen_hip_memcheck(zen_hip_memcheck_report* out);
 /* test hook: one thread stores `value` at dev + byte_offset (through the instrumented store path) and the call synchronises */

@@ -101,7 +101,7 @@ def test_a_product_kernel_writing_past_its_destination_is_caught(z):
     assert rep["corrupt_words"] >= 900, rep                 # (1000 floats minus the 256-byte alignment slack behind the buffer)
     assert "back red zone" in rep["first_message"] or rep["bounds_violations"] > 0
     if rep["bounds_build"]:
-        assert rep["bounds_violations"] > 0 and "median47" in rep["first_message"]
+        assert rep["bounds_violations"] > 0 and "median47" in rep["first_violation"]
     assert r.returncode == 86
 
 
@@ -230,3 +230,59 @@ def test_pipeline_buffers_are_sized_before_the_first_range(z):
                 assert z.memcheck()["allocations"] == a0
     finally:
         z.set_option("offline_range", 0)
+
+
+# ---------------------------------------------------------------------------- resident kernel at the long hops
+def _per_hop(rt, io, x, hop, n_hops, copy, pause_every=0, pause_s=0.0):
+    import time
+    out = np.zeros(hop * n_hops, np.float32)
+    for i in range(n_hops):
+        io.host_in[:] = x[i * hop:(i + 1) * hop]
+        rt.process_next_hop(io.device_in)
+        copy(io.device_out)
+        out[i * hop:(i + 1) * hop] = io.host_out
+        if pause_every and i % pause_every == pause_every - 1:
+            time.sleep(pause_s)
+    return out
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("hop,fs", [(2048, 44100.0), (4096, 44100.0), (2048, 48000.0), (4096, 22050.0)])
+@pytest.mark.parametrize("flags,key", [(o.OUTPUT_PERCUSSIVE, "P"), (o.OUTPUT_HARMONIC, "H")])
+def test_resident_kernel_at_long_hops_vs_oracle(z, hop, fs, flags, key):
+    """zen_hip_hpr_set_resident at hop 2048 / 4096 (nfft 8192 / 16384; the reference's published sweep covers them,
+    docs/cpu_vs_gpu.png): the COOPERATIVE single-hop kernel (2 / 4 workgroups, five grid barriers per hop) stays on the device,
+    workgroup 0 takes each hop from the mailbox and hands its decision to the others (rt_wide.hip rt_wide_resident_kernel).
+    Same samples as the oracle hop for hop: back to back; with pauses longer than the idle time (all workgroups leave together
+    and are launched again, more than once); with a block call, a reset and per-launch hops in between."""
+    n_hops = 44
+    x = _clip(hop * n_hops, 31 + hop)
+    ref = o.HPR(fs, hop, 2.0, flags, o.TIME_CAUSAL).process_stream(x)[key]
+    io = z.IOGPU(hop)
+    rt = z.HPRRealtime(fs, hop, 2.0, flags)
+    copy = rt.copy_percussive if key == "P" else rt.copy_harmonic
+    eng = rt.p_impl
+    eng.set_resident(200)
+    got = _per_hop(rt, io, x, hop, n_hops, copy)
+    st = eng.resident_stats()
+    assert np.array_equal(got, ref) and np.any(ref != 0)
+    assert st["launches"] == 1 and st["active"]
+    # the kernel leaves after 5 ms without a hop: pauses of 40 ms every 9 hops
+    eng.reset_buffers()
+    eng.set_resident(5)
+    got = _per_hop(rt, io, x, hop, n_hops, copy, pause_every=9, pause_s=0.04)
+    assert np.array_equal(got, ref)
+    assert eng.resident_stats()["launches"] >= 1 + 4
+    # per-launch hops, a block call, resident again: the barrier word's account and the vote words survive every change of hands
+    eng.reset_buffers()
+    eng.set_resident(100)
+    a = _per_hop(rt, io, x, hop, 11, copy)
+    eng.set_resident(0)
+    b = _per_hop(rt, io, x[11 * hop:], hop, 7, copy)                        # per launch (an odd count: the vote parity flips)
+    blk = eng.process_stream_host(x[18 * hop:26 * hop])[key]
+    eng.set_resident(100)
+    c = _per_hop(rt, io, x[26 * hop:], hop, 9, copy)
+    eng.set_resident(3)
+    d = _per_hop(rt, io, x[35 * hop:], hop, n_hops - 35, copy, pause_every=2, pause_s=0.03)
+    assert np.array_equal(np.concatenate([a, b, blk, c, d]), ref)
+    del rt, eng                                                             # destroy with the kernels resident

@@ -71,8 +71,13 @@ struct Plan {
 #define ZEN_FFT16K_PAD 3
 #endif
 	static constexpr int PAD_SHIFT = LOG2N == 14 ? ZEN_FFT16K_PAD : (LOG2N >= 13 ? 3 : 4);
-	static constexpr int LDS_FLOAT2 = N + (N >> PAD_SHIFT); // padded frame image in LDS
-	static __device__ __forceinline__ int pad(int i) { return i + (i >> PAD_SHIFT); }
+#ifdef ZEN_FFT_SWIZZLE // A/B (re-measured in round 5): an unpadded image, element i at i ^ ((i >> 3) & 31)
+	static constexpr bool SWZ = LOG2N >= 13;
+#else
+	static constexpr bool SWZ = false;
+#endif
+	static constexpr int LDS_FLOAT2 = SWZ ? N : N + (N >> PAD_SHIFT); // padded frame image in LDS
+	static __device__ __forceinline__ int pad(int i) { return SWZ ? (i ^ ((i >> 3) & 31)) : i + (i >> PAD_SHIFT); }
 	static constexpr int FRAMES_PER_BLOCK = (TF >= 256) ? 1 : 256 / TF;
 	static constexpr int THREADS = TF * FRAMES_PER_BLOCK;
 };

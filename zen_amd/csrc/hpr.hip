@@ -301,6 +301,41 @@ void fused_args(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, RtF
 	a.stamps = e->dbg_stamps;
 }
 
+// what a cooperative single-hop launch (rt_wide.hip) needs on top of fused_args, and the engine's account of the stream's
+// barrier word: every call adds rt_wide_arrivals to it and takes the other of the two placement-vote words.  A resident
+// launch votes once and leaves its word full: the words are cleared (on `stream`, which is ordered behind the kernel that
+// left) before the next launch of either kind.
+int wide_args(zen_hip_hpr* e, RtFusedArgs& a, hipStream_t stream, bool clear_votes = true)
+{
+	ZH_TRY(ensure_estimates(e, false));
+	if (!e->d_wide_xch) {
+		ZH_HIP(zh_malloc((void**)&e->d_wide_xch, sizeof(float2) * e->n_streams * e->nfft));
+		ZH_HIP(zh_malloc((void**)&e->d_wide_bar, sizeof(unsigned) * 4 * e->n_streams + 16)); // (+ the resident launch's `go` word)
+		ZH_HIP(hipMemsetAsync(e->d_wide_bar, 0, sizeof(unsigned) * 4 * e->n_streams + 16, e->stream));
+		e->wide_arrivals = 0;
+		e->wide_calls = 0;
+		void* dev = nullptr;
+		ZH_HIP(zh_host_malloc((void**)&e->wide_fail_host, 64, hipHostMallocMapped | hipHostMallocPortable));
+		*e->wide_fail_host = 0;
+		ZH_HIP(zh_host_device_pointer(&dev, e->wide_fail_host));
+		e->wide_fail_dev = (unsigned*)dev;
+	}
+	if (e->wide_votes_stale && clear_votes) {
+		for (size_t st = 0; st < e->n_streams; ++st)
+			ZH_HIP(hipMemsetAsync(e->d_wide_bar + 4 * st + 2, 0, 2 * sizeof(unsigned), stream));
+		e->wide_votes_stale = false;
+	}
+	a.wide_fail = e->wide_fail_dev;
+	a.P = e->d_P;
+	a.p_stream_stride = (long long)(e->max_hops * e->nfft);
+	a.xch = e->d_wide_xch;
+	a.bar = e->d_wide_bar;
+	a.bar_base = e->wide_arrivals;
+	a.bar_parity = (int)(e->wide_calls++ & 1u);
+	e->wide_arrivals += rt_wide_arrivals(e->log2n, a.n_out);
+	return ZEN_HIP_OK;
+}
+
 int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, HopKernel kind = HOP_FUSED)
 {
 	const bool sse = kind == HOP_SSE;
@@ -309,29 +344,8 @@ int run_hop_fused(zen_hip_hpr* e, const float* in, size_t in_stride, size_t M, H
 			ZH_TRY(ensure_rows(e, o));
 	RtFusedArgs a;
 	fused_args(e, in, in_stride, M, a);
-	if (kind == HOP_WIDE) {
-		ZH_TRY(ensure_estimates(e, false));
-		if (!e->d_wide_xch) {
-			ZH_HIP(zh_malloc((void**)&e->d_wide_xch, sizeof(float2) * e->n_streams * e->nfft));
-			ZH_HIP(zh_malloc((void**)&e->d_wide_bar, sizeof(unsigned) * 4 * e->n_streams));
-			ZH_HIP(hipMemsetAsync(e->d_wide_bar, 0, sizeof(unsigned) * 4 * e->n_streams, e->stream));
-			e->wide_arrivals = 0;
-			e->wide_calls = 0;
-			void* dev = nullptr;
-			ZH_HIP(zh_host_malloc((void**)&e->wide_fail_host, 64, hipHostMallocMapped | hipHostMallocPortable));
-			*e->wide_fail_host = 0;
-			ZH_HIP(zh_host_device_pointer(&dev, e->wide_fail_host));
-			e->wide_fail_dev = (unsigned*)dev;
-		}
-		a.wide_fail = e->wide_fail_dev;
-		a.P = e->d_P;
-		a.p_stream_stride = (long long)(e->max_hops * e->nfft);
-		a.xch = e->d_wide_xch;
-		a.bar = e->d_wide_bar;
-		a.bar_base = e->wide_arrivals;
-		a.bar_parity = (int)(e->wide_calls++ & 1u);
-		e->wide_arrivals += rt_wide_arrivals(e->log2n, a.n_out);
-	}
+	if (kind == HOP_WIDE)
+		ZH_TRY(wide_args(e, a, e->stream));
 	// block calls of the headline configuration: the kernel finishes the hops itself where the caller has said where they go
 	int direct_o = -1;
 	for (int o = 0; o < 3; ++o)
@@ -409,6 +423,12 @@ int advance_drain(zen_hip_hpr* e)
 // (the exit word carries the last sequence number the kernel processed).
 inline void store_fence() { __builtin_ia32_sfence(); }
 
+// hops 2048 / 4096 on the median path: the cooperative kernel of rt_wide.hip (where run_chunk would pick it)
+bool resident_wide(const zen_hip_hpr* e)
+{
+	return !e->use_sse && !rt_fused_available(e->log2n, e->mf) && e->n_streams <= 8 && rt_wide_available(e->log2n, e->mf);
+}
+
 bool resident_eligible(const zen_hip_hpr* e)
 {
 	int n_out = 0, o1 = -1;
@@ -417,7 +437,8 @@ bool resident_eligible(const zen_hip_hpr* e)
 			++n_out;
 			o1 = o;
 		}
-	const bool kernel = e->use_sse ? rt_sse_available(e->log2n, e->mt, e->mf) : rt_fused_available(e->log2n, e->mf);
+	const bool kernel = e->use_sse ? rt_sse_available(e->log2n, e->mt, e->mf)
+	                               : (rt_fused_available(e->log2n, e->mf) || resident_wide(e));
 	return e->res_idle_ms > 0 && e->causality == ZEN_HIP_TIME_CAUSAL && !g_opt_no_rt_fused && e->n_streams == 1 && n_out == 1
 	       && e->ready_host[o1] != nullptr && kernel && !e->prof && !e->dbg_stamps && !(e->drain[0] | e->drain[1] | e->drain[2]);
 }
@@ -448,7 +469,15 @@ int resident_launch(zen_hip_hpr* e) // from res_args: the hop whose number is re
 	ZH_HIP(hipEventRecord(e->res_event, e->stream));
 	ZH_HIP(hipStreamWaitEvent(e->res_stream, e->res_event, 0));
 	const unsigned long long ticks = (unsigned long long)e->res_idle_ms * 100000ull; // s_memrealtime: 100 MHz
-	if (e->use_sse) // the single-launch SSE kernel's body (rt_sse.hip); box lengths and factors as run_hop_fused passes them
+	if (resident_wide(e)) { // the cooperating workgroups agree through a word behind the barrier words (wide_args); zeroed per launch
+		unsigned long long* go = reinterpret_cast<unsigned long long*>(e->d_wide_bar + 4 * e->n_streams);
+		ZH_HIP(hipMemsetAsync(go, 0, sizeof(unsigned long long), e->res_stream));
+		ZH_HIP(hipMemsetAsync(e->d_wide_bar + 2, 0, 2 * sizeof(unsigned), e->res_stream)); // both vote words (one stream: resident_eligible)
+		ZH_TRY(launch_rt_wide_resident(e->log2n, e->mf, e->res_args, e->res_ctl_dev, e->res_out_dev, go, seq_start, ticks, 0x7fffffffu,
+		                               e->res_stream));
+		e->wide_votes_stale = true; // (it votes once and never clears its word)
+	}
+	else if (e->use_sse) // the single-launch SSE kernel's body (rt_sse.hip); box lengths and factors as run_hop_fused passes them
 		ZH_TRY(launch_rt_sse_resident(e->log2n, e->res_args, e->mt, e->mf, (float)e->l_harm + 1.0F, (float)e->l_perc + 1.0F, e->res_ctl_dev,
 		                              e->res_out_dev, seq_start, ticks, 0x7fffffffu, e->res_stream));
 	else
@@ -516,6 +545,8 @@ int resident_post(zen_hip_hpr* e, const float* in)
 		ZH_TRY(resident_stop(e));              // normally the same for every hop): another buffer, another launch
 	fused_args(e, in, e->hop, 1, e->res_args);
 	e->res_args.stamps = nullptr;
+	if (resident_wide(e)) // (the engine's account of the barrier word advances hop by hop, as the kernel's does: a relaunch, or a
+		ZH_TRY(wide_args(e, e->res_args, e->stream, /*clear_votes=*/false)); // per-launch hop later, starts from the right count)
 	ZH_TRY(resident_kick(e));
 	if (!e->res_active)
 		ZH_TRY(resident_launch(e));

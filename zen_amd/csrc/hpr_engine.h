@@ -95,6 +95,7 @@ struct zen_hip_hpr {
 	unsigned* d_wide_bar = nullptr;
 	unsigned wide_arrivals = 0;
 	unsigned wide_calls = 0;
+	bool wide_votes_stale = false; // a resident launch of the cooperative kernel left a placement-vote word full (hpr.hip wide_args)
 	unsigned* wide_fail_host = nullptr; // pinned, mapped: a grid barrier of rt_wide.hip that gave up waiting sets it;
 	unsigned* wide_fail_dev = nullptr;  // every copy_* looks at it (a hop computed past a timed-out barrier is garbage)
 	unsigned hop_seq = 0; // number of the last single-hop call; the kernels publish it behind the finished hop

@@ -319,14 +319,15 @@ int zen_hip_memcheck(zen_hip_memcheck_report* out)
 	memcpy(out->first_message, g.first_msg, sizeof(out->first_message));
 	if (g.fail) {
 		out->bounds_violations = __atomic_load_n(&g.fail->count, __ATOMIC_ACQUIRE);
-		if (out->bounds_violations && !out->first_message[0]) {
+		if (out->bounds_violations) {
 			const ZhViolation& v = g.fail->first[0];
 			char name[9] = {0};
 			for (int i = 0; i < 8; ++i)
 				name[i] = (char)((v.tag >> (8 * i)) & 0xff);
-			snprintf(out->first_message, sizeof(out->first_message),
-			         "zen_hip memguard: %llu out-of-bounds accesses; first: %u bytes at %#llx from %s*:%u", (unsigned long long)out->bounds_violations,
-			         v.bytes, v.addr, name, v.line);
+			snprintf(out->first_violation, sizeof(out->first_violation), "%u bytes at %#llx from %s*:%u (of %llu out-of-bounds accesses)", v.bytes,
+			         v.addr, name, v.line, (unsigned long long)out->bounds_violations);
+			if (!out->first_message[0])
+				snprintf(out->first_message, sizeof(out->first_message), "zen_hip memguard: out of bounds: %s", out->first_violation);
 		}
 	}
 	return ZEN_HIP_OK;

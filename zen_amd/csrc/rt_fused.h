@@ -186,5 +186,9 @@ int launch_rt_sse(int log2n, const RtFusedArgs& a, int len_t, int len_f, float f
 bool rt_wide_available(int log2n, int freq_len);
 unsigned rt_wide_arrivals(int log2n, int n_out);
 int launch_rt_wide(int log2n, int freq_len, const RtFusedArgs& a, hipStream_t stream);
+// the same as a resident kernel (zen_hip_hpr_set_resident): `go` is a zeroed 8-byte word of device memory the cooperating
+// workgroups of the launch agree through
+int launch_rt_wide_resident(int log2n, int freq_len, const RtFusedArgs& a, const ResidentCtl* ctl, ResidentOut* ro, unsigned long long* go,
+                            unsigned seq_start, unsigned long long idle_ticks, unsigned max_hops, hipStream_t stream);
 
 } // namespace zen_hip_impl

@@ -269,21 +269,37 @@ struct InvBOut { // x[kappa + M*q], q < J/2 (HALF_OUT): the nwin real outputs th
 	}
 };
 
+// What changes from hop to hop of a stream (HopOfArgs / HopVar of rt_fused.h), and what a resident launch carries from one hop
+// to the next: the arrival count of the stream's barrier word and the outcome of the placement vote (the workgroups do not
+// move while they stay).  (The twiddles of both steps are loaded again every hop: kept across the loop -- with every address the
+// compiler then hoists out of it -- the kernel needs 540 bytes of scratch per lane on top of 256 + 256 registers.)
+struct WideHop {
+	unsigned seq;
+	long long row0;
+	const float* tail_prev;
+	float* tail_next;
+	int prev_frames;
+};
+template <int LOG2N>
+struct WideKeep {
+	unsigned arrivals;
+	bool light, voted;
+};
+
+// one hop by the G cooperating workgroups (the per-launch kernel runs it once; the resident one once per hop it is handed)
 template <int LOG2N, int W>
-__global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(1, 1))) void rt_wide_kernel(RtFusedArgs a)
+__device__ __forceinline__ void rt_wide_body(const RtFusedArgs& a, const WideHop& hv, WideKeep<LOG2N>& keep, const int g, const int s,
+                                             const int t, float2* lds)
 {
 	using GEO = WideGeo<LOG2N>;
 	using PA = typename GEO::PA;
 	using PB = typename GEO::PB;
 	using GM = zbig::Geo<W>;
 	constexpr int N = GEO::N, G = GEO::G, LOG2M = GEO::LOG2M, LOG2J = GEO::LOG2J;
-	if (blockIdx.x % XCDS != 0)
-		return; // see "XCD-aware launch" above
-	const int g = blockIdx.x / XCDS, s = blockIdx.y, t = threadIdx.x, hop = a.hop;
+	const int hop = a.hop;
 	const int u = g * WGT + t; // thread of the frame
-	extern __shared__ float2 lds[];
 	unsigned* bar = a.bar + 4 * s;
-	unsigned arrivals = a.bar_base;
+	unsigned& arrivals = keep.arrivals;
 	// diagnostic (tools/rt_latency.cpp --stamps): 100 MHz stamps of workgroup 0 around every phase and barrier
 	unsigned long long stamps[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 	auto stamp = [&](int k) { // (k is a literal everywhere: the array stays in registers)
@@ -291,23 +307,24 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 			stamps[k] = __builtin_amdgcn_s_memrealtime();
 	};
 	unsigned* vote = bar + 2 + (a.bar_parity & 1);
-	if (t == 0) // the placement vote (grid_sync): counted long before the first barrier asks for it
+	if (t == 0 && !keep.voted) // the placement vote (grid_sync): counted long before the first barrier asks for it
 		__hip_atomic_fetch_add(vote, xcc_vote(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	bool light = false;
+	bool& light = keep.light;
 	auto sync = [&](int k) { // stamps k (arrival) and k + 1 (release)
 		stamp(k);
 		arrivals += G;
-		if (k == 1) {
+		if (k == 1 && !keep.voted) { // (a resident launch: once, before its first barrier)
 			light = placement_vote_result<G>(vote) && a.diag != 4; // ("rt_fused_diag" 4: agent-scope barriers, for timing)
 			if (g == 0 && t == 0)
 				__hip_atomic_store(bar + 2 + ((a.bar_parity & 1) ^ 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			keep.voted = true;
 		}
 		grid_sync(bar, arrivals, light, a.wide_fail);
 		stamp(k + 1);
 	};
 	stamp(0);
 
-	const long long row = (a.row0 % a.ring_rows) + (long long)s * a.ring_rows;
+	const long long row = (hv.row0 % a.ring_rows) + (long long)s * a.ring_rows;
 	float2* Srow = a.S + row * a.s_stride;
 	float* mrow = a.mag + row * N;
 	float* prow = a.P + (long long)s * a.p_stream_stride;
@@ -332,12 +349,12 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 			v[i] = cur[u + i * (G * WGT)];
 #pragma unroll
 		for (int i = 0; i < CP; ++i)
-			a.tail_next[(long long)s * hop + u + i * (G * WGT)] = v[i];
-		if (a.prev_frames > 0) {
+			hv.tail_next[(long long)s * hop + u + i * (G * WGT)] = v[i];
+		if (hv.prev_frames > 0) {
 			for (int o = 0; o < 3; ++o) {
 				if (!a.carry[o])
 					continue;
-				const float* y = a.Y[o] + (long long)s * a.y_stream_stride + (long long)(a.prev_frames - 1) * (2 * hop) + hop;
+				const float* y = a.Y[o] + (long long)s * a.y_stream_stride + (long long)(hv.prev_frames - 1) * (2 * hop) + hop;
 #pragma unroll
 				for (int i = 0; i < CP; ++i)
 					v[i] = y[u + i * (G * WGT)];
@@ -349,7 +366,7 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 	}
 	{
 		const int j = jA, tf = tfA;
-		FwdAIn<LOG2J> in{a.tail_prev + (long long)s * hop, a.in + (long long)s * a.in_stride, a.window, hop, j};
+		FwdAIn<LOG2J> in{hv.tail_prev + (long long)s * hop, a.in + (long long)s * a.in_stride, a.window, hop, j};
 		XchOut<LOG2J> out{T, j};
 		zfft::PassRunner<LOG2M, 0, false, true, false, FwdAIn<LOG2J>, XchOut<LOG2J>, false, zfft::TwRegs<LOG2M>>::run(
 		    tf, lds + fA * PA::LDS_FLOAT2, twA, in, out, true);
@@ -447,7 +464,7 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 			else
 				sync(12);
 			if (a.publish_seq && g == 0 && t == 0)
-				__hip_atomic_store(reinterpret_cast<unsigned*>(ready + hop), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+				__hip_atomic_store(reinterpret_cast<unsigned*>(ready + hop), hv.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
 		else { // the call's last barrier: nobody waits, whoever arrives last publishes the hop
 			stamp(oi == 0 ? 9 : 12);
@@ -457,7 +474,7 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 			if (t == 0) {
 				const unsigned before = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
 				if (before + 1 == arrivals && a.publish_seq)
-					__hip_atomic_store(reinterpret_cast<unsigned*>(ready + hop), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+					__hip_atomic_store(reinterpret_cast<unsigned*>(ready + hop), hv.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 			}
 			stamp(oi == 0 ? 10 : 12);
 		}
@@ -469,6 +486,91 @@ __global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 	}
 	if (a.stamps && s == 0 && t == 0) // where the cooperating workgroups ran, and whether the barriers were light
 		a.stamps[12 + g] = xcc_id() | (light ? 16u : 0u);
+}
+
+template <int LOG2N, int W>
+__global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(1, 1))) void rt_wide_kernel(RtFusedArgs a)
+{
+	if (blockIdx.x % XCDS != 0)
+		return; // see "XCD-aware launch" above
+	extern __shared__ float2 lds[];
+	WideKeep<LOG2N> keep;
+	keep.arrivals = a.bar_base;
+	keep.light = false;
+	keep.voted = false;
+	const WideHop hv{a.seq, a.row0, a.tail_prev, a.tail_next, a.prev_frames};
+	rt_wide_body<LOG2N, W>(a, hv, keep, (int)(blockIdx.x / XCDS), (int)blockIdx.y, (int)threadIdx.x, lds);
+}
+
+// The same as a RESIDENT kernel for the per-hop API (zen_hip_hpr_set_resident; rt_fused.hip rt_fused_resident_kernel is the
+// one-workgroup form): the G cooperating workgroups stay on their CUs between the hops of the stream.  Workgroup 0 alone
+// watches the host's mailbox (resident_next_hop: a hop, the stop word, or idle for too long) and hands its decision to the
+// others through a word of device memory -- they must agree on every hop and on when to leave, or one of them would wait at
+// a grid barrier for a workgroup that has gone.  The word: (number of the decision << 33) | (leave << 32) | sequence number;
+// a follower waits for decision k + 1, then takes the system-scope acquire fence the leader took (the host wrote the hop's
+// samples before the mailbox word).  Carried from hop to hop: the barrier's arrival count and the placement vote's outcome
+// (nobody moves).  One stream (the launcher checks).
+template <int LOG2N, int W>
+__global__ __launch_bounds__(WGT) __attribute__((amdgpu_waves_per_eu(1, 1))) void rt_wide_resident_kernel(RtFusedArgs a0, const ResidentCtl* ctl,
+                                                                                                      ResidentOut* ro, unsigned long long* go,
+                                                                                                      unsigned seq_start,
+                                                                                                      unsigned long long idle_ticks, unsigned max_hops)
+{
+	if (blockIdx.x % XCDS != 0)
+		return;
+	extern __shared__ float2 lds[];
+	__shared__ unsigned s_cmd[2];
+	const int g = blockIdx.x / XCDS, t = threadIdx.x;
+	WideKeep<LOG2N> keep;
+	keep.arrivals = a0.bar_base;
+	keep.light = false;
+	keep.voted = false;
+	unsigned last = seq_start, k = 0;
+	for (;;) {
+		unsigned sq = last;
+		bool have;
+		if (g == 0) {
+			have = resident_next_hop(ctl, last, idle_ticks, k >= max_hops, s_cmd, &sq);
+			if (t == 0) // (release: nothing of this workgroup's last hop is still in flight -- its last barrier drained the counter)
+				__hip_atomic_store(go, ((unsigned long long)(k + 1) << 33) | ((unsigned long long)(have ? 0 : 1) << 32) | sq, __ATOMIC_RELEASE,
+				                   __HIP_MEMORY_SCOPE_AGENT);
+		}
+		else {
+			if (t == 0) {
+				unsigned long long w;
+				for (;;) { // (the leader decides within idle_ticks: a bounded wait)
+					w = __hip_atomic_load(go, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+					if ((unsigned)(w >> 33) == k + 1)
+						break;
+					__builtin_amdgcn_s_sleep(1);
+				}
+				s_cmd[0] = (unsigned)(w >> 32) & 1u;
+				s_cmd[1] = (unsigned)w;
+			}
+			__syncthreads();
+			have = s_cmd[0] == 0u;
+			sq = s_cmd[1];
+			if (have)
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+		}
+		if (!have)
+			break;
+		WideHop hv;
+		hv.seq = sq;
+		hv.row0 = a0.row0 + k;
+		hv.tail_prev = (k & 1u) ? a0.tail_next : a0.tail_prev; // the two input-tail buffers flip with every call
+		hv.tail_next = (k & 1u) ? const_cast<float*>(a0.tail_prev) : a0.tail_next;
+		hv.prev_frames = k > 0u ? 1 : a0.prev_frames;
+		int t_o = t, g_o = g; // (opaque per hop: otherwise every address of the body -- all functions of the thread's place alone --
+		asm volatile("" : "+v"(t_o)); // is hoisted out of the loop and kept in registers the kernel does not have)
+		asm volatile("" : "+s"(g_o));
+		rt_wide_body<LOG2N, W>(a0, hv, keep, g_o, 0, t_o, lds);
+		__syncthreads(); // (s_cmd is rewritten next)
+		last = sq;
+		++k;
+	}
+	if (g == 0)
+		resident_leave(ro, last, k);
 }
 
 template <int LOG2N, int W>
@@ -487,7 +589,46 @@ int launch_wide_t(const RtFusedArgs& a, hipStream_t stream)
 	return ZEN_HIP_OK;
 }
 
+template <int LOG2N, int W>
+int launch_wide_res_t(const RtFusedArgs& a, const ResidentCtl* ctl, ResidentOut* ro, unsigned long long* go, unsigned seq_start,
+                      unsigned long long idle_ticks, unsigned max_hops, hipStream_t stream)
+{
+	using GEO = WideGeo<LOG2N>;
+	using GM = zbig::Geo<W>;
+	constexpr int NT = (GM::m + 15) / 16, HALO = GM::a + GM::b + 3;
+	constexpr size_t lds_med = sizeof(int) * RSTR * (size_t)((WGT + HALO + NT + HALO) + (WGT + GM::NB - 1 + NT + GM::NB - 1));
+	constexpr size_t lds = lds_med > (size_t)GEO::LDS_FFT ? lds_med : (size_t)GEO::LDS_FFT;
+	auto kern = rt_wide_resident_kernel<LOG2N, W>;
+	if (lds > 64 * 1024)
+		ZH_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	hipLaunchKernelGGL(kern, dim3(XCDS * GEO::G, 1), dim3(WGT), lds, stream, a, ctl, ro, go, seq_start, idle_ticks, max_hops);
+	ZH_HIP(hipGetLastError());
+	return ZEN_HIP_OK;
+}
+
 } // namespace
+
+int launch_rt_wide_resident(int log2n, int freq_len, const RtFusedArgs& a, const ResidentCtl* ctl, ResidentOut* ro, unsigned long long* go,
+                            unsigned seq_start, unsigned long long idle_ticks, unsigned max_hops, hipStream_t stream)
+{
+	if (a.n_out != 1 || a.n_frames != 1 || a.n_streams != 1 || !a.publish_seq || a.stamps)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "resident wide kernel: one stream, one output, single hops, host-mapped hop buffer");
+#define ZH_WR(L, W_) return launch_wide_res_t<L, W_>(a, ctl, ro, go, seq_start, idle_ticks, max_hops, stream)
+	switch (log2n * 1000 + freq_len) {
+	case 13085: ZH_WR(13, 85);
+	case 13093: ZH_WR(13, 93);
+	case 13129: ZH_WR(13, 129);
+	case 13171: ZH_WR(13, 171);
+	case 13187: ZH_WR(13, 187);
+	case 14085: ZH_WR(14, 85);
+	case 14093: ZH_WR(14, 93);
+	case 14129: ZH_WR(14, 129);
+	case 14171: ZH_WR(14, 171);
+	case 14187: ZH_WR(14, 187);
+	default: ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "no resident wide kernel for nfft 2^%d with a %d-tap mask", log2n, freq_len);
+	}
+#undef ZH_WR
+}
 
 // hop 2048 and 4096 at 44.1 / 48 kHz (l_perc = 93 / 85 and 187 / 171 taps), and the other sample rates whose masks
 // the block-merge median covers: hop 2048 at 22.05 / 24 / 32 kHz (187 / 171 / 129), hop 4096 at 88.2 / 96 / 64 kHz

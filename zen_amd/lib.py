@@ -38,7 +38,8 @@ class _Params(C.Structure):
 class _MemcheckReport(C.Structure):
     _fields_ = [("redzone_bytes", C.c_ulonglong), ("allocations", C.c_ulonglong), ("live_allocations", C.c_ulonglong),
                 ("corrupt_words", C.c_ulonglong), ("corrupt_allocations", C.c_ulonglong),
-                ("bounds_violations", C.c_ulonglong), ("bounds_build", C.c_int), ("first_message", C.c_char * 256)]
+                ("bounds_violations", C.c_ulonglong), ("bounds_build", C.c_int), ("first_message", C.c_char * 256),
+                ("first_violation", C.c_char * 160)]
 
 
 class _HostStats(C.Structure):
@@ -196,6 +197,7 @@ def memcheck():
     _ck(load().zen_hip_memcheck(C.byref(r)))
     d = {k: getattr(r, k) for k, _ in _MemcheckReport._fields_}
     d["first_message"] = d["first_message"].decode(errors="replace")
+    d["first_violation"] = d["first_violation"].decode(errors="replace")
     return d
 
 
