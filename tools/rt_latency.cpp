@@ -46,7 +46,9 @@ int main(int argc, char** argv)
 			if (sse)
 				CK(zen_hip_hpr_use_sse_filter(h));
 			const int resident_ms = std::getenv("ZEN_RT_RESIDENT") ? std::atoi(std::getenv("ZEN_RT_RESIDENT")) : 0;
-			const bool resident = resident_ms > 0 && hop <= 1024 && !(argc > 2); // (median path and SSE path: hops the one-workgroup kernels cover)
+			// (median path: every hop -- the one-workgroup kernel up to 1024, the cooperative one at 2048 / 4096; SSE path: the hops the
+			// one-workgroup SSE kernel covers)
+			const bool resident = resident_ms > 0 && (!sse || hop <= 1024) && !(argc > 2);
 			if (resident)
 				CK(zen_hip_hpr_set_resident(h, resident_ms));
 			void *hin, *din, *hout, *dout;

@@ -255,6 +255,7 @@ struct InvBOut { // x[kappa + M*q], q < J/2 (HALF_OUT): the nwin real outputs th
 	float* ready;
 	const float* carry;
 	int hop, kappa;
+	bool through; // the finished hop goes to host-mapped memory with system-scope (write-through) stores: rt_fused.hip publish_ready<LIGHT>
 	__device__ __forceinline__ void operator()(int q, float2 x, bool, int) const
 	{
 		const int idx = kappa + (q << LOG2M);
@@ -264,7 +265,11 @@ struct InvBOut { // x[kappa + M*q], q < J/2 (HALF_OUT): the nwin real outputs th
 		if (idx < hop) {
 			ZH_CHK(ready + idx, 1);
 			ZH_CHK(carry + idx, 1);
-			ready[idx] = carry[idx] + y; // hps.cu:526-528 + :341-363
+			const float v = carry[idx] + y; // hps.cu:526-528 + :341-363
+			if (through)
+				__hip_atomic_store(ready + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			else
+				ready[idx] = v;
 		}
 	}
 };
@@ -452,19 +457,29 @@ __device__ __forceinline__ void rt_wide_body(const RtFusedArgs& a, const WideHop
 		{
 			const int kappa = u / PB::TF, tf = u % PB::TF;
 			XchIn<LOG2J> in{T, kappa};
-			InvBOut<LOG2M> out{a.Y[which] + (long long)s * a.y_stream_stride, a.cola, ready, a.carry[which] + (long long)s * hop, hop, kappa};
+			InvBOut<LOG2M> out{a.Y[which] + (long long)s * a.y_stream_stride, a.cola, ready, a.carry[which] + (long long)s * hop, hop, kappa,
+			                   a.publish_seq == 1};
 			zfft::PassRunner<LOG2J, 0, true, false, true, XchIn<LOG2J>, InvBOut<LOG2M>, false, zfft::TwRegs<LOG2J, false>>::run(
 			    tf, lds + (t / PB::TF) * PB::LDS_FLOAT2, twB, in, out, true);
 		}
-		if (a.publish_seq)
-			__threadfence_system(); // the finished hop is host-mapped: visible there before the sequence word
+		// The finished hop is host-mapped: visible there before the sequence word.  publish_seq == 1 (default): its samples
+		// went out as write-through stores and are on their way once the memory counter has counted them off (release_stores
+		// waits for it in front of every arrival) -- no write-back of the XCD's whole L2 (Y row, rings, exchange buffer: device
+		// memory the host never reads), as in the one-workgroup kernels (rt_fused.hip publish_ready<LIGHT>; "publish_release"
+		// selects the fence)
+		if (a.publish_seq == 2)
+			__threadfence_system();
+		else if (a.publish_seq)
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		if (oi + 1 < a.n_out) { // the exchange buffer is needed again: a full barrier
 			if (oi == 0)
 				sync(9);
 			else
 				sync(12);
-			if (a.publish_seq && g == 0 && t == 0)
+			if (a.publish_seq == 2 && g == 0 && t == 0)
 				__hip_atomic_store(reinterpret_cast<unsigned*>(ready + hop), hv.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+			else if (a.publish_seq && g == 0 && t == 0)
+				__hip_atomic_store(reinterpret_cast<unsigned*>(ready + hop), hv.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
 		else { // the call's last barrier: nobody waits, whoever arrives last publishes the hop
 			stamp(oi == 0 ? 9 : 12);
@@ -473,8 +488,10 @@ __device__ __forceinline__ void rt_wide_body(const RtFusedArgs& a, const WideHop
 			__syncthreads();
 			if (t == 0) {
 				const unsigned before = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-				if (before + 1 == arrivals && a.publish_seq)
+				if (before + 1 == arrivals && a.publish_seq == 2)
 					__hip_atomic_store(reinterpret_cast<unsigned*>(ready + hop), hv.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+				else if (before + 1 == arrivals && a.publish_seq) // (every workgroup drained its write-through stores before it arrived)
+					__hip_atomic_store(reinterpret_cast<unsigned*>(ready + hop), hv.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 			}
 			stamp(oi == 0 ? 10 : 12);
 		}
