@@ -109,3 +109,19 @@ def test_round4_kernels(usage):
             k = kernel(usage, "istft.hip", "istft_run_wide_kernel<%d, %d>" % (n, ng))
             assert k["vgprs"] <= 128 and k["scratch"] <= 32, (n, ng, k)     # (12 and 28 bytes in three of the builds)
     assert kernel(usage, "istft.hip", "istft_run_wide_kernel<14, 2>")["scratch"] == 0   # pass 1 of the offline batch
+
+
+def test_round5_kernels(usage):
+    """The real-input analysis kernels (stft_real_kernel, rfft_dev.h): four waves per SIMD -- two 512-thread workgroups per CU at
+    nfft 16384, whose 74 KB images both fit the LDS (the point of halving the image) -- and nothing spilled at the sizes the
+    offline path and the SSE block run; the resident cooperative single-hop kernels hold a hop in registers (a first build
+    that carried the twiddles from hop to hop needed 540 bytes of scratch per lane)."""
+    for n in range(5, 15):
+        k = kernel(usage, "stft.hip", "stft_real_kernel<%d>" % n)
+        assert k["vgprs"] <= 128 and k["occupancy"] >= 4, (n, k)
+        if n in (9, 10, 11, 12, 13, 14):
+            assert k["scratch"] == 0, (n, k)
+    res = {n: k for n, k in usage["rt_wide.hip"].items() if "rt_wide_resident_kernel" in n}
+    assert len(res) == 10
+    for name, k in res.items():
+        assert k["scratch"] == 0, (name, k)
