@@ -20,6 +20,7 @@
 // 1/|S|^2 row with its borders, behind it the H row (bins 0..nfft/2: H is mirror symmetric, P is not).  The masks of a
 // thread's sixteen bins are in registers before the first transform starts, next to the spectrum.
 #include "common.h"
+#include "exact_div.h"
 #include "fft_dev.h"
 #include "fft_launch.h"
 #include "masks.h"
@@ -129,9 +130,18 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, LOG2N <= 11 ? 4 : 3) void sse
 			ZH_CHK(mrow + (i < 8 ? tf + i * TF : N / 2), 1);
 			m[i] = mrow[i < 8 ? tf + i * TF : N / 2]; // (slot 8: every thread reads bin nfft/2, thread 0 uses it)
 		}
+		{ // (1 / (|S| |S|)) * 1 (hps.h:91-98, :45-56) by the short exact reciprocal (exact_div.h)
+			float sq[NLO], z[NLO];
+#pragma unroll
+			for (int i = 0; i < NLO; ++i)
+				sq[i] = m[i] * m[i];
+			zdiv::recip_batch<NLO>(sq, z);
+#pragma unroll
+			for (int i = 0; i < NLO; ++i)
+				own[i] = z[i] * 1.0F;
+		}
 #pragma unroll
 		for (int i = 0; i < NLO; ++i) {
-			own[i] = (1.0f / (m[i] * m[i])) * 1.0F;
 			const int idx = i < 8 ? tf + i * TF : N / 2;
 			if (i < 8 || tf == 0) {
 				pre[HALO + idx] = own[i];
@@ -150,9 +160,14 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, LOG2N <= 11 ? 4 : 3) void sse
 						acc[i] = (j0 + jj) == 0 ? own[i] : acc[i] + own[i];
 				}
 				else {
+					float sq[NLO], z[NLO];
+#pragma unroll
+					for (int i = 0; i < NLO; ++i)
+						sq[i] = m[jj][i] * m[jj][i];
+					zdiv::recip_batch<NLO>(sq, z);
 #pragma unroll
 					for (int i = 0; i < NLO; ++i) {
-						const float v = (1.0f / (m[jj][i] * m[jj][i])) * 1.0F;
+						const float v = z[i] * 1.0F;
 						acc[i] = (j0 + jj) == 0 ? v : acc[i] + v;
 					}
 				}
@@ -170,11 +185,13 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, LOG2N <= 11 ? 4 : 3) void sse
 			tap_sum(j0, m, d, acc);
 		}
 		const float flen_t = (float)b.len_t;
+		float rt[NLO], zt[NLO];
+		zdiv::div_const_batch<NLO>(acc, flen_t, 1.0f / flen_t, rt); // the box mean: sum / length (box.h:266-286)
+		zdiv::recip_batch<NLO>(rt, zt);
 #pragma unroll
 		for (int i = 0; i < NLO; ++i) {
-			const float rt = acc[i] / flen_t;
 			if (i < 8 || tf == 0)
-				Hrow[i < 8 ? tf + i * TF : N / 2] = (1.0f / rt) * b.fac_h; // hps.cu:602-604
+				Hrow[i < 8 ? tf + i * TF : N / 2] = zt[i] * b.fac_h; // (1 / mean) * (l_harm + 1): hps.cu:602-604
 		}
 	}
 	zfft::frame_sync<TF>();
@@ -209,10 +226,13 @@ __global__ __launch_bounds__(Plan<LOG2N>::THREADS, LOG2N <= 11 ? 4 : 3) void sse
 			__builtin_amdgcn_sched_barrier(0);
 		}
 		const float flen_f = (float)b.len_f;
+		float rf[16], zf[16];
+		zdiv::div_const_batch<16>(accf, flen_f, 1.0f / flen_f, rf);
+		zdiv::recip_batch<16>(rf, zf);
 #pragma unroll
 		for (int i = 0; i < 16; ++i) {
 			const int idx = tf + i * TF;
-			pm[i] = (1.0f / (accf[i] / flen_f)) * b.fac_p; // hps.cu:599-601
+			pm[i] = zf[i] * b.fac_p; // (1 / mean) * (l_perc + 1): hps.cu:599-601
 			hm[i] = Hrow[idx > N / 2 ? N - idx : idx];
 			if (idx > N / 2)
 				z[i].y = -z[i].y;
