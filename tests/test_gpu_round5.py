@@ -286,3 +286,18 @@ def test_resident_kernel_at_long_hops_vs_oracle(z, hop, fs, flags, key):
     d = _per_hop(rt, io, x[35 * hop:], hop, n_hops - 35, copy, pause_every=2, pause_s=0.03)
     assert np.array_equal(np.concatenate([a, b, blk, c, d]), ref)
     del rt, eng                                                             # destroy with the kernels resident
+
+
+# ---------------------------------------------------------------------------- exact short divisions (exact_div.h)
+@pytest.mark.timeout(600)
+def test_short_divisions_equal_ieee_division_for_every_float(z):
+    """zen_amd/csrc/exact_div.h: the reciprocal and the division by a mask length the SSE kernels use (three instructions each
+    instead of the compiler's ~15) against the compiler's IEEE division -- EVERY float in the range the kernels let them handle,
+    every divisor 1..255: 4.2e9 reciprocals and 9.7e11 quotients, bit for bit (tools/check_div.hip; under a second on the GPU)."""
+    exe = os.path.join(ROOT, "tools", "bin", "check_div")
+    if not os.path.exists(exe):
+        from zen_amd import build
+        build.build_tools()
+    r = subprocess.run([exe], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=500)
+    assert r.returncode == 0 and "all identical" in r.stdout, r.stdout[-2000:] + r.stderr[-500:]
+    assert "recip_exact: 0 of 42" in r.stdout and "div_const_exact: 0 of 96" in r.stdout, r.stdout

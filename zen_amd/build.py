@@ -204,6 +204,25 @@ def build_host(verbose=False):
     return libzen, cli, texe
 
 
+def build_tools(verbose=False):
+    """The small gfx950 programs the GPU tier and bench.py run beside the library (tools/bin/, git-ignored, travels with the tree):
+    the exhaustive proof of exact_div.h, the tuned copy kernel that is bench.py's practical HBM denominator, the store-pattern
+    micro-benchmark."""
+    root = os.path.dirname(HERE)
+    bindir = os.path.join(root, "tools", "bin")
+    os.makedirs(bindir, exist_ok=True)
+    jobs = {"check_div": ["-ffp-contract=off", "-fno-fast-math"], "ubench_copy": [], "ubench_rowwrite": []}
+    for name, extra in jobs.items():
+        src, exe = os.path.join(root, "tools", name + ".hip"), os.path.join(bindir, name)
+        deps = [src, os.path.join(CSRC, "exact_div.h")] if name == "check_div" else [src]
+        if os.path.exists(exe) and all(os.path.getmtime(exe) >= os.path.getmtime(d) for d in deps):
+            continue
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-Wno-unused-result"] + extra + [src, "-o", exe])
+        if verbose:
+            print("built", exe)
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
     build_host(verbose=True)
+    build_tools(verbose=True)

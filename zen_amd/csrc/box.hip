@@ -13,6 +13,7 @@
 //   time      : a workgroup owns 64 columns x RB rows (+ the halo rows); lanes are consecutive columns.
 // Masks too long for the time tile fall back to the direct kernel.
 #include "common.h"
+#include "exact_div.h"
 #include "filters.h"
 
 #pragma clang fp contract(off)
@@ -20,14 +21,54 @@
 namespace zen_hip_impl {
 namespace {
 
+// K values at once: the divisions of the SSE path are IEEE-exact in three instructions each where their operands are in range
+// (exact_div.h: proven exhaustively); a wavefront that holds a zero, an infinity or a value next to the denormals takes the
+// compiler's division for the batch.
+template <int K>
+__device__ __forceinline__ void pre_of(const float (&v)[K], int sse_pre, float (&out)[K])
+{
+	if (sse_pre) { // hps.h:91-98 powf(abs,2) then hps.h:45-56 (1/x)*1
+		float sq[K], z[K];
+#pragma unroll
+		for (int i = 0; i < K; ++i)
+			sq[i] = v[i] * v[i];
+		zdiv::recip_batch<K>(sq, z);
+#pragma unroll
+		for (int i = 0; i < K; ++i)
+			out[i] = z[i] * 1.0F;
+	}
+	else {
+#pragma unroll
+		for (int i = 0; i < K; ++i)
+			out[i] = v[i];
+	}
+}
+template <int K>
+__device__ __forceinline__ void post_of(const float (&acc)[K], float flen, float rlen, int sse_post, float post_factor, float (&out)[K])
+{
+	float res[K];
+	zdiv::div_const_batch<K>(acc, flen, rlen, res); // the box mean: sum / length (box.h:266-286)
+	if (sse_post) { // hps.cu:599-604
+		float z[K];
+		zdiv::recip_batch<K>(res, z);
+#pragma unroll
+		for (int i = 0; i < K; ++i)
+			out[i] = z[i] * post_factor;
+	}
+	else {
+#pragma unroll
+		for (int i = 0; i < K; ++i)
+			out[i] = res[i];
+	}
+}
 __device__ __forceinline__ float pre_of(float v, int sse_pre)
 {
-	return sse_pre ? (1.0f / (v * v)) * 1.0F : v; // hps.h:91-98 powf(abs,2) then hps.h:45-56 (1/x)*1
+	return sse_pre ? (1.0f / (v * v)) * 1.0F : v; // (the direct-form kernel: one value at a time, the compiler's division)
 }
 __device__ __forceinline__ float post_of(float acc, float flen, int sse_post, float post_factor)
 {
 	const float res = acc / flen;
-	return sse_post ? (1.0f / res) * post_factor : res; // hps.cu:599-604
+	return sse_post ? (1.0f / res) * post_factor : res;
 }
 
 constexpr int FREQ_OUTS = 1024;   // outputs per workgroup (4 per thread)
@@ -53,10 +94,12 @@ __global__ __launch_bounds__(256) void box_freq_kernel(FilterArgs a, int segs_pe
 			ZH_CHK(srow + c, 1);
 			v[u] = srow[c];
 		}
+		float pv[NT];
+		pre_of<NT>(v, a.sse_pre, pv);
 #pragma unroll
 		for (int u = 0; u < NT; ++u)
 			if (tid + 256 * u < span)
-				tile[tid + 256 * u] = pre_of(v[u], a.sse_pre);
+				tile[tid + 256 * u] = pv[u];
 	}
 	__syncthreads();
 	const float flen = (float)len;
@@ -79,12 +122,14 @@ __global__ __launch_bounds__(256) void box_freq_kernel(FilterArgs a, int segs_pe
 			acc[k] = acc[k] + t[k];
 		__builtin_amdgcn_sched_barrier(0);
 	}
+	float res[K];
+	post_of<K>(acc, flen, 1.0f / flen, a.sse_post, a.post_factor, res);
 #pragma unroll
 	for (int k = 0; k < K; ++k) {
 		const int o = tid + 256 * k;
 		if (col0 + o < cols) {
 			ZH_CHK(drow + col0 + o, 1);
-			drow[col0 + o] = post_of(acc[k], flen, a.sse_post, a.post_factor);
+			drow[col0 + o] = res[k];
 		}
 	}
 }
@@ -119,10 +164,12 @@ __global__ __launch_bounds__(256) void box_time_kernel(FilterArgs a, int rows_pe
 				ZH_CHK(src + ((r % a.ring_rows) * cols + col), 1);
 				v[u] = src[(r % a.ring_rows) * cols + col];
 			}
+			float pv[8];
+			pre_of<8>(v, a.sse_pre, pv);
 #pragma unroll
 			for (int u = 0; u < 8; ++u)
 				if (i0 + 4 * u < nrows)
-					tile[(i0 + 4 * u) * TIME_COLS + lane_col] = pre_of(v[u], a.sse_pre);
+					tile[(i0 + 4 * u) * TIME_COLS + lane_col] = pv[u];
 		}
 	}
 	__syncthreads();
@@ -152,11 +199,13 @@ __global__ __launch_bounds__(256) void box_time_kernel(FilterArgs a, int rows_pe
 				acc[u] = acc[u] + t[u];
 			__builtin_amdgcn_sched_barrier(0);
 		}
+		float res[4];
+		post_of<4>(acc, flen, 1.0f / flen, a.sse_post, a.post_factor, res);
 #pragma unroll
 		for (int u = 0; u < 4; ++u)
 			if (qb + 4 * u < nq) {
 				ZH_CHK(dst + ((long long)(q0 + q[u]) * cols + col), 1);
-				dst[(long long)(q0 + q[u]) * cols + col] = post_of(acc[u], flen, a.sse_post, a.post_factor);
+				dst[(long long)(q0 + q[u]) * cols + col] = res[u];
 			}
 	}
 }

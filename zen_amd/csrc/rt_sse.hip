@@ -20,6 +20,7 @@
 // (sum of the taps in ascending order, then / len, then (1/x)*factor): bit-identical outputs, interchangeable
 // call by call with the four-launch path.
 #include "common.h"
+#include "exact_div.h"
 #include "fft_dev.h"
 #include "masks.h"
 #include "rt_fused.h"
@@ -62,7 +63,10 @@ struct SseFwdOut {
 		r->S[slot] = X;
 		if (lower || idx == (n >> 1)) { // |S[n-k]| == |S[k]| bit for bit: one hypot per pair
 			const float m = zfft::cabs_exact(X.x, X.y);
-			const float p = (1.0f / (m * m)) * 1.0F;
+			const float sq[1] = {m * m};
+			float z[1];
+			zdiv::recip_batch<1>(sq, z); // the short exact reciprocal (exact_div.h)
+			const float p = z[0] * 1.0F;
 			const int mir = (idx == 0 || idx == (n >> 1)) ? idx : n - idx;
 			ZH_CHK(S + idx, 1);
 			ZH_CHK(mag + idx, 1);
@@ -221,9 +225,14 @@ __device__ __forceinline__ void rt_sse_body(const RtFusedArgs& a, int len_t, int
 #pragma unroll
 			for (int jj = 0; jj < 8; ++jj) {
 				if (j0 + jj < mid_t) {
+					float sq[BH], z[BH]; // (1 / (|S| |S|)) * 1 by the short exact reciprocal (exact_div.h)
+#pragma unroll
+					for (int i = 0; i < BH; ++i)
+						sq[i] = m[jj][i] * m[jj][i];
+					zdiv::recip_batch<BH>(sq, z);
 #pragma unroll
 					for (int i = 0; i < BH; ++i) {
-						const float v = (1.0f / (m[jj][i] * m[jj][i])) * 1.0F;
+						const float v = z[i] * 1.0F;
 						hist[i] = (j0 + jj) == 0 ? v : hist[i] + v;
 					}
 				}
@@ -303,11 +312,17 @@ __device__ __forceinline__ void rt_sse_body(const RtFusedArgs& a, int len_t, int
 			for (int i = 0; i < BH; ++i)
 				acct[i] = acct[i] + own[i];
 		}
+		{ // the box means (sum / length) and their reciprocals, IEEE-exact in three instructions each (exact_div.h)
+			float rf[BH], rt[BH], zf[BH], zt[BH];
+			zdiv::div_const_batch<BH>(accf, flen_f, 1.0f / flen_f, rf);
+			zdiv::div_const_batch<BH>(acct, flen_t, 1.0f / flen_t, rt);
+			zdiv::recip_batch<BH>(rf, zf);
+			zdiv::recip_batch<BH>(rt, zt);
 #pragma unroll
-		for (int i = 0; i < BH; ++i) {
-			const float rf = accf[i] / flen_f, rt = acct[i] / flen_t;
-			Prow[idx[i]] = (1.0f / rf) * fac_p;
-			Hrow[idx[i]] = (1.0f / rt) * fac_h;
+			for (int i = 0; i < BH; ++i) {
+				Prow[idx[i]] = zf[i] * fac_p;
+				Hrow[idx[i]] = zt[i] * fac_h;
+			}
 		}
 	}
 	__syncthreads(); // the estimates are complete; nobody reads the FFT image between the transforms
