@@ -52,7 +52,7 @@ FS = 44100.0
 HOP = 1024
 BETA = 2.0
 # HBM bytes per launch measured with rocprofv3 --pmc (tools/pmc_cmd.sh); re-collected whenever a kernel changes
-TRAFFIC_FILE = "r04_hbm_traffic.json"   # {demangled kernel name: {elements, rows, cols, hbm_bytes_per_launch, ...}}
+TRAFFIC_FILE = "r05_hbm_traffic.json"   # {demangled kernel name: {elements, rows, cols, hbm_bytes_per_launch, ...}}
 K_FUSED_P = "rt_fused_kernel<12, 47, 3, true, true, true>"
 K_FUSED_HPR = "rt_fused_kernel<12, 47, 3, false, true, true>"
 K_MEDIAN_WHOLE = "median47_dpp_kernel<false, 0, false>"   # through plain zen_hip_mfilt_run: the build that checks sign bits
@@ -252,9 +252,9 @@ def offline_rooflines(prof, steps, frames, nfft, hop, n_out1, copy_bw, freq_mask
     return roof, out
 
 
-OFFLINE_PMC_FILE = "r04_offline_batch_pmc.json"   # tools/pmc_cmd.sh _kernel python3 bench.py --workload offline_batch ... (collect_profiles.sh)
-OFFLINE_PMC_KERNELS = {"pass1.stft": "stft_kernel<14>", "pass1.freq_filter": "median_big_kernel<187", "pass1.istft": "istft_run_wide_kernel<14, 2>",
-                       "pass2.stft": "stft_kernel<10>", "pass2.freq_filter": "median_tf_herm_bits_kernel<11, 13>",
+OFFLINE_PMC_FILE = "r05_offline_batch_pmc.json"   # tools/pmc_cmd.sh _kernel python3 bench.py --workload offline_batch ... (collect_profiles.sh)
+OFFLINE_PMC_KERNELS = {"pass1.stft": "stft_real_kernel<14>", "pass1.freq_filter": "median_big_kernel<187", "pass1.istft": "istft_run_wide_kernel<14, 2>",
+                       "pass2.stft": "stft_real_kernel<10>", "pass2.freq_filter": "median_tf_herm_bits_kernel<11, 13>",
                        "pass2.istft": "istft_run_kernel<10>"}
 
 

@@ -1,13 +1,16 @@
 #!/bin/bash
-# Everything profiles/ holds for one build, in one GPU-box call:  gpurun -- 'tools/collect_profiles.sh r04_a'
-# Writes gpurun_out/prof_<tag>/ ; copy what should be judged into profiles/<tag>_* (and hbm_traffic.json -> r04_hbm_traffic.json).
+# Everything profiles/ holds for one build, in one GPU-box call:  gpurun -- 'tools/collect_profiles.sh r05'
+# Writes gpurun_out/prof_<tag>/ ; copy what should be judged into profiles/<tag>_* (hbm_traffic.json and offline_batch_pmc.json also go
+# to profiles/<round>_*.json, where bench.py looks for them: <round> = the tag up to its first underscore).
 # The build label comes from .build_rev, which zen_amd/build.py writes from `git rev-parse` where the library is built.
 TAG=${1:-x}
+RND=${TAG%%_*}
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG; mkdir -p $OUT
 REV=$(cat .build_rev 2>/dev/null || echo unknown)
 echo "$REV" > $OUT/build_rev.txt
+cat .build_kernel_rev >> $OUT/build_rev.txt 2>/dev/null
 # per-kernel durations of the default bench command, legs included (the averages must agree with bench.py's HIP events)
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-realtime > $OUT/stats_run.log 2>&1
 # (the legs start helper processes that use the GPU too -- tools/offline_host.cpp, tools/rt_latency.cpp -- and each gets a
@@ -44,8 +47,8 @@ python3 tools/traffic_json.py $T "$REV" $OUT/pmc_median47_half.json "median47_dp
 python3 tools/traffic_json.py $T "$REV" $OUT/pmc_median47_whole.json "median47_dpp_kernel<false, 0, false>" $((25840*4096)) 25840 4096 "whole rows through plain zen_hip_mfilt_run: the build that checks the sign bits of what it stages (BASELINE's median metric)" >> $OUT/pmc.err 2>&1
 python3 tools/traffic_json.py $T "$REV" $OUT/pmc_sse_synth.json "sse_synth_kernel<11>" $((51680*2048)) 51680 2048 "config 5: time box + frequency box + Wiener mask + inverse transform per frame" >> $OUT/pmc.err 2>&1
 # the records bench.py quotes (traffic, valu_issue_frac) are the ones just collected: put them where it looks for them, then the lines
-cp $T profiles/r04_hbm_traffic.json
-cp $OUT/offline_batch_pmc.json profiles/r04_offline_batch_pmc.json
+cp $T profiles/${RND}_hbm_traffic.json
+cp $OUT/offline_batch_pmc.json profiles/${RND}_offline_batch_pmc.json
 python3 bench.py > $OUT/bench_default_line.json 2> $OUT/bench_default.err
 cp gpurun_out/bench_detail.json $OUT/bench_default.json
 python3 bench.py --workload offline_batch --detail > $OUT/bench_offline_batch.json 2>> $OUT/bench_default.err
@@ -57,6 +60,9 @@ python3 tools/bench_median.py --suite path --nonneg >> $OUT/median_path_shapes.j
 mkdir -p /tmp/ub
 g++ -O2 -std=c++17 -I include tools/rt_latency.cpp -o /tmp/ub/rt -L zen_amd -lzen_hip -Wl,-rpath,$PWD/zen_amd && { /tmp/ub/rt 3000 --stamps; ZEN_RT_RESIDENT=100 /tmp/ub/rt 3000; } > $OUT/rt_latency.jsonl 2>&1
 tools/bin/probe_pcie 2048 > $OUT/probe_pcie.json 2>&1
+tools/bin/ubench_rowwrite > $OUT/ubench_rowwrite.jsonl 2>&1
+tools/bin/ubench_copy --json > $OUT/ubench_copy.json 2>&1
+tools/bin/check_div > $OUT/check_div.txt 2>&1
 tools/bin/probe_alloc > $OUT/probe_alloc.jsonl 2>&1
 # the shape sweeps of the reference's three bench harnesses on this build
 python3 tools/bench_sweeps.py > $OUT/sweeps.jsonl 2>> $OUT/bench_default.err
