@@ -301,3 +301,59 @@ def test_short_divisions_equal_ieee_division_for_every_float(z):
     r = subprocess.run([exe], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=500)
     assert r.returncode == 0 and "all identical" in r.stdout, r.stdout[-2000:] + r.stderr[-500:]
     assert "recip_exact: 0 of 42" in r.stdout and "div_const_exact: 0 of 96" in r.stdout, r.stdout
+
+
+# ---------------------------------------------------------------------------- analysis of real frames (rfft_dev.h)
+@pytest.mark.parametrize("fs,hop", [(44100.0, 256), (44100.0, 512), (44100.0, 1024), (48000.0, 2048), (44100.0, 4096), (16000.0, 64),
+                                    (8000.0, 32), (22050.0, 128)])
+@pytest.mark.parametrize("mode", ["hard", "soft", "sse"])
+def test_real_input_analysis_equals_the_complex_transform_and_the_oracle(z, fs, hop, mode):
+    """Blocks of frames through the analysis kernel that transforms the REAL frame with the Hermitian half of the radix-2 DAG
+    (stft_real_kernel, rfft_dev.h; hps.cu:456-465) against the round 1-4 kernel that runs the full complex transform
+    ("no_rfft") and against the oracle: identical samples, every transform size 128 ... 16384, all three mask types, state
+    carried over block boundaries (blocks of 1, 3, 17 and the rest: the chunk's first frame takes the saved tail, the last
+    W - 1 frames of a call keep whole magnitude rows), two streams."""
+    try:
+        ho = o.HPR(fs, hop, 2.0, ALL if mode == "hard" else o.OUTPUT_HARMONIC | o.OUTPUT_PERCUSSIVE, o.TIME_ANTICAUSAL)
+    except Exception:
+        pytest.skip("the reference refuses this geometry")
+    flags = ALL if mode == "hard" else o.OUTPUT_HARMONIC | o.OUTPUT_PERCUSSIVE
+    n_hops = min(2 * ho.stft_width + 30, 90 if hop >= 2048 else 400)
+    rng = np.random.default_rng(int(fs) + hop)
+    x = np.stack([_clip(hop * n_hops, 5 + hop), (rng.uniform(-1, 1, hop * n_hops) * (rng.uniform(0, 1, hop * n_hops) < 0.6)).astype(np.float32)])
+
+    def engine():
+        g = z.HPR(fs, hop, 2.0, flags, z.TIME_ANTICAUSAL, True, 2, 0)
+        if mode == "soft":
+            g.use_soft_mask()
+        if mode == "sse":
+            g.use_sse_filter()
+        return g
+
+    def run(g):
+        outs = {k: [] for k in "PHR"}
+        pos = 0
+        for blk in (1, 3, 17, n_hops - 21):
+            r = g.process_stream_host(x[:, pos * hop:(pos + blk) * hop])
+            for k in outs:
+                outs[k].append(r[k])
+            pos += blk
+        return {k: np.concatenate(v, axis=1) for k, v in outs.items()}
+
+    new = run(engine())
+    z.set_option("no_rfft", 1)
+    try:
+        old = run(engine())
+    finally:
+        z.set_option("no_rfft", 0)
+    keys = "PHR" if mode == "hard" else "PH"
+    for s_ in range(2):
+        oo = o.HPR(fs, hop, 2.0, flags, o.TIME_ANTICAUSAL)
+        if mode == "soft":
+            oo.use_soft_mask()
+        if mode == "sse":
+            oo.use_sse_filter()
+        ref = oo.process_stream(x[s_])
+        for k in keys:
+            assert np.array_equal(new[k][s_], ref[k], equal_nan=True), (k, s_, "real-input analysis vs oracle")
+            assert np.array_equal(old[k][s_], ref[k], equal_nan=True), (k, s_, "complex analysis vs oracle")
