@@ -177,14 +177,14 @@ def test_one_hop_block_calls_with_the_resident_kernel_enabled(z, hop):
 
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("release", [0, 1])
-@pytest.mark.parametrize("mode,hop", [("median", 1024), ("median", 256), ("sse", 512)])
+@pytest.mark.parametrize("mode,hop", [("median", 1024), ("median", 256), ("sse", 512), ("median", 2048)])
 @pytest.mark.parametrize("resident", [False, True])
 def test_publication_of_a_hop_host_poll_stress(z, release, mode, hop, resident):
     """The host polls the sequence word behind a finished hop and copies the hop from mapped memory (hpr.hip copy_output).
     Both publication forms -- write-through sample stores + relaxed flag (default) and system-scope release fence + release
     store ("publish_release", ZEN_HIP_PUBLISH_RELEASE) -- over several thousand hops, per launch and resident, EVERY sample
     against the oracle: a hop handed over before its samples arrived shows up as a mismatch."""
-    n_hops = 3000 if hop <= 512 else 2000
+    n_hops = 3000 if hop <= 512 else (2000 if hop <= 1024 else 1000)      # (hop 2048: the cooperative kernel, rt_wide.hip)
     rng = np.random.default_rng(hop + release)
     x = rng.uniform(-1, 1, hop * n_hops).astype(np.float32)          # every hop different from the one before
     ho = o.HPR(FS, hop, 2.0, o.OUTPUT_PERCUSSIVE, o.TIME_CAUSAL)
