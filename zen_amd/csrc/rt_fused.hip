@@ -76,8 +76,8 @@ struct FwdInPre {
 	__device__ __forceinline__ float2 operator()(int, int slot) const { return make_float2(x[slot] * w[slot], 0.0f); }
 };
 
-template <int T>
-struct FwdOut {
+template <int T, int TFN>
+struct FwdOut { // TFN: threads per frame (idx = tf + slot * TFN)
 	Regs* r;
 	float2* S;   // ring row (bins 0..n/2)
 	float* mag;  // ring row
@@ -92,8 +92,14 @@ struct FwdOut {
 			const float m = zfft::cabs_exact(X.x, X.y); // complex_abs_functor hps.h:82-89
 			const int key = __float_as_int(m);          // |S| >= +0: the bits are the ordering key
 			const int mir = (idx == 0 || idx == (n >> 1)) ? idx : n - idx;
-			img[RtImage<T>::addr(idx + mid_al)] = key;
-			img[RtImage<T>::addr(mir + mid_al)] = key;
+			// idx = tf + slot * TF with TF a multiple of the image's chunk length: the chunk arithmetic once per thread (tf's
+			// share), the slot's share a compile-time offset -- for the mirror image counted downwards
+			static_assert(TFN % T == 0, "whole chunks per slot");
+			constexpr int CH = (TFN / T) * RtImage<T>::STRIDE;
+			const int tfl = idx - slot * TFN;
+			const int a0 = RtImage<T>::addr(tfl + mid_al), a1 = RtImage<T>::addr(n - tfl + mid_al);
+			img[a0 + slot * CH] = key;
+			img[(idx == 0 || idx == (n >> 1)) ? a0 + slot * CH : a1 - slot * CH] = key;
 			if (S) { // the spectrum ring is only kept for single-hop calls
 				ZH_CHK(S + idx, 1);
 				S[idx] = X;
@@ -165,7 +171,8 @@ struct InvInLean {
 		else
 			pi = (idx > N / 2 && idx < N - MID) ? N - idx : (idx > N / 2 ? idx - (N - 512) + LEAN_PC_TAIL : idx);
 		const int g = idx + 24;
-		const float mag = __int_as_float(img[(g >> 4) * 20 + (g & 15)]);
+		const int g0 = g - slot * TF; // (tf + 24: the chunk arithmetic once per thread, the slot's share an immediate)
+		const float mag = __int_as_float(img[(g0 >> 4) * 20 + (g0 & 15) + slot * (TF / 16) * 20]);
 		const float2 z = r->S[slot];
 		float m;
 		if constexpr (HARDP)
@@ -195,7 +202,9 @@ __device__ __forceinline__ unsigned lean_mask_bits(const int* img, const float* 
 		else
 			pi = (idx > N / 2 && idx < N - MID) ? N - idx : (idx > N / 2 ? idx - (N - 512) + LEAN_PC_TAIL : idx);
 		const int g = idx + 24;
-		const float h = __int_as_float(img[(g >> 4) * 20 + (g & 15)]), p = pc[pi]; // H = |S|: causal, SURVEY Q1
+		const int g0 = tf + 24; // (InvInLean: the chunk arithmetic once per thread)
+		const float h = __int_as_float(img[(g0 >> 4) * 20 + (g0 & 15) + slot * (TF / 16) * 20]), p = pc[pi]; // H = |S|: causal, SURVEY Q1
+		(void)g;
 		unsigned pm, hm;
 		if constexpr (HARDP) { // both thresholds are there (the launcher checked): comparisons only, no divide variants compiled in
 			pm = cfg.out_p ? (unsigned)(hard_mask_exact(p, h + FLT_EPSILON, thr_p) != 0.0f) : 0u; // hps.cu:501-505
@@ -626,7 +635,7 @@ __device__ __forceinline__ void rt_fused_body(const RtFusedArgs& a, const unsign
 		in.tail = (MINB == 1 || f != a.n_frames - 1) ? nullptr : hv.tail_next() + (long long)s * hop;
 		in.hop = hop;
 		const long long row = ((hv.row0() + f) % a.ring_rows) + (long long)s * a.ring_rows;
-		FwdOut<T> out;
+		FwdOut<T, TF> out;
 		out.r = &r;
 		out.S = a.S ? a.S + row * a.s_stride : nullptr;
 		// A later use_sse_filter() (allowed at any time, hps.h:289) makes the next hop's causal time box filter
