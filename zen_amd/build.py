@@ -39,6 +39,12 @@ FLAGS = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-co
 # where they are (A/B of every file on the three bench workloads, round 2).
 FILE_FLAGS = {"rt_fused.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-amdgpu-use-amdgpu-trackers=1"],
               "rt_fused_multi.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+              # -DZEN_FFT_FOLD_ADDR (fft_dev.h Plan::pad_off: the padding arithmetic of the LDS image once per base address, the rest
+              # immediates): measured per translation unit in round 5 -- the three-output lean fused kernel gains 2.4 % (0.8205 ->
+              # 0.8005 ms per 25 840 hops, 160 -> 149 VGPRs); the one-output headline build loses 1 % with it (its own image
+              # arithmetic is folded by hand in rt_fused.hip), the synthesis kernels of istft.hip are neutral to -1 % at nfft 16384
+              # (+3 % at nfft 1024) although they drop 10-20 registers and every spill: they do not wait for VALU issue
+              "rt_fused_multi_lean.hip": ["-DZEN_FFT_FOLD_ADDR"],
               "median47.hip": ["-mllvm", "-amdgpu-use-amdgpu-trackers=1"],
               "istft.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
               # (round 3: with the loads of a frame in flight together the analysis kernels gain from it too: nfft 16384

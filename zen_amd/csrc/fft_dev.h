@@ -78,6 +78,17 @@ struct Plan {
 #endif
 	static constexpr int LDS_FLOAT2 = SWZ ? N : N + (N >> PAD_SHIFT); // padded frame image in LDS
 	static __device__ __forceinline__ int pad(int i) { return SWZ ? (i ^ ((i >> 3) & 31)) : i + (i >> PAD_SHIFT); }
+	// pad(base + off) for a compile-time offset: where off is a multiple of the padding period its share of the padded address
+	// is a constant of the access (an immediate of the LDS instruction) and the shift / add runs once per base, not once per
+	// access.  Per translation unit (ZEN_FFT_FOLD_ADDR): the kernels that sit at a register limit keep the code they have.
+	static __device__ __forceinline__ int pad_off(int base, int off)
+	{
+#ifdef ZEN_FFT_FOLD_ADDR
+		if (!SWZ && (off & ((1 << PAD_SHIFT) - 1)) == 0)
+			return pad(base) + off + (off >> PAD_SHIFT);
+#endif
+		return pad(base + off);
+	}
 	static constexpr int FRAMES_PER_BLOCK = (TF >= 256) ? 1 : 256 / TF;
 	static constexpr int THREADS = TF * FRAMES_PER_BLOCK;
 };
@@ -405,7 +416,11 @@ struct PassRunner {
 					v[i][m] = in(m * J + j, /*slot=*/m * NB + i);
 				}
 				else {
+#ifdef ZEN_FFT_FOLD_ADDR
+					v[i][m] = lds[PL::pad_off(k * R * J + j, m * J)];
+#else
 					v[i][m] = lds[PL::pad((k * R + m) * J + j)];
+#endif
 				}
 			}
 		}
@@ -429,7 +444,11 @@ struct PassRunner {
 					}
 				}
 				else {
+#ifdef ZEN_FFT_FOLD_ADDR
+					lds[PL::pad_off(b, c * (N / R))] = v[i][c];
+#else
 					lds[PL::pad(idx)] = v[i][c];
+#endif
 				}
 			}
 		}
