@@ -395,9 +395,14 @@ __device__ __forceinline__ void rt_wide_body(const RtFusedArgs& a, const WideHop
 		constexpr int NRAW_A = WGT + HALO, NSORT_A = WGT + GM::NB - 1;
 		int* raw = reinterpret_cast<int*>(lds);
 		int* srt = raw + (NRAW_A + NT + HALO) * RSTR;
-		const int bA = g * WGT;
-		const int nA = MAIN + 1 - bA < 0 ? 0 : (MAIN + 1 - bA > WGT ? WGT : MAIN + 1 - bA);
-		const bool ownsB = (MAIN + 1) / WGT == g;
+		// The MAIN + 1 blocks of piece A in equal shares (round 5; they used to go out 256 at a time: at nfft 16384 two workgroups
+		// staged and sorted 256 blocks each, the third one 13, the fourth none -- the selection itself is one block per thread
+		// either way, the staging and sorting loops in front of it are half as long now); the tail with the last share.
+		constexpr int PER = (MAIN + 1 + G - 1) / G;
+		static_assert(PER + NT <= WGT, "a workgroup's blocks: one per thread");
+		const int bA = g * PER;
+		const int nA = MAIN + 1 - bA < 0 ? 0 : (MAIN + 1 - bA > PER ? PER : MAIN + 1 - bA);
+		const bool ownsB = g == G - 1;
 		const int nB = ownsB ? NT : 0;
 		const int rawA = nA ? nA + HALO : 0, rawB = nB ? nB + HALO : 0;     // raw chunks of either piece
 		const int srtA = nA ? nA + GM::NB - 1 : 0, srtB = nB ? nB + GM::NB - 1 : 0;
