@@ -1164,7 +1164,7 @@ def main():
     ap.add_argument("--no-block-fused", action="store_true",
                     help="realtime_block: STFT / median / iSTFT kernels instead of the fused per-hop kernel")
     ap.add_argument("--fused-minb", type=int, default=0, help="tuning: occupancy the fused kernel is built for")
-    ap.add_argument("--settle-ms", type=float, default=300.0,
+    ap.add_argument("--settle-ms", type=float, default=1000.0,
                     help="untimed steps run for this long before the W warm-up steps, so that the clocks have "
                          "settled when the timed region starts (the timed region is still exactly K steps)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
