@@ -95,6 +95,9 @@ int zen_hip_event_destroy(void* event);
  * write-through sample stores followed by a relaxed flag store.  The default form relies on gfx950's write-through
  * system-scope stores and on posted writes reaching host memory in order; set this on a host where either is in doubt
  * (PCIe relaxed ordering).  Costs about a microsecond per hop.
+ * "no_rfft" = 1: the analysis kernels of blocks of frames run the full complex transform on their real frames (rounds
+ * 1-4) instead of the Hermitian half; "no_sse_lat" = 1: single hops of the causal SSE path run the two-wavefront kernels
+ * of rounds 2-4 (rt_sse.hip) instead of the layout that spreads the frame over all four SIMDs of a CU (rt_sse_lat.hip).
  * Timing diagnostics whose outputs are NOT the reference's ("median47_variant" 2..4, "rt_fused_diag") and the
  * divide-based cross-check of the hard masks ("mask_divide") exist in -DZEN_HIP_DIAG builds of the library only; the
  * shipped build answers ZEN_HIP_E_UNSUPPORTED. */

@@ -125,3 +125,15 @@ def test_round5_kernels(usage):
     assert len(res) == 10
     for name, k in res.items():
         assert k["scratch"] == 0, (name, k)
+
+
+def test_latency_layout_kernels(usage):
+    """The single-hop kernels that spread one frame over all four SIMDs (rt_sse_lat.hip, rt_hop_lat.hip, lfft_dev.h): one workgroup
+    per CU, so registers are not the limit -- but nothing may go to scratch (a build that chose the carries of an output by
+    indexing one array put them there: a trip to memory in front of the hop's stores)."""
+    sse = usage["rt_sse_lat.hip"]
+    hop = usage["rt_hop_lat.hip"]
+    assert sum("rt_sse_lat_kernel" in n for n in sse) == 4 and sum("rt_sse_lat_resident_kernel" in n for n in sse) == 4
+    assert sum("rt_hop_lat_kernel" in n for n in hop) == 5 and sum("rt_hop_lat_resident_kernel" in n for n in hop) == 5
+    for name, k in list(sse.items()) + list(hop.items()):
+        assert k["scratch"] == 0, (name, k)

@@ -231,6 +231,23 @@ def test_real_input_transform_on_the_host(tmp_path, oracle):
     assert r.returncode == 0 and "bit-identical" in r.stdout, r.stdout[-2000:]
 
 
+def test_latency_layout_transform_on_the_host(tmp_path, oracle):
+    """zen_amd/csrc/lfft_dev.h compiled for the CPU (tests/cpp/test_lfft_host.cpp): the transform of the single-hop kernels --
+    4, 8 or 16 values per thread, two LDS images, one barrier per pass -- run thread by thread in lock step and one thread
+    after the other (only legal because a pass writes the image it does not read): bit-identical to the oracle's transform
+    (fftw.h:51-129) forward (zero-padded and full frames) and inverse (all samples, first half only) for nfft 64..8192."""
+    clang = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(clang):
+        pytest.skip("no host clang++ (the header uses clang vector extensions)")
+    exe = str(tmp_path / "test_lfft_host")
+    odir = os.path.join(ROOT, "oracle")
+    subprocess.check_call([clang, "-std=c++17", "-O1", "-ffp-contract=off", "-Wno-everything", "-I/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "cpp", "test_lfft_host.cpp"), "-o", exe, "-L", odir, "-lzen_oracle",
+                           "-Wl,-rpath," + odir])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "bit-identical" in r.stdout, r.stdout[-2000:]
+
+
 @pytest.mark.gpu
 def test_cli_batch_over_two_processes_matches_one(tmp_path):
     """`zen batch --gpus 2` (SURVEY 8(e), configs[3]): the parent starts two copies of itself before anything has

@@ -357,3 +357,173 @@ def test_real_input_analysis_equals_the_complex_transform_and_the_oracle(z, fs, 
         for k in keys:
             assert np.array_equal(new[k][s_], ref[k], equal_nan=True), (k, s_, "real-input analysis vs oracle")
             assert np.array_equal(old[k][s_], ref[k], equal_nan=True), (k, s_, "complex analysis vs oracle")
+
+
+# ---------------------------------------------------------------------------- single hops of the SSE path over all four SIMDs
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("fs,hop,flags,streams", [(44100.0, 128, ALL, 2), (44100.0, 256, o.OUTPUT_HARMONIC | o.OUTPUT_PERCUSSIVE, 1),
+                                                  (44100.0, 512, o.OUTPUT_PERCUSSIVE, 1), (48000.0, 512, ALL, 3),
+                                                  (44100.0, 1024, ALL, 1), (22050.0, 1024, o.OUTPUT_HARMONIC, 2),
+                                                  (96000.0, 256, ALL, 1), (16000.0, 128, o.OUTPUT_PERCUSSIVE, 1)])
+def test_sse_single_hops_latency_layout_vs_the_two_wavefront_kernel_and_the_oracle(z, fs, hop, flags, streams):
+    """One hop of the causal SSE path per call (HPRRealtime::process_next_hop -> apply_sse_filter, hps.cu:429-486, :582-652)
+    through rt_sse_lat.hip -- the frame's transform in 4 / 8 / 16 values per thread on 128 or 256 threads (lfft_dev.h: the
+    same radix-2 DAG in more, shorter passes), estimates and masks in the registers of the thread that owns the bin, the
+    replicate border as a clamped index -- and through rt_sse.hip's kernel (option "no_sse_lat"): both bit-identical to the
+    oracle, per launch, mixed with block calls in both directions, and changing hands between the two kernels in mid-stream.
+    The time boxes here are 5 to 69 frames long: history of fewer than eight rows, of several batches of eight, and the first
+    frames of a stream whose history is clamped at row 0."""
+    n_hops = 40
+    x = np.stack([_clip(hop * n_hops, 70 + 3 * s + hop, ) for s in range(streams)])
+    xs = (lambda a, b: x[:, a * hop:b * hop]) if streams > 1 else (lambda a, b: x[0, a * hop:b * hop])
+    refs = []
+    for s in range(streams):
+        ho = o.HPR(fs, hop, 2.0, flags, o.TIME_CAUSAL)
+        ho.use_sse_filter()
+        refs.append(ho.process_stream(x[s]))
+    keys = [k for k, f in (("P", o.OUTPUT_PERCUSSIVE), ("H", o.OUTPUT_HARMONIC)) if flags & f]
+
+    def run(schedule):
+        g = z.HPR(fs, hop, 2.0, flags, z.TIME_CAUSAL, True, streams)
+        g.use_sse_filter()
+        parts, pos = [], 0
+        for n, block, old in schedule:
+            z.set_option("no_sse_lat", old)
+            try:
+                parts.append(g.process_stream_host(xs(pos, pos + n), block=block))
+            finally:
+                z.set_option("no_sse_lat", 0)
+            pos += n
+        assert pos == n_hops
+        return parts
+
+    for name, schedule in (("new", [(n_hops, 1, 0)]), ("old", [(n_hops, 1, 1)]),
+                           ("mixed", [(7, 1, 0), (5, 4, 0), (6, 1, 1), (3, 1, 0), (9, 3, 0), (10, 1, 0)])):
+        parts = run(schedule)
+        for s in range(streams):
+            for k in keys:
+                got = np.concatenate([(p[k][s] if streams > 1 else p[k]) for p in parts])
+                assert np.array_equal(got, refs[s][k], equal_nan=True), (name, k, s)
+                assert np.any(np.nan_to_num(refs[s][k]) != 0)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("hop", [128, 256, 512, 1024])
+def test_sse_resident_kernel_in_both_layouts(z, hop):
+    """The resident kernel of the SSE path (zen_hip_hpr_set_resident) with the latency layout's body -- twiddles and window
+    loaded once per launch, the previous hop and the overlap-add carries kept in registers from hop to hop -- and with
+    rt_sse.hip's ("no_sse_lat"): the same samples as the oracle, back to back, with idle exits (the registers' contents are
+    then picked up from memory by the next launch), and with per-launch hops of the other layout in between."""
+    n_hops = 48
+    x = _clip(hop * n_hops, 23 + hop)
+    ho = o.HPR(FS, hop, 2.0, o.OUTPUT_PERCUSSIVE, o.TIME_CAUSAL)
+    ho.use_sse_filter()
+    ref = ho.process_stream(x)["P"]
+    for old in (0, 1):
+        z.set_option("no_sse_lat", old)
+        try:
+            io = z.IOGPU(hop)
+            rt = z.HPRRealtime(FS, hop, 2.0, o.OUTPUT_PERCUSSIVE)
+            rt.use_sse_filter()
+            eng = rt.p_impl
+            eng.set_resident(200)
+            got = _per_hop(rt, io, x, hop, n_hops, rt.copy_percussive)
+            assert np.array_equal(got, ref, equal_nan=True), old
+            assert eng.resident_stats()["launches"] == 1
+            eng.reset_buffers()
+            eng.set_resident(4)
+            a = _per_hop(rt, io, x, hop, 20, rt.copy_percussive, pause_every=6, pause_s=0.03)
+            eng.set_resident(0)
+            z.set_option("no_sse_lat", 1 - old)                           # per launch, the other layout
+            b = _per_hop(rt, io, x[20 * hop:], hop, 5, rt.copy_percussive)
+            z.set_option("no_sse_lat", old)
+            eng.set_resident(50)
+            c = _per_hop(rt, io, x[25 * hop:], hop, n_hops - 25, rt.copy_percussive)
+            assert np.array_equal(np.concatenate([a, b, c]), ref, equal_nan=True), old
+            del rt, eng
+        finally:
+            z.set_option("no_sse_lat", 0)
+
+
+# ---------------------------------------------------------------------------- single hops of the median path over all four SIMDs
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("fs,hop", [(44100.0, 128), (44100.0, 256), (48000.0, 256), (44100.0, 512), (48000.0, 512), (48000.0, 1024),
+                                    (44100.0, 1024)])
+@pytest.mark.parametrize("flags,soft,streams", [(o.OUTPUT_PERCUSSIVE, False, 1), (ALL, False, 2), (o.OUTPUT_HARMONIC | o.OUTPUT_RESIDUAL, True, 1),
+                                                (o.OUTPUT_HARMONIC, False, 3)])
+def test_median_single_hops_latency_layout_vs_the_block_kernels_build_and_the_oracle(z, fs, hop, flags, soft, streams):
+    """One hop of the causal median path per call (HPRRealtime::process_next_hop, hps.cu:334-339, :429-486, :488-580) through
+    rt_hop_lat.hip -- lfft_dev.h's transform on 128 to 512 threads, |S| in an LDS row image of its own, the 47-tap block scheme or
+    the sorting-network medians in chunks of 4 / 8, masks by exact comparison -- and through rt_fused.hip's single-hop builds
+    (option "no_hop_lat"): bit-identical to the oracle for every (transform size, frequency mask) pair the engine has a
+    single-launch kernel for, one to three outputs, hard and soft masks, one to three streams; mixed with block calls in both
+    directions and changing hands between the two kernels in mid-stream."""
+    n_hops = 36
+    x = np.stack([_clip(hop * n_hops, 90 + 5 * s + hop) for s in range(streams)])
+    xs = (lambda a, b: x[:, a * hop:b * hop]) if streams > 1 else (lambda a, b: x[0, a * hop:b * hop])
+    refs = []
+    for s in range(streams):
+        ho = o.HPR(fs, hop, 2.0, flags, o.TIME_CAUSAL)
+        if soft:
+            ho.use_soft_mask()
+        refs.append(ho.process_stream(x[s]))
+    keys = [k for k, f in (("P", o.OUTPUT_PERCUSSIVE), ("H", o.OUTPUT_HARMONIC), ("R", o.OUTPUT_RESIDUAL)) if flags & f]
+
+    def run(schedule):
+        g = z.HPR(fs, hop, 2.0, flags, z.TIME_CAUSAL, True, streams)
+        if soft:
+            g.use_soft_mask()
+        parts, pos = [], 0
+        for n, block, old in schedule:
+            z.set_option("no_hop_lat", old)
+            try:
+                parts.append(g.process_stream_host(xs(pos, pos + n), block=block))
+            finally:
+                z.set_option("no_hop_lat", 0)
+            pos += n
+        assert pos == n_hops
+        return parts
+
+    for name, schedule in (("new", [(n_hops, 1, 0)]), ("old", [(n_hops, 1, 1)]),
+                           ("mixed", [(6, 1, 0), (5, 4, 0), (5, 1, 1), (3, 1, 0), (8, 3, 0), (9, 1, 0)])):
+        parts = run(schedule)
+        for s in range(streams):
+            for k in keys:
+                got = np.concatenate([(p[k][s] if streams > 1 else p[k]) for p in parts])
+                assert np.array_equal(got, refs[s][k]), (name, k, s)
+            assert any(np.any(refs[s][k] != 0) for k in keys)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("fs,hop", [(44100.0, 128), (44100.0, 256), (48000.0, 512), (44100.0, 512), (44100.0, 1024), (48000.0, 1024)])
+def test_median_resident_kernel_in_both_layouts(z, fs, hop):
+    """The resident kernel of the median path (zen_hip_hpr_set_resident) with the latency layout's body (twiddles, window, the
+    previous hop and the carries in registers from hop to hop) and with rt_fused.hip's ("no_hop_lat"): the oracle's samples back
+    to back, with idle exits, with per-launch hops of the other layout and a block call in between."""
+    n_hops = 50
+    x = _clip(hop * n_hops, 29 + hop)
+    ref = o.HPR(fs, hop, 2.0, o.OUTPUT_PERCUSSIVE, o.TIME_CAUSAL).process_stream(x)["P"]
+    for old in (0, 1):
+        z.set_option("no_hop_lat", old)
+        try:
+            io = z.IOGPU(hop)
+            rt = z.HPRRealtime(fs, hop, 2.0, o.OUTPUT_PERCUSSIVE)
+            eng = rt.p_impl
+            eng.set_resident(200)
+            got = _per_hop(rt, io, x, hop, n_hops, rt.copy_percussive)
+            assert np.array_equal(got, ref), old
+            assert eng.resident_stats()["launches"] == 1
+            eng.reset_buffers()
+            eng.set_resident(4)
+            a = _per_hop(rt, io, x, hop, 17, rt.copy_percussive, pause_every=5, pause_s=0.03)
+            eng.set_resident(0)
+            z.set_option("no_hop_lat", 1 - old)                           # per launch, the other layout
+            b = _per_hop(rt, io, x[17 * hop:], hop, 5, rt.copy_percussive)
+            z.set_option("no_hop_lat", old)
+            blk = eng.process_stream_host(x[22 * hop:29 * hop])["P"]
+            eng.set_resident(50)
+            c = _per_hop(rt, io, x[29 * hop:], hop, n_hops - 29, rt.copy_percussive)
+            assert np.array_equal(np.concatenate([a, b, blk, c]), ref), old
+            del rt, eng
+        finally:
+            z.set_option("no_hop_lat", 0)

@@ -3,13 +3,15 @@
 // without an interpreter in the loop.  Prints one JSON line per hop size.
 // Arguments: [hops per configuration, default 2000] [--stamps: also print the phase stamps of one single-hop kernel
 // of every kind].  Environment: ZEN_RT_RESIDENT=<idle ms>: the per-hop calls go through the resident kernel
-// (zen_hip_hpr_set_resident; hops 256..1024 of the median path and SSE hop 512, "resident": 1 in their lines); ZEN_RT_ONLY_SSE=1 (only the SSE configurations), ZEN_RT_DIAG=<n> (sets the library's
+// (zen_hip_hpr_set_resident; every hop of the median path and SSE hop 512, "resident": 1 in their lines; with --stamps: the
+// phase stamps are then those of a resident hop); ZEN_RT_OPT="name=value,..." (zen_hip_set_option), ZEN_RT_ONLY_SSE=1 (only the SSE configurations), ZEN_RT_DIAG=<n> (sets the library's
 // "rt_fused_diag" option: timing diagnostics, results not valid; 4 = agent-scope grid barriers in rt_wide.hip).
 //   g++ -O2 -std=c++17 -I include tools/rt_latency.cpp -o /tmp/rt_latency -L zen_amd -lzen_hip -Wl,-rpath,$PWD/zen_amd
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "zen_hip.h"
@@ -36,10 +38,22 @@ int main(int argc, char** argv)
 	CK(zen_hip_init(0));
 	if (const char* d = std::getenv("ZEN_RT_DIAG")) // timing diagnostics of the single-hop kernels (results not valid)
 		CK(zen_hip_set_option("rt_fused_diag", std::atoi(d)));
+	if (const char* o = std::getenv("ZEN_RT_OPT")) { // "name=value,name=value": zen_hip_set_option (e.g. no_sse_lat=1)
+		std::string all(o);
+		size_t pos = 0;
+		while (pos < all.size()) {
+			const size_t end = all.find(',', pos) == std::string::npos ? all.size() : all.find(',', pos);
+			const std::string kv = all.substr(pos, end - pos);
+			const size_t eq = kv.find('=');
+			if (eq != std::string::npos)
+				CK(zen_hip_set_option(kv.substr(0, eq).c_str(), std::atoi(kv.c_str() + eq + 1)));
+			pos = end + 1;
+		}
+	}
 	const bool only_sse = std::getenv("ZEN_RT_ONLY_SSE") != nullptr;
 	for (int sse = only_sse ? 1 : 0; sse < 2; ++sse) {
 		for (size_t hop : {256, 512, 1024, 2048, 4096}) {
-			if (sse && hop != 512 && hop != 2048)
+			if (sse && hop != 512 && hop != 1024 && hop != 2048)
 				continue;
 			zen_hip_hpr_t h = nullptr;
 			CK(zen_hip_hpr_create(44100.f, hop, 2.0f, ZEN_HIP_OUTPUT_PERCUSSIVE, ZEN_HIP_TIME_CAUSAL, 1, 1, 64, &h));
@@ -48,9 +62,13 @@ int main(int argc, char** argv)
 			const int resident_ms = std::getenv("ZEN_RT_RESIDENT") ? std::atoi(std::getenv("ZEN_RT_RESIDENT")) : 0;
 			// (median path: every hop -- the one-workgroup kernel up to 1024, the cooperative one at 2048 / 4096; SSE path: the hops the
 			// one-workgroup SSE kernel covers)
-			const bool resident = resident_ms > 0 && (!sse || hop <= 1024) && !(argc > 2);
+			const bool resident = resident_ms > 0 && (!sse || hop <= 1024);
 			if (resident)
 				CK(zen_hip_hpr_set_resident(h, resident_ms));
+			if (argc > 2) { // (before the first hop: a resident kernel keeps the arguments of its launch)
+				unsigned long long* st0 = nullptr;
+				CK(zen_hip_hpr_debug_stamps(h, &st0));
+			}
 			void *hin, *din, *hout, *dout;
 			CK(zen_hip_host_alloc_mapped(hop * 4, 1, &hin, &din));
 			CK(zen_hip_host_alloc_mapped(hop * 4, 0, &hout, &dout));

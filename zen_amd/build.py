@@ -17,7 +17,7 @@ _VARIANT = os.environ.get("ZEN_HIP_VARIANT", "")
 OUT = os.path.join(HERE, "libzen_hip%s.so" % ("_" + _VARIANT if _VARIANT else ""))
 OBJDIR = os.path.join(HERE, "build" + ("_" + _VARIANT if _VARIANT else ""))
 RESOURCES = os.path.join(HERE, "kernel_resources%s.json" % ("_" + _VARIANT if _VARIANT else ""))   # per-kernel registers / scratch / LDS of the last build
-SOURCES = ["api.hip", "hpr.hip", "hpri.hip", "stft.hip", "istft.hip", "median.hip", "median_net.hip", "median47.hip", "median_big.hip", "rt_fused.hip", "rt_fused_multi.hip", "rt_fused_multi_lean.hip", "rt_sse.hip", "rt_wide.hip", "box.hip", "fft_big.hip", "sse_block.hip", "rt_resident.hip", "memguard.hip"]
+SOURCES = ["api.hip", "hpr.hip", "hpri.hip", "stft.hip", "istft.hip", "median.hip", "median_net.hip", "median47.hip", "median_big.hip", "rt_fused.hip", "rt_fused_multi.hip", "rt_fused_multi_lean.hip", "rt_sse.hip", "rt_sse_lat.hip", "rt_hop_lat.hip", "rt_wide.hip", "box.hip", "fft_big.hip", "sse_block.hip", "rt_resident.hip", "memguard.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 EXTRA = os.environ.get("ZEN_HIP_EXTRA_FLAGS", "").split()
 # A/B builds that differ in a few files only: ZEN_HIP_VARIANT_FILES="stft.hip,istft.hip" compiles just those with the extra

@@ -36,6 +36,8 @@ opt_t g_opt_istft_run_wide{0};
 opt_t g_opt_offline_range{0};
 opt_t g_opt_offline_no_register{0};
 opt_t g_opt_no_rfft{0};
+opt_t g_opt_no_sse_lat{0};
+opt_t g_opt_no_hop_lat{0};
 // (the environment decides the default: a host whose PCIe root complex relaxes the order of posted writes, or whose
 // mapped host memory is not write-through for the device, sets ZEN_HIP_PUBLISH_RELEASE=1 without touching the caller)
 opt_t g_opt_publish_release{[] { const char* v = getenv("ZEN_HIP_PUBLISH_RELEASE"); return (v && *v && *v != '0') ? 1 : 0; }()};
@@ -197,7 +199,9 @@ int zen_hip_set_option(const char* name, int value)
 	             {"offline_range", &g_opt_offline_range},
 	             {"offline_no_register", &g_opt_offline_no_register},
 	             {"publish_release", &g_opt_publish_release},
-	             {"no_rfft", &g_opt_no_rfft}};
+	             {"no_rfft", &g_opt_no_rfft},
+	             {"no_sse_lat", &g_opt_no_sse_lat},
+	             {"no_hop_lat", &g_opt_no_hop_lat}};
 #ifndef ZEN_HIP_DIAG
 	if (name && (!strcmp(name, "rt_fused_diag") || !strcmp(name, "mask_divide") || (!strcmp(name, "median47_variant") && value > 1)))
 		ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "zen_hip_set_option: '%s' = %d is a diagnostic of -DZEN_HIP_DIAG builds", name, value);

@@ -35,6 +35,8 @@ extern opt_t g_opt_istft_run_wide;     // "istft_run_wide": the same for istft_r
 extern opt_t g_opt_istft_run;          // "istft_run": consecutive frames per wavefront of istft_run_kernel (0: default 16)
 extern opt_t g_opt_no_median_tf;        // "no_median_tf": time median and frequency median + mask bits as two launches
 extern opt_t g_opt_no_median_bits;      // "no_median_bits": the mask bits always come from mask_bits_kernel, never from a median kernel
+extern opt_t g_opt_no_hop_lat;         // "no_hop_lat": single hops of the median path through rt_fused.hip's builds (rounds 1-4)
+extern opt_t g_opt_no_sse_lat;         // "no_sse_lat": single hops of the SSE path through rt_sse.hip's two-wavefront kernels (rounds 2-4)
 extern opt_t g_opt_no_rfft;            // "no_rfft": the analysis kernel runs the full complex transform on its real frames (rounds 1-4)
 extern opt_t g_opt_publish_release;   // "publish_release": single hops are published with the system-scope release form (fence + release store)
 extern opt_t g_opt_no_mask_bits;        // "no_mask_bits": the synthesis kernels compare H and P themselves (no mask_bits_kernel)

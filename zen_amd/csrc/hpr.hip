@@ -440,7 +440,7 @@ bool resident_eligible(const zen_hip_hpr* e)
 	const bool kernel = e->use_sse ? rt_sse_available(e->log2n, e->mt, e->mf)
 	                               : (rt_fused_available(e->log2n, e->mf) || resident_wide(e));
 	return e->res_idle_ms > 0 && e->causality == ZEN_HIP_TIME_CAUSAL && !g_opt_no_rt_fused && e->n_streams == 1 && n_out == 1
-	       && e->ready_host[o1] != nullptr && kernel && !e->prof && !e->dbg_stamps && !(e->drain[0] | e->drain[1] | e->drain[2]);
+	       && e->ready_host[o1] != nullptr && kernel && !e->prof && !(e->dbg_stamps && resident_wide(e)) && !(e->drain[0] | e->drain[1] | e->drain[2]);
 }
 
 int resident_launch(zen_hip_hpr* e) // from res_args: the hop whose number is res_args.seq is the first the kernel will see
@@ -544,7 +544,7 @@ int resident_post(zen_hip_hpr* e, const float* in)
 	if (e->res_active && e->res_args.in != in) // the kernel reads the input buffer it was launched with (IOGPU::device_in,
 		ZH_TRY(resident_stop(e));              // normally the same for every hop): another buffer, another launch
 	fused_args(e, in, e->hop, 1, e->res_args);
-	e->res_args.stamps = nullptr;
+	e->res_args.stamps = e->dbg_stamps; // (diagnostic: the phase stamps of every resident hop, tools/rt_latency.cpp)
 	if (resident_wide(e)) // (the engine's account of the barrier word advances hop by hop, as the kernel's does: a relaunch, or a
 		ZH_TRY(wide_args(e, e->res_args, e->stream, /*clear_votes=*/false)); // per-launch hop later, starts from the right count)
 	ZH_TRY(resident_kick(e));

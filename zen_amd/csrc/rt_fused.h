@@ -174,12 +174,22 @@ bool rt_fused_direct_out_available(int log2n, int freq_len, const RtFusedArgs& a
 int launch_rt_fused_fixup(const RtFusedArgs& a, hipStream_t stream);
 int launch_rt_fused(int log2n, int freq_len, const RtFusedArgs& a, hipStream_t stream);
 int launch_rt_fused_multi(int log2n, int freq_len, const RtFusedArgs& a, hipStream_t stream); // n_out > 1 (rt_fused_multi.hip)
+// rt_hop_lat.hip: single hops (n_frames == 1, any number of outputs and streams) with the frame spread over all four SIMDs of
+// a CU -- what launch_rt_fused / launch_rt_fused_resident run for them unless option "no_hop_lat" is set
+int launch_rt_hop_lat(int log2n, int freq_len, const RtFusedArgs& a, hipStream_t stream);
+int launch_rt_hop_lat_resident(int log2n, int freq_len, const RtFusedArgs& a, const ResidentCtl* ctl, ResidentOut* ro, unsigned seq_start,
+                               unsigned long long idle_ticks, unsigned max_hops, hipStream_t stream);
 int launch_rt_fused_multi_lean(const RtFusedArgs& a, hipStream_t stream); // nfft 4096, 47 taps, n_out > 1, hard masks, blocks (rt_fused_multi_lean.hip)
 
 // rt_sse.hip: the causal SSE path (apply_sse_filter, hps.cu:582-652) for ONE hop per stream in one launch.  len_t /
 // len_f: the odd box lengths (time, frequency), fac_h / fac_p: l_harm + 1, l_perc + 1 (hps.cu:599-604).
 bool rt_sse_available(int log2n, int len_t, int len_f);
 int launch_rt_sse(int log2n, const RtFusedArgs& a, int len_t, int len_f, float fac_h, float fac_p, hipStream_t stream);
+// rt_sse_lat.hip: the same call with the frame spread over all four SIMDs of the CU (what the two above run unless option
+// "no_sse_lat" is set)
+int launch_rt_sse_lat(int log2n, const RtFusedArgs& a, int len_t, int len_f, float fac_h, float fac_p, hipStream_t stream);
+int launch_rt_sse_lat_resident(int log2n, const RtFusedArgs& a, int len_t, int len_f, float fac_h, float fac_p, const ResidentCtl* ctl,
+                               ResidentOut* ro, unsigned seq_start, unsigned long long idle_ticks, unsigned max_hops, hipStream_t stream);
 
 // rt_wide.hip: ONE hop per stream of the causal median path at nfft 8192 / 16384 in one launch, the frame spread
 // over nfft/4096 cooperating workgroups.  rt_wide_arrivals: what a call adds to every stream's barrier word.

@@ -1094,6 +1094,8 @@ int launch_rt_fused_resident(int log2n, int freq_len, const RtFusedArgs& a, cons
 {
 	if (a.n_out != 1 || a.n_frames != 1 || a.n_streams != 1 || !a.publish_seq)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "resident kernel: one stream, one output, single hops, host-mapped hop buffer");
+	if (log2n <= 11 && !g_opt_no_hop_lat && !a.diag) // (launch_rt_fused)
+		return launch_rt_hop_lat_resident(log2n, freq_len, a, ctl, ro, seq_start, idle_ticks, max_hops, stream);
 	switch (log2n * 100 + freq_len) {
 	case 907: return launch_res_t<9, 7>(a, ctl, ro, seq_start, idle_ticks, max_hops, stream);
 	case 1011: return launch_res_t<10, 11>(a, ctl, ro, seq_start, idle_ticks, max_hops, stream);
@@ -1180,6 +1182,11 @@ bool rt_fused_available(int log2n, int freq_len)
 
 int launch_rt_fused(int log2n, int freq_len, const RtFusedArgs& a, hipStream_t stream)
 {
+	// single hops up to nfft 2048 (one or two wavefronts here): the frame over all four SIMDs of a CU (rt_hop_lat.hip).  At nfft
+	// 4096 this file's builds already run four wavefronts of sixteen values, and the shorter passes of the latency layout cost
+	// more instructions in total than they hide: 12.6-13.9 against 12.0 us per resident hop, measured.
+	if (a.n_frames == 1 && log2n <= 11 && !g_opt_no_hop_lat && !a.diag)
+		return launch_rt_hop_lat(log2n, freq_len, a, stream);
 	switch (log2n * 100 + freq_len) {
 	case 907: return launch_t<9, 7>(a, stream);
 	case 1011: return launch_t<10, 11>(a, stream);

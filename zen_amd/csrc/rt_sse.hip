@@ -456,6 +456,8 @@ int launch_rt_sse_resident(int log2n, const RtFusedArgs& a, int len_t, int len_f
 {
 	if (a.n_out != 1 || a.n_frames != 1 || a.n_streams != 1 || !a.publish_seq)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "resident kernel: one stream, one output, single hops, host-mapped hop buffer");
+	if (!g_opt_no_sse_lat) // the frame over all four SIMDs (rt_sse_lat.hip)
+		return launch_rt_sse_lat_resident(log2n, a, len_t, len_f, fac_h, fac_p, ctl, ro, seq_start, idle_ticks, max_hops, stream);
 	switch (log2n) {
 	case 9: return launch_sse_res_t<9>(a, len_t, len_f, fac_h, fac_p, ctl, ro, seq_start, idle_ticks, max_hops, stream);
 	case 10: return launch_sse_res_t<10>(a, len_t, len_f, fac_h, fac_p, ctl, ro, seq_start, idle_ticks, max_hops, stream);
@@ -473,6 +475,8 @@ bool rt_sse_available(int log2n, int len_t, int len_f)
 
 int launch_rt_sse(int log2n, const RtFusedArgs& a, int len_t, int len_f, float fac_h, float fac_p, hipStream_t stream)
 {
+	if (!g_opt_no_sse_lat)
+		return launch_rt_sse_lat(log2n, a, len_t, len_f, fac_h, fac_p, stream);
 	switch (log2n) {
 	case 9: return launch_sse_t<9>(a, len_t, len_f, fac_h, fac_p, stream);
 	case 10: return launch_sse_t<10>(a, len_t, len_f, fac_h, fac_p, stream);
