@@ -141,9 +141,13 @@ int main(int argc, char** argv)
 					while (now_us() - t0 < 2000.0) {}
 				}
 				std::printf("{\"hop\": %zu, \"phase_us\": {\"housekeeping\": %.2f, \"forward_fft_abs\": %.2f, \"border_median\": %.2f, "
-				            "\"mask_inverse_fft_store_publish\": %.2f}, \"kernel_us\": %.2f}\n",
+				            "\"mask_inverse_fft_store_publish\": %.2f}, \"kernel_us\": %.2f",
 				            hop, (st[1] - st[0]) / 100.0, (st[2] - st[1]) / 100.0, (st[3] - st[2]) / 100.0,
 				            (st[5] - st[3]) / 100.0, (st[5] - st[0]) / 100.0);
+				if (st[6] > st[3] && st[8] >= st[7]) // rt_hop_lat.hip: the synthesis in three parts
+					std::printf(", \"synthesis_us\": {\"masks\": %.2f, \"inverse_fft_stores\": %.2f, \"publish\": %.2f}", (st[6] - st[3]) / 100.0,
+					            (st[7] - st[6]) / 100.0, (st[8] - st[7]) / 100.0);
+				std::printf("}\n");
 			}
 			unsigned long long res_launches = 0;
 			if (resident)

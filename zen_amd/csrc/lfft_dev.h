@@ -37,7 +37,10 @@ struct LPlan {
 	}
 	static constexpr int RMAX = BASE + (REM ? 1 : 0);
 	static constexpr int TF = N / V; // threads of the frame
-	static constexpr int PAD_SHIFT = 4;
+#ifndef ZEN_LFFT_PAD_V8
+#define ZEN_LFFT_PAD_V8 4
+#endif
+	static constexpr int PAD_SHIFT = LOG2V == 3 ? ZEN_LFFT_PAD_V8 : 4; // (one 8-byte slot of padding per 2^PAD_SHIFT values, fft_dev.h)
 	static constexpr int IMG = N + (N >> PAD_SHIFT);   // one padded image
 	static constexpr int LDS_FLOAT2 = 2 * IMG;         // the two of them
 	static __device__ __forceinline__ int pad(int i) { return i + (i >> PAD_SHIFT); }

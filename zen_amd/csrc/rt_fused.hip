@@ -32,6 +32,12 @@ namespace {
 
 using zfft::Plan;
 
+#ifdef ZEN_HOP_LAT_4096 // A/B: rt_hop_lat.hip's kernels at nfft 4096 too (see launch_rt_fused)
+constexpr int HOP_LAT_MAX_LOG2N = 12;
+#else
+constexpr int HOP_LAT_MAX_LOG2N = 11;
+#endif
+
 // LDS row image of the median stage: T-word chunks spaced T+PAD apart (see median_net.hip RowImage)
 template <int T>
 struct RtImage {
@@ -1094,7 +1100,7 @@ int launch_rt_fused_resident(int log2n, int freq_len, const RtFusedArgs& a, cons
 {
 	if (a.n_out != 1 || a.n_frames != 1 || a.n_streams != 1 || !a.publish_seq)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "resident kernel: one stream, one output, single hops, host-mapped hop buffer");
-	if (log2n <= 11 && !g_opt_no_hop_lat && !a.diag) // (launch_rt_fused)
+	if (log2n <= HOP_LAT_MAX_LOG2N && !g_opt_no_hop_lat && !a.diag) // (launch_rt_fused)
 		return launch_rt_hop_lat_resident(log2n, freq_len, a, ctl, ro, seq_start, idle_ticks, max_hops, stream);
 	switch (log2n * 100 + freq_len) {
 	case 907: return launch_res_t<9, 7>(a, ctl, ro, seq_start, idle_ticks, max_hops, stream);
@@ -1185,7 +1191,7 @@ int launch_rt_fused(int log2n, int freq_len, const RtFusedArgs& a, hipStream_t s
 	// single hops up to nfft 2048 (one or two wavefronts here): the frame over all four SIMDs of a CU (rt_hop_lat.hip).  At nfft
 	// 4096 this file's builds already run four wavefronts of sixteen values, and the shorter passes of the latency layout cost
 	// more instructions in total than they hide: 12.6-13.9 against 12.0 us per resident hop, measured.
-	if (a.n_frames == 1 && log2n <= 11 && !g_opt_no_hop_lat && !a.diag)
+	if (a.n_frames == 1 && log2n <= HOP_LAT_MAX_LOG2N && !g_opt_no_hop_lat && !a.diag)
 		return launch_rt_hop_lat(log2n, freq_len, a, stream);
 	switch (log2n * 100 + freq_len) {
 	case 907: return launch_t<9, 7>(a, stream);

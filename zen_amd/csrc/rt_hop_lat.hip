@@ -21,12 +21,13 @@
 // Same arithmetic, same carry protocol, same rings as rt_fused.hip's single-hop builds: interchangeable call by call with them,
 // with block calls and with the three-kernel path.  Option "no_hop_lat" (zen_hip_set_option) selects rt_fused.hip's builds.
 //
-// Used up to nfft 2048 (hops 128 .. 512: per launch 15.7 / 16.3 -> 12.4 / 13.7-14.6 us at hop 256 / 512, resident 9.2 / 11.4 ->
-// 6.6-7.0 / 8.9-9.9 us).  At nfft 4096 rt_fused.hip's build already runs four wavefronts of sixteen values; eight values on 512
-// threads (-DZEN_HOP_LAT_4096 builds them, with the 47-tap block scheme of median47_core.h on three of the eight wavefronts) make
-// the forward transform faster (3.9 -> 2.7 us) and the inverse slower (3.0 -> 4.5 us: four passes of radix 8 are more
-// instructions in total than three of radix 16, and all four SIMDs were busy before): 12.6-13.9 against 12.0 us per resident
-// hop, not dispatched.
+// Used up to nfft 2048 (hops 128 .. 512: per launch 15.7 / 16.3 -> 12.1-12.4 / 14.0 us at hop 256 / 512, resident 9.2-9.7 /
+// 10.9-11.4 -> 6.7-7.0 / 9.2-10.0 us).  At nfft 4096 rt_fused.hip's build already runs four wavefronts of sixteen values: eight
+// values on 512 threads (-DZEN_HOP_LAT_4096 builds and dispatches them, with the 47-tap block scheme of median47_core.h on three
+// of the eight wavefronts) make the forward transform faster (3.9 -> 2.7 us) but the masks, which that build folds into the first
+// pass of its inverse transform, are a step of their own here (0.9-1.4 us by the stamps; the inverse transform itself 2.3
+// against about 2.1 us, the same 820 instructions per SIMD): 16.6-17.1 against 16.7-17.0 us per launch, 12.2-12.8 against
+// 11.5-12.0 us per resident hop -- not dispatched.
 #include "common.h"
 #include "lfft_dev.h"
 #include "masks.h"
@@ -167,7 +168,7 @@ __device__ __forceinline__ void rt_hop_lat_body(const RtFusedArgs& a, const unsi
 	const int hop = a.hop, s = bid;
 	const float* cur = hv.in() + (long long)s * a.in_stride;
 	// diagnostic (tools/rt_latency.cpp --stamps): phase times of the call (100 MHz), kept in registers until the end
-	unsigned long long stamps[6] = {0, 0, 0, 0, 0, 0};
+	unsigned long long stamps[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // (6..8: inside the last output's synthesis)
 	auto stamp = [&](int k) {
 		if (a.stamps)
 			stamps[k] = __builtin_amdgcn_s_memrealtime();
@@ -372,6 +373,7 @@ __device__ __forceinline__ void rt_hop_lat_body(const RtFusedArgs& a, const unsi
 					v[i] = make_float2(r.S[i].x * m, r.S[i].y * m);
 				}
 			}
+			stamp(6);
 			HopInvIn<V> in{v};
 			float cw[QV], kp[QV];
 #pragma unroll
@@ -384,6 +386,7 @@ __device__ __forceinline__ void rt_hop_lat_body(const RtFusedArgs& a, const unsi
 			out.cv = cw;
 			out.keep = kp;
 			zfft::lfft_frame<LOG2N, LOG2V, true, false, true>(t, lds, twr, in, out);
+			stamp(7);
 			if (RESIDENT) {
 #pragma unroll
 				for (int i = 0; i < QV; ++i)
@@ -406,12 +409,13 @@ __device__ __forceinline__ void rt_hop_lat_body(const RtFusedArgs& a, const unsi
 					__hip_atomic_store(reinterpret_cast<unsigned*>(ready + hop), hv.seq(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 			}
 		}
+		stamp(8);
 		__syncthreads(); // (the next transform's first pass writes the image this one's last pass has read)
 	}
 	stamp(5);
 	if (a.stamps && bid == 0 && t == 0) {
 #pragma unroll
-		for (int k = 0; k < 6; ++k)
+		for (int k = 0; k < 9; ++k)
 			a.stamps[k] = stamps[k];
 	}
 }
