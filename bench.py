@@ -1038,6 +1038,10 @@ def compact_line(full):
         cfg["per_hop_api_us"] = full["realtime"].get("us_per_hop")
         cfg["per_hop_api_hops_per_s"] = full["realtime"].get("hops_per_s")
         cfg["per_hop_api_resident_us"] = full["realtime"].get("resident_us_per_hop")
+        # the same call at the other hops of the reference's sweep and on the SSE path (BASELINE configs[4]: hop 512), C++ loop
+        by, rby = full["realtime"].get("per_hop_us_by_hop", {}), full["realtime"].get("resident_us_by_hop", {})
+        cfg["per_hop_api_us_by_hop"] = {k: by[k] for k in ("256", "512", "2048", "4096", "sse_512") if k in by}
+        cfg["per_hop_api_resident_us_by_hop"] = {k: rby[k] for k in ("256", "512", "2048", "4096", "sse_512") if k in rby}
     line["config"] = cfg
     if legs:
         line["legs"] = legs

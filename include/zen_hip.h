@@ -98,7 +98,7 @@ int zen_hip_event_destroy(void* event);
  * "no_rfft" = 1: the analysis kernels of blocks of frames run the full complex transform on their real frames (rounds
  * 1-4) instead of the Hermitian half; "no_sse_lat" = 1: single hops of the causal SSE path run the two-wavefront kernels
  * of rounds 2-4 (rt_sse.hip) instead of the layout that spreads the frame over all four SIMDs of a CU (rt_sse_lat.hip).
- * "no_hop_lat" = 1: the same for single hops of the median path up to hop 512 (rt_fused.hip's builds instead of rt_hop_lat.hip).
+ * "no_hop_lat" = 1: the same for single hops of the median path (rt_fused.hip's single-hop builds instead of rt_hop_lat.hip).
  * Timing diagnostics whose outputs are NOT the reference's ("median47_variant" 2..4, "rt_fused_diag") and the
  * divide-based cross-check of the hard masks ("mask_divide") exist in -DZEN_HIP_DIAG builds of the library only; the
  * shipped build answers ZEN_HIP_E_UNSUPPORTED. */

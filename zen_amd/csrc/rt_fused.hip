@@ -32,11 +32,15 @@ namespace {
 
 using zfft::Plan;
 
-#ifdef ZEN_HOP_LAT_4096 // A/B: rt_hop_lat.hip's kernels at nfft 4096 too (see launch_rt_fused)
-constexpr int HOP_LAT_MAX_LOG2N = 12;
-#else
-constexpr int HOP_LAT_MAX_LOG2N = 11;
-#endif
+// which single hops go to rt_hop_lat.hip (launch_rt_fused, launch_rt_fused_resident): everything up to nfft 2048; at nfft 4096
+// the percussive output with a hard mask (the realtime default: its HARDP build there), not the builds that carry every mask
+// variant (measured no faster than this file's at that size)
+inline bool hop_lat_takes(int log2n, const RtFusedArgs& a)
+{
+	if (a.n_frames != 1 || g_opt_no_hop_lat || a.diag)
+		return false;
+	return log2n <= 11 || (log2n == 12 && a.n_out == 1 && a.out_id[0] == 0 && !a.soft && a.thr != 0.0);
+}
 
 // LDS row image of the median stage: T-word chunks spaced T+PAD apart (see median_net.hip RowImage)
 template <int T>
@@ -1100,7 +1104,7 @@ int launch_rt_fused_resident(int log2n, int freq_len, const RtFusedArgs& a, cons
 {
 	if (a.n_out != 1 || a.n_frames != 1 || a.n_streams != 1 || !a.publish_seq)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "resident kernel: one stream, one output, single hops, host-mapped hop buffer");
-	if (log2n <= HOP_LAT_MAX_LOG2N && !g_opt_no_hop_lat && !a.diag) // (launch_rt_fused)
+	if (hop_lat_takes(log2n, a)) // (launch_rt_fused)
 		return launch_rt_hop_lat_resident(log2n, freq_len, a, ctl, ro, seq_start, idle_ticks, max_hops, stream);
 	switch (log2n * 100 + freq_len) {
 	case 907: return launch_res_t<9, 7>(a, ctl, ro, seq_start, idle_ticks, max_hops, stream);
@@ -1188,10 +1192,8 @@ bool rt_fused_available(int log2n, int freq_len)
 
 int launch_rt_fused(int log2n, int freq_len, const RtFusedArgs& a, hipStream_t stream)
 {
-	// single hops up to nfft 2048 (one or two wavefronts here): the frame over all four SIMDs of a CU (rt_hop_lat.hip).  At nfft
-	// 4096 this file's builds already run four wavefronts of sixteen values, and the shorter passes of the latency layout cost
-	// more instructions in total than they hide: 12.6-13.9 against 12.0 us per resident hop, measured.
-	if (a.n_frames == 1 && log2n <= HOP_LAT_MAX_LOG2N && !g_opt_no_hop_lat && !a.diag)
+	// single hops: the frame over all four SIMDs of a CU, two wavefronts per SIMD at the larger sizes (rt_hop_lat.hip)
+	if (hop_lat_takes(log2n, a))
 		return launch_rt_hop_lat(log2n, freq_len, a, stream);
 	switch (log2n * 100 + freq_len) {
 	case 907: return launch_t<9, 7>(a, stream);

@@ -7,12 +7,13 @@
 // (hop 1024: 3.9 us forward, 3.1 us inverse of a 10.2 us kernel, profiles/r05_rt_latency.jsonl).  Here, as in
 // rt_sse_lat.hip:
 //
-//   * lfft_dev.h's transform: 4 values per thread (128 to 512 threads: two wavefronts per SIMD at nfft 2048), one barrier per
-//     pass; the spectrum stays in the registers of the thread that owns the bin (idx = t + slot * TF) from the forward
-//     transform's last pass to the inverse transform's first;
+//   * lfft_dev.h's transform: 4 values per thread up to nfft 2048, 8 at nfft 4096 (128 to 512 threads: two wavefronts per
+//     SIMD at the two large sizes), one barrier per pass; the spectrum stays in the registers of the thread that owns the bin
+//     (idx = t + slot * TF) from the forward transform's last pass to the inverse transform's first;
 //   * |S| goes to an LDS row image of its own (median_net.h's chunk layout with the replicate border), the frequency-direction
-//     median reads it -- the sorting-network medians of median_net.h in chunks of four outputs, every thread busy -- and writes
-//     a P row; nothing aliases the frame images, so no barrier guards them;
+//     median reads it -- the sorting-network medians of median_net.h in chunks of four or eight outputs, every thread busy; at
+//     nfft 4096 with 47 taps the block scheme of median47_core.h on three of the eight wavefronts -- and writes a P row;
+//     nothing aliases the frame images, so no barrier guards them;
 //   * the hard masks by exact comparison (masks.h mask_value_thr), the causal time median is the identity (H = |S| of the same
 //     row);
 //   * every load that does not depend on this frame at the top (twiddles, window, previous hop, carries); a resident launch
@@ -21,13 +22,11 @@
 // Same arithmetic, same carry protocol, same rings as rt_fused.hip's single-hop builds: interchangeable call by call with them,
 // with block calls and with the three-kernel path.  Option "no_hop_lat" (zen_hip_set_option) selects rt_fused.hip's builds.
 //
-// Used up to nfft 2048 (hops 128 .. 512: per launch 15.7 / 16.3 -> 12.1-12.4 / 14.0 us at hop 256 / 512, resident 9.2-9.7 /
-// 10.9-11.4 -> 6.7-7.0 / 9.2-10.0 us).  At nfft 4096 rt_fused.hip's build already runs four wavefronts of sixteen values: eight
-// values on 512 threads (-DZEN_HOP_LAT_4096 builds and dispatches them, with the 47-tap block scheme of median47_core.h on three
-// of the eight wavefronts) make the forward transform faster (3.9 -> 2.7 us) but the masks, which that build folds into the first
-// pass of its inverse transform, are a step of their own here (0.9-1.4 us by the stamps; the inverse transform itself 2.3
-// against about 2.1 us, the same 820 instructions per SIMD): 16.6-17.1 against 16.7-17.0 us per launch, 12.2-12.8 against
-// 11.5-12.0 us per resident hop -- not dispatched.
+// Same box, profiles/r05_rt_latency*.jsonl and the A/B runs of DESIGN.md section 5: per launch 14.8 / 16.8 / 16.7-18.0 -> 10.5 /
+// 12.3 / 14.7-15.1 us at hop 256 / 512 / 1024, resident 10.1 / 11.4 / 11.8-12.3 -> 6.0-6.5 / 8.2-8.6 / 11.1-12.1 us.  The HARDP
+// builds (the percussive output alone, hard mask) matter: with every mask variant compiled in, the masks of a thread's four
+// bins took 0.9-1.1 us by the stamps (0.04-0.12 without them) and nfft 4096 was no faster than rt_fused.hip's build, which has
+// such a build of its own; at that size only the HARDP configuration is dispatched here (rt_fused.hip hop_lat_takes).
 #include "common.h"
 #include "lfft_dev.h"
 #include "masks.h"
@@ -103,6 +102,7 @@ struct HopFwdOut {
 		// the owner of bin k <= n/2 computes the double-precision hypot once and stores it for both bins.
 		if (lower || (slot == GEO::V / 2 && idx == (n >> 1))) {
 			const float m = zfft::cabs_exact(X.x, X.y); // complex_abs_functor hps.h:82-89
+			r->mag[slot] = m;
 			const int key = __float_as_int(m);          // |S| >= +0: the bits are the ordering key
 			const int mir = (idx == 0 || idx == (n >> 1)) ? idx : n - idx;
 			img[GEO::IM::addr(idx + GEO::MID_AL)] = key;
@@ -153,7 +153,10 @@ struct HopKeep { // what a resident launch keeps in registers from one hop to th
 	bool valid;
 };
 
-template <int LOG2N, int W, bool RESIDENT, class HV>
+// HARDP: the percussive output alone, hard mask by exact comparison (the realtime default, rt_fused.hip's HARDP builds): nothing
+// else is compiled in -- the other outputs' carries, the soft-mask and divide variants of every bin's mask are cold code threaded
+// through the hot path otherwise.
+template <int LOG2N, int W, bool RESIDENT, bool HARDP, class HV>
 __device__ __forceinline__ void rt_hop_lat_body(const RtFusedArgs& a, const unsigned bid, const HV& hv, const int t, const int ring_slot,
                                                 const zfft::LTwRegs<LOG2N, HopGeo<LOG2N, W>::LOG2V>& twr,
                                                 const float (&win)[HopGeo<LOG2N, W>::V / 2], HopKeep<HopGeo<LOG2N, W>::QV>& keep)
@@ -162,6 +165,7 @@ __device__ __forceinline__ void rt_hop_lat_body(const RtFusedArgs& a, const unsi
 	using PL = typename GEO::PL;
 	using IM = typename GEO::IM;
 	constexpr int N = GEO::N, V = GEO::V, TF = GEO::TF, QV = GEO::QV, LOG2V = GEO::LOG2V, T = GEO::T, MID = GEO::MID, MID_AL = GEO::MID_AL;
+	constexpr int NO = HARDP ? 1 : 3; // output ids that can be enabled
 	extern __shared__ float2 lds[]; // [two FFT images | magnitude image | P row | wave-edge records of the 47-tap scheme]
 	int* img = reinterpret_cast<int*>(lds + PL::LDS_FLOAT2);
 	float* Prow = reinterpret_cast<float*>(img + GEO::IMG_WORDS);
@@ -200,7 +204,7 @@ __device__ __forceinline__ void rt_hop_lat_body(const RtFusedArgs& a, const unsi
 			}
 		}
 #pragma unroll
-		for (int o = 0; o < 3; ++o) {
+		for (int o = 0; o < NO; ++o) {
 			if (!a.carry[o]) {
 #pragma unroll
 				for (int i = 0; i < QV; ++i)
@@ -253,7 +257,7 @@ __device__ __forceinline__ void rt_hop_lat_body(const RtFusedArgs& a, const unsi
 	}
 	if (hv.prev_frames() > 0) {
 #pragma unroll
-		for (int o = 0; o < 3; ++o) {
+		for (int o = 0; o < NO; ++o) {
 			if (!a.carry[o])
 				continue;
 #pragma unroll
@@ -318,9 +322,10 @@ __device__ __forceinline__ void rt_hop_lat_body(const RtFusedArgs& a, const unsi
 				*reinterpret_cast<int4*>(&Prow[ch * T + 4 * v]) = make_int4(out[4 * v], out[4 * v + 1], out[4 * v + 2], out[4 * v + 3]);
 		}
 	}
-	// the thread's own magnitudes back from the image (the upper half of the row was written by the owners of the lower)
+	// the magnitudes of the thread's upper-half bins from the image (written by the owners of their mirror bins; the lower half
+	// is in registers since the forward transform)
 #pragma unroll
-	for (int slot = 0; slot < V; ++slot)
+	for (int slot = V / 2; slot < V; ++slot)
 		r.mag[slot] = __int_as_float(img[IM::addr(t + slot * TF + MID_AL)]);
 	__syncthreads(); // P row complete
 	stamp(3);
@@ -345,32 +350,34 @@ __device__ __forceinline__ void rt_hop_lat_body(const RtFusedArgs& a, const unsi
 		pv[slot] = Prow[pi];
 	}
 	stamp(4);
-	for (int oi = 0; oi < a.n_out; ++oi) {
-		const int which = a.out_id[oi];
+	for (int oi = 0; oi < (HARDP ? 1 : a.n_out); ++oi) {
+		const int which = HARDP ? 0 : a.out_id[oi];
 		float* ready = (a.ready[which]) ? a.ready[which] + (long long)s * hop : nullptr;
 		{
 			// the mask of every bin (mask_value_thr), the kind of mask decided once per output and not once per bin: the hard masks by
 			// exact comparison are a handful of instructions each, the cold variants stay out of their way
 			float2 v[V]; // S * mask (apply_mask_functor hps.h:58-66)
-			if (which == 0 && !a.soft && a.thr != 0.0) {
+			if (HARDP || (which == 0 && !a.soft && a.thr != 0.0)) {
 #pragma unroll
 				for (int i = 0; i < V; ++i) {
 					const float m = hard_mask_exact(pv[i], r.mag[i] + FLT_EPSILON, a.thr); // hps.cu:501-505
 					v[i] = make_float2(r.S[i].x * m, r.S[i].y * m);
 				}
 			}
-			else if (which == 1 && !a.soft && a.thr_h != 0.0) {
+			else if constexpr (!HARDP) {
+				if (which == 1 && !a.soft && a.thr_h != 0.0) {
 #pragma unroll
-				for (int i = 0; i < V; ++i) {
-					const float m = hard_mask_exact(r.mag[i], pv[i] + FLT_EPSILON, a.thr_h); // hps.cu:535-540
-					v[i] = make_float2(r.S[i].x * m, r.S[i].y * m);
+					for (int i = 0; i < V; ++i) {
+						const float m = hard_mask_exact(r.mag[i], pv[i] + FLT_EPSILON, a.thr_h); // hps.cu:535-540
+						v[i] = make_float2(r.S[i].x * m, r.S[i].y * m);
+					}
 				}
-			}
-			else {
+				else {
 #pragma unroll
-				for (int i = 0; i < V; ++i) {
-					const float m = mask_value_thr(which, r.mag[i], pv[i], cfg, thr);
-					v[i] = make_float2(r.S[i].x * m, r.S[i].y * m);
+					for (int i = 0; i < V; ++i) {
+						const float m = mask_value_thr(which, r.mag[i], pv[i], cfg, thr);
+						v[i] = make_float2(r.S[i].x * m, r.S[i].y * m);
+					}
 				}
 			}
 			stamp(6);
@@ -378,7 +385,7 @@ __device__ __forceinline__ void rt_hop_lat_body(const RtFusedArgs& a, const unsi
 			float cw[QV], kp[QV];
 #pragma unroll
 			for (int i = 0; i < QV; ++i)
-				cw[i] = which == 0 ? cvp[i] : (which == 1 ? cvh[i] : cvr[i]);
+				cw[i] = (HARDP || which == 0) ? cvp[i] : (which == 1 ? cvh[i] : cvr[i]);
 			HopInvOut<V> out;
 			out.Y = a.Y[which] + (long long)s * a.y_stream_stride;
 			out.cola = a.cola;
@@ -431,7 +438,7 @@ __device__ __forceinline__ void hop_window(const float* __restrict__ window, int
 	}
 }
 
-template <int LOG2N, int W>
+template <int LOG2N, int W, bool HARDP>
 __global__ __launch_bounds__((HopGeo<LOG2N, W>::TF)) void rt_hop_lat_kernel(RtFusedArgs a)
 {
 	using GEO = HopGeo<LOG2N, W>;
@@ -443,12 +450,12 @@ __global__ __launch_bounds__((HopGeo<LOG2N, W>::TF)) void rt_hop_lat_kernel(RtFu
 	HopKeep<GEO::QV> keep;
 	keep.valid = false;
 	// (the ring slot of the frame: one 64-bit remainder per call, scalar, behind the loads above)
-	rt_hop_lat_body<LOG2N, W, false>(a, blockIdx.x, HopOfArgs{a}, t, (int)(a.row0 % a.ring_rows), twr, win, keep);
+	rt_hop_lat_body<LOG2N, W, false, HARDP>(a, blockIdx.x, HopOfArgs{a}, t, (int)(a.row0 % a.ring_rows), twr, win, keep);
 }
 
 // The same body inside a kernel that stays on its CU between the hops of a stream (rt_fused.hip rt_fused_resident_kernel:
 // mailbox, idle time-out, exit word; hpr.hip resident_*).
-template <int LOG2N, int W>
+template <int LOG2N, int W, bool HARDP>
 __global__ __launch_bounds__((HopGeo<LOG2N, W>::TF)) void rt_hop_lat_resident_kernel(RtFusedArgs a0, const ResidentCtl* ctl, ResidentOut* ro,
                                                                                     unsigned seq_start, unsigned long long idle_ticks,
                                                                                     unsigned max_hops)
@@ -480,7 +487,7 @@ __global__ __launch_bounds__((HopGeo<LOG2N, W>::TF)) void rt_hop_lat_resident_ke
 		// in registers, rt_sse.hip)
 		int t_o = t;
 		asm volatile("" : "+v"(t_o));
-		rt_hop_lat_body<LOG2N, W, true, HopVar>(a0, 0u, hv, t_o, ring_slot, twr, win, keep);
+		rt_hop_lat_body<LOG2N, W, true, HARDP, HopVar>(a0, 0u, hv, t_o, ring_slot, twr, win, keep);
 		__syncthreads();
 		last = sq;
 		++k;
@@ -494,7 +501,14 @@ int launch_hop_t(const RtFusedArgs& a, hipStream_t stream)
 {
 	using GEO = HopGeo<LOG2N, W>;
 	const size_t lds = GEO::LDS_BYTES;
-	auto kern = rt_hop_lat_kernel<LOG2N, W>;
+	const bool hardp = a.n_out == 1 && a.out_id[0] == 0 && !a.soft && a.thr != 0.0;
+	auto kern = rt_hop_lat_kernel<LOG2N, W, true>;
+	if constexpr (LOG2N < 12) { // (nfft 4096: only the HARDP build exists, rt_fused.hip hop_lat_takes)
+		if (!hardp)
+			kern = rt_hop_lat_kernel<LOG2N, W, false>;
+	}
+	else if (!hardp)
+		ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "rt_hop_lat: nfft 4096 is built for the percussive output with a hard mask alone");
 	if (lds > 60 * 1024)
 		ZH_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	hipLaunchKernelGGL(kern, dim3((unsigned)a.n_streams), dim3(GEO::TF), lds, stream, a);
@@ -508,7 +522,14 @@ int launch_hop_res_t(const RtFusedArgs& a, const ResidentCtl* ctl, ResidentOut* 
 {
 	using GEO = HopGeo<LOG2N, W>;
 	const size_t lds = GEO::LDS_BYTES + 16;
-	auto kern = rt_hop_lat_resident_kernel<LOG2N, W>;
+	const bool hardp = a.n_out == 1 && a.out_id[0] == 0 && !a.soft && a.thr != 0.0;
+	auto kern = rt_hop_lat_resident_kernel<LOG2N, W, true>;
+	if constexpr (LOG2N < 12) {
+		if (!hardp)
+			kern = rt_hop_lat_resident_kernel<LOG2N, W, false>;
+	}
+	else if (!hardp)
+		ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "rt_hop_lat: nfft 4096 is built for the percussive output with a hard mask alone");
 	if (lds > 60 * 1024)
 		ZH_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	hipLaunchKernelGGL(kern, dim3(1), dim3(GEO::TF), lds, stream, a, ctl, ro, seq_start, idle_ticks, max_hops);
@@ -529,10 +550,8 @@ int launch_rt_hop_lat(int log2n, int freq_len, const RtFusedArgs& a, hipStream_t
 	case 1013: return launch_hop_t<10, 13>(a, stream);
 	case 1121: return launch_hop_t<11, 21>(a, stream);
 	case 1123: return launch_hop_t<11, 23>(a, stream);
-#ifdef ZEN_HOP_LAT_4096 // (measured slower than rt_fused.hip's builds at this size: not dispatched, not built)
 	case 1243: return launch_hop_t<12, 43>(a, stream);
 	case 1247: return launch_hop_t<12, 47>(a, stream);
-#endif
 	default: ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "no single-hop kernel for nfft 2^%d, mask %d", log2n, freq_len);
 	}
 }
@@ -546,10 +565,8 @@ int launch_rt_hop_lat_resident(int log2n, int freq_len, const RtFusedArgs& a, co
 	case 1013: return launch_hop_res_t<10, 13>(a, ctl, ro, seq_start, idle_ticks, max_hops, stream);
 	case 1121: return launch_hop_res_t<11, 21>(a, ctl, ro, seq_start, idle_ticks, max_hops, stream);
 	case 1123: return launch_hop_res_t<11, 23>(a, ctl, ro, seq_start, idle_ticks, max_hops, stream);
-#ifdef ZEN_HOP_LAT_4096
 	case 1243: return launch_hop_res_t<12, 43>(a, ctl, ro, seq_start, idle_ticks, max_hops, stream);
 	case 1247: return launch_hop_res_t<12, 47>(a, ctl, ro, seq_start, idle_ticks, max_hops, stream);
-#endif
 	default: ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "no resident single-hop kernel for nfft 2^%d, mask %d", log2n, freq_len);
 	}
 }
