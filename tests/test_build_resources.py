@@ -134,7 +134,7 @@ def test_latency_layout_kernels(usage):
     sse = usage["rt_sse_lat.hip"]
     hop = usage["rt_hop_lat.hip"]
     assert sum("rt_sse_lat_kernel" in n for n in sse) == 4 and sum("rt_sse_lat_resident_kernel" in n for n in sse) == 4
-    # five sizes up to nfft 2048 with and without the HARDP specialisation, the two nfft-4096 shapes as HARDP builds only
-    assert sum("rt_hop_lat_kernel" in n for n in hop) == 12 and sum("rt_hop_lat_resident_kernel" in n for n in hop) == 12
+    # seven (transform size, mask) shapes with and without the HARDP specialisation
+    assert sum("rt_hop_lat_kernel" in n for n in hop) == 14 and sum("rt_hop_lat_resident_kernel" in n for n in hop) == 14
     for name, k in list(sse.items()) + list(hop.items()):
         assert k["scratch"] == 0, (name, k)

@@ -61,6 +61,8 @@ mkdir -p /tmp/ub
 g++ -O2 -std=c++17 -I include tools/rt_latency.cpp -o /tmp/ub/rt -L zen_amd -lzen_hip -Wl,-rpath,$PWD/zen_amd && { /tmp/ub/rt 3000 --stamps; ZEN_RT_RESIDENT=100 /tmp/ub/rt 3000; } > $OUT/rt_latency.jsonl 2>&1
 # the single-hop kernels of rounds 1-4 (rt_fused.hip / rt_sse.hip single-hop builds) on the same box, for the latency layout's A/B
 { ZEN_RT_OPT=no_sse_lat=1,no_hop_lat=1 /tmp/ub/rt 3000 --stamps; ZEN_RT_OPT=no_sse_lat=1,no_hop_lat=1 ZEN_RT_RESIDENT=100 /tmp/ub/rt 3000; } > $OUT/rt_latency_round4_kernels.jsonl 2>&1
+# the harmonic output alone (the single-hop builds that carry every mask variant), both generations of kernels
+{ ZEN_RT_OUTPUT=H /tmp/ub/rt 3000; ZEN_RT_OUTPUT=H ZEN_RT_RESIDENT=100 /tmp/ub/rt 3000; echo '{"option": "no_sse_lat=1,no_hop_lat=1"}'; ZEN_RT_OUTPUT=H ZEN_RT_OPT=no_sse_lat=1,no_hop_lat=1 /tmp/ub/rt 3000; ZEN_RT_OUTPUT=H ZEN_RT_OPT=no_sse_lat=1,no_hop_lat=1 ZEN_RT_RESIDENT=100 /tmp/ub/rt 3000; } > $OUT/rt_latency_harmonic.jsonl 2>&1
 tools/bin/probe_pcie 2048 > $OUT/probe_pcie.json 2>&1
 tools/bin/ubench_rowwrite > $OUT/ubench_rowwrite.jsonl 2>&1
 tools/bin/ubench_copy --json > $OUT/ubench_copy.json 2>&1

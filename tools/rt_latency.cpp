@@ -4,7 +4,7 @@
 // Arguments: [hops per configuration, default 2000] [--stamps: also print the phase stamps of one single-hop kernel
 // of every kind].  Environment: ZEN_RT_RESIDENT=<idle ms>: the per-hop calls go through the resident kernel
 // (zen_hip_hpr_set_resident; every hop of the median path and SSE hop 512, "resident": 1 in their lines; with --stamps: the
-// phase stamps are then those of a resident hop); ZEN_RT_OPT="name=value,..." (zen_hip_set_option), ZEN_RT_ONLY_SSE=1 (only the SSE configurations), ZEN_RT_DIAG=<n> (sets the library's
+// phase stamps are then those of a resident hop); ZEN_RT_OPT="name=value,..." (zen_hip_set_option), ZEN_RT_OUTPUT=H (the harmonic output), ZEN_RT_ONLY_SSE=1 (only the SSE configurations), ZEN_RT_DIAG=<n> (sets the library's
 // "rt_fused_diag" option: timing diagnostics, results not valid; 4 = agent-scope grid barriers in rt_wide.hip).
 //   g++ -O2 -std=c++17 -I include tools/rt_latency.cpp -o /tmp/rt_latency -L zen_amd -lzen_hip -Wl,-rpath,$PWD/zen_amd
 #include <chrono>
@@ -50,13 +50,15 @@ int main(int argc, char** argv)
 			pos = end + 1;
 		}
 	}
+	// ZEN_RT_OUTPUT=H: the harmonic output instead of the percussive one (the single-hop builds that carry every mask variant)
+	const int out_flag = (std::getenv("ZEN_RT_OUTPUT") && std::getenv("ZEN_RT_OUTPUT")[0] == 'H') ? ZEN_HIP_OUTPUT_HARMONIC : ZEN_HIP_OUTPUT_PERCUSSIVE;
 	const bool only_sse = std::getenv("ZEN_RT_ONLY_SSE") != nullptr;
 	for (int sse = only_sse ? 1 : 0; sse < 2; ++sse) {
 		for (size_t hop : {256, 512, 1024, 2048, 4096}) {
 			if (sse && hop != 512 && hop != 1024 && hop != 2048)
 				continue;
 			zen_hip_hpr_t h = nullptr;
-			CK(zen_hip_hpr_create(44100.f, hop, 2.0f, ZEN_HIP_OUTPUT_PERCUSSIVE, ZEN_HIP_TIME_CAUSAL, 1, 1, 64, &h));
+			CK(zen_hip_hpr_create(44100.f, hop, 2.0f, out_flag, ZEN_HIP_TIME_CAUSAL, 1, 1, 64, &h));
 			if (sse)
 				CK(zen_hip_hpr_use_sse_filter(h));
 			const int resident_ms = std::getenv("ZEN_RT_RESIDENT") ? std::atoi(std::getenv("ZEN_RT_RESIDENT")) : 0;
@@ -82,7 +84,7 @@ int main(int argc, char** argv)
 				std::memcpy(hin, src, hop * 4);
 				CK(zen_hip_hpr_process_next_hop(h, (const float*)din));
 				const double t1 = now_us();
-				CK(zen_hip_hpr_copy_output(h, ZEN_HIP_OUTPUT_PERCUSSIVE, (float*)dout));
+				CK(zen_hip_hpr_copy_output(h, out_flag, (float*)dout));
 				const double t2 = now_us();
 				std::memcpy(y.data(), hout, hop * 4);
 				const double t3 = now_us();
@@ -98,7 +100,7 @@ int main(int argc, char** argv)
 				std::memcpy(hin, x.data(), hop * 4);
 				for (int rep = 0; rep < 3; ++rep) {
 					CK(zen_hip_hpr_process_next_hop(h, (const float*)din));
-					CK(zen_hip_hpr_copy_output(h, ZEN_HIP_OUTPUT_PERCUSSIVE, (float*)dout));
+					CK(zen_hip_hpr_copy_output(h, out_flag, (float*)dout));
 				}
 				{ // the stamps are written after the flag the copy call waits for
 					const double t0 = now_us();
@@ -115,7 +117,7 @@ int main(int argc, char** argv)
 				std::memcpy(hin, x.data(), hop * 4);
 				for (int rep = 0; rep < 3; ++rep) {
 					CK(zen_hip_hpr_process_next_hop(h, (const float*)din));
-					CK(zen_hip_hpr_copy_output(h, ZEN_HIP_OUTPUT_PERCUSSIVE, (float*)dout));
+					CK(zen_hip_hpr_copy_output(h, out_flag, (float*)dout));
 				}
 				{
 					const double t0 = now_us();
@@ -134,7 +136,7 @@ int main(int argc, char** argv)
 				std::memcpy(hin, x.data(), hop * 4);
 				for (int rep = 0; rep < 3; ++rep) {
 					CK(zen_hip_hpr_process_next_hop(h, (const float*)din));
-					CK(zen_hip_hpr_copy_output(h, ZEN_HIP_OUTPUT_PERCUSSIVE, (float*)dout));
+					CK(zen_hip_hpr_copy_output(h, out_flag, (float*)dout));
 				}
 				{ // the stamps are written after the flag the copy call waits for
 					const double t0 = now_us();

@@ -32,14 +32,10 @@ namespace {
 
 using zfft::Plan;
 
-// which single hops go to rt_hop_lat.hip (launch_rt_fused, launch_rt_fused_resident): everything up to nfft 2048; at nfft 4096
-// the percussive output with a hard mask (the realtime default: its HARDP build there), not the builds that carry every mask
-// variant (measured no faster than this file's at that size)
+// which single hops go to rt_hop_lat.hip (launch_rt_fused, launch_rt_fused_resident): all of them, unless option "no_hop_lat"
 inline bool hop_lat_takes(int log2n, const RtFusedArgs& a)
 {
-	if (a.n_frames != 1 || g_opt_no_hop_lat || a.diag)
-		return false;
-	return log2n <= 11 || (log2n == 12 && a.n_out == 1 && a.out_id[0] == 0 && !a.soft && a.thr != 0.0);
+	return a.n_frames == 1 && log2n <= 12 && !g_opt_no_hop_lat && !a.diag;
 }
 
 // LDS row image of the median stage: T-word chunks spaced T+PAD apart (see median_net.hip RowImage)

@@ -22,11 +22,14 @@
 // Same arithmetic, same carry protocol, same rings as rt_fused.hip's single-hop builds: interchangeable call by call with them,
 // with block calls and with the three-kernel path.  Option "no_hop_lat" (zen_hip_set_option) selects rt_fused.hip's builds.
 //
-// Same box, profiles/r05_rt_latency*.jsonl and the A/B runs of DESIGN.md section 5: per launch 14.8 / 16.8 / 16.7-18.0 -> 10.5 /
-// 12.3 / 14.7-15.1 us at hop 256 / 512 / 1024, resident 10.1 / 11.4 / 11.8-12.3 -> 6.0-6.5 / 8.2-8.6 / 11.1-12.1 us.  The HARDP
-// builds (the percussive output alone, hard mask) matter: with every mask variant compiled in, the masks of a thread's four
-// bins took 0.9-1.1 us by the stamps (0.04-0.12 without them) and nfft 4096 was no faster than rt_fused.hip's build, which has
-// such a build of its own; at that size only the HARDP configuration is dispatched here (rt_fused.hip hop_lat_takes).
+// Same box, profiles/r05_rt_latency*.jsonl and the A/B runs of DESIGN.md section 5: per launch 14.4 / 16.1 / 16.6-18.0 -> 10.4-10.9 /
+// 12.3-12.6 / 14.7-15.5 us at hop 256 / 512 / 1024, resident 9.2-10.1 / 10.7-11.4 / 11.7-12.3 -> 6.0-6.7 / 8.2-8.8 / 11.1-12.1 us.
+// Two things about the masks mattered as much as the layout.  The HARDP builds (the percussive output alone, hard mask: the
+// realtime default) have nothing else in them.  And in the builds that carry every variant the masks must not be
+// loop-invariant: |S| and P do not change from one output to the next, so the compiler computed the masks of EVERY kind in
+// front of the output loop -- the divisions of the variants nobody asked for included, 600 instructions per thread,
+// 0.9-1.1 us by the stamps -- and chose by selects; an empty asm on the inputs inside the loop keeps each variant in its
+// branch (harmonic output: 13.1-13.3 -> 12.5-12.8 us per call at hop 512, resident 9.1-9.2 -> 8.5-8.8).
 #include "common.h"
 #include "lfft_dev.h"
 #include "masks.h"
@@ -357,6 +360,14 @@ __device__ __forceinline__ void rt_hop_lat_body(const RtFusedArgs& a, const unsi
 			// the mask of every bin (mask_value_thr), the kind of mask decided once per output and not once per bin: the hard masks by
 			// exact comparison are a handful of instructions each, the cold variants stay out of their way
 			float2 v[V]; // S * mask (apply_mask_functor hps.h:58-66)
+			if constexpr (!HARDP) {
+				// (opaque per output: |S| and P do not change from one output to the next, so the masks of EVERY kind -- the
+				// divisions of the variants nobody asked for included -- were computed in front of the loop and chosen by
+				// selects: 600 instructions per thread, 0.9-1.1 us, where the branch taken needs 30)
+#pragma unroll
+				for (int i = 0; i < V; ++i)
+					asm volatile("" : "+v"(r.mag[i]), "+v"(pv[i]));
+			}
 			if (HARDP || (which == 0 && !a.soft && a.thr != 0.0)) {
 #pragma unroll
 				for (int i = 0; i < V; ++i) {
@@ -502,13 +513,7 @@ int launch_hop_t(const RtFusedArgs& a, hipStream_t stream)
 	using GEO = HopGeo<LOG2N, W>;
 	const size_t lds = GEO::LDS_BYTES;
 	const bool hardp = a.n_out == 1 && a.out_id[0] == 0 && !a.soft && a.thr != 0.0;
-	auto kern = rt_hop_lat_kernel<LOG2N, W, true>;
-	if constexpr (LOG2N < 12) { // (nfft 4096: only the HARDP build exists, rt_fused.hip hop_lat_takes)
-		if (!hardp)
-			kern = rt_hop_lat_kernel<LOG2N, W, false>;
-	}
-	else if (!hardp)
-		ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "rt_hop_lat: nfft 4096 is built for the percussive output with a hard mask alone");
+	auto kern = hardp ? rt_hop_lat_kernel<LOG2N, W, true> : rt_hop_lat_kernel<LOG2N, W, false>;
 	if (lds > 60 * 1024)
 		ZH_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	hipLaunchKernelGGL(kern, dim3((unsigned)a.n_streams), dim3(GEO::TF), lds, stream, a);
@@ -523,13 +528,7 @@ int launch_hop_res_t(const RtFusedArgs& a, const ResidentCtl* ctl, ResidentOut* 
 	using GEO = HopGeo<LOG2N, W>;
 	const size_t lds = GEO::LDS_BYTES + 16;
 	const bool hardp = a.n_out == 1 && a.out_id[0] == 0 && !a.soft && a.thr != 0.0;
-	auto kern = rt_hop_lat_resident_kernel<LOG2N, W, true>;
-	if constexpr (LOG2N < 12) {
-		if (!hardp)
-			kern = rt_hop_lat_resident_kernel<LOG2N, W, false>;
-	}
-	else if (!hardp)
-		ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "rt_hop_lat: nfft 4096 is built for the percussive output with a hard mask alone");
+	auto kern = hardp ? rt_hop_lat_resident_kernel<LOG2N, W, true> : rt_hop_lat_resident_kernel<LOG2N, W, false>;
 	if (lds > 60 * 1024)
 		ZH_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	hipLaunchKernelGGL(kern, dim3(1), dim3(GEO::TF), lds, stream, a, ctl, ro, seq_start, idle_ticks, max_hops);
