@@ -20,12 +20,12 @@ OUT=gpurun_out/${TAG}_fuzz_summary.txt
   echo " interiors, zen_hip_memcheck after every case)"
 } > $OUT
 RC=0
-for seed in 501 502 503; do
+for seed in ${FUZZ_SEEDS:-501 502 503}; do   # (FUZZ_SEEDS / FUZZ_OFFLINE_SEEDS: other seeds, for an extra run under another tag)
   L=$(python3 tools/fuzz_parity.py --seconds $SECS --seed $seed 2>&1 | tail -3 | tr '\n' ' ')
   echo "seed $seed ($SECS s):            $L" >> $OUT
   case "$L" in *"mismatches 0"*"memcheck clean"*) ;; *) RC=1;; esac
 done
-for seed in 511 512 513; do
+for seed in ${FUZZ_OFFLINE_SEEDS:-511 512 513}; do
   L=$(python3 tools/fuzz_parity.py --offline --seconds $SECS --seed $seed 2>&1 | tail -3 | tr '\n' ' ')
   echo "seed $seed (--offline, $SECS s): $L" >> $OUT
   case "$L" in *"mismatches 0"*"memcheck clean"*) ;; *) RC=1;; esac
