@@ -52,7 +52,12 @@ FILE_FLAGS = {"rt_fused.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mll
               "stft.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
               "sse_block.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
               "median_big.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-minreg"],
-              "rt_wide.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-minreg"]}
+              "rt_wide.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-minreg"],
+              # the latency-layout single-hop kernels (round 5; tools/ab_lat_flags.sh, same box, shipped build before and after):
+              # resident hop 256 / 512 / 1024 6.3-6.5 / 8.4-8.7 / 11.1-11.6 -> 5.6 / 7.8 / 11.0 us, SSE hop 512 11.1-11.4 -> 10.6;
+              # per launch 0.1-0.4 us.  max-ilp alone: about half of that.
+              "rt_hop_lat.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-amdgpu-use-amdgpu-trackers=1"],
+              "rt_sse_lat.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-amdgpu-use-amdgpu-trackers=1"]}
 FILE_FLAGS_ENV = os.environ.get("ZEN_HIP_FILE_FLAGS", "")   # A/B hook: "median_net.hip=-mllvm,-amdgpu-sched-strategy=max-ilp"
 for _item in filter(None, FILE_FLAGS_ENV.split(";")):
     _name, _, _fl = _item.partition("=")
