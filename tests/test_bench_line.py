@@ -58,3 +58,20 @@ def test_compact_line_without_legs_and_at_several_ranks():
     line = b.compact_line(many)                                # --gpus 8: the sharded figure where the record keeps it
     assert line["config"]["offline_batch_sharded_x_realtime"] == 2.0e6
     assert line["config"]["offline_batch_sharded_ranks_reported"] == 8 and line["config"]["offline_batch_sharded_clips_total"] == 512
+
+
+def test_compact_line_of_round_5_carries_the_per_hop_sweep():
+    """Round 5: the per-hop call of the reference's API at the other hops of its sweep and on the SSE path (BASELINE configs[4],
+    hop 512) inside `config`, per launch and with the resident kernel -- from the full record of the round's final collection."""
+    b = bench()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_default.json")))
+    line = b.compact_line(full)
+    assert len(json.dumps(line)) < 6000
+    cfg = line["config"]
+    for key in ("per_hop_api_us_by_hop", "per_hop_api_resident_us_by_hop"):
+        assert set(cfg[key]) == {"256", "512", "2048", "4096", "sse_512"}, cfg[key]
+        assert all(0 < v < 100 for v in cfg[key].values())
+    assert cfg["per_hop_api_resident_us_by_hop"]["sse_512"] < 15.0          # VERDICT r4's target for the resident SSE hop
+    assert cfg["per_hop_api_resident_us_by_hop"]["2048"] < 30.0 and cfg["per_hop_api_resident_us_by_hop"]["4096"] < 40.0
+    recorded = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_default_line.json")))
+    assert recorded["config"]["per_hop_api_us_by_hop"] == cfg["per_hop_api_us_by_hop"]
