@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential test: HIP engine vs CPU oracle on random configurations (sample rate, hop, output
 flags, causality, mask type, blocking, streams).  Test infrastructure; run on the GPU box:
-    python tools/fuzz_parity.py --seconds 120 --seed 1
+    python tools/fuzz_parity.py --seconds 120 --seed 1          (--offline: the two-pass driver; --resident: the per-hop API)
 Prints every mismatch with its configuration and exits non-zero if there was one."""
 import argparse
 import os
@@ -173,6 +173,81 @@ def run_offline(seconds, seed):
     return n_ok, n_bad, n_skip, len(seen)
 
 
+def run_resident(seconds, seed):
+    """The per-hop API of the reference (HPRRealtime::process_next_hop + copy_* through IOGPU, zen/fakert.h:221-247) with the
+    resident kernels (zen_hip_hpr_set_resident): random sample rate, hop, output, mask, idle time-out, pauses longer than it,
+    resets, per-launch hops and block calls in between.  Returns (ok, mismatches, skipped, distinct configurations)."""
+    rng = np.random.default_rng(seed)
+    zen_amd.init(0)
+    t_end = time.time() + seconds
+    n_ok = n_bad = n_skip = 0
+    seen = set()
+    while time.time() < t_end:
+        fs = float(rng.choice([8000, 11025, 16000, 22050, 24000, 32000, 44100, 48000, 88200, 96000]))
+        hop = int(rng.choice([128, 256, 512, 1024, 2048, 4096]))
+        beta = float(rng.choice([1.5, 2.0, 2.5, 3.0]))
+        key, flag = [("P", o.OUTPUT_PERCUSSIVE), ("H", o.OUTPUT_HARMONIC), ("R", o.OUTPUT_RESIDUAL)][int(rng.integers(0, 3))]
+        mode = str(rng.choice(["hard", "hard", "soft", "sse"]))
+        if mode == "sse" and key == "R":
+            key, flag = "P", o.OUTPUT_PERCUSSIVE                  # (the SSE path has no residual, hps.cu:582-652)
+        try:
+            ho = o.HPR(fs, hop, beta, flag, o.TIME_CAUSAL)
+        except Exception:
+            n_skip += 1
+            continue
+        if (ho.l_perc | 1) > 255 or (ho.stft_width | 1) > 255:
+            n_skip += 1
+            continue
+        if mode == "soft":
+            ho.use_soft_mask()
+        if mode == "sse":
+            ho.use_sse_filter()
+        n_hops = int(rng.integers(20, 60 if hop <= 1024 else 30))
+        x = rng.uniform(-1, 1, hop * n_hops).astype(np.float32)
+        x *= (rng.uniform(0, 1, x.shape) < 0.7)
+        ref = ho.process_stream(x)[key]
+        try:
+            io = zen_amd.IOGPU(hop)
+            rt = zen_amd.HPRRealtime(fs, hop, beta, flag)
+        except Exception:
+            n_skip += 1
+            continue
+        if mode == "soft":
+            rt.use_soft_mask()
+        if mode == "sse":
+            rt.use_sse_filter()
+        copy = {"P": rt.copy_percussive, "H": rt.copy_harmonic, "R": rt.copy_residual}[key]
+        eng = rt.p_impl
+        idle_ms = int(rng.choice([2, 5, 50, 200]))
+        eng.set_resident(idle_ms)
+        out = np.zeros_like(x)
+        i = 0
+        while i < n_hops:
+            what = int(rng.integers(0, 12))
+            if what == 0 and i + 3 <= n_hops:                    # a block call in mid-stream (the kernel goes home first)
+                blk = eng.process_stream_host(x[i * hop:(i + 3) * hop])[key]
+                out[i * hop:(i + 3) * hop] = blk
+                i += 3
+                continue
+            if what == 1:
+                eng.set_resident(0 if rng.integers(0, 2) else idle_ms)   # per-launch hops for a while, or back
+            if what == 2:
+                time.sleep(idle_ms / 1e3 * 2.5)                   # longer than the idle time-out: the kernel leaves
+            io.host_in[:] = x[i * hop:(i + 1) * hop]
+            rt.process_next_hop(io.device_in)
+            copy(io.device_out)
+            out[i * hop:(i + 1) * hop] = io.host_out
+            i += 1
+        seen.add((fs, hop, key, mode))
+        if np.array_equal(out, ref, equal_nan=True):
+            n_ok += 1
+        else:
+            n_bad += 1
+            print("MISMATCH resident", dict(fs=fs, hop=hop, beta=beta, out=key, mode=mode, idle_ms=idle_ms, n_hops=n_hops), flush=True)
+        del rt, eng, io
+    return n_ok, n_bad, n_skip, len(seen)
+
+
 def memcheck_line():
     """Red zones (ZEN_HIP_REDZONE, set by tools/fuzz_final.sh) of everything still alive, plus what the frees found."""
     r = zen_amd.memcheck()
@@ -188,7 +263,13 @@ def main():
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--offline", action="store_true", help="fuzz the two-pass offline driver instead of the streaming engine")
+    ap.add_argument("--resident", action="store_true", help="fuzz the per-hop API with the resident kernels (zen_hip_hpr_set_resident)")
     args = ap.parse_args()
+    if args.resident:
+        n_ok, n_bad, n_skip, n_seen = run_resident(args.seconds, args.seed)
+        mc, bad = memcheck_line()
+        print("resident: ok %d  mismatches %d  skipped %d  distinct (fs, hop, output, mode): %d  %s" % (n_ok, n_bad, n_skip, n_seen, mc))
+        return 1 if n_bad or bad else 0
     if args.offline:
         n_ok, n_bad, n_skip, n_seen = run_offline(args.seconds, args.seed)
         mc, bad = memcheck_line()
