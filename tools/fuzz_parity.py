@@ -16,14 +16,17 @@ from oracle import oracle as o  # noqa: E402
 
 
 def run(seconds, seed):
-    """Returns (ok, mismatches, skipped, distinct configurations)."""
+    """Returns (ok, mismatches, skipped, refused, distinct configurations).  `skipped`: the ORACLE's constructor threw (a
+    configuration the reference rejects or cannot run: l_harm or l_perc rounds to 0, a mask longer than its dimension);
+    `refused`: the oracle accepted and the GPU engine did not -- counted as a failure."""
     rng = np.random.default_rng(seed)
     zen_amd.init(0)
     t_end = time.time() + seconds
-    n_ok = n_bad = n_skip = 0
+    n_ok = n_bad = n_skip = n_refused = 0
     seen = set()
     while time.time() < t_end:
-        fs = float(rng.choice([2000, 3000, 4000, 8000, 11025, 16000, 22050, 24000, 32000, 44100, 48000, 88200, 96000]))
+        fs = float(rng.choice([2000, 3000, 4000, 8000, 11025, 16000, 22050, 24000, 31000, 32000, 44100, 48000, 64000, 88200, 96000,
+                               128000]))
         hop = int(rng.choice([32, 64, 128, 256, 512, 1024, 2048, 4096]))
         beta = float(rng.choice([1.5, 2.0, 2.5, 3.0]))
         flags = int(rng.integers(1, 8))
@@ -37,12 +40,13 @@ def run(seconds, seed):
             continue
         time_len = h.l_harm | 1 if not causal else h.stft_width | 1     # odd mask lengths (mfilt.h:89)
         freq_len = h.l_perc | 1
-        if freq_len > 255 or time_len > 255:
-            n_skip += 1
-            continue
         n_hops = int(min(max(2 * h.stft_width + 5, 12), 40 if hop >= 2048 else 400))
         if hop * n_hops * h.stft_width > 3e7:       # keep the oracle (O(W) work per hop) quick
             n_hops = max(6, int(3e7 / (hop * h.stft_width)))
+        # (the oracle filters the whole sliding matrix every hop, a sliding insertion per sample: ~W nfft (mt + mf) / 2 per hop)
+        per_hop = h.stft_width * 4 * hop * ((h.l_harm | 1) + freq_len) / 2
+        if per_hop * n_hops > 3e9:
+            n_hops = max(6, int(3e9 / per_hop), (0 if causal else h.l_harm + 6))   # (anticausal: past the lag, or all is zeros)
         x = rng.uniform(-1, 1, (streams, hop * n_hops)).astype(np.float32)
         x *= (rng.uniform(0, 1, x.shape) < 0.7)       # some exact zeros / ties
         refs = []
@@ -58,9 +62,9 @@ def run(seconds, seed):
         try:
             g = zen_amd.HPR(fs, hop, beta, flags, zen_amd.TIME_CAUSAL if causal else zen_amd.TIME_ANTICAUSAL, True,
                             streams, chunk)
-        except zen_amd.ZenHipError as e:
-            print("GPU refused", fs, hop, e)
-            n_skip += 1
+        except zen_amd.ZenHipError as e:              # the oracle accepted the configuration: a refusal is a failure
+            print("GPU REFUSED", dict(fs=fs, hop=hop, causal=causal, time_len=time_len, freq_len=freq_len), e, flush=True)
+            n_refused += 1
             continue
         if mode == "soft":
             g.use_soft_mask()
@@ -83,21 +87,21 @@ def run(seconds, seed):
             n_bad += 1
             print("MISMATCH", dict(fs=fs, hop=hop, beta=beta, flags=flags, causal=causal, mode=str(mode), streams=streams,
                                    block=block, chunk=chunk, time_len=time_len, freq_len=freq_len), flush=True)
-    return n_ok, n_bad, n_skip, len(seen)
+    return n_ok, n_bad, n_skip, n_refused, len(seen)
 
 
 def run_offline(seconds, seed):
     """The two-pass offline driver (HPRIOffline::process on host vectors) on random clips, hops, sample rates and mask
     types, with the engines' chunk size and the run lengths of the synthesis-in-runs kernels drawn at random too (0 = the
-    library's own choice).  Returns (ok, mismatches, skipped, distinct configurations)."""
+    library's own choice).  Returns (ok, mismatches, skipped, refused, distinct configurations) as run() does."""
     rng = np.random.default_rng(seed)
     zen_amd.init(0)
     t_end = time.time() + seconds
-    n_ok = n_bad = n_skip = 0
+    n_ok = n_bad = n_skip = n_refused = 0
     seen = set()
     opts = ("offline_chunk_hops", "istft_run", "istft_run_wide", "no_istft_runs", "offline_range")
     while time.time() < t_end:
-        fs = float(rng.choice([8000, 16000, 22050, 32000, 44100, 48000, 96000]))
+        fs = float(rng.choice([4000, 8000, 16000, 22050, 31000, 32000, 44100, 48000, 96000]))
         hop_p = int(rng.choice([32, 64, 128, 256, 512]))
         hop_h = hop_p * int(rng.choice([1, 2, 4, 8, 16]))
         if hop_h > 4096:
@@ -110,9 +114,6 @@ def run_offline(seconds, seed):
             eh = o.HPR(fs, hop_h, beta_h, 7, o.TIME_ANTICAUSAL)
             ep = o.HPR(fs, hop_p, beta_p, 1, o.TIME_ANTICAUSAL)
         except Exception:
-            n_skip += 1
-            continue
-        if max(eh.l_perc | 1, ep.l_perc | 1, eh.l_harm | 1, ep.l_harm | 1) > 255:
             n_skip += 1
             continue
         if mode == "soft":
@@ -157,8 +158,9 @@ def run_offline(seconds, seed):
                 for b in (din, dh, dp, dr):
                     b.free()
         except zen_amd.ZenHipError as e:      # the oracle accepted the configuration: a refusal is a failure
-            print("GPU refused", dict(fs=fs, hop_h=hop_h, hop_p=hop_p, mode=mode, n=n, clips=clips, **cfg), e, flush=True)
+            print("GPU REFUSED", dict(fs=fs, hop_h=hop_h, hop_p=hop_p, mode=mode, n=n, clips=clips, **cfg), e, flush=True)
             ok = False
+            n_refused += 1
         finally:
             for k in opts:
                 zen_amd.set_option(k, 0)
@@ -170,17 +172,17 @@ def run_offline(seconds, seed):
         else:
             n_bad += 1
             print("MISMATCH offline", dict(fs=fs, hop_h=hop_h, hop_p=hop_p, beta_h=beta_h, beta_p=beta_p, mode=mode, n=n, clips=clips, **cfg), flush=True)
-    return n_ok, n_bad, n_skip, len(seen)
+    return n_ok, n_bad, n_skip, n_refused, len(seen)
 
 
 def run_resident(seconds, seed):
     """The per-hop API of the reference (HPRRealtime::process_next_hop + copy_* through IOGPU, zen/fakert.h:221-247) with the
     resident kernels (zen_hip_hpr_set_resident): random sample rate, hop, output, mask, idle time-out, pauses longer than it,
-    resets, per-launch hops and block calls in between.  Returns (ok, mismatches, skipped, distinct configurations)."""
+    resets, per-launch hops and block calls in between.  Returns (ok, mismatches, skipped, refused, distinct configurations)."""
     rng = np.random.default_rng(seed)
     zen_amd.init(0)
     t_end = time.time() + seconds
-    n_ok = n_bad = n_skip = 0
+    n_ok = n_bad = n_skip = n_refused = 0
     seen = set()
     while time.time() < t_end:
         fs = float(rng.choice([8000, 11025, 16000, 22050, 24000, 32000, 44100, 48000, 88200, 96000]))
@@ -195,9 +197,6 @@ def run_resident(seconds, seed):
         except Exception:
             n_skip += 1
             continue
-        if (ho.l_perc | 1) > 255 or (ho.stft_width | 1) > 255:
-            n_skip += 1
-            continue
         if mode == "soft":
             ho.use_soft_mask()
         if mode == "sse":
@@ -209,8 +208,9 @@ def run_resident(seconds, seed):
         try:
             io = zen_amd.IOGPU(hop)
             rt = zen_amd.HPRRealtime(fs, hop, beta, flag)
-        except Exception:
-            n_skip += 1
+        except Exception as e:
+            print("GPU REFUSED", dict(fs=fs, hop=hop), e, flush=True)
+            n_refused += 1
             continue
         if mode == "soft":
             rt.use_soft_mask()
@@ -245,7 +245,7 @@ def run_resident(seconds, seed):
             n_bad += 1
             print("MISMATCH resident", dict(fs=fs, hop=hop, beta=beta, out=key, mode=mode, idle_ms=idle_ms, n_hops=n_hops), flush=True)
         del rt, eng, io
-    return n_ok, n_bad, n_skip, len(seen)
+    return n_ok, n_bad, n_skip, n_refused, len(seen)
 
 
 def memcheck_line():
@@ -266,19 +266,22 @@ def main():
     ap.add_argument("--resident", action="store_true", help="fuzz the per-hop API with the resident kernels (zen_hip_hpr_set_resident)")
     args = ap.parse_args()
     if args.resident:
-        n_ok, n_bad, n_skip, n_seen = run_resident(args.seconds, args.seed)
+        n_ok, n_bad, n_skip, n_ref, n_seen = run_resident(args.seconds, args.seed)
         mc, bad = memcheck_line()
-        print("resident: ok %d  mismatches %d  skipped %d  distinct (fs, hop, output, mode): %d  %s" % (n_ok, n_bad, n_skip, n_seen, mc))
-        return 1 if n_bad or bad else 0
+        print("resident: ok %d  mismatches %d  oracle-rejected %d  GPU-refused %d  distinct (fs, hop, output, mode): %d  %s"
+              % (n_ok, n_bad, n_skip, n_ref, n_seen, mc))
+        return 1 if n_bad or bad or n_ref else 0
     if args.offline:
-        n_ok, n_bad, n_skip, n_seen = run_offline(args.seconds, args.seed)
+        n_ok, n_bad, n_skip, n_ref, n_seen = run_offline(args.seconds, args.seed)
         mc, bad = memcheck_line()
-        print("offline: ok %d  mismatches %d  skipped %d  distinct (fs, hop_h, hop_p, mode): %d  %s" % (n_ok, n_bad, n_skip, n_seen, mc))
-        return 1 if n_bad or bad else 0
-    n_ok, n_bad, n_skip, n_seen = run(args.seconds, args.seed)
+        print("offline: ok %d  mismatches %d  oracle-rejected %d  GPU-refused %d  distinct (fs, hop_h, hop_p, mode): %d  %s"
+              % (n_ok, n_bad, n_skip, n_ref, n_seen, mc))
+        return 1 if n_bad or bad or n_ref else 0
+    n_ok, n_bad, n_skip, n_ref, n_seen = run(args.seconds, args.seed)
     mc, bad = memcheck_line()
-    print("ok %d  mismatches %d  skipped %d  distinct (fs, hop, masks, causality, mode): %d  %s" % (n_ok, n_bad, n_skip, n_seen, mc))
-    return 1 if n_bad or bad else 0
+    print("ok %d  mismatches %d  oracle-rejected %d  GPU-refused %d  distinct (fs, hop, masks, causality, mode): %d  %s"
+          % (n_ok, n_bad, n_skip, n_ref, n_seen, mc))
+    return 1 if n_bad or bad or n_ref else 0
 
 
 if __name__ == "__main__":

@@ -447,8 +447,6 @@ static int filter_create(int time, int frequency, int filter_len, int direction,
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "filter_create: null handle");
 	int odd = 0;
 	ZH_TRY(check_filter_len(time, frequency, filter_len, direction, &odd));
-	if (!is_box && odd > 255)
-		ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "median mask length %d > 255", odd);
 	zen_hip_filter* f = new zen_hip_filter;
 	f->time = time;
 	f->frequency = frequency;

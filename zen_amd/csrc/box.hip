@@ -134,6 +134,50 @@ __global__ __launch_bounds__(256) void box_freq_kernel(FilterArgs a, int segs_pe
 	}
 }
 
+// masks beyond MAX_LEN taps (any length the LDS holds): the same tile, sized by the launch, staged in a loop; the mean by the
+// compiler's IEEE division (zdiv::div_const_batch is proven for lengths 1..255 only, tools/check_div.hip)
+__global__ __launch_bounds__(256) void box_freq_long_kernel(FilterArgs a, int segs_per_row)
+{
+	extern __shared__ float ltile[];
+	const int tid = threadIdx.x;
+	const int row = blockIdx.x / segs_per_row, seg = blockIdx.x - row * segs_per_row;
+	const int cols = a.cols, len = a.len, mid = len >> 1, col0 = seg * FREQ_OUTS;
+	const long long ring_row = (a.first_row + row) % a.ring_rows;
+	const float* __restrict__ srow = a.src + (long long)blockIdx.y * a.src_stream_stride + ring_row * cols;
+	float* __restrict__ drow = a.dst + (long long)blockIdx.y * a.dst_stream_stride + (long long)row * cols;
+	const int span = FREQ_OUTS + len - 1;
+	for (int u = tid; u < span; u += 256) {
+		int c = col0 - mid + u;
+		c = c < 0 ? 0 : (c > cols - 1 ? cols - 1 : c);
+		ZH_CHK(srow + c, 1);
+		ltile[u] = pre_of(srow[c], a.sse_pre);
+	}
+	__syncthreads();
+	const float flen = (float)len;
+	constexpr int K = FREQ_OUTS / 256;
+	float acc[K];
+#pragma unroll
+	for (int k = 0; k < K; ++k)
+		acc[k] = ltile[tid + 256 * k];
+	for (int j = 1; j < len; ++j) {
+		float t[K];
+#pragma unroll
+		for (int k = 0; k < K; ++k)
+			t[k] = ltile[tid + 256 * k + j];
+#pragma unroll
+		for (int k = 0; k < K; ++k)
+			acc[k] = acc[k] + t[k];
+	}
+#pragma unroll
+	for (int k = 0; k < K; ++k) {
+		const int o = tid + 256 * k;
+		if (col0 + o < cols) {
+			ZH_CHK(drow + col0 + o, 1);
+			drow[col0 + o] = post_of(acc[k], flen, a.sse_post, a.post_factor);
+		}
+	}
+}
+
 constexpr int TIME_COLS = 64;
 constexpr int TIME_TILE_ROWS = 192; // 48 KB of LDS
 
@@ -262,6 +306,18 @@ int launch_box(const FilterArgs& a, hipStream_t stream)
 		const long long blocks = (long long)a.n_out_rows * segs;
 		if (blocks <= 0x7fffffffLL) {
 			hipLaunchKernelGGL(box_freq_kernel, dim3((unsigned)blocks, (unsigned)a.n_streams), dim3(256), 0, stream, a, segs);
+			ZH_HIP(hipGetLastError());
+			return ZEN_HIP_OK;
+		}
+	}
+	if (a.direction == ZEN_HIP_FREQUENCY && a.len > MAX_LEN && sizeof(float) * (size_t)(FREQ_OUTS + a.len - 1) <= 150 * 1024) {
+		const int segs = (a.cols + FREQ_OUTS - 1) / FREQ_OUTS;
+		const long long blocks = (long long)a.n_out_rows * segs;
+		const size_t lds = sizeof(float) * (size_t)(FREQ_OUTS + a.len - 1);
+		if (blocks <= 0x7fffffffLL) {
+			if (lds > 64 * 1024)
+				ZH_HIP(hipFuncSetAttribute((const void*)box_freq_long_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+			hipLaunchKernelGGL(box_freq_long_kernel, dim3((unsigned)blocks, (unsigned)a.n_streams), dim3(256), lds, stream, a, segs);
 			ZH_HIP(hipGetLastError());
 			return ZEN_HIP_OK;
 		}

@@ -1272,8 +1272,10 @@ int zen_hip_hpr_create(float fs, size_t hop, float beta, unsigned output_flags, 
 	int mt = 0, mf = 0; // the four filter objects of hps.h:246-258 may throw
 	ZH_TRY(check_filter_len((int)W, (int)nfft, l_harm, causality, &mt));
 	ZH_TRY(check_filter_len((int)W, (int)nfft, l_perc, ZEN_HIP_FREQUENCY, &mf));
-	if (mt > 255 || mf > 255)
-		ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "hpr_create: mask lengths %d/%d exceed 255", mt, mf);
+	// (any mask length the reference accepts: beyond the specialised kernels' lengths the general kernels of median.hip /
+	// box.hip take over.  In an engine neither mask exceeds 267 taps: l_harm >= 1 needs fs / hop >= 7.5, where l_perc =
+	// 2000 hop / fs is 267 at most; l_perc >= 1 needs fs / hop <= 4000, where l_harm = fs / (15 hop) is 267 at most.  The
+	// drop-in filter classes take any length up to the matrix dimension.)
 
 	zen_hip_hpr* e = new zen_hip_hpr;
 	e->fs = fs;

@@ -286,7 +286,8 @@ int launch_sse_block_t(const SseBlockArgs& b, hipStream_t stream)
 // no residual, hps.cu:582-652), rows of the ring within an int
 bool sse_block_available(int log2n, int len_t, int len_f, int n_out, long long ring_rows)
 {
-	return log2n >= 9 && log2n <= 12 && len_f >= 1 && len_f <= 2 * HALO - 1 && len_t >= 1 && len_t < ring_rows && n_out >= 1
+	// (len_t <= 255: the box means divide by the mask length through zdiv::div_const_batch, proven for 1..255: tools/check_div.hip)
+	return log2n >= 9 && log2n <= 12 && len_f >= 1 && len_f <= 2 * HALO - 1 && len_t >= 1 && len_t <= 255 && len_t < ring_rows && n_out >= 1
 	       && n_out <= 2 && ring_rows < 0x7fffffffLL && !g_opt_no_sse_block;
 }
 
