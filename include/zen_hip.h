@@ -163,6 +163,10 @@ int zen_hip_fft_destroy(zen_hip_fft_t h);
  * MedianFilterGPU   (libzen/mfilt.h:33-268; ctor :61-66, filter() :227-267)
  * filter_len > the filtered dimension => ZEN_HIP_E_FILTER_TOO_BIG (mfilt.h:78-86), checked before
  * the length is made odd (mfilt.h:89).  src and dst must not alias (reference: distinct vectors).
+ * Every length the reference accepts is accepted (mfilt.h:296-305: any filter_len <= the dimension): sorting-network /
+ * block-merge kernels up to 63 taps and for the engine's long masks, the general sliding-window kernels (csrc/median.hip)
+ * for every other odd length -- register windows up to 2047 taps, the sorted window in LDS up to 38 400 taps, in device
+ * memory beyond (that launch allocates a scratch buffer and synchronises the stream before it returns).
  * ------------------------------------------------------------------------------------------- */
 int zen_hip_mfilt_create(int time, int frequency, int filter_len, int direction, int copy_bord,
                          zen_hip_mfilt_t* h);

@@ -818,5 +818,5 @@ def test_random_configurations_differential(z):
     spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(root, "tools", "fuzz_parity.py"))
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
-    n_ok, n_bad, _, n_seen = fuzz.run(12.0, 7)
-    assert n_bad == 0 and n_ok >= 10 and n_seen >= 10
+    n_ok, n_bad, _, n_refused, n_seen = fuzz.run(12.0, 7)
+    assert n_bad == 0 and n_refused == 0 and n_ok >= 10 and n_seen >= 10   # (refused: the oracle accepted, the engine did not)
