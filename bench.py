@@ -377,9 +377,27 @@ def realtime_leg(zen_amd, x, n_hops=400):
         # the same loop with the opt-in resident kernel (zen_hip_hpr_set_resident): no launch per hop
         res_lines = subprocess.run([exe, "2000"], capture_output=True, text=True, timeout=120,
                                    env=dict(os.environ, ZEN_RT_RESIDENT="100")).stdout.splitlines()
+        # both again with the light publication (write-through sample stores + relaxed flag: the default of rounds 4-5, opt-in
+        # since round 6 -- ZEN_HIP_PUBLISH_LIGHT=1; the default is the system-scope release form)
+        light_lines = subprocess.run([exe, "2000"], capture_output=True, text=True, timeout=120,
+                                     env=dict(os.environ, ZEN_HIP_PUBLISH_LIGHT="1")).stdout.splitlines()
+        light_res_lines = subprocess.run([exe, "2000"], capture_output=True, text=True, timeout=120,
+                                         env=dict(os.environ, ZEN_HIP_PUBLISH_LIGHT="1", ZEN_RT_RESIDENT="100")).stdout.splitlines()
         os.remove(exe)
         sweep = [json.loads(ln) for ln in lines if ln.startswith("{")]
         rsweep = [json.loads(ln) for ln in res_lines if ln.startswith("{")]
+        lsweep = [json.loads(ln) for ln in light_lines if ln.startswith("{")]
+        lrsweep = [json.loads(ln) for ln in light_res_lines if ln.startswith("{")]
+        res["publication"] = ("default: system-scope release fence + release store; *_light_*: ZEN_HIP_PUBLISH_LIGHT=1 (write-through "
+                              "sample stores + relaxed flag)")
+        res["light_us_by_hop"] = {("sse_" if r["sse"] else "") + str(r["hop"]): r["us_per_hop"] for r in lsweep}
+        res["light_resident_us_by_hop"] = {("sse_" if r["sse"] else "") + str(r["hop"]): r["us_per_hop"] for r in lrsweep if r.get("resident")}
+        lat = [r for r in lsweep if r["hop"] == HOP and not r["sse"]]
+        lrat = [r for r in lrsweep if r.get("resident") and r["hop"] == HOP and not r["sse"]]
+        if lat:
+            res["light_us_per_hop"] = lat[0]["us_per_hop"]
+        if lrat:
+            res["light_resident_us_per_hop"] = lrat[0]["us_per_hop"]
         res["resident_us_by_hop"] = {("sse_" if r["sse"] else "") + str(r["hop"]): r["us_per_hop"] for r in rsweep if r.get("resident")}
         rat = [r for r in rsweep if r.get("resident") and r["hop"] == HOP and not r["sse"]]
         if rat:
@@ -432,8 +450,9 @@ def traffic_record(kernel, elems):
     if int(rec.get("elements", -1)) != int(elems):
         return None, "profiles/%s: the record of %s is for %s elements per launch, this launch has %d" % (
             TRAFFIC_FILE, kernel, rec.get("elements"), elems)
-    return rec["hbm_bytes_per_launch"], ("profiles/%s (rocprofv3 --pmc, FETCH_SIZE and WRITE_SIZE in passes of their own, "
-                                         "FETCH doubled per the gfx950 correction; build %s)" % (TRAFFIC_FILE, tj.get("build", "?")))
+    return rec["hbm_bytes_per_launch"], ("committed PMC record profiles/%s, build %s -- replayed, NOT measured in this run (rocprofv3 --pmc "
+                                         "cannot run inside this process; FETCH_SIZE and WRITE_SIZE in passes of their own, FETCH doubled per "
+                                         "the gfx950 correction; keyed by exact kernel name and elements per launch)" % (TRAFFIC_FILE, tj.get("build", "?")))
 
 
 def valu_issue_frac(kernel, elems, launch_s):
@@ -638,6 +657,53 @@ def median_rooflines(zen_amd, run, S, M, copy_bw):
     return roof, three
 
 
+# BASELINE's second metric on every shape BASELINE.md / SURVEY 8(d) list: (rows, cols, taps, direction).  Path shapes: 10 minutes of
+# 44.1 kHz audio at hop 1024 / 256 / 512 / 4096 / 2048 (time and frequency masks of each); the reference's own bench:
+# dim x dim, 11 taps, both directions (libzen/mfilt.bench.cu:222-262), at its two largest sizes.
+MEDIAN_SHAPES = ((25840, 4096, 3, "t"), (25840, 4096, 47, "f"), (103360, 1024, 11, "t"), (103360, 1024, 13, "f"),
+                 (51680, 2048, 7, "t"), (51680, 2048, 23, "f"), (12920, 8192, 93, "f"), (6460, 16384, 187, "f"),
+                 (8192, 8192, 11, "t"), (8192, 8192, 11, "f"), (16384, 16384, 11, "t"), (16384, 16384, 11, "f"))
+
+
+def median_shapes(zen_amd, seconds=1.0, shapes=MEDIAN_SHAPES, nonneg=False):
+    """ONE protocol for all of them, the one `roofline.median47` is quoted on: >= `seconds` of back-to-back launches of the plain
+    drop-in wrapper (zen_hip_mfilt_run; no option, no promise unless `nonneg`) on a matrix of magnitudes, timed with HIP events
+    around the whole run on the stream the launches go to; 8 B per element."""
+    out = []
+    for rows, cols, flen, d in shapes:
+        rng = np.random.default_rng(flen)
+        src = zen_amd.DeviceBuffer.from_host(rng.random((rows, cols), dtype=np.float32))
+        dst = zen_amd.DeviceBuffer(rows * cols)
+        f = zen_amd.MedianFilterGPU(rows, cols, flen, zen_amd.FREQUENCY if d == "f" else zen_amd.TIME_ANTICAUSAL)
+        if nonneg:
+            f.assume_nonneg()
+        for _ in range(3):
+            f.filter(src, dst)
+        zen_amd.synchronize()
+        e0, e1 = zen_amd.Event(), zen_amd.Event()
+        t_probe = time.perf_counter()
+        f.filter(src, dst)
+        zen_amd.synchronize()
+        per = max(time.perf_counter() - t_probe, 1e-5)
+        batch = int(min(200, max(2, 0.03 / per)))          # ~30 ms of device work between the host's looks at the clock
+        n_l, t_host = 0, time.perf_counter()
+        e0.record()
+        while time.perf_counter() - t_host < seconds:
+            for _ in range(batch):
+                f.filter(src, dst)
+            n_l += batch
+            zen_amd.synchronize()
+        e1.record()
+        ms = e0.elapsed_ms(e1) / n_l
+        gb = 8.0 * rows * cols / (1e-3 * ms) / 1e9
+        out.append({"rows": rows, "cols": cols, "taps": flen, "direction": "frequency" if d == "f" else "time", "avg_launch_ms": ms,
+                    "launches": n_l, "seconds": 1e-3 * ms * n_l, "GBps": gb, "frac": gb / 8000.0, "assume_nonneg": bool(nonneg)})
+        del f
+        src.free()
+        dst.free()
+    return out
+
+
 def long_mask_shapes(zen_amd, iters=30):
     """The long frequency masks through the plain wrapper, so that every instantiation of median_big_kernel a user can reach has
     a number in the line: 93 taps on 8192-bin rows (hop 2048 at 44.1 kHz), 187 taps on 16384-bin rows (hop 4096: pass 1 of the
@@ -794,6 +860,65 @@ def offline_long_run(zen_amd, zdist, grp, rank, world, steps, warmup, settle_ms,
     for bfr in d_in + [d_h, d_p]:
         bfr.free()
     return res, ch0, (n1, n2)
+
+
+def block_host_run(zen_amd, x, M, steps=8, warmup=3):
+    """The headline block with HOST buffers on both sides -- the reference's timed region (zen/fakert.h:221-247: host hop in,
+    process_next_hop, copy_percussive, host hop out) for the whole 25 840-hop block: zen_hip_hpr_process_host, pieces of the block
+    going up / through the fused kernel / back down on three streams.  Pinned buffers; 4 bytes per sample each way, so the
+    roof is the slower direction of the host link, measured here with the same buffers (one copy up, one down, at once)."""
+    import ctypes as C
+    n = M * HOP
+    pin_in, pin_out = zen_amd.PinnedHost(n), zen_amd.PinnedHost(n)
+    pin_in.array[:] = x[:n]
+    eng = zen_amd.HPR(FS, HOP, BETA, zen_amd.OUTPUT_PERCUSSIVE, zen_amd.TIME_CAUSAL, True, 1, 0)
+    for _ in range(warmup):
+        eng.process_host(pin_in.array, perc=pin_out.array)
+    walls = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        eng.process_host(pin_in.array, perc=pin_out.array)
+        walls.append(1e3 * (time.perf_counter() - t0))
+    chk = float(np.abs(pin_out.array[:4096]).sum())
+    # the link with the same buffers: n floats up and n floats down at once on two streams
+    lib = zen_amd.load()
+    d_a, d_b = zen_amd.DeviceBuffer(n), zen_amd.DeviceBuffer(n)
+    d_b.zero()
+    s1, s2 = C.c_void_p(), C.c_void_p()
+    lib.zen_hip_stream_create(C.byref(s1))
+    lib.zen_hip_stream_create(C.byref(s2))
+    best = {"up": 1e30, "down": 1e30, "both": 1e30}
+    for what in ("up", "down", "both"):
+        for _ in range(4):
+            zen_amd.synchronize()
+            t0 = time.perf_counter()
+            if what != "down":
+                lib.zen_hip_memcpy_h2d_async(d_a.ptr, pin_in.array.ctypes.data, 4 * n, s1)
+            if what != "up":
+                lib.zen_hip_memcpy_d2h_async(pin_out.array.ctypes.data, d_b.ptr, 4 * n, s2)
+            zen_amd.synchronize(s1)
+            zen_amd.synchronize(s2)
+            best[what] = min(best[what], 1e3 * (time.perf_counter() - t0))
+    lib.zen_hip_stream_destroy(s1)
+    lib.zen_hip_stream_destroy(s2)
+    eng = None
+    d_a.free()
+    d_b.free()
+    pin_in.free()
+    pin_out.free()
+    wall = float(np.median(walls))
+    return {"value": M / (1e-3 * wall), "unit": "hops/s", "wall_ms": wall, "wall_ms_min": min(walls), "steps": steps,
+            "x_realtime": M / (1e-3 * wall) * HOP / FS, "hops_per_step": M, "checksum": chk,
+            "link": {"h2d_ms": best["up"], "d2h_ms": best["down"], "both_ms": best["both"], "h2d_GBps": 4e-6 * n / best["up"],
+                     "d2h_GBps": 4e-6 * n / best["down"]},
+            # the roof: the slower direction alone (a full-duplex link moves the other one at the same time); `both_ms` is what
+            # two whole-block copies issued at once on two streams take on this box (1.2-2x the roof: they share the link's
+            # engines unevenly), the practical floor of ANY schedule of these bytes
+            "roofline": {"bound": "host link (full duplex: 4 B per sample up, 4 B down)", "roof_ms": max(best["up"], best["down"]),
+                         "achieved_ms": wall, "frac": max(best["up"], best["down"]) / wall, "both_directions_at_once_ms": best["both"]},
+            "config": {"workload": "the headline block (hop 1024, P only, hard mask, causal; %d hops) from pinned HOST memory back to "
+                                   "pinned host memory: zen_hip_hpr_process_host, wall clock of the call" % M,
+                       "timed_region": "zen/fakert.h:221-247 for the whole block: host in -> process -> host out"}}
 
 
 def link_roof(zen_amd, n, reps=5):
@@ -1034,10 +1159,20 @@ def compact_line(full):
     for name in ("all_outputs", "s_noise", "sse_block"):
         if name in full:
             cfg[name + "_hops_per_s"] = full[name].get("value")
+    bh = full.get("block_host")
+    if bh:     # `value` with the host copies inside the timed region (zen/fakert.h:221-247), PCIe-bound
+        cfg["block_host_hops_per_s"] = bh.get("value")
+        legs["block_host"] = {"hops_per_s": bh.get("value"), "wall_ms": bh.get("wall_ms"), "x_realtime": bh.get("x_realtime"),
+                              "frac_of_link_roof": bh.get("roofline", {}).get("frac"), "link_roof_ms": bh.get("roofline", {}).get("roof_ms"),
+                              "h2d_GBps": bh.get("link", {}).get("h2d_GBps"), "d2h_GBps": bh.get("link", {}).get("d2h_GBps"),
+                              "api": "zen_hip_hpr_process_host (pinned host in -> pinned host out)"}
     if "realtime" in full:
         cfg["per_hop_api_us"] = full["realtime"].get("us_per_hop")
         cfg["per_hop_api_hops_per_s"] = full["realtime"].get("hops_per_s")
         cfg["per_hop_api_resident_us"] = full["realtime"].get("resident_us_per_hop")
+        cfg["per_hop_api_light_us"] = full["realtime"].get("light_us_per_hop")            # (opt-in publication, ZEN_HIP_PUBLISH_LIGHT=1)
+        cfg["per_hop_api_light_resident_us"] = full["realtime"].get("light_resident_us_per_hop")
+        cfg["per_hop_publication"] = "release (default); *_light_*: ZEN_HIP_PUBLISH_LIGHT=1"
         # the same call at the other hops of the reference's sweep and on the SSE path (BASELINE configs[4]: hop 512), C++ loop
         by, rby = full["realtime"].get("per_hop_us_by_hop", {}), full["realtime"].get("resident_us_by_hop", {})
         cfg["per_hop_api_us_by_hop"] = {k: by[k] for k in ("256", "512", "2048", "4096", "sse_512") if k in by}
@@ -1047,7 +1182,7 @@ def compact_line(full):
         line["legs"] = legs
     if "roofline" in full:
         r = full["roofline"]
-        roof = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "limiter", "valu_issue_frac",
+        roof = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "limiter", "valu_issue_frac",
                                       "avg_launch_ms", "launches", "hops_per_launch", "algorithmic_bytes_per_hop",
                                       "hbm_bytes_moved_per_hop_by_design", "device_copy_GBps", "algorithmic_bytes_per_frame",
                                       "frames_per_step", "roof_ms", "achieved_ms", "split_ms", "elements_per_launch") if k in r}
@@ -1058,10 +1193,19 @@ def compact_line(full):
                                 "sustained": {"frac": m["sustained"]["frac"], "avg_launch_us": 1e3 * m["sustained"]["avg_launch_ms"],
                                               "launches": m["sustained"]["launches"], "seconds": m["sustained"]["seconds"]},
                                 "burst_frac": m["burst"]["frac"], "cold_frac": m["cold"]["frac"],
-                                "traffic": m.get("traffic"), "frac_of_device_copy": m.get("frac_of_device_copy"),
+                                "traffic": m.get("traffic"), "traffic_source": m.get("traffic_source"),
+                                "frac_of_device_copy": m.get("frac_of_device_copy"),
                                 "through": "plain zen_hip_mfilt_run, no option, no promise",
                                 "long_masks_frac": {"%d taps / %d bins" % (x["taps"], x["cols"]): round(x["frac"], 4)
                                                     for x in m.get("long_masks", [])}}
+            if m.get("shapes"):   # every shape BASELINE.md lists, >= 1 s of back-to-back launches each, 8 B per element
+                def tag(x):
+                    return "%dx%d/%s%d" % (x["rows"], x["cols"], x["direction"][0], x["taps"])
+                roof["median_shapes"] = {"frac": {tag(x): round(x["frac"], 4) for x in m["shapes"]},
+                                         "frac_plain_wrapper": {tag(x): round(x["frac"], 4) for x in m.get("shapes_plain", [])},
+                                         "protocol": ">= 1 s of back-to-back zen_hip_mfilt_run per shape, HIP events around the run, 8 B/element; "
+                                                     "`frac`: handles with zen_hip_mfilt_assume_nonneg (the engine's launches: |S| >= +0); "
+                                                     "`frac_plain_wrapper`: no promise, 0.35 s per shape"}
             roof["device_copy_is"] = m.get("device_copy", {}).get("device_copy_GBps_is")
             roof["hipMemcpy_d2d_GBps"] = m.get("device_copy", {}).get("hipMemcpy_d2d_GBps")
         line["roofline"] = roof
@@ -1267,12 +1411,18 @@ def main():
                 "roofline": roof})
             if legs and fused and world == 1:
                 out["roofline_median"], out["three_kernel_path"] = median_rooflines(zen_amd, run, S, M, copy_bw)
+                # BASELINE's second metric on every listed shape, one sustained protocol: the engine's launches (handles with the
+                # non-negativity promise: |S| >= +0), and the plain wrapper beside it for a shorter run
+                out["roofline_median"]["shapes"] = median_shapes(zen_amd, 1.0, nonneg=True)
+                out["roofline_median"]["shapes_plain"] = median_shapes(zen_amd, 0.35, nonneg=False)
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline_realtime(x[0])
                 out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
             if world == 1 and not args.no_realtime:
                 out["realtime"] = realtime_leg(zen_amd, x[0])
         free_run(run)
+        if legs and rank == 0 and world == 1 and fused:
+            out["block_host"] = block_host_run(zen_amd, x[0], M)
         if legs:
             ls, lw = args.leg_steps, 2
 

@@ -252,6 +252,14 @@ int zen_hip_hpr_resident_stats(zen_hip_hpr_t h, unsigned long long* launches, un
  * any other overlap of an output range with the input range is undefined, as are overlapping outputs. */
 int zen_hip_hpr_process(zen_hip_hpr_t h, const float* in_dev, size_t n_hops, size_t in_stride,
                         float* out_harm_dev, float* out_perc_dev, float* out_resid_dev, size_t out_stride);
+/* The block form on HOST buffers (one stream per engine): n_hops*hop floats in, n_hops*hop floats into each non-NULL
+ * output -- the region zen/fakert.h:221-247 times per hop (host hop in, process_next_hop, copy_*, host hop out) for a whole
+ * block: pieces of the block go up, through zen_hip_hpr_process and back down on three streams.  Buffers from
+ * zen_hip_host_alloc_mapped are copied asynchronously; pageable ones are registered for the duration of the call.  The
+ * outputs must not overlap the input or each other.  Synchronous: returns when the outputs are in the caller's buffers.
+ * Same samples as the per-hop API, hop for hop. */
+int zen_hip_hpr_process_host(zen_hip_hpr_t h, const float* in_host, size_t n_hops, float* out_harm_host, float* out_perc_host,
+                             float* out_resid_host);
 
 /* profiling hook for bench.py: HIP events around every kernel launch on the engine's stream.  get() synchronises and returns the summed kernel time and launch count. */
 int zen_hip_hpr_profile(zen_hip_hpr_t h, int enable);

@@ -51,7 +51,10 @@ def memcheck_after_gpu_test(request):
         yield
         return
     import zen_amd
-    before = zen_amd.memcheck()
+    try:
+        before = zen_amd.memcheck()
+    except zen_amd.ZenHipError as e:      # no GPU here: a gpu-marked test is skipped in its own name, not an error of this fixture
+        pytest.skip("GPU test on a box without a usable GPU: %s" % e)
     yield
     after = zen_amd.memcheck()
     if request.node.get_closest_marker("memcheck_expected") is not None:

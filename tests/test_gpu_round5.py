@@ -181,8 +181,8 @@ def test_one_hop_block_calls_with_the_resident_kernel_enabled(z, hop):
 @pytest.mark.parametrize("resident", [False, True])
 def test_publication_of_a_hop_host_poll_stress(z, release, mode, hop, resident):
     """The host polls the sequence word behind a finished hop and copies the hop from mapped memory (hpr.hip copy_output).
-    Both publication forms -- write-through sample stores + relaxed flag (default) and system-scope release fence + release
-    store ("publish_release", ZEN_HIP_PUBLISH_RELEASE) -- over several thousand hops, per launch and resident, EVERY sample
+    Both publication forms -- system-scope release fence + release store (the default since round 6) and write-through sample
+    stores + relaxed flag ("publish_release" 0, ZEN_HIP_PUBLISH_LIGHT=1) -- over several thousand hops, per launch and resident, EVERY sample
     against the oracle: a hop handed over before its samples arrived shows up as a mismatch."""
     n_hops = 3000 if hop <= 512 else (2000 if hop <= 1024 else 1000)      # (hop 2048: the cooperative kernel, rt_wide.hip)
     rng = np.random.default_rng(hop + release)
@@ -208,7 +208,7 @@ def test_publication_of_a_hop_host_poll_stress(z, release, mode, hop, resident):
         bad = np.flatnonzero(~((got == ref) | (np.isnan(got) & np.isnan(ref))))
         assert bad.size == 0, ("first mismatch in hop", int(bad[0]) // hop, "of", n_hops, bad.size, "samples differ")
     finally:
-        z.set_option("publish_release", 0)
+        z.set_option("publish_release", 1)      # (the default)
 
 
 def test_pipeline_buffers_are_sized_before_the_first_range(z):

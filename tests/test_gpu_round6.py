@@ -196,3 +196,65 @@ def test_cli_offline_defaults_on_a_32k_file(tmp_path):
         rfs, got = read_wav_pcm16(str(tmp_path / name))
         peak = max(-ref.min(), ref.max())
         assert rfs == fs and np.array_equal(got.astype(np.int64), pcm16(ref / np.float32(peak))), name
+
+
+# ---------------------------------------------------------------------------- zen_hip_hpr_process_host
+@pytest.mark.parametrize("hop,flags,mode", [(1024, o.OUTPUT_PERCUSSIVE, "hard"), (1024, ALL, "hard"), (256, ALL, "soft"),
+                                            (512, o.OUTPUT_PERCUSSIVE | o.OUTPUT_HARMONIC, "sse"), (2048, o.OUTPUT_HARMONIC, "hard")])
+@pytest.mark.parametrize("pinned", [True, False])
+def test_block_of_hops_from_host_buffers(z, hop, flags, mode, pinned):
+    """zen_hip_hpr_process_host: the timed region of zen/fakert.h:221-247 (host hop in, process, host hop out) for a block:
+    pieces go up / are processed / come down on three streams.  Pinned and pageable buffers, piece lengths that do and do
+    not divide the block, two calls continuing one stream: the samples of the per-hop oracle."""
+    fs, n_hops = 44100.0, 57
+    x = _stream(hop * n_hops, hop + flags)
+    ref_e = o.HPR(fs, hop, 2.0, flags, o.TIME_CAUSAL)
+    g = z.HPR(fs, hop, 2.0, flags, z.TIME_CAUSAL, True, 1, 0)
+    if mode == "soft":
+        ref_e.use_soft_mask()
+        g.use_soft_mask()
+    if mode == "sse":
+        ref_e.use_sse_filter()
+        g.use_sse_filter()
+    ref = ref_e.process_stream(x)
+    keep = []
+
+    def buf(n):
+        if pinned:
+            keep.append(z.PinnedHost(n))
+            return keep[-1].array
+        return np.empty(n, np.float32)
+    xin = buf(x.size)
+    xin[:] = x
+    want = {"P": bool(flags & o.OUTPUT_PERCUSSIVE), "H": bool(flags & o.OUTPUT_HARMONIC),
+            "R": bool(flags & o.OUTPUT_RESIDUAL) and mode == "hard"}
+    try:
+        for piece in (0, 5, 19, 64):
+            z.set_option("host_block_hops", piece)
+            g.reset_buffers()
+            outs = {k: (buf(x.size) if w else None) for k, w in want.items()}
+            for a in outs.values():
+                if a is not None:
+                    a[:] = np.nan
+            cut = 23 * hop                           # two calls: the second continues the stream of the first
+            g.process_host(xin[:cut], harm=None if outs["H"] is None else outs["H"][:cut],
+                           perc=None if outs["P"] is None else outs["P"][:cut], resid=None if outs["R"] is None else outs["R"][:cut])
+            g.process_host(xin[cut:], harm=None if outs["H"] is None else outs["H"][cut:],
+                           perc=None if outs["P"] is None else outs["P"][cut:], resid=None if outs["R"] is None else outs["R"][cut:])
+            for k, a in outs.items():
+                if a is not None:
+                    assert np.array_equal(a, ref[k], equal_nan=True), (k, piece)
+    finally:
+        z.set_option("host_block_hops", 0)
+        for b in keep:
+            b.free()
+
+
+def test_block_from_host_refuses_overlap_and_several_streams(z):
+    g = z.HPR(44100.0, 256, 2.0, o.OUTPUT_PERCUSSIVE, z.TIME_CAUSAL, True, 1, 0)
+    x = np.zeros(256 * 8, np.float32)
+    with pytest.raises(z.ZenHipError):
+        g.process_host(x, perc=x)
+    g2 = z.HPR(44100.0, 256, 2.0, o.OUTPUT_PERCUSSIVE, z.TIME_CAUSAL, True, 2, 0)
+    with pytest.raises(z.ZenHipError):
+        g2.process_host(x, perc=np.zeros_like(x))

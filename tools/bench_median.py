@@ -42,7 +42,10 @@ def run(rows, cols, flen, direction, iters, general=False, nonneg=False):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--suite", default="path", choices=["path", "squares", "one"])
+    ap.add_argument("--suite", default="path", choices=["path", "squares", "one", "sustained"])
+    ap.add_argument("--seconds", type=float, default=1.0)
+    ap.add_argument("--opt", action="append", default=[], help="zen_hip_set_option name=value (A/B switches), repeatable")
+    ap.add_argument("--shapes", default="", help='--suite sustained: "rows,cols,taps,t|f;..." instead of bench.py\'s list')
     ap.add_argument("--rows", type=int, default=25840)
     ap.add_argument("--cols", type=int, default=4096)
     ap.add_argument("--len", type=int, default=47)
@@ -56,7 +59,17 @@ if __name__ == "__main__":
     for opt in ("median47_blocks", "median47_shared"):
         if os.environ.get("ZEN_" + opt.upper()):
             zen_amd.set_option(opt, int(os.environ["ZEN_" + opt.upper()]))
+    for kv in args.opt:
+        zen_amd.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     F, Tm = zen_amd.FREQUENCY, zen_amd.TIME_ANTICAUSAL
+    if args.suite == "sustained":   # bench.py's protocol (>= 1 s of back-to-back launches per shape), every listed shape
+        import bench
+        shapes = bench.MEDIAN_SHAPES
+        if args.shapes:
+            shapes = [(int(a), int(b), int(c), d) for a, b, c, d in (x.split(",") for x in args.shapes.split(";") if x)]
+        for rec in bench.median_shapes(zen_amd, args.seconds, shapes=shapes, nonneg=args.nonneg):
+            print(json.dumps(rec), flush=True)
+        sys.exit(0)
     if args.suite == "one":
         cases = [(args.rows, args.cols, args.len, F if args.dir == "frequency" else Tm)]
     elif args.suite == "path":   # SURVEY 8(d) path shapes

@@ -7,6 +7,6 @@ library is missing or no GPU is present the calls raise.
 """
 from .lib import (  # noqa: F401
     FREQUENCY, OUTPUT_HARMONIC, OUTPUT_PERCUSSIVE, OUTPUT_RESIDUAL, TIME_ANTICAUSAL, TIME_CAUSAL,
-    BoxFilterGPU, DeviceBuffer, Event, FFTC2CWrapperGPU, HPR, HPRIOffline, HPRRealtime, IOGPU, MedianFilterGPU,
+    BoxFilterGPU, DeviceBuffer, Event, FFTC2CWrapperGPU, HPR, HPRIOffline, HPRRealtime, IOGPU, MedianFilterGPU, PinnedHost,
     ZenHipError, ZgException, debug_poke, device_name, init, load, memcheck, run_plan, set_option, synchronize,
 )

@@ -38,9 +38,19 @@ opt_t g_opt_offline_no_register{0};
 opt_t g_opt_no_rfft{0};
 opt_t g_opt_no_sse_lat{0};
 opt_t g_opt_no_hop_lat{0};
-// (the environment decides the default: a host whose PCIe root complex relaxes the order of posted writes, or whose
-// mapped host memory is not write-through for the device, sets ZEN_HIP_PUBLISH_RELEASE=1 without touching the caller)
-opt_t g_opt_publish_release{[] { const char* v = getenv("ZEN_HIP_PUBLISH_RELEASE"); return (v && *v && *v != '0') ? 1 : 0; }()};
+opt_t g_opt_host_block_hops{0};
+// How a single hop is published to its host-mapped buffer (rt_fused.hip publish_ready).  Default since round 6: the form the
+// memory model backs -- system-scope release fence + release store -- as the reference's synchronising thrust::copy made
+// host_out readable (hps.cu:341-363).  The light form (write-through sample stores + a relaxed flag: ~1-1.5 us less per
+// hop, and it leans on the order of posted writes on the way to host memory) is opt-in: ZEN_HIP_PUBLISH_LIGHT=1, or
+// zen_hip_set_option("publish_release", 0).  (ZEN_HIP_PUBLISH_RELEASE=0 / 1, the switch of round 5, is still read.)
+opt_t g_opt_publish_release{[] {
+	const char* r = getenv("ZEN_HIP_PUBLISH_RELEASE");
+	if (r && *r)
+		return *r != '0' ? 1 : 0;
+	const char* l = getenv("ZEN_HIP_PUBLISH_LIGHT");
+	return (l && *l && *l != '0') ? 0 : 1;
+}()};
 std::atomic<unsigned> g_host_free_gen{0};
 
 void set_error(const char* fmt, ...)
@@ -201,7 +211,8 @@ int zen_hip_set_option(const char* name, int value)
 	             {"publish_release", &g_opt_publish_release},
 	             {"no_rfft", &g_opt_no_rfft},
 	             {"no_sse_lat", &g_opt_no_sse_lat},
-	             {"no_hop_lat", &g_opt_no_hop_lat}};
+	             {"no_hop_lat", &g_opt_no_hop_lat},
+	             {"host_block_hops", &g_opt_host_block_hops}};
 #ifndef ZEN_HIP_DIAG
 	if (name && (!strcmp(name, "rt_fused_diag") || !strcmp(name, "mask_divide") || (!strcmp(name, "median47_variant") && value > 1)))
 		ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "zen_hip_set_option: '%s' = %d is a diagnostic of -DZEN_HIP_DIAG builds", name, value);

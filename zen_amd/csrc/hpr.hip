@@ -19,6 +19,7 @@
 #include "memguard.h"
 #include "filters.h"
 #include "hpr_engine.h"
+#include "host_pipe.h"
 
 #include <algorithm>
 #include <functional>
@@ -100,6 +101,16 @@ void free_all(zen_hip_hpr* e)
 		(void)hipEventDestroy(e->res_event);
 		e->res_ctl = nullptr;
 	}
+	(void)zh_free(e->hstage_in);
+	for (int o = 0; o < 3; ++o)
+		(void)zh_free(e->hstage_out[o]);
+	if (e->hs_in)
+		(void)hipStreamDestroy(e->hs_in);
+	if (e->hs_out)
+		(void)hipStreamDestroy(e->hs_out);
+	for (hipEvent_t ev : e->hevents)
+		(void)hipEventDestroy(ev);
+	e->hevents.clear();
 	(void)zh_free(e->d_window);
 	(void)zh_free(e->d_tw);
 	(void)zh_free(e->d_tail[0]);
@@ -1516,6 +1527,104 @@ int zen_hip_hpr_process(zen_hip_hpr_t h, const float* in_dev, size_t n_hops, siz
 		for (int o = 0; o < 3; ++o)
 			h->direct_done[o] = false;
 	}
+	return ZEN_HIP_OK;
+}
+
+// The block form on HOST buffers: the timed region of the reference's realtime tool -- host hop in, process, host hop out
+// (zen/fakert.h:221-247) -- for a block of hops at once.  Pieces of the block go up, through zen_hip_hpr_process and back
+// down on three streams (the pattern of zen_hip_hpri_process): piece k is processed while piece k+1 arrives and piece k-1
+// leaves.  Pinned buffers (zen_hip_host_alloc_mapped) are copied asynchronously; pageable ones are registered for the
+// duration of the call ("offline_no_register": not), and where that fails their copies block and the loop issues the
+// upload of piece k+1 before the download of piece k.  Returns when the outputs are in the caller's buffers.
+int zen_hip_hpr_process_host(zen_hip_hpr_t h, const float* in_host, size_t n_hops, float* out_harm_host, float* out_perc_host,
+                             float* out_resid_host)
+{
+	if (!h || !in_host)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpr_process_host: null argument");
+	if (h->n_streams != 1)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpr_process_host: one stream per engine (host blocks of several streams: one engine each)");
+	if (n_hops == 0)
+		return ZEN_HIP_OK;
+	float* hosts[3] = {out_perc_host, out_harm_host, out_resid_host};
+	const size_t n = n_hops * h->hop;
+	for (int o = 0; o < 3; ++o) {
+		const char *a0 = (const char*)in_host, *a1 = (const char*)(in_host + n);
+		if (hosts[o] && (const char*)hosts[o] < a1 && a0 < (const char*)(hosts[o] + n))
+			ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpr_process_host: an output overlaps the input (pieces come down while later pieces go up)");
+	}
+	ZH_TRY(resident_stop(h));
+	if (n > h->hstage_cap || (hosts[0] && !h->hstage_out[0]) || (hosts[1] && !h->hstage_out[1]) || (hosts[2] && !h->hstage_out[2])) {
+		ZH_HIP(hipStreamSynchronize(h->stream));
+		const size_t cap = n > h->hstage_cap ? n : h->hstage_cap;
+		if (cap > h->hstage_cap) {
+			(void)zh_free(h->hstage_in);
+			h->hstage_in = nullptr;
+			for (int o = 0; o < 3; ++o) {
+				(void)zh_free(h->hstage_out[o]);
+				h->hstage_out[o] = nullptr;
+			}
+			h->hstage_cap = 0;
+			ZH_HIP(zh_malloc((void**)&h->hstage_in, sizeof(float) * cap));
+			h->hstage_cap = cap;
+		}
+		for (int o = 0; o < 3; ++o)
+			if (hosts[o] && !h->hstage_out[o])
+				ZH_HIP(zh_malloc((void**)&h->hstage_out[o], sizeof(float) * h->hstage_cap));
+	}
+	// pieces of ~8 MiB of input (2048 hops at hop 1024): long enough for full-rate copies and full-size launches, short
+	// enough that the first upload and the last download -- which nothing overlaps -- stay a small share of the call
+	size_t piece = g_opt_host_block_hops > 0 ? (size_t)g_opt_host_block_hops : ((size_t)2 << 20) / h->hop;
+	if (piece < 1)
+		piece = 1;
+	const size_t n_pieces = (n_hops + piece - 1) / piece;
+	if (!h->hs_in)
+		ZH_HIP(hipStreamCreateWithFlags(&h->hs_in, hipStreamNonBlocking));
+	if (!h->hs_out)
+		ZH_HIP(hipStreamCreateWithFlags(&h->hs_out, hipStreamNonBlocking));
+	while (h->hevents.size() < 2 * n_pieces + 1) {
+		hipEvent_t ev;
+		ZH_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+		h->hevents.push_back(ev);
+	}
+	ZH_TRY(hpr_reserve_hops(h, piece < n_hops ? piece : n_hops)); // (the engine's growth synchronises: before the first copy is queued)
+	const bool try_register = g_opt_offline_no_register.load(std::memory_order_relaxed) == 0;
+	Registered reg_in, reg_out[3];
+	reg_in.take(in_host, sizeof(float) * n, try_register);
+	for (int o = 0; o < 3; ++o)
+		reg_out[o].take(hosts[o], sizeof(float) * n, try_register);
+	auto upload = [&](size_t k) -> int { // event 2k
+		const size_t b = k * piece * h->hop, e = (k + 1) * piece < n_hops ? (k + 1) * piece * h->hop : n;
+		ZH_HIP(hipMemcpyAsync(h->hstage_in + b, in_host + b, sizeof(float) * (e - b), hipMemcpyHostToDevice, h->hs_in));
+		ZH_HIP(hipEventRecord(h->hevents[2 * k], h->hs_in));
+		return ZEN_HIP_OK;
+	};
+	auto feed = [&]() -> int {
+		// behind whatever the caller queued on the engine's stream (and an earlier call's kernels, which may still read the stage)
+		ZH_HIP(hipEventRecord(h->hevents[2 * n_pieces], h->stream));
+		ZH_HIP(hipStreamWaitEvent(h->hs_in, h->hevents[2 * n_pieces], 0));
+		ZH_TRY(upload(0));
+		for (size_t k = 0; k < n_pieces; ++k) {
+			const size_t h0 = k * piece, m = (k + 1) * piece < n_hops ? piece : n_hops - h0, b = h0 * h->hop;
+			ZH_HIP(hipStreamWaitEvent(h->stream, h->hevents[2 * k], 0));
+			ZH_TRY(zen_hip_hpr_process(h, h->hstage_in + b, m, m * h->hop, hosts[1] ? h->hstage_out[1] + b : nullptr,
+			                           hosts[0] ? h->hstage_out[0] + b : nullptr, hosts[2] ? h->hstage_out[2] + b : nullptr, m * h->hop));
+			ZH_HIP(hipEventRecord(h->hevents[2 * k + 1], h->stream));
+			if (k + 1 < n_pieces)
+				ZH_TRY(upload(k + 1));
+			ZH_HIP(hipStreamWaitEvent(h->hs_out, h->hevents[2 * k + 1], 0));
+			for (int o = 0; o < 3; ++o)
+				if (hosts[o])
+					ZH_HIP(hipMemcpyAsync(hosts[o] + b, h->hstage_out[o] + b, sizeof(float) * m * h->hop, hipMemcpyDeviceToHost, h->hs_out));
+		}
+		return ZEN_HIP_OK;
+	};
+	const int rc = feed();
+	// nothing may be in flight when the caller's buffers are unregistered and handed back
+	const hipError_t e_out = hipStreamSynchronize(h->hs_out), e_run = hipStreamSynchronize(h->stream), e_in = hipStreamSynchronize(h->hs_in);
+	ZH_TRY(rc);
+	ZH_HIP(e_out);
+	ZH_HIP(e_run);
+	ZH_HIP(e_in);
 	return ZEN_HIP_OK;
 }
 

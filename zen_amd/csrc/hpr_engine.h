@@ -120,6 +120,14 @@ struct zen_hip_hpr {
 	zen_hip_impl::RtFusedArgs res_args;               // the arguments of the hop posted last: what a relaunch starts from
 	unsigned long long res_launches = 0, res_hops = 0; // statistics (zen_hip_hpr_resident_stats)
 
+	// zen_hip_hpr_process_host: device images of the caller's host block (input, one per delivered output), the two copy
+	// streams and the events of the pieces
+	float* hstage_in = nullptr;
+	float* hstage_out[3] = {nullptr, nullptr, nullptr};
+	size_t hstage_cap = 0; // floats
+	hipStream_t hs_in = nullptr, hs_out = nullptr;
+	std::vector<hipEvent_t> hevents;
+
 	// profiling hook (bench.py): HIP events around every launch, per kernel class
 	enum { K_STFT = 0, K_FREQ = 1, K_TIME = 2, K_ISTFT = 3, K_FINALIZE = 4, K_FUSED = 5, K_COUNT = 6 };
 	bool prof = false;

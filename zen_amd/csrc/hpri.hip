@@ -9,6 +9,7 @@
 #include "common.h"
 #include "memguard.h"
 #include "hpr_engine.h"
+#include "host_pipe.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -377,42 +378,6 @@ extern "C++" {
 namespace {
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-
-// Is this host range known to the runtime (hipHostMalloc / hipHostRegister)?  Copies from / to such memory are
-// asynchronous; from / to pageable memory hipMemcpyAsync returns when the bytes have moved.
-bool host_pinned(const void* p)
-{
-	hipPointerAttribute_t at;
-	if (hipPointerGetAttributes(&at, p) == hipSuccess)
-		return at.type == hipMemoryTypeHost;
-	(void)hipGetLastError();
-	return false;
-}
-
-struct Registered { // a caller's buffer pinned for the duration of one call
-	void* p = nullptr;
-	bool pinned = false;
-	void take(const void* q, size_t bytes, bool try_register)
-	{
-		if (!q)
-			return;
-		if (host_pinned(q)) {
-			pinned = true;
-			return;
-		}
-		if (try_register && hipHostRegister(const_cast<void*>(q), bytes, hipHostRegisterDefault) == hipSuccess) {
-			p = const_cast<void*>(q);
-			pinned = true;
-			return;
-		}
-		(void)hipGetLastError();
-	}
-	~Registered()
-	{
-		if (p)
-			(void)hipHostUnregister(p);
-	}
-};
 
 void zero_host(float* dst, size_t n) // the reference's never-written residual_out (hps.cu:45-48, :200-204)
 {

@@ -95,12 +95,23 @@ __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowM
 	const int herm = a.hermitian;
 	const int o0 = col0 + tid * T; // this thread's first output column
 	const bool wanted = !herm || o0 <= (cols >> 1) || o0 + T > cols - mid;
+	// Keys: the raw bits, which order non-negative samples (magnitudes) as they are.  Without the caller's promise (NONNEG)
+	// every wave ORs the sign bits of what it stages; only a workgroup that saw one re-keys its windows (and maps its results
+	// back): a row of magnitudes costs what it costs with the promise.
+	__shared__ int wneg[4];
+	int sgn = 0;
 	if (vec_ok) { // cols % 4 == 0 and 16-byte aligned rows: a vector is wholly inside or wholly outside
 		constexpr int NLD = (SPANV + 255) / 256;
 		int4 k[NLD];
 #pragma unroll
-		for (int i = 0; i < NLD; ++i) // all loads in flight before the first use
-			k[i] = row_vec_keys<NONNEG>(srow, c_lo + 4 * (tid + 256 * i), cols, herm);
+		for (int i = 0; i < NLD; ++i) { // all loads in flight before the first use
+			// (the last round covers SPANV - 256 (NLD - 1) vectors only: its other lanes ask for the image's last vector again --
+			// one cache line -- instead of the next segment's first 4 KB, which they used to fetch and throw away: rows of
+			// several segments moved up to twice their bytes through the L1)
+			const int vi = tid + 256 * i < SPANV ? tid + 256 * i : SPANV - 1;
+			k[i] = row_vec_keys<true>(srow, c_lo + 4 * vi, cols, herm);
+			sgn |= k[i].x | k[i].y | k[i].z | k[i].w;
+		}
 #pragma unroll
 		for (int i = 0; i < NLD; ++i) {
 			const int vi = tid + 256 * i;
@@ -113,10 +124,26 @@ __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowM
 			int c = c_lo + g;
 			c = c < 0 ? 0 : (c > cols - 1 ? cols - 1 : c);
 			ZH_CHK(srow + c, 1);
-			tile[IM::addr(g)] = to_key<NONNEG>(srow[c]);
+			const int b = __float_as_int(srow[c]);
+			sgn |= b;
+			tile[IM::addr(g)] = b;
 		}
 	}
+	if constexpr (!NONNEG) {
+		const bool any = __ballot(sgn < 0) != 0ull;
+		if ((tid & 63) == 0)
+			wneg[tid >> 6] = any ? 1 : 0;
+	}
 	__syncthreads();
+	bool neg = false; // workgroup-uniform; read BEHIND the window's own LDS reads (in front of them the compiler waited for the
+	                  // flags first: a dependent LDS round trip per workgroup).  The re-keying blocks are marked unlikely: laid
+	                  // out in line, the two branches a workgroup of magnitudes TOOK around them cost 4.5 % of the launch
+	                  // (0.674 against 0.704 of 8 TB/s, 13 taps on 1024-bin rows; variant builds, same box)
+	auto read_neg = [&]() {
+		if constexpr (!NONNEG)
+			neg = __builtin_amdgcn_readfirstlane(wneg[0] | wneg[1] | wneg[2] | wneg[3]) != 0;
+	};
+	auto rekey = [](int b) { return b ^ ((b >> 31) & 0x7fffffff); }; // raw bits <-> ordering key (an involution: znet::f2key)
 
 	int out[T];
 #pragma unroll
@@ -143,6 +170,15 @@ __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowM
 				e[47 + q] = hi[q];
 			}
 		}
+		read_neg();
+		if (__builtin_expect(neg, 0)) {
+#pragma unroll
+			for (int q = 0; q < W + T - 1; ++q)
+				e[q] = rekey(e[q]);
+#pragma unroll
+			for (int q = 0; q < 16; ++q)
+				A[q] = rekey(A[q]);
+		}
 		znet::sort_net<16>(A);
 		const int lane = tid & 63, wave = tid >> 6;
 		if (lane == 0 && wave > 0)
@@ -150,6 +186,11 @@ __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowM
 		if (tid == 255) { // the right neighbour of the last block belongs to nobody
 			int X[16];
 			znet::lds_load<16>(mine + IM::caddr(32), X);
+			if (__builtin_expect(neg, 0)) {
+#pragma unroll
+				for (int q = 0; q < 16; ++q)
+					X[q] = rekey(X[q]);
+			}
 			znet::sort_net<16>(X);
 			znet::lds_store<16>(edge[3], X);
 		}
@@ -176,9 +217,20 @@ __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowM
 #pragma unroll
 		for (int q = 0; q < W + T - 1; ++q)
 			e[q] = ld[q + DELTA];
+		read_neg();
 		__syncthreads(); // every window is in registers: the image can take the results
+		if (__builtin_expect(neg, 0)) {
+#pragma unroll
+			for (int q = 0; q < W + T - 1; ++q)
+				e[q] = rekey(e[q]);
+		}
 		if (wanted)
 			znet::medians<W, T, W + T - 1>(e, out);
+	}
+	if (__builtin_expect(neg, 0)) { // back to the samples' bits
+#pragma unroll
+		for (int i = 0; i < T; ++i)
+			out[i] = rekey(out[i]);
 	}
 #pragma unroll
 	for (int v = 0; v < T / 4; ++v)
@@ -195,10 +247,10 @@ __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowM
 				const int4 k = *reinterpret_cast<const int4*>(&tile[IM::addr(g)]);
 				float* dq = reinterpret_cast<float*>(__builtin_assume_aligned(drow + c, 16)); // streaming store
 				ZH_CHK(dq, 4);
-				__builtin_nontemporal_store(from_key<NONNEG>(k.x), dq);
-				__builtin_nontemporal_store(from_key<NONNEG>(k.y), dq + 1);
-				__builtin_nontemporal_store(from_key<NONNEG>(k.z), dq + 2);
-				__builtin_nontemporal_store(from_key<NONNEG>(k.w), dq + 3);
+				__builtin_nontemporal_store(__int_as_float(k.x), dq);
+				__builtin_nontemporal_store(__int_as_float(k.y), dq + 1);
+				__builtin_nontemporal_store(__int_as_float(k.z), dq + 2);
+				__builtin_nontemporal_store(__int_as_float(k.w), dq + 3);
 			}
 		}
 	}
@@ -207,7 +259,7 @@ __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowM
 			const int c = col0 + g;
 			if (c < cols) {
 				ZH_CHK(drow + c, 1);
-				drow[c] = from_key<NONNEG>(tile[IM::addr(g)]);
+				drow[c] = __int_as_float(tile[IM::addr(g)]);
 			}
 		}
 	}
@@ -518,10 +570,32 @@ __device__ __forceinline__ void store_keys(float* p, const int (&k)[VC])
 
 constexpr int time_vc(int W) { return W <= 15 ? 4 : (W <= 31 ? 2 : 1); }
 
+// out[g] = median(e[g..g+W-1]), g < T.  Three taps: a v_med3 per output, any T; else the shared-sort scheme (T <= mid + 1)
+template <int W, int T, int NE>
+__device__ __forceinline__ void time_medians(const int (&e)[NE], int (&out)[T])
+{
+	if constexpr (W == 3) {
+#pragma unroll
+		for (int g = 0; g < T; ++g)
+			out[g] = znet::med3i(e[g], e[g + 1], e[g + 2]);
+	}
+	else {
+		znet::medians<W, T, NE>(e, out);
+	}
+}
+
+// rows per step of the time kernel: the sorting scheme's outputs per thread; three taps (no sharing to be had): eight rows, so
+// that a thread has 8 x 16 B in flight instead of 2 x 16
+constexpr int time_rows(int W) { return W == 3 ? 8 : znet::outputs_per_thread(W); }
+
+// (Round 6, measured and not kept: the NEXT step's T rows requested before this step's medians are computed and stored -- gfx9
+// counts loads and stores in one in-order counter, so the wait for a step's loads first drains the previous step's stores.
+// Interleaved A/B on one box, fraction of 8 TB/s: 103 360 x 1024 / 11 taps 0.661 against 0.649, but 8192^2 0.612 against 0.660,
+// 16384^2 0.697 against 0.732, 3 / 7 taps 0.679 / 0.693 against 0.687 / 0.698: the 14-16 registers cost a wave of occupancy.)
 template <int W, int VC>
 __global__ __launch_bounds__(256) void median_net_time_kernel(FilterArgs a, RowMap rm, int rows_per_block)
 {
-	constexpr int T = znet::outputs_per_thread(W), mid = W / 2, NE = W + T - 1;
+	constexpr int T = time_rows(W), mid = W / 2, NE = W + T - 1;
 	const int cols = a.cols;
 	const int pitch = a.pitch ? a.pitch : cols; // floats between rows (rows of which only the first cols are filtered)
 	// thread -> (column vector, block of rows), the column fastest: a row of 516 columns (the stored half of a 1024-bin
@@ -560,7 +634,7 @@ __global__ __launch_bounds__(256) void median_net_time_kernel(FilterArgs a, RowM
 		int out[VC][T];
 #pragma unroll
 		for (int v = 0; v < VC; ++v)
-			znet::medians<W, T, NE>(e[v], out[v]);
+			time_medians<W, T, NE>(e[v], out[v]);
 #pragma unroll
 		for (int g = 0; g < T; ++g) {
 			if (rr + g < rend) {
@@ -731,10 +805,12 @@ int launch_freq_guard(const FilterArgs& a, const RowMap& rm, hipStream_t stream,
 template <int W, int VC>
 int launch_time_vc(const FilterArgs& a, const RowMap& rm, hipStream_t stream)
 {
-	constexpr int T = znet::outputs_per_thread(W);
+	constexpr int T = time_rows(W);
 	const int vecs = (a.cols + VC - 1) / VC; // column vectors of a row
 	// enough blocks of rows to fill the chip (>= ~1024 full workgroups), but long enough to amortise the W-1 halo
 	int rpb = 256;
+	// (round 6, interleaved A/B on the path shapes and the reference's squares: 512 / 768 / 2048 workgroups instead of 1024 lose
+	// 1-30 %; two columns per thread -- twice the threads per row, blocks of rows twice as long, half the halo -- lose 4-20 %)
 	while (rpb > 4 * T && rpb > 32 && (long long)vecs * ((a.n_out_rows + rpb - 1) / rpb) * a.n_streams < 1024LL * 256)
 		rpb >>= 1;
 	rpb = (rpb + T - 1) / T * T;

@@ -40,6 +40,7 @@ struct Guard {
 	ZhFail* fail_dev = nullptr;
 	bool users_set = false;
 	bool table_dirty = true;
+	bool table_overflow_reported = false;
 };
 Guard& G()
 {
@@ -62,7 +63,8 @@ void report_at_exit()
 	if (g.corrupt_allocs || viol) {
 		fprintf(stderr, "zen_hip memguard: %llu red-zone words overwritten in %llu zones, %llu out-of-bounds accesses recorded; exit status 86\n",
 		        g.corrupt_words, g.corrupt_allocs, viol);
-		fflush(stderr);
+		fflush(nullptr); // this handler was registered late and runs early: the program's buffered stdout (the CLI's report, a test's
+		                 // verdict) must not be lost with the exit status that asks somebody to read it
 		_exit(86);
 	}
 }
@@ -163,8 +165,14 @@ hipError_t push_table(Guard& g)
 	t->fail = g.fail_dev;
 	unsigned n = 0;
 	for (const auto& kv : g.live) {
-		if (n >= ZH_TABLE_CAP)
+		if (n >= ZH_TABLE_CAP) { // more live allocations than the table holds: accesses to the rest would read as violations
+			if (!g.table_overflow_reported) {
+				fprintf(stderr, "zen_hip memguard: %zu live allocations, the bounds table holds %u: accesses to the others will be "
+				                "reported as out of bounds\n", g.live.size(), (unsigned)ZH_TABLE_CAP);
+				g.table_overflow_reported = true;
+			}
 			break;
+		}
 		t->r[n].begin = (uintptr_t)kv.second.dev;
 		t->r[n].end = (uintptr_t)kv.second.dev + ((kv.second.bytes + 255) / 256 * 256); // (incl. the alignment slack, see verify)
 		++n;
@@ -337,6 +345,14 @@ int zen_hip_debug_poke(void* dev, long long byte_offset, unsigned value)
 {
 	if (!dev)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "debug_poke: null argument");
+	// a store to any device address: only what the memory-checking tests are for -- red zones on, or the bounds build
+	{
+		Guard& g = G();
+		std::lock_guard<std::mutex> lk(g.mu);
+		lazy_init(g);
+	}
+	if (!BOUNDS_BUILD && G().zone == 0)
+		ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "debug_poke: a diagnostic of runs with ZEN_HIP_REDZONE (or of the -DZEN_HIP_BOUNDS build)");
 	hipLaunchKernelGGL(poke_kernel, dim3(1), dim3(1), 0, nullptr, (unsigned*)((char*)dev + byte_offset), value);
 	ZH_HIP(hipGetLastError());
 	ZH_HIP(hipDeviceSynchronize());

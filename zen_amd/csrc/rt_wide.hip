@@ -467,23 +467,25 @@ __device__ __forceinline__ void rt_wide_body(const RtFusedArgs& a, const WideHop
 			zfft::PassRunner<LOG2J, 0, true, false, true, XchIn<LOG2J>, InvBOut<LOG2M>, false, zfft::TwRegs<LOG2J, false>>::run(
 			    tf, lds + (t / PB::TF) * PB::LDS_FLOAT2, twB, in, out, true);
 		}
-		// The finished hop is host-mapped: visible there before the sequence word.  publish_seq == 1 (default): its samples
-		// went out as write-through stores and are on their way once the memory counter has counted them off (release_stores
-		// waits for it in front of every arrival) -- no write-back of the XCD's whole L2 (Y row, rings, exchange buffer: device
-		// memory the host never reads), as in the one-workgroup kernels (rt_fused.hip publish_ready<LIGHT>; "publish_release"
-		// selects the fence)
-		if (a.publish_seq == 2)
+		// The finished hop is host-mapped: visible there before the sequence word.  publish_seq == 2 (default): system-scope fence
+		// + release store.  publish_seq == 1 (opt-in light form): the samples went out as write-through stores and are on their
+		// way once the memory counter has counted them off (release_stores waits for it in front of every arrival) -- no
+		// write-back of the XCD's whole L2, as in the one-workgroup kernels (rt_fused.hip publish_ready<LIGHT>).  The light form
+		// only where the cooperating workgroups share an XCD (`light`: the placement vote): the flag is stored by whoever
+		// arrives last, and from another XCD its order behind the other workgroups' samples would rest on nothing.
+		const int pub = (a.publish_seq == 1 && !light) ? 2 : a.publish_seq;
+		if (pub == 2)
 			__threadfence_system();
-		else if (a.publish_seq)
+		else if (pub)
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		if (oi + 1 < a.n_out) { // the exchange buffer is needed again: a full barrier
 			if (oi == 0)
 				sync(9);
 			else
 				sync(12);
-			if (a.publish_seq == 2 && g == 0 && t == 0)
+			if (pub == 2 && g == 0 && t == 0)
 				__hip_atomic_store(reinterpret_cast<unsigned*>(ready + hop), hv.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-			else if (a.publish_seq && g == 0 && t == 0)
+			else if (pub && g == 0 && t == 0)
 				__hip_atomic_store(reinterpret_cast<unsigned*>(ready + hop), hv.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
 		else { // the call's last barrier: nobody waits, whoever arrives last publishes the hop
@@ -493,9 +495,9 @@ __device__ __forceinline__ void rt_wide_body(const RtFusedArgs& a, const WideHop
 			__syncthreads();
 			if (t == 0) {
 				const unsigned before = __hip_atomic_fetch_add(bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-				if (before + 1 == arrivals && a.publish_seq == 2)
+				if (before + 1 == arrivals && pub == 2)
 					__hip_atomic_store(reinterpret_cast<unsigned*>(ready + hop), hv.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-				else if (before + 1 == arrivals && a.publish_seq) // (every workgroup drained its write-through stores before it arrived)
+				else if (before + 1 == arrivals && pub) // (every workgroup drained its write-through stores before it arrived)
 					__hip_atomic_store(reinterpret_cast<unsigned*>(ready + hop), hv.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 			}
 			stamp(oi == 0 ? 10 : 12);

@@ -101,6 +101,7 @@ SYMBOLS = [
     ("zen_hip_hpr_copy_output", _i, [_vp, _u, _vp]),
     ("zen_hip_hpr_copy_output_async", _i, [_vp, _u, _vp]),
     ("zen_hip_hpr_process", _i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _sz]),
+    ("zen_hip_hpr_process_host", _i, [_vp, _vp, _sz, _vp, _vp, _vp]),
     ("zen_hip_hpr_debug_stamps", _i, [_vp, C.POINTER(C.POINTER(C.c_ulonglong))]),
     ("zen_hip_hpr_profile", _i, [_vp, _i]),
     ("zen_hip_hpr_profile_get", _i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong),
@@ -277,6 +278,26 @@ class IOGPU:
             self._hi = None
 
 
+class PinnedHost:
+    """n float32 of pinned host memory (zen_hip_host_alloc_mapped, not write-combined) as a numpy array: what asynchronous
+    copies want on the host side (zen_hip_hpr_process_host, zen_hip_hpri_process)."""
+
+    def __init__(self, n):
+        h, d = C.c_void_p(), C.c_void_p()
+        _ck(load().zen_hip_host_alloc_mapped(n * 4, 0, C.byref(h), C.byref(d)))
+        self._h = h.value
+        self.array = np.ctypeslib.as_array(C.cast(h, C.POINTER(C.c_float)), shape=(n,))
+
+    def free(self):
+        if getattr(self, "_h", None):
+            self.array = None
+            load().zen_hip_host_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.free()
+
+
 class FFTC2CWrapperGPU:
     """libzen/fftw.h:20-49: public nfft, public fft_vec (device), forward(), backward()."""
 
@@ -409,6 +430,19 @@ class HPR:
         in_stride = n_hops * self.hop if in_stride is None else in_stride
         out_stride = n_hops * self.hop if out_stride is None else out_stride
         _ck(load().zen_hip_hpr_process(self._h, in_dev, n_hops, in_stride, harm, perc, resid, out_stride))
+
+    def process_host(self, x, harm=None, perc=None, resid=None):
+        """zen_hip_hpr_process_host: x and the wanted outputs are HOST float32 arrays of n_hops * hop samples (numpy arrays,
+        pageable or views of pinned memory); the others None.  Synchronous."""
+        n_hops = x.size // self.hop
+        assert x.dtype == np.float32 and x.flags["C_CONTIGUOUS"] and x.size == n_hops * self.hop
+
+        def ptr(a):
+            if a is None:
+                return None
+            assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"] and a.size == x.size
+            return a.ctypes.data_as(C.c_void_p)
+        _ck(load().zen_hip_hpr_process_host(self._h, x.ctypes.data_as(C.c_void_p), n_hops, ptr(harm), ptr(perc), ptr(resid)))
 
     def profile(self, enable=True):
         _ck(load().zen_hip_hpr_profile(self._h, int(enable)))
