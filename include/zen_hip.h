@@ -304,6 +304,16 @@ typedef struct {
 	double total_ms;                  /* the whole call */
 } zen_hip_hpri_host_stats;
 int zen_hip_hpri_host_stats_get(zen_hip_hpri_t h, zen_hip_hpri_host_stats* out);
+/* The same call for a caller that BUILDS its result buffers (HPRIOffline::process returns three new std::vector<float>,
+ * hps.cu:131, :219-220: fresh memory, which is slow to pin and which a value-initialising constructor writes once for
+ * nothing): the ranges of the clip come down into pinned staging memory of the handle and are handed to `sink` from there --
+ * sink(user, output, begin, samples, count) with output 0 = harmonic, 1 = percussive; for each output the ranges arrive in
+ * ascending order, each exactly once, together covering [0, n); the two outputs' calls come from two threads of the library
+ * and may overlap each other; `samples` is valid for the duration of the call.  The residual is all zeros:
+ * nothing is delivered for it.  Returns when every range has been handed over. */
+typedef void (*zen_hip_hpri_sink_fn)(void* user, int output, size_t begin, const float* samples, size_t count);
+int zen_hip_hpri_process_sink(zen_hip_hpri_t h, const float* audio_host, size_t n, int want_harm, int want_perc,
+                              zen_hip_hpri_sink_fn sink, void* user);
 /* Device-resident batch of n_clips equal-length clips (rows `stride` floats apart, n samples used).
  * Outputs may be NULL.  Asynchronous. */
 int zen_hip_hpri_process_device(zen_hip_hpri_t h, const float* audio_dev, size_t n, size_t stride,

@@ -258,3 +258,32 @@ def test_block_from_host_refuses_overlap_and_several_streams(z):
     g2 = z.HPR(44100.0, 256, 2.0, o.OUTPUT_PERCUSSIVE, z.TIME_CAUSAL, True, 2, 0)
     with pytest.raises(z.ZenHipError):
         g2.process_host(x, perc=np.zeros_like(x))
+
+
+# ---------------------------------------------------------------------------- zen_hip_hpri_process_sink
+@pytest.mark.parametrize("n,rng_len,want", [(3 * 1323000 + 77, 0, (True, True)), (700001, 4096 * 40, (True, True)),
+                                            (700001, 4096 * 40, (False, True)), (30000, 0, (True, False)), (1500000, 4096 * 31, (True, True))])
+def test_offline_ranges_handed_to_a_sink(z, n, rng_len, want):
+    """HPRIOffline::process builds its result vectors from this (round 6): every range of the clip is handed over exactly
+    once per wanted output, in ascending order, from pinned staging memory -- and the samples are those of the whole-clip call."""
+    fs = 44100.0
+    x = _stream(n, n % 1000)
+    g = z.HPRIOffline(fs, 4096, 256, 2.0, 2.0)
+    z.set_option("offline_range", rng_len)
+    try:
+        h, p, ranges = g.process_sink(x, want)
+        rh, rp, _ = g.process(x)
+    finally:
+        z.set_option("offline_range", 0)
+    for got, ref, w, rr in ((h, rh, want[0], ranges[0]), (p, rp, want[1], ranges[1])):
+        if not w:
+            assert got is None and rr == []
+            continue
+        assert np.array_equal(got, ref, equal_nan=True)
+        pos = 0
+        for b, c in rr:
+            assert b == pos and c > 0
+            pos += c
+        assert pos == n
+    if rng_len:
+        assert len(ranges[1]) == -(-n // rng_len)      # more ranges than staging slots: the slots are reused

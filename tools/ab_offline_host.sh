@@ -1,12 +1,9 @@
 #!/bin/bash
-# kernels-alone and wall time of the one-hour host-vector pipeline with / without the synthesis in runs for its pass 1
-CFGS=("$@")
-[ ${#CFGS[@]} -eq 0 ] && CFGS=(no_istft_runs=2 no_istft_runs=0)
-for cfg in "${CFGS[@]}"; do
-  ZEN_HIP_OPTIONS=$cfg python bench.py --workload offline_host --steps 4 --warmup 1 --no-cpu-baseline > gpurun_out/ab_h.json 2> gpurun_out/ab_h.err
-  python - "$cfg" <<EOF
-import json,sys
-d=json.load(open("gpurun_out/bench_detail.json"))
-print(sys.argv[1], "wall_ms", round(d.get("wall_ms",0),3), "kernels_alone_ms", round(d.get("compute_ms",0),3))
-EOF
+# HPRIOffline<GPU>::process(std::vector<float>) (tools/offline_host.cpp, one hour of audio): the round-6 path (result vectors
+# appended from the sink while the separation runs) against the path of rounds 4-5 (ZEN_PROCESS_PLAIN=1: vectors first), alternating.
+cd "$(dirname "$0")/.." || exit 1
+g++ -O2 -std=c++17 -I include -I zen_amd/libzen tools/offline_host.cpp -o /tmp/offline_host -L zen_amd -lzen -lzen_hip -Wl,-rpath,$PWD/zen_amd || exit 1
+for r in 1 2; do
+  echo "sink:";  ZEN_TRACE_PROCESS=${TRACE:-} /tmp/offline_host ${1:-3600} 3 2>&1 | tail -${TAILN:-1}
+  echo "plain:"; ZEN_PROCESS_PLAIN=1 /tmp/offline_host ${1:-3600} 3 2>&1 | tail -1
 done

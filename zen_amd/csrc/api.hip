@@ -39,6 +39,7 @@ opt_t g_opt_no_rfft{0};
 opt_t g_opt_no_sse_lat{0};
 opt_t g_opt_no_hop_lat{0};
 opt_t g_opt_host_block_hops{0};
+opt_t g_opt_offline_sink_register{[] { const char* v = getenv("ZEN_HIP_SINK_REGISTER"); return (v && *v && *v != '0') ? 1 : 0; }()};
 // How a single hop is published to its host-mapped buffer (rt_fused.hip publish_ready).  Default since round 6: the form the
 // memory model backs -- system-scope release fence + release store -- as the reference's synchronising thrust::copy made
 // host_out readable (hps.cu:341-363).  The light form (write-through sample stores + a relaxed flag: ~1-1.5 us less per
@@ -212,7 +213,8 @@ int zen_hip_set_option(const char* name, int value)
 	             {"no_rfft", &g_opt_no_rfft},
 	             {"no_sse_lat", &g_opt_no_sse_lat},
 	             {"no_hop_lat", &g_opt_no_hop_lat},
-	             {"host_block_hops", &g_opt_host_block_hops}};
+	             {"host_block_hops", &g_opt_host_block_hops},
+	             {"offline_sink_register", &g_opt_offline_sink_register}};
 #ifndef ZEN_HIP_DIAG
 	if (name && (!strcmp(name, "rt_fused_diag") || !strcmp(name, "mask_divide") || (!strcmp(name, "median47_variant") && value > 1)))
 		ZH_FAIL(ZEN_HIP_E_UNSUPPORTED, "zen_hip_set_option: '%s' = %d is a diagnostic of -DZEN_HIP_DIAG builds", name, value);

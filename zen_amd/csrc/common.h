@@ -39,6 +39,7 @@ extern opt_t g_opt_no_hop_lat;         // "no_hop_lat": single hops of the media
 extern opt_t g_opt_no_sse_lat;         // "no_sse_lat": single hops of the SSE path through rt_sse.hip's two-wavefront kernels (rounds 2-4)
 extern opt_t g_opt_no_rfft;            // "no_rfft": the analysis kernel runs the full complex transform on its real frames (rounds 1-4)
 extern opt_t g_opt_publish_release;   // "publish_release": single hops are published with the system-scope release form (fence + release store)
+extern opt_t g_opt_offline_sink_register; // "offline_sink_register": zen_hip_hpri_process_sink pins the caller's clip (hipHostRegister) like zen_hip_hpri_process does
 extern opt_t g_opt_host_block_hops;    // "host_block_hops": hops per piece of zen_hip_hpr_process_host's pipeline (0: ~8 MiB of input)
 extern opt_t g_opt_no_mask_bits;        // "no_mask_bits": the synthesis kernels compare H and P themselves (no mask_bits_kernel)
 // Diagnostics whose results are not the reference's (timing experiments) or that only exist to cross-check a formulation

@@ -17,6 +17,7 @@
 #include <cmath>
 #include <chrono>
 #include <cstring>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -39,6 +40,10 @@ struct zen_hip_hpri {
 	hipStream_t s_in = nullptr, s_out = nullptr;
 	std::vector<hipEvent_t> events;
 	zen_hip_hpri_host_stats stats = {};
+	// zen_hip_hpri_process_sink: pinned staging slots the ranges come down into (per output a ring of SINK_SLOTS), handed to
+	// the caller's sink from there
+	float* pin[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+	size_t pin_cap = 0; // floats per slot
 };
 
 namespace {
@@ -103,6 +108,10 @@ int zen_hip_hpri_destroy(zen_hip_hpri_t h)
 			(void)zh_free(h->stage_out[i]);
 		for (hipEvent_t e : h->events)
 			(void)hipEventDestroy(e);
+		for (int i = 0; i < 2; ++i)
+			for (int k = 0; k < 4; ++k)
+				if (h->pin[i][k])
+					(void)zh_host_free(h->pin[i][k]);
 		if (h->s_in)
 			(void)hipStreamDestroy(h->s_in);
 		if (h->s_out)
@@ -430,8 +439,52 @@ int ensure_copy_streams(zen_hip_hpri* h, size_t n_events)
 } // namespace
 } // extern "C++"
 
+extern "C++" {
+namespace {
+constexpr int SINK_SLOTS = 4;
+
+// Pinned staging for the sink form: SINK_SLOTS slots of `range` samples per wanted output, kept for the handle's life.
+int ensure_pins(zen_hip_hpri* h, size_t range, const bool (&want)[2])
+{
+	if (range > h->pin_cap) {
+		for (int i = 0; i < 2; ++i)
+			for (int k = 0; k < SINK_SLOTS; ++k)
+				if (h->pin[i][k]) {
+					(void)zh_host_free(h->pin[i][k]);
+					h->pin[i][k] = nullptr;
+				}
+		h->pin_cap = range;
+	}
+	for (int i = 0; i < 2; ++i)
+		for (int k = 0; k < SINK_SLOTS; ++k)
+			if (want[i] && !h->pin[i][k])
+				ZH_HIP(zh_host_malloc((void**)&h->pin[i][k], sizeof(float) * h->pin_cap, hipHostMallocDefault));
+	return ZEN_HIP_OK;
+}
+
+int hpri_process_impl(zen_hip_hpri_t h, const float* audio_host, size_t n, float* harm_host, float* perc_host, float* resid_host,
+                      zen_hip_hpri_sink_fn sink, void* sink_user, bool sink_harm, bool sink_perc);
+} // namespace
+} // extern "C++"
+
 int zen_hip_hpri_process(zen_hip_hpri_t h, const float* audio_host, size_t n, float* harm_host,
                          float* perc_host, float* resid_host)
+{
+	return hpri_process_impl(h, audio_host, n, harm_host, perc_host, resid_host, nullptr, nullptr, false, false);
+}
+
+int zen_hip_hpri_process_sink(zen_hip_hpri_t h, const float* audio_host, size_t n, int want_harm, int want_perc,
+                              zen_hip_hpri_sink_fn sink, void* user)
+{
+	if (!sink)
+		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_process_sink: null sink");
+	return hpri_process_impl(h, audio_host, n, nullptr, nullptr, nullptr, sink, user, want_harm != 0, want_perc != 0);
+}
+
+extern "C++" {
+namespace {
+int hpri_process_impl(zen_hip_hpri_t h, const float* audio_host, size_t n, float* harm_host, float* perc_host, float* resid_host,
+                      zen_hip_hpri_sink_fn sink, void* sink_user, bool sink_harm, bool sink_perc)
 {
 	if (!h)
 		ZH_FAIL(ZEN_HIP_E_BAD_ARG, "hpri_process: null handle");
@@ -466,6 +519,7 @@ int zen_hip_hpri_process(zen_hip_hpri_t h, const float* audio_host, size_t n, fl
 		h->stage_cap = n;
 	}
 	float* hosts[2] = {harm_host, perc_host};
+	const bool want_o[2] = {sink ? sink_harm : harm_host != nullptr, sink ? sink_perc : perc_host != nullptr};
 	// ranges of the pipeline: equal lengths, a multiple of hop_h (the buffers are sized for the largest one up front, below)
 	size_t want = (size_t)g_opt_offline_range.load(std::memory_order_relaxed);
 	if (want == 0) {
@@ -501,18 +555,24 @@ int zen_hip_hpri_process(zen_hip_hpri_t h, const float* audio_host, size_t n, fl
 				t.join();
 		}
 	} joiner{zero_thread};
+	if (sink)
+		ZH_TRY(ensure_pins(h, range < n ? range : n, want_o));
 	if (n_ranges == 1) { // a short clip: up, both passes, down
 		ZH_HIP(hipMemcpyAsync(h->stage_in, audio_host, sizeof(float) * n, hipMemcpyHostToDevice, h->stream));
-		ZH_TRY(zen_hip_hpri_process_device(h, h->stage_in, n, n, harm_host ? h->stage_out[0] : nullptr,
-		                                   perc_host ? h->stage_out[1] : nullptr, nullptr, n));
+		ZH_TRY(zen_hip_hpri_process_device(h, h->stage_in, n, n, want_o[0] ? h->stage_out[0] : nullptr,
+		                                   want_o[1] ? h->stage_out[1] : nullptr, nullptr, n));
 		for (int i = 0; i < 2; ++i)
-			if (hosts[i])
-				ZH_HIP(hipMemcpyAsync(hosts[i], h->stage_out[i], sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
+			if (want_o[i])
+				ZH_HIP(hipMemcpyAsync(sink ? h->pin[i][0] : hosts[i], h->stage_out[i], sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
 		ZH_HIP(hipStreamSynchronize(h->stream));
+		if (sink)
+			for (int i = 0; i < 2; ++i)
+				if (want_o[i])
+					sink(sink_user, i, 0, h->pin[i][0], n);
 		st.total_ms = now_ms() - t_start;
 		return ZEN_HIP_OK;
 	}
-	ZH_TRY(ensure_copy_streams(h, 2 * n_ranges + 1));
+	ZH_TRY(ensure_copy_streams(h, 3 * n_ranges + 1)); // per range: upload, kernels, download; + the call's start
 	{ // Range 0 is the cheapest one (no warm-up halo in front of it): sized by it, pass 2's input buffer and the engines would
 	  // grow again at range 1 -- a device-wide synchronisation, hipFree and hipMalloc in the middle of the pipeline.  Size
 	  // everything for the largest range before the first copy is queued.
@@ -536,7 +596,10 @@ int zen_hip_hpri_process(zen_hip_hpri_t h, const float* audio_host, size_t n, fl
 	}
 	const bool try_register = g_opt_offline_no_register.load(std::memory_order_relaxed) == 0;
 	Registered reg_in, reg_out[2];
-	reg_in.take(audio_host, sizeof(float) * n, try_register);
+	// (sink form, round 6: the caller is HPRIOffline::process, whose clip is a vector nobody has pinned -- pinning 635 MB takes
+	// 33 ms before the first byte moves, the runtime's staged copy of a pageable range costs the feeding thread about as much
+	// but spread over the loop, under the kernels and the downloads; "offline_sink_register": pin it all the same)
+	reg_in.take(audio_host, sizeof(float) * n, try_register && (!sink || g_opt_offline_sink_register));
 	for (int i = 0; i < 2; ++i)
 		reg_out[i].take(hosts[i], sizeof(float) * n, try_register);
 	st.input_pinned = reg_in.pinned;
@@ -557,12 +620,87 @@ int zen_hip_hpri_process(zen_hip_hpri_t h, const float* audio_host, size_t n, fl
 		ZH_HIP(hipEventRecord(h->events[2 * k], h->s_in));
 		return ZEN_HIP_OK;
 	};
+	// Sink form: range k comes down into slot k % SINK_SLOTS of each wanted output's pinned ring; one consumer thread per
+	// output waits for the range's download event and hands the slot to the caller's sink, in order.  The feeding loop does
+	// not queue a download into a slot before both consumers are done with the range that was there.
+	std::atomic<size_t> enq{0};                 // downloads queued so far (their events recorded)
+	std::atomic<size_t> done[2] = {{0}, {0}};   // ranges each consumer has handed over
+	std::atomic<int> abort_flag{0};
+	std::thread consumers[2];
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	struct JoinAll {
+		std::thread (&t)[2];
+		std::atomic<int>& abort_flag;
+		~JoinAll()
+		{
+			abort_flag.store(1);
+			for (auto& x : t)
+				if (x.joinable())
+					x.join();
+		}
+	} join_consumers{consumers, abort_flag};
+	bool inline_sink = false; // no thread to be had: the feeding loop hands the ranges over itself
+	if (sink) {
+		for (int i = 0; i < 2 && !inline_sink; ++i) {
+			if (!want_o[i])
+				continue;
+			try {
+				consumers[i] = std::thread([&, i] {
+					(void)hipSetDevice(dev);
+					for (size_t k = 0; k < n_ranges; ++k) {
+						while (enq.load(std::memory_order_acquire) <= k) {
+							if (abort_flag.load(std::memory_order_relaxed))
+								return;
+							std::this_thread::yield();
+						}
+						if (hipEventSynchronize(h->events[2 * n_ranges + 1 + k]) != hipSuccess) {
+							abort_flag.store(2);
+							return;
+						}
+						const size_t b = k * range, e = b + range < n ? b + range : n;
+						sink(sink_user, i, b, h->pin[i][k % SINK_SLOTS], e - b);
+						done[i].store(k + 1, std::memory_order_release);
+					}
+				});
+			}
+			catch (...) {
+				inline_sink = true;
+			}
+		}
+		if (inline_sink) { // (whatever was started goes home first)
+			abort_flag.store(1);
+			for (auto& x : consumers)
+				if (x.joinable())
+					x.join();
+			abort_flag.store(0);
+		}
+	}
 	auto download = [&](size_t k) -> int {
 		const size_t b = k * range, e = b + range < n ? b + range : n;
+		if (sink && k >= (size_t)SINK_SLOTS && !inline_sink) { // the slot's previous range must have been handed over
+			for (int i = 0; i < 2; ++i)
+				while (want_o[i] && done[i].load(std::memory_order_acquire) < k - SINK_SLOTS + 1) {
+					if (abort_flag.load(std::memory_order_relaxed))
+						ZH_FAIL(ZEN_HIP_E_HIP, "hpri_process_sink: a consumer thread failed waiting for its range");
+					std::this_thread::yield();
+				}
+		}
 		ZH_HIP(hipStreamWaitEvent(h->s_out, h->events[2 * k + 1], 0));
 		for (int i = 0; i < 2; ++i)
-			if (hosts[i])
-				ZH_HIP(hipMemcpyAsync(hosts[i] + b, h->stage_out[i] + b, sizeof(float) * (e - b), hipMemcpyDeviceToHost, h->s_out));
+			if (want_o[i])
+				ZH_HIP(hipMemcpyAsync(sink ? h->pin[i][k % SINK_SLOTS] : hosts[i] + b, h->stage_out[i] + b, sizeof(float) * (e - b),
+				                      hipMemcpyDeviceToHost, h->s_out));
+		if (sink) {
+			ZH_HIP(hipEventRecord(h->events[2 * n_ranges + 1 + k], h->s_out));
+			enq.store(k + 1, std::memory_order_release);
+			if (inline_sink) {
+				ZH_HIP(hipEventSynchronize(h->events[2 * n_ranges + 1 + k]));
+				for (int i = 0; i < 2; ++i)
+					if (want_o[i])
+						sink(sink_user, i, b, h->pin[i][k % SINK_SLOTS], e - b);
+			}
+		}
 		return ZEN_HIP_OK;
 	};
 	// the copy streams do not know the handle's stream: order them behind whatever the caller queued there (and behind an
@@ -574,8 +712,8 @@ int zen_hip_hpri_process(zen_hip_hpri_t h, const float* audio_host, size_t n, fl
 		for (size_t k = 0; k < n_ranges; ++k) {
 			const size_t b = k * range, e = b + range < n ? b + range : n;
 			ZH_HIP(hipStreamWaitEvent(h->stream, h->events[2 * k], 0));
-			ZH_TRY(zen_hip_hpri_process_range(h, h->stage_in, n, b, e, harm_host ? h->stage_out[0] + b : nullptr,
-			                                  perc_host ? h->stage_out[1] + b : nullptr));
+			ZH_TRY(zen_hip_hpri_process_range(h, h->stage_in, n, b, e, want_o[0] ? h->stage_out[0] + b : nullptr,
+			                                  want_o[1] ? h->stage_out[1] + b : nullptr));
 			ZH_HIP(hipEventRecord(h->events[2 * k + 1], h->stream));
 			if (k + 1 < n_ranges)
 				ZH_TRY(upload_to(k + 1));
@@ -585,16 +723,25 @@ int zen_hip_hpri_process(zen_hip_hpri_t h, const float* audio_host, size_t n, fl
 	};
 	const int rc = feed();
 	st.enqueue_ms = now_ms() - t_start - st.setup_ms;
+	if (rc != ZEN_HIP_OK)
+		abort_flag.store(1);
 	// Whatever happened above, nothing may still be in flight when the caller's buffers are unregistered (end of this
-	// scope) and handed back: wait for all three streams, then report the first failure.
+	// scope) and handed back: wait for all three streams (and the consumers), then report the first failure.
 	const hipError_t e_out = hipStreamSynchronize(h->s_out), e_run = hipStreamSynchronize(h->stream), e_in = hipStreamSynchronize(h->s_in);
+	for (auto& x : consumers)
+		if (x.joinable())
+			x.join();
 	ZH_TRY(rc);
 	ZH_HIP(e_out);
 	ZH_HIP(e_run);
 	ZH_HIP(e_in);
+	if (abort_flag.load() == 2)
+		ZH_FAIL(ZEN_HIP_E_HIP, "hpri_process_sink: a consumer thread failed waiting for its range");
 	st.total_ms = now_ms() - t_start;
 	return ZEN_HIP_OK;
 }
+} // namespace
+} // extern "C++"
 
 int zen_hip_hpri_host_stats_get(zen_hip_hpri_t h, zen_hip_hpri_host_stats* out)
 {

@@ -113,6 +113,7 @@ SYMBOLS = [
     ("zen_hip_hpri_use_sse_filter", _i, [_vp]),
     ("zen_hip_hpri_use_soft_mask", _i, [_vp]),
     ("zen_hip_hpri_process", _i, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    ("zen_hip_hpri_process_sink", _i, [_vp, _vp, _sz, _i, _i, _vp, _vp]),
     ("zen_hip_hpri_host_stats_get", _i, [_vp, C.POINTER(_HostStats)]),
     ("zen_hip_hpri_process_device", _i, [_vp, _vp, _sz, _sz, _vp, _vp, _vp, _sz]),
     ("zen_hip_hpri_range_halo", _i, [_vp, _sz, _sz, _sz, C.POINTER(_sz), C.POINTER(_sz)]),
@@ -560,6 +561,24 @@ class HPRIOffline:
         a, b = C.c_size_t(), C.c_size_t()
         _ck(load().zen_hip_hpri_hop_counts(self._h, n, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def process_sink(self, audio, want=(True, True)):
+        """zen_hip_hpri_process_sink: the ranges of the clip handed to a callback (two library threads, one per output).
+        Returns (harm, perc, ranges): the assembled outputs (None where not wanted) and, per output, the list of (begin, count)
+        in arrival order."""
+        audio = np.ascontiguousarray(audio, dtype=np.float32)
+        n = audio.size
+        outs = [np.full(n, np.nan, np.float32) if w else None for w in want]
+        ranges = ([], [])
+        FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_size_t, C.POINTER(C.c_float), C.c_size_t)
+
+        def sink(user, which, begin, samples, count):
+            outs[which][begin:begin + count] = np.ctypeslib.as_array(samples, shape=(count,))
+            ranges[which].append((begin, count))
+        cb = FN(sink)
+        _ck(load().zen_hip_hpri_process_sink(self._h, audio.ctypes.data_as(C.c_void_p), n, int(want[0]), int(want[1]),
+                                             C.cast(cb, C.c_void_p), None))
+        return outs[0], outs[1], ranges
 
     def process(self, audio, out=None):
         """std::array<std::vector<float>,3> process(std::vector<float>) : (harm, perc, resid).

@@ -346,18 +346,92 @@ namespace hps {
 		}
 	} // namespace
 
+	namespace {
+		// The pages of a vector's RESERVED capacity asked for as transparent huge pages and faulted in by helper threads that
+		// nobody waits for until the end of the call: the ranges of the clip are appended behind them (below).  Only advice to
+		// the kernel about memory the vector owns; where it is refused the appends fault the pages in themselves.
+		struct Populator {
+			std::vector<std::thread> th;
+			void start(void* p, std::size_t bytes)
+			{
+				const std::uintptr_t page = 4096, huge = (std::uintptr_t)2 << 20;
+				std::uintptr_t a = ((std::uintptr_t)p + page - 1) & ~(page - 1), e = ((std::uintptr_t)p + bytes) & ~(page - 1);
+				if (e < a + 8 * huge)
+					return;
+				(void)madvise((void*)a, e - a, MADV_HUGEPAGE);
+				unsigned k = std::thread::hardware_concurrency() / 8;
+				k = k < 1 ? 1 : k > 6 ? 6 : k;
+				// pieces dealt round robin, so that the helpers together advance through the vector from its start -- the order
+				// in which the ranges arrive
+				const std::uintptr_t piece = 16 * huge;
+				for (unsigned i = 0; i < k; ++i) {
+					try {
+						th.emplace_back([=] {
+							for (std::uintptr_t b0 = a + i * piece; b0 < e; b0 += k * piece)
+								(void)madvise((void*)b0, (b0 + piece < e ? piece : e - b0), MADV_POPULATE_WRITE);
+						});
+					}
+					catch (...) {
+						break;
+					}
+				}
+			}
+			~Populator()
+			{
+				for (auto& t : th)
+					if (t.joinable())
+						t.join();
+			}
+		};
+
+		// n zeros: the value-initialising resize runs BEHIND the helpers that fault the pages in (where it overtakes them it
+		// faults the pages itself): one pass of the kernel's zeroing and one of the constructor's, overlapped, instead of one
+		// after the other
+		void fresh_zeros_overlapped(std::vector<float>& v, std::size_t n)
+		{
+			v.reserve(n);
+			Populator p;
+			p.start(v.data(), n * sizeof(float));
+			v.resize(n);
+		}
+
+		struct AppendCtx {
+			std::vector<float>* v[2];
+			bool out_of_order = false;
+		};
+		// zen_hip_hpri_sink_fn: the range is appended to its vector (capacity reserved: no allocation, nothing to throw)
+		extern "C" void append_range(void* user, int output, std::size_t begin, const float* samples, std::size_t count)
+		{
+			AppendCtx* c = static_cast<AppendCtx*>(user);
+			std::vector<float>& v = *c->v[output];
+			if (begin != v.size() || v.capacity() - v.size() < count) {
+				c->out_of_order = true;
+				return;
+			}
+			v.insert(v.end(), samples, samples + count);
+		}
+	} // namespace
+
 	template <>
 	std::array<std::vector<float>, 3> HPRIOffline<Backend::GPU>::process(std::vector<float> audio)
 	{
 		// return same-sized vectors as a result (hps.cu:131, :219-220)
 		const std::size_t n = audio.size();
 		static const bool trace = std::getenv("ZEN_TRACE_PROCESS") != nullptr; // stderr: where the wall time of a call goes
+		static const bool plain = std::getenv("ZEN_PROCESS_PLAIN") != nullptr; // the path of rounds 4-5 (vectors first, then the call)
 		const auto t0 = std::chrono::steady_clock::now();
 		std::vector<float> harmonic_out, percussive_out, residual_out;
-		if (n >= ((std::size_t)1 << 21)) { // the three vectors at once (a thread that cannot be had: its vector is built here)
-			// A worker's std::bad_alloc is carried back to this thread and thrown after both have been joined; the joiner also
-			// covers an exception out of this thread's own fresh_zeros (a joinable std::thread destroyed during unwinding would
-			// call std::terminate, where a plain vector construction gives the caller something to catch).
+		if (n >= ((std::size_t)1 << 21) && !plain) {
+			// Long clips (round 6).  The signature hands back three fresh std::vector<float>(n): 12 bytes of never-touched memory
+			// per sample.  Built first and then filled (rounds 4-5) that was: fault the pages in, write zeros over them (the
+			// value-initialising resize), pin them for the copies, and only then separate -- 50 + 20 + 26 ms per hour of audio,
+			// one after the other.  Now the harmonic and percussive vectors only RESERVE their memory; the separation runs at
+			// once and hands every finished range over from pinned staging memory of the engine
+			// (zen_hip_hpri_process_sink), where it is appended to its vector -- written once, by a thread per output, while
+			// the later ranges are still on the device; helper threads fault the reserved pages in ahead of the appends.  The
+			// residual (all zeros: hps.cu:45-48, :200-204) is value-initialised on a thread of its own.
+			harmonic_out.reserve(n);
+			percussive_out.reserve(n);
 			struct Worker {
 				std::thread t;
 				std::exception_ptr err;
@@ -366,55 +440,91 @@ namespace hps {
 					if (t.joinable())
 						t.join();
 				}
-			} w1, w2;
-			auto start = [n](Worker& w, std::vector<float>& v) {
+			} wr;
+			bool resid_started = false;
+			try {
+				wr.t = std::thread([&wr, &residual_out, n] {
+					try {
+						fresh_zeros_overlapped(residual_out, n);
+					}
+					catch (...) {
+						wr.err = std::current_exception();
+					}
+				});
+				resid_started = true;
+			}
+			catch (const std::system_error&) {
+			}
+			int rc;
+			AppendCtx ctx{{&harmonic_out, &percussive_out}};
+			{
+				Populator ph, pp;
+				ph.start(harmonic_out.data(), n * sizeof(float));
+				pp.start(percussive_out.data(), n * sizeof(float));
+				rc = zen_hip_hpri_process_sink(static_cast<zen_hip_hpri_t>(engine), audio.data(), n, 1, 1, append_range, &ctx);
+			}
+			if (!resid_started)
+				fresh_zeros_overlapped(residual_out, n);
+			if (wr.t.joinable())
+				wr.t.join();
+			if (wr.err)
+				std::rethrow_exception(wr.err);
+			throw_or_die(rc, "HPRIOffline::process");
+			if (ctx.out_of_order || harmonic_out.size() != n || percussive_out.size() != n)
+				throw ZgException("HPRIOffline::process: the ranges of the clip did not arrive in order (internal)");
+		}
+		else {
+			if (n >= ((std::size_t)1 << 21)) { // ZEN_PROCESS_PLAIN (A/B: rounds 4-5): the three vectors first, populated and zeroed by threads
+				std::thread t1, t2;
+				std::exception_ptr e1, e2;
+				struct Join {
+					std::thread& t;
+					~Join()
+					{
+						if (t.joinable())
+							t.join();
+					}
+				} j1{t1}, j2{t2};
+				bool s1 = false, s2 = false;
 				try {
-					w.t = std::thread([&w, &v, n] {
-						try {
-							fresh_zeros(v, n);
-						}
-						catch (...) {
-							w.err = std::current_exception();
-						}
-					});
+					t1 = std::thread([&] { try { fresh_zeros(harmonic_out, n); } catch (...) { e1 = std::current_exception(); } });
+					s1 = true;
+					t2 = std::thread([&] { try { fresh_zeros(percussive_out, n); } catch (...) { e2 = std::current_exception(); } });
+					s2 = true;
 				}
 				catch (const std::system_error&) {
 				}
-			};
-			start(w1, harmonic_out);
-			start(w2, percussive_out);
-			fresh_zeros(residual_out, n);
-			for (Worker* w : {&w1, &w2}) {
-				std::vector<float>& v = w == &w1 ? harmonic_out : percussive_out;
-				if (w->t.joinable())
-					w->t.join();
-				else
-					fresh_zeros(v, n);
+				fresh_zeros(residual_out, n);
+				if (t1.joinable())
+					t1.join();
+				if (t2.joinable())
+					t2.join();
+				if (!s1)
+					fresh_zeros(harmonic_out, n);
+				if (!s2)
+					fresh_zeros(percussive_out, n);
+				if (e1)
+					std::rethrow_exception(e1);
+				if (e2)
+					std::rethrow_exception(e2);
 			}
-			for (Worker* w : {&w1, &w2})
-				if (w->err)
-					std::rethrow_exception(w->err);
-		}
-		else {
 			harmonic_out.resize(n);
 			percussive_out.resize(n);
 			residual_out.resize(n);
+			// residual_out stays as value-initialised: pass 2's residual is never written (hps.cu:45-48, :200-204),
+			// so there is nothing to fetch for it
+			if (n > 0)
+				throw_or_die(zen_hip_hpri_process(static_cast<zen_hip_hpri_t>(engine), audio.data(), n,
+				                                  harmonic_out.data(), percussive_out.data(), nullptr),
+				             "HPRIOffline::process");
 		}
-		const auto t1 = std::chrono::steady_clock::now();
-		// residual_out stays as value-initialised: pass 2's residual is never written (hps.cu:45-48, :200-204),
-		// so there is nothing to fetch for it
-		if (n > 0)
-			throw_or_die(zen_hip_hpri_process(static_cast<zen_hip_hpri_t>(engine), audio.data(), n,
-			                                  harmonic_out.data(), percussive_out.data(), nullptr),
-			             "HPRIOffline::process");
 		if (trace) {
 			const auto t2 = std::chrono::steady_clock::now();
 			zen_hip_hpri_host_stats st{};
 			zen_hip_hpri_host_stats_get(static_cast<zen_hip_hpri_t>(engine), &st);
-			std::cerr << "HPRIOffline::process: " << n << " samples, result vectors "
-			          << std::chrono::duration<double, std::milli>(t1 - t0).count() << " ms, separation + copies "
-			          << std::chrono::duration<double, std::milli>(t2 - t1).count() << " ms (" << st.n_ranges << " ranges, setup "
-			          << st.setup_ms << " ms, enqueue " << st.enqueue_ms << " ms)" << std::endl;
+			std::cerr << "HPRIOffline::process: " << n << " samples, " << std::chrono::duration<double, std::milli>(t2 - t0).count()
+			          << " ms (" << st.n_ranges << " ranges, setup " << st.setup_ms << " ms, enqueue " << st.enqueue_ms << " ms, pipeline "
+			          << st.total_ms << " ms)" << std::endl;
 		}
 		// The by-value clip dies with this call: returning its pages to the system takes 25-60 ms per hour of audio (one
 		// munmap of 635 MB), on the caller's clock.  A helper thread does it while the caller goes on.
