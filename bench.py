@@ -52,7 +52,7 @@ FS = 44100.0
 HOP = 1024
 BETA = 2.0
 # HBM bytes per launch measured with rocprofv3 --pmc (tools/pmc_cmd.sh); re-collected whenever a kernel changes
-TRAFFIC_FILE = "r05_hbm_traffic.json"   # {demangled kernel name: {elements, rows, cols, hbm_bytes_per_launch, ...}}
+TRAFFIC_FILE = "r06_hbm_traffic.json"   # {demangled kernel name: {elements, rows, cols, hbm_bytes_per_launch, ...}}
 K_FUSED_P = "rt_fused_kernel<12, 47, 3, true, true, true>"
 K_FUSED_HPR = "rt_fused_kernel<12, 47, 3, false, true, true>"
 K_MEDIAN_WHOLE = "median47_dpp_kernel<false, 0, false>"   # through plain zen_hip_mfilt_run: the build that checks sign bits
@@ -217,7 +217,7 @@ def offline_rooflines(prof, steps, frames, nfft, hop, n_out1, copy_bw, freq_mask
         N, h, F = nfft[ps], hop[ps], frames[ps]
         nout = n_out1 if ps == "pass1" else 1
         mf = freq_mask[ps]
-        half = mf <= 63 or mf in (65, 85, 93, 129, 171, 187, 255)  # hpr.hip run_chunk: half rows on the median path
+        half = mf <= 63 or mf in (65, 85, 93, 129, 171, 187, 255, 257)  # hpr.hip run_chunk: half rows on the median path
         per_frame = {"stft": 4 * h + 12 * (N // 2 + 1),
                      "freq_filter": 8 * (N // 2 + 1 + mf // 2) if half else 8 * N,
                      "time_filter": 8 * (N // 2 + 1) if half else 8 * N,

@@ -37,7 +37,7 @@ def _matrix(rows, cols, seed, kind):
 
 # (rows, cols, filter_len): register windows of 5..32 registers (257..2047 taps), the window in LDS (beyond), even
 # lengths (made odd, mfilt.h:305), a length equal to the dimension, and one window that does not fit the LDS
-LONG_FREQ = [(5, 700, 257), (4, 700, 256), (3, 1500, 511), (3, 1300, 600), (3, 2500, 1025), (2, 2600, 1536), (2, 3000, 2047),
+LONG_FREQ = [(5, 700, 257), (4, 700, 256), (6, 4096, 257), (3, 16384, 256), (70, 2048, 257), (3, 1500, 511), (3, 1300, 600), (3, 2500, 1025), (2, 2600, 1536), (2, 3000, 2047),
              (2, 3000, 2049), (2, 2100, 2100), (3, 5000, 4999), (1, 9000, 8191), (2, 20000, 16383)]
 LONG_TIME = [(700, 70, 257), (300, 130, 299), (300, 64, 300), (1300, 33, 1025), (2200, 5, 2049), (2500, 3, 2500)]
 

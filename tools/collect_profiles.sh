@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything profiles/ holds for one build, in one GPU-box call:  gpurun -- 'tools/collect_profiles.sh r05'
+# Everything profiles/ holds for one build, in one GPU-box call:  gpurun -- 'tools/collect_profiles.sh r06'
 # Writes gpurun_out/prof_<tag>/ ; copy what should be judged into profiles/<tag>_* (hbm_traffic.json and offline_batch_pmc.json also go
 # to profiles/<round>_*.json, where bench.py looks for them: <round> = the tag up to its first underscore).
 # The build label comes from .build_rev, which zen_amd/build.py writes from `git rev-parse` where the library is built.
@@ -31,6 +31,9 @@ timeout 1300 tools/pmc_cmd.sh rt_fused_kernel $B --outputs HPR > $OUT/pmc_fused_
 timeout 1300 tools/pmc_cmd.sh median47_dpp_kernel $B --no-block-fused > $OUT/pmc_median47_half.json 2>> $OUT/pmc.err
 timeout 1300 tools/pmc_cmd.sh median47_dpp_kernel python3 tools/bench_median.py --suite one --rows 25840 --cols 4096 --len 47 --iters 6 > $OUT/pmc_median47_whole.json 2>> $OUT/pmc.err
 timeout 1300 tools/pmc_cmd.sh sse_synth_kernel python3 tools/sse_ab.py > $OUT/pmc_sse_synth.json 2>> $OUT/pmc.err
+# the network median kernels on the path shapes (round 6: what bounds the time-direction kernel)
+{ for sh in "103360 1024 11" "25840 4096 3" "51680 2048 7" "16384 16384 11"; do set -- $sh; echo "== time direction, $1 x $2, $3 taps"; timeout 600 tools/pmc_cmd.sh median_net_time_kernel python3 tools/bench_median.py --suite one --rows $1 --cols $2 --len $3 --dir time --iters 6; done
+  for sh in "103360 1024 13" "51680 2048 23" "16384 16384 11"; do set -- $sh; echo "== frequency direction, $1 x $2, $3 taps (plain wrapper)"; timeout 600 tools/pmc_cmd.sh median_net_freq_kernel python3 tools/bench_median.py --suite one --rows $1 --cols $2 --len $3 --iters 6; done; } > $OUT/pmc_median_net_kernels.txt 2>> $OUT/pmc.err
 # every kernel of the offline batch step (valu_issue_frac of its VALU-bound kernels: bench.py offline_valu_issue)
 timeout 1300 tools/pmc_cmd.sh _kernel python3 bench.py --workload offline_batch --steps 2 --warmup 1 --settle-ms 0 --no-cpu-baseline > $OUT/pmc_offline_batch_raw.json 2>> $OUT/pmc.err
 python3 - $OUT/pmc_offline_batch_raw.json "$REV" > $OUT/offline_batch_pmc.json <<'PY'
@@ -54,8 +57,12 @@ cp gpurun_out/bench_detail.json $OUT/bench_default.json
 python3 bench.py --workload offline_batch --detail > $OUT/bench_offline_batch.json 2>> $OUT/bench_default.err
 python3 bench.py --workload offline_long --detail > $OUT/bench_offline_long.json 2>> $OUT/bench_default.err
 python3 bench.py --workload offline_host --host-variants --detail > $OUT/bench_offline_host.json 2>> $OUT/bench_default.err
-python3 tools/bench_median.py --suite path > $OUT/median_path_shapes.jsonl 2>> $OUT/bench_default.err
-python3 tools/bench_median.py --suite path --nonneg >> $OUT/median_path_shapes.jsonl 2>> $OUT/bench_default.err
+# BASELINE's second metric, every listed shape, the sustained protocol of the bench line (plain wrapper, then with the promise)
+python3 tools/bench_median.py --suite sustained > $OUT/median_shapes_sustained.jsonl 2>> $OUT/bench_default.err
+python3 tools/bench_median.py --suite sustained --nonneg >> $OUT/median_shapes_sustained.jsonl 2>> $OUT/bench_default.err
+python3 tools/probe_lowrate.py > $OUT/lowrate_257_taps.jsonl 2>> $OUT/bench_default.err
+python3 tools/ab_block_host.py > $OUT/block_host_piece_lengths.txt 2>> $OUT/bench_default.err
+tools/ab_offline_host.sh > $OUT/offline_host_cpp_ab.txt 2>> $OUT/bench_default.err
 # micro-benchmarks the design decisions lean on
 mkdir -p /tmp/ub
 g++ -O2 -std=c++17 -I include tools/rt_latency.cpp -o /tmp/ub/rt -L zen_amd -lzen_hip -Wl,-rpath,$PWD/zen_amd && { /tmp/ub/rt 3000 --stamps; ZEN_RT_RESIDENT=100 /tmp/ub/rt 3000; } > $OUT/rt_latency.jsonl 2>&1

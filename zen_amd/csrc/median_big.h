@@ -1,4 +1,4 @@
-// median_big.h -- register-resident exact sliding median for odd windows 65..255 (the frequency masks of
+// median_big.h -- register-resident exact sliding median for odd windows 65..267 (the frequency masks of
 // hop 2048/4096 at 44.1 and 48 kHz: 85, 93, 171, 187 taps; 65 and 129 taps at 16/32 kHz).  Extends the
 // scheme of median_net.h:
 //
@@ -36,7 +36,7 @@ struct Geo {
 	static constexpr int NR = REST * 16 + NX;    // second sorted list
 	static constexpr int RREAL = 32 + 16 * REST; // R slots in use: 32 for the loose samples + the blocks
 	static constexpr int NRP = RREAL <= 32 ? 32 : (RREAL <= 64 ? 64 : (RREAL <= 128 ? 128 : 256));
-	static constexpr bool supported = (W & 1) && W >= 65 && W <= 255;
+	static constexpr bool supported = (W & 1) && W >= 65 && W <= 267; // (255..267: fifteen whole blocks, 0..6 loose samples a side)
 };
 
 template <int N, int TOTAL, int OFF = 0>

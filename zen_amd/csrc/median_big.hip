@@ -338,10 +338,11 @@ int launch_w(const FilterArgs& a, hipStream_t stream, int* bits_done)
 	return ZEN_HIP_OK;
 }
 
-// l_perc of hops 512..4096 at the usual sample rates (8..96 kHz), and the longest mask the API accepts
+// l_perc of hops 512..4096 at the usual sample rates (8..96 kHz); 255; and 257 = l_perc 256 made odd: fs / hop = 7.8125, the
+// lowest rate every hop runs at (32 kHz at hop 4096 -- the CLI's default hop_h --, 16 kHz at 2048, 8 kHz at 1024)
 bool median_big_available(int len)
 {
-	return len == 65 || len == 85 || len == 93 || len == 129 || len == 171 || len == 187 || len == 255;
+	return len == 65 || len == 85 || len == 93 || len == 129 || len == 171 || len == 187 || len == 255 || len == 257;
 }
 
 } // namespace
@@ -370,6 +371,7 @@ int launch_median_big(const FilterArgs& a, hipStream_t stream, bool* handled, in
 	case 129: return launch_w<129>(a, stream, bits_done);
 	case 171: return launch_w<171>(a, stream, bits_done);
 	case 187: return launch_w<187>(a, stream, bits_done);
+	case 257: return launch_w<257>(a, stream, bits_done);
 	default: return launch_w<255>(a, stream, bits_done);
 	}
 }

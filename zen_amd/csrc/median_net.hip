@@ -883,7 +883,7 @@ bool filter_supports_hermitian(int len, int cols)
 	if (len >= 3 && len <= 63)
 		return true;
 	// the long masks of median_big.hip (hop 2048 / 4096): whole 16-bin blocks, the two pieces of the tail apart
-	const bool big = len == 65 || len == 85 || len == 93 || len == 129 || len == 171 || len == 187 || len == 255;
+	const bool big = len == 65 || len == 85 || len == 93 || len == 129 || len == 171 || len == 187 || len == 255 || len == 257;
 	return big && cols % 32 == 0 && (cols >> 5) >= (len / 2 + 15) / 16 + 1;
 }
 
