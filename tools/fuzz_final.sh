@@ -1,6 +1,6 @@
 #!/bin/bash
 # The round's closing fuzz run, on the GPU box:   gpurun -- 'tools/fuzz_final.sh r05'
-# >= 3 realtime + 3 --offline + 1 --resident seeds x 150 s of tools/fuzz_parity.py (HIP engine vs CPU oracle, tolerance 0, red zones on, every
+# >= 3 realtime + 3 --offline + 1 --resident + 1 --filters seeds x 150 s of tools/fuzz_parity.py (HIP engine vs CPU oracle, tolerance 0, red zones on, every
 # case followed by zen_hip_memcheck) on the build that is in the tree.  REFUSES to write a summary for a library that was built
 # from uncommitted kernel sources (.build_kernel_rev, written by zen_amd/build.py where the library is built): the summary names
 # the last commit that touched zen_amd/csrc / include / build.py, and tests/test_profiles.py fails the CPU tier when that is
@@ -35,6 +35,11 @@ done
 for seed in ${FUZZ_RESIDENT_SEEDS:-521}; do   # the per-hop API through the resident kernels (round 5)
   L=$(python3 tools/fuzz_parity.py --resident --seconds $SECS --seed $seed 2>&1 | tail -3 | tr '\n' ' ')
   echo "seed $seed (--resident, $SECS s): $L" >> $OUT
+  case "$L" in *"mismatches 0"*"GPU-refused 0"*"memcheck clean"*) ;; *) RC=1;; esac
+done
+for seed in ${FUZZ_FILTER_SEEDS:-531}; do   # the drop-in filter classes, any shape and length (round 6)
+  L=$(python3 tools/fuzz_parity.py --filters --seconds $SECS --seed $seed 2>&1 | tail -3 | tr '\n' ' ')
+  echo "seed $seed (--filters, $SECS s): $L" >> $OUT
   case "$L" in *"mismatches 0"*"GPU-refused 0"*"memcheck clean"*) ;; *) RC=1;; esac
 done
 echo "kernel_commit $KREV" >> $OUT

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised differential test: HIP engine vs CPU oracle on random configurations (sample rate, hop, output
 flags, causality, mask type, blocking, streams).  Test infrastructure; run on the GPU box:
-    python tools/fuzz_parity.py --seconds 120 --seed 1          (--offline: the two-pass driver; --resident: the per-hop API)
+    python tools/fuzz_parity.py --seconds 120 --seed 1          (--offline: the two-pass driver; --resident: the per-hop API;
+                                                                 --filters: the drop-in median / box filter classes)
 Prints every mismatch with its configuration and exits non-zero if there was one."""
 import argparse
 import os
@@ -248,6 +249,76 @@ def run_resident(seconds, seed):
     return n_ok, n_bad, n_skip, n_refused, len(seen)
 
 
+def run_filters(seconds, seed):
+    """The drop-in filter classes (MedianFilterGPU / BoxFilterGPU: libzen/mfilt.h:33-268, box.h:30-215) on random matrices:
+    any shape, ANY filter_len the reference accepts (1 .. the filtered dimension, mfilt.h:296-305), both directions, data with
+    ties / ramps / signs, with and without the non-negativity promise.  Returns (ok, mismatches, rejected, refused, distinct)."""
+    rng = np.random.default_rng(seed)
+    zen_amd.init(0)
+    t_end = time.time() + seconds
+    n_ok = n_bad = n_skip = n_refused = 0
+    seen = set()
+    while time.time() < t_end:
+        kind = str(rng.choice(["median", "median", "median", "box"]))
+        direction = str(rng.choice(["f", "t"]))
+        shape = str(rng.choice(["small", "wide", "tall", "aligned"]))
+        if shape == "small":
+            rows, cols = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        elif shape == "wide":
+            rows, cols = int(rng.integers(1, 12)), int(rng.integers(40, 6000))
+        elif shape == "tall":
+            rows, cols = int(rng.integers(40, 3000)), int(rng.integers(1, 24))
+        else:
+            rows, cols = int(rng.integers(1, 40)), int(rng.choice([256, 512, 1024, 2048, 4096, 8192]))
+        dim = cols if direction == "f" else rows
+        pick = str(rng.choice(["short", "any", "near", "special"]))
+        if pick == "short":
+            flen = int(rng.integers(1, min(dim, 64) + 1))
+        elif pick == "any":
+            flen = int(rng.integers(1, dim + 1))
+        elif pick == "near":
+            flen = max(1, dim - int(rng.integers(0, 3)))
+        else:
+            flen = min(dim, int(rng.choice([47, 63, 64, 65, 93, 187, 255, 256, 257, 258, 511, 1024, 2047, 2048, 2049, 4097])))
+        if rows * cols * flen > 6e8:                      # (the oracle: a sliding insertion per sample)
+            continue
+        data = str(rng.choice(["uniform", "ties", "ramp", "nonneg", "nonneg"]))
+        if data == "uniform":
+            a = rng.uniform(-1, 1, (rows, cols)).astype(np.float32)
+        elif data == "ties":
+            a = rng.integers(-3, 4, (rows, cols)).astype(np.float32)
+        elif data == "ramp":
+            a = (np.arange(rows * cols, dtype=np.float32).reshape(rows, cols) * (1 if rng.integers(0, 2) else -1)).astype(np.float32)
+        else:
+            a = rng.random((rows, cols), dtype=np.float32)
+            a *= (rng.uniform(0, 1, a.shape) < 0.8)
+        promise = data == "nonneg" and kind == "median" and bool(rng.integers(0, 2))
+        od = o.FREQUENCY if direction == "f" else (o.TIME_CAUSAL if rng.integers(0, 2) else o.TIME_ANTICAUSAL)
+        zd = zen_amd.FREQUENCY if direction == "f" else (zen_amd.TIME_CAUSAL if od == o.TIME_CAUSAL else zen_amd.TIME_ANTICAUSAL)
+        try:
+            ref = (o.median_filter if kind == "median" else o.box_filter)(a, flen, od)
+        except Exception:
+            n_skip += 1
+            continue
+        try:
+            f = (zen_amd.MedianFilterGPU if kind == "median" else zen_amd.BoxFilterGPU)(rows, cols, flen, zd)
+            if promise:
+                f.assume_nonneg()
+            got = f.filter_host(a)
+        except zen_amd.ZenHipError as e:
+            print("GPU REFUSED", dict(kind=kind, rows=rows, cols=cols, flen=flen, direction=direction), e, flush=True)
+            n_refused += 1
+            continue
+        ok = np.array_equal(got.view(np.uint32), ref.view(np.uint32)) and not zen_amd.memcheck()["corrupt_words"]
+        seen.add((kind, direction, flen | 1, cols if direction == "f" else rows))
+        if ok:
+            n_ok += 1
+        else:
+            n_bad += 1
+            print("MISMATCH filter", dict(kind=kind, rows=rows, cols=cols, flen=flen, direction=direction, data=data, promise=promise), flush=True)
+    return n_ok, n_bad, n_skip, n_refused, len(seen)
+
+
 def memcheck_line():
     """Red zones (ZEN_HIP_REDZONE, set by tools/fuzz_final.sh) of everything still alive, plus what the frees found."""
     r = zen_amd.memcheck()
@@ -264,7 +335,14 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--offline", action="store_true", help="fuzz the two-pass offline driver instead of the streaming engine")
     ap.add_argument("--resident", action="store_true", help="fuzz the per-hop API with the resident kernels (zen_hip_hpr_set_resident)")
+    ap.add_argument("--filters", action="store_true", help="fuzz the drop-in MedianFilterGPU / BoxFilterGPU classes (any shape, any length)")
     args = ap.parse_args()
+    if args.filters:
+        n_ok, n_bad, n_skip, n_ref, n_seen = run_filters(args.seconds, args.seed)
+        mc, bad = memcheck_line()
+        print("filters: ok %d  mismatches %d  oracle-rejected %d  GPU-refused %d  distinct (kind, direction, taps, dimension): %d  %s"
+              % (n_ok, n_bad, n_skip, n_ref, n_seen, mc))
+        return 1 if n_bad or bad or n_ref else 0
     if args.resident:
         n_ok, n_bad, n_skip, n_ref, n_seen = run_resident(args.seconds, args.seed)
         mc, bad = memcheck_line()
