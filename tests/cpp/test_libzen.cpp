@@ -260,6 +260,31 @@ static void test_demo_front_end(float fs, std::size_t hop, float beta, unsigned 
 	zo_hpr_destroy(o);
 }
 
+// The block of hops from host buffers (HPRRealtime::process_hops_host, an MI355X extension: the loop of zen/fakert.h:221-247
+// for a whole block): pageable vectors and IOGPU's pinned buffer, against the per-hop CPU path.
+static void test_block_from_host(std::size_t hop, std::size_t n_hops)
+{
+	auto x = generate_data_normalized(n_hops * hop);
+	zen::hps::HPRRealtime<Backend::GPU> rt(44100.0F, hop, 2.0F, zen::hps::OUTPUT_PERCUSSIVE | zen::hps::OUTPUT_HARMONIC);
+	std::vector<float> perc(x.size(), -1.0F);
+	zen::io::IOGPU pinned(x.size());
+	rt.process_hops_host(x.data(), n_hops, pinned.host_out, perc.data(), nullptr);
+	int err = 0;
+	zo_hpr* o = zo_hpr_create(44100.0F, hop, 2.0F, ZO_OUTPUT_PERCUSSIVE | ZO_OUTPUT_HARMONIC, ZO_TIME_CAUSAL, 1, &err);
+	CHECK(o != nullptr);
+	bool same = true, any = false;
+	for (std::size_t i = 0; i < n_hops; ++i) {
+		zo_hpr_process_next_hop(o, x.data() + i * hop);
+		for (std::size_t j = 0; j < hop; ++j) {
+			same = same && perc[i * hop + j] == zo_hpr_percussive_out(o)[j] && pinned.host_out[i * hop + j] == zo_hpr_harmonic_out(o)[j];
+			any = any || perc[i * hop + j] != 0.0F;
+		}
+	}
+	CHECK(same);
+	CHECK(any);
+	zo_hpr_destroy(o);
+}
+
 // HPRIOffline<GPU>::process on a clip long enough for the host-vector pipeline (ranges of 4 Mi samples, result vectors
 // populated by threads): equal, sample for sample, to the same call on its first part run alone wherever the two must
 // agree -- an offline output sample depends on a few hops around it -- and the residual is zeros (hps.cu:219-220, Q8).
@@ -310,6 +335,8 @@ int main()
 	test_demo_front_end(48000.0F, 256, 2.5F, zen::hps::OUTPUT_PERCUSSIVE, 80);
 	test_demo_front_end(44100.0F, 256, 2.5F, zen::hps::OUTPUT_PERCUSSIVE, 80, 50);  // ... through the resident kernel
 	test_demo_front_end(44100.0F, 1024, 2.0F, zen::hps::OUTPUT_HARMONIC, 40, 50);
+	test_block_from_host(1024, 37);
+	test_block_from_host(256, 4500); // (several pieces of the pipeline)
 	test_offline_long_clip();
 	std::printf("%d checks, %d failures\n", g_checks, g_fail);
 	return g_fail ? 1 : 0;

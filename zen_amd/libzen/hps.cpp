@@ -214,6 +214,12 @@ namespace hps {
 	}
 
 	template <>
+	void HPRRealtime<Backend::GPU>::process_hops_host(const float* in, std::size_t n_hops, float* harm, float* perc, float* resid)
+	{
+		throw_or_die(zen_hip_hpr_process_host(p_impl->engine, in, n_hops, harm, perc, resid), "process_hops_host");
+	}
+
+	template <>
 	void HPRRealtime<Backend::GPU>::use_resident_kernel(int idle_ms)
 	{
 		throw_or_die(zen_hip_hpr_set_resident(p_impl->engine, idle_ms), "use_resident_kernel");

@@ -71,6 +71,12 @@ namespace hps {
 		void process_hops(thrust::device_ptr<float> in, std::size_t n_hops, thrust::device_ptr<float> harm,
 		                  thrust::device_ptr<float> perc, thrust::device_ptr<float> resid);
 
+		// MI355X extension: the same for HOST buffers (n_hops * hop floats in, n_hops * hop floats into every non-null
+		// output) -- what zen/fakert.h:221-247 does hop by hop (host hop in, process_next_hop, copy_*, host hop out), for a
+		// whole block, its pieces going up / through the engine / back down on three streams.  Returns when the outputs are
+		// in the caller's buffers; buffers from zen::io::IOGPU (or any pinned memory) are copied asynchronously.
+		void process_hops_host(const float* in, std::size_t n_hops, float* harm, float* perc, float* resid);
+
 	private:
 		zen::internal::hps::HPR<B>* p_impl;
 	};
