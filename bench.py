@@ -39,6 +39,7 @@ and reported as `offline_batch_sharded` next to it; `ranks_reported` is an all-r
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -1118,6 +1119,16 @@ def offline_host_run(zen_amd, seconds=3600.0, reps=4, cpu_baseline=True, variant
     return res
 
 
+def short_source(src):
+    """The provenance of a replayed counter record in under 160 characters (what the driver's record keeps of a string)."""
+    if not src:
+        return src
+    mm = re.search(r"profiles/(\S+?), build (\S+)", src)
+    if mm and src.startswith("committed PMC record"):
+        return "REPLAYED from committed PMC record profiles/%s (build %s), not measured in this run" % (mm.group(1), mm.group(2))
+    return src[:150]
+
+
 def compact_line(full):
     """The one line the driver keeps (it stores the contract keys, `config`, `roofline`, `cpu_baseline` and only the NAMES of
     anything else, and cuts the tail of long lines): everything both BASELINE metrics and the north-star targets need sits
@@ -1162,6 +1173,7 @@ def compact_line(full):
     bh = full.get("block_host")
     if bh:     # `value` with the host copies inside the timed region (zen/fakert.h:221-247), PCIe-bound
         cfg["block_host_hops_per_s"] = bh.get("value")
+        cfg["block_host_frac_of_link_roof"] = bh.get("roofline", {}).get("frac")
         legs["block_host"] = {"hops_per_s": bh.get("value"), "wall_ms": bh.get("wall_ms"), "x_realtime": bh.get("x_realtime"),
                               "frac_of_link_roof": bh.get("roofline", {}).get("frac"), "link_roof_ms": bh.get("roofline", {}).get("roof_ms"),
                               "h2d_GBps": bh.get("link", {}).get("h2d_GBps"), "d2h_GBps": bh.get("link", {}).get("d2h_GBps"),
@@ -1186,26 +1198,30 @@ def compact_line(full):
                                       "avg_launch_ms", "launches", "hops_per_launch", "algorithmic_bytes_per_hop",
                                       "hbm_bytes_moved_per_hop_by_design", "device_copy_GBps", "algorithmic_bytes_per_frame",
                                       "frames_per_step", "roof_ms", "achieved_ms", "split_ms", "elements_per_launch") if k in r}
+        # The driver's record keeps the SCALARS of `roofline` and `config` (strings cut at ~160 characters, nested objects
+        # dropped): everything a reader of that record needs is a flat scalar here, the nested objects repeat it with detail.
+        if r.get("traffic_source"):
+            roof["traffic_source"] = short_source(r["traffic_source"])
         m = full.get("roofline_median")
-        if m:      # BASELINE's second metric, where the driver's record keeps it
-            roof["median47"] = {"kernel": K_MEDIAN_WHOLE, "shape": "%d x %d, 47 taps, frequency direction" % (m["rows"], m["cols"]),
-                                "algorithmic_bytes_per_element": 8, "frac": m["frac"], "GBps": m["achieved"],
-                                "sustained": {"frac": m["sustained"]["frac"], "avg_launch_us": 1e3 * m["sustained"]["avg_launch_ms"],
-                                              "launches": m["sustained"]["launches"], "seconds": m["sustained"]["seconds"]},
-                                "burst_frac": m["burst"]["frac"], "cold_frac": m["cold"]["frac"],
-                                "traffic": m.get("traffic"), "traffic_source": m.get("traffic_source"),
-                                "frac_of_device_copy": m.get("frac_of_device_copy"),
-                                "through": "plain zen_hip_mfilt_run, no option, no promise",
+        if m:      # BASELINE's second metric
+            roof["median47_frac"] = m["frac"]
+            roof["median47_avg_launch_us"] = 1e3 * m["sustained"]["avg_launch_ms"]
+            roof["median47_launches"] = m["sustained"]["launches"]
+            roof["median47_traffic"] = m.get("traffic")
+            roof["median47_is"] = ("%s, %d x %d, 47 taps, plain zen_hip_mfilt_run (no promise), >= 1 s back to back, 8 B/element"
+                                   % (K_MEDIAN_WHOLE, m["rows"], m["cols"]))
+            for x in m.get("shapes", []):      # every shape BASELINE.md lists: >= 1 s of back-to-back launches, 8 B per element
+                roof["median_frac_%dx%d_%s%d" % (x["rows"], x["cols"], x["direction"][0], x["taps"])] = round(x["frac"], 4)
+            if m.get("shapes"):
+                roof["median_frac_is"] = ("rows x cols _ t|f taps: >= 1 s of back-to-back zen_hip_mfilt_run per shape on a handle with "
+                                          "zen_hip_mfilt_assume_nonneg (the engine's launches); plain wrapper: median_shapes_plain")
+            roof["median47"] = {"sustained_seconds": m["sustained"]["seconds"], "burst_frac": m["burst"]["frac"], "cold_frac": m["cold"]["frac"],
+                                "traffic_source": short_source(m.get("traffic_source")), "frac_of_device_copy": m.get("frac_of_device_copy"),
                                 "long_masks_frac": {"%d taps / %d bins" % (x["taps"], x["cols"]): round(x["frac"], 4)
                                                     for x in m.get("long_masks", [])}}
-            if m.get("shapes"):   # every shape BASELINE.md lists, >= 1 s of back-to-back launches each, 8 B per element
-                def tag(x):
-                    return "%dx%d/%s%d" % (x["rows"], x["cols"], x["direction"][0], x["taps"])
-                roof["median_shapes"] = {"frac": {tag(x): round(x["frac"], 4) for x in m["shapes"]},
-                                         "frac_plain_wrapper": {tag(x): round(x["frac"], 4) for x in m.get("shapes_plain", [])},
-                                         "protocol": ">= 1 s of back-to-back zen_hip_mfilt_run per shape, HIP events around the run, 8 B/element; "
-                                                     "`frac`: handles with zen_hip_mfilt_assume_nonneg (the engine's launches: |S| >= +0); "
-                                                     "`frac_plain_wrapper`: no promise, 0.35 s per shape"}
+            if m.get("shapes_plain"):
+                roof["median_shapes_plain"] = {"%dx%d/%s%d" % (x["rows"], x["cols"], x["direction"][0], x["taps"]): round(x["frac"], 3)
+                                               for x in m["shapes_plain"]}
             roof["device_copy_is"] = m.get("device_copy", {}).get("device_copy_GBps_is")
             roof["hipMemcpy_d2d_GBps"] = m.get("device_copy", {}).get("hipMemcpy_d2d_GBps")
         line["roofline"] = roof

@@ -34,9 +34,14 @@ def test_compact_line_carries_both_baseline_metrics_and_the_targets():
     r = line["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert r["traffic"] and 0.2 < r["valu_issue_frac"] < 1.0
-    m = r["median47"]                                          # BASELINE's second metric, inside a field the driver keeps
-    assert m["algorithmic_bytes_per_element"] == 8 and 0.5 < m["sustained"]["frac"] < 1.0 and m["sustained"]["seconds"] >= 1.0
-    assert abs(m["traffic"] / (25840 * 4096) - 8.0) < 0.1
+    # BASELINE's second metric as flat scalars of `roofline` (the driver's record keeps the scalars of `roofline` and `config`,
+    # cuts strings at ~160 characters and drops nested objects), the detail nested beside them
+    assert 0.5 < r["median47_frac"] < 1.0 and r["median47_launches"] > 1000 and "8 B/element" in r["median47_is"]
+    assert abs(r["median47_traffic"] / (25840 * 4096) - 8.0) < 0.1
+    assert r["median47"]["sustained_seconds"] >= 1.0
+    for k, v in r.items():
+        if isinstance(v, str):
+            assert len(v) <= 200, (k, len(v))
     cfg = line["config"]                                       # the north star's offline target, and the host-vector figure
     assert cfg["offline_batch_x_realtime"] > 10000 and cfg["offline_long_x_realtime"] > 10000
     assert cfg["offline_host_x_realtime"] > 10000 and cfg["per_hop_api_us"] > 0 and cfg["per_hop_api_resident_us"] > 0
