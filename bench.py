@@ -253,7 +253,7 @@ def offline_rooflines(prof, steps, frames, nfft, hop, n_out1, copy_bw, freq_mask
     return roof, out
 
 
-OFFLINE_PMC_FILE = "r05_offline_batch_pmc.json"   # tools/pmc_cmd.sh _kernel python3 bench.py --workload offline_batch ... (collect_profiles.sh)
+OFFLINE_PMC_FILE = "r06_offline_batch_pmc.json"   # tools/pmc_cmd.sh _kernel python3 bench.py --workload offline_batch ... (collect_profiles.sh)
 OFFLINE_PMC_KERNELS = {"pass1.stft": "stft_real_kernel<14>", "pass1.freq_filter": "median_big_kernel<187", "pass1.istft": "istft_run_wide_kernel<14, 2>",
                        "pass2.stft": "stft_real_kernel<10>", "pass2.freq_filter": "median_tf_herm_bits_kernel<11, 13>",
                        "pass2.istft": "istft_run_kernel<10>"}
