@@ -76,8 +76,27 @@ struct Plan {
 #else
 	static constexpr bool SWZ = false;
 #endif
+	// In-place exchanges (PassRunner; -DZEN_FFT_INPLACE, the 16384-point plan of 4 + 4 + 3 + 3 stages): digit d_0 of the index
+	// (bits 13..10) is what consecutive lanes differ in during the last two passes, so the unpadded image is XOR-swizzled
+	// with those bits: slot bits [4:3] ^= i[11:10], [2] ^= i[13], [1] ^= i[12], [0] ^= i[6] -- every wave instruction of
+	// every pass then touches each of the 32 eight-byte bank pairs exactly twice (worked out per pass in DESIGN.md section 8)
+#if defined(ZEN_FFT_INPLACE)
+	static constexpr bool INPLACE = LOG2N == 14 && V == 16;
+#else
+	static constexpr bool INPLACE = false;
+#endif
+#if defined(ZEN_FFT_INPLACE)
+	static constexpr int LDS_FLOAT2 = (SWZ || INPLACE) ? N : N + (N >> PAD_SHIFT);
+	static __device__ __forceinline__ int pad(int i)
+	{
+		if (INPLACE)
+			return i ^ ((((i >> 10) & 3) << 3) | (((i >> 13) & 1) << 2) | (((i >> 12) & 1) << 1) | ((i >> 6) & 1));
+		return SWZ ? (i ^ ((i >> 3) & 31)) : i + (i >> PAD_SHIFT);
+	}
+#else
 	static constexpr int LDS_FLOAT2 = SWZ ? N : N + (N >> PAD_SHIFT); // padded frame image in LDS
 	static __device__ __forceinline__ int pad(int i) { return SWZ ? (i ^ ((i >> 3) & 31)) : i + (i >> PAD_SHIFT); }
+#endif
 	// pad(base + off) for a compile-time offset: where off is a multiple of the padding period its share of the padded address
 	// is a constant of the access (an immediate of the LDS instruction) and the shift / add runs once per base, not once per
 	// access.  Per translation unit (ZEN_FFT_FOLD_ADDR): the kernels that sit at a register limit keep the code they have.
@@ -381,6 +400,29 @@ struct PassRunner {
 		constexpr bool FIRST = PASS == 0, LAST = PASS == PL::P - 1;
 		constexpr bool ZUP = ZU && FIRST;
 		constexpr bool PRE = tw_preloads<TW>::value;
+		// In-place exchanges (-DZEN_FFT_INPLACE, per translation unit).  The autosort layout writes a pass's results where the
+		// NEXT pass wants them (addr = k * (N/2^s) + j), other positions than the pass read: a barrier between its reads and its
+		// writes, and one behind the writes.  In place, output c of a sub-transform goes where input m = c came from; a thread
+		// then overwrites nothing but what it read itself and the first of the two barriers is only needed in the last pass
+		// (whose reads the next transform's first pass must not overtake): P barriers per transform instead of 2P - 2.  Same
+		// butterflies, same operands, same twiddles -- the values do not know where they are kept.  The price is the address of
+		// a later pass's inputs: the digits c_0 .. c_{p-1} the earlier passes produced sit in the image in the order they were
+		// made (c_0 on top), the reverse of their order in k.
+#ifdef ZEN_FFT_INPLACE
+		constexpr bool INPL = PL::INPLACE;
+		auto image_k = [](int k) -> int { // where the sub-transforms of output index k sit in the image
+			if constexpr (!INPL || PASS < 2) {
+				return k;
+			}
+			else {
+				int rv = 0;
+#pragma unroll
+				for (int g = 0; g < PASS; ++g)
+					rv |= ((k >> PL::s(g)) & ((1 << PL::r(g)) - 1)) << (sL - PL::s(g + 1));
+				return rv;
+			}
+		};
+#endif
 		TwPassRegs<LOG2N, PASS, TW::PACKED> twp;
 		if constexpr (PRE)
 			twp.fill(tf, tw.p);
@@ -404,7 +446,11 @@ struct PassRunner {
 #pragma unroll
 		for (int i = 0; i < NB; ++i) {
 			const int b = tf + i * TF;
+#ifdef ZEN_FFT_INPLACE
+			const int k = image_k(b >> log2J), j = b & (J - 1);
+#else
 			const int k = b >> log2J, j = b & (J - 1);
+#endif
 #pragma unroll
 			for (int m = 0; m < R; ++m) {
 				if (ZUP && m >= R / 2) {
@@ -424,8 +470,13 @@ struct PassRunner {
 				}
 			}
 		}
+#ifdef ZEN_FFT_INPLACE
+		if ((FIRST && SYNC_FIRST) || (!FIRST && (!INPL || LAST)))
+			frame_sync<TF>(); // (in place: only the next transform's first pass overwrites what others read)
+#else
 		if (!FIRST || SYNC_FIRST)
 			frame_sync<TF>(); // every thread has its inputs in registers: LDS may be overwritten
+#endif
 #pragma unroll
 		for (int i = 0; i < NB; ++i) {
 			const int b = tf + i * TF;
@@ -443,6 +494,11 @@ struct PassRunner {
 							out(idx, v[i][c], /*lower_half=*/c < R / 2, /*slot=*/c * NB + i);
 					}
 				}
+#ifdef ZEN_FFT_INPLACE
+				else if constexpr (INPL) {
+					lds[PL::pad((image_k(k) * R + c) * J + (b & (J - 1)))] = v[i][c];
+				}
+#endif
 				else {
 #ifdef ZEN_FFT_FOLD_ADDR
 					lds[PL::pad_off(b, c * (N / R))] = v[i][c];
