@@ -15,6 +15,8 @@
 // ~210 min/max per output at 171/187 taps, all with compile-time indices (no data-dependent addressing),
 // instead of ~60 wave-wide instructions per output in the sliding wave-window kernel.
 #pragma once
+#include <type_traits>
+
 #include "median_net.h"
 
 namespace zbig {
@@ -69,6 +71,15 @@ struct MergeLevelR {
 // loads of one phase are not hoisted into the previous one: peak register use stays near 128.
 __device__ __forceinline__ void phase_fence() { asm volatile("" ::: "memory"); }
 
+// A loader may also offer sorted32(i, v): blocks t-a+i and t-a+i+1 merged (i even) -- the first level of the merge tree, which
+// neighbouring threads share: thread t's pairs (t-a, t-a+1), (t-a+2, t-a+3), ... are thread t+2's shifted by one.  A kernel that
+// merges every adjacent pair of sorted blocks ONCE (median_big.hip: an image of sorted 32-blocks next to the sorted 16-blocks)
+// saves each thread BIG/2 - 1 of its BIG/2 merges of 32.
+template <class T, class = void>
+struct has_sorted32 : std::false_type {};
+template <class T>
+struct has_sorted32<T, std::void_t<decltype(&T::sorted32)>> : std::true_type {};
+
 template <int W, class LD>
 __device__ __forceinline__ void medians_big(const LD& ld, int (&out)[16])
 {
@@ -80,16 +91,28 @@ __device__ __forceinline__ void medians_big(const LD& ld, int (&out)[16])
 	int An[AHI - ALO + 1];
 	{
 		int A[G::NA];
+		if constexpr (has_sorted32<LD>::value && G::BIG >= 2) {
 #pragma unroll
-		for (int i = 0; i < G::BIG; ++i) {
-			int B[16];
-			ld.sorted(i, B);
+			for (int i = 0; i < G::BIG; i += 2) {
+				int B[32];
+				ld.sorted32(i, B);
 #pragma unroll
-			for (int j = 0; j < 16; ++j)
-				A[16 * i + j] = B[j];
+				for (int j = 0; j < 32; ++j)
+					A[16 * i + j] = B[j];
+			}
 		}
-		if constexpr (G::NA >= 32)
-			MergeLevel<32, G::NA>::run(A);
+		else {
+#pragma unroll
+			for (int i = 0; i < G::BIG; ++i) {
+				int B[16];
+				ld.sorted(i, B);
+#pragma unroll
+				for (int j = 0; j < 16; ++j)
+					A[16 * i + j] = B[j];
+			}
+			if constexpr (G::NA >= 32)
+				MergeLevel<32, G::NA>::run(A);
+		}
 		if constexpr (G::NA >= 64)
 			MergeLevel<64, G::NA>::run(A);
 		if constexpr (G::NA >= 128)

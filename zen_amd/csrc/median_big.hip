@@ -24,6 +24,9 @@ using znet::to_key;
 #ifndef ZEN_BIG_MINB
 #define ZEN_BIG_MINB 2
 #endif
+#ifndef ZEN_BIG_SHARE32_MAX_LDS
+#define ZEN_BIG_SHARE32_MAX_LDS (80 * 1024 + 512) // two workgroups per CU (187 taps: 80 432 B); 255 / 257 taps (82 256 B) take it too: below
+#endif
 // nblk_main: the leading blocks of a row that are filtered (all of them; Hermitian rows: bins 0..cols/2 - 1, the
 // rest is median_big_tail_kernel's).
 // Two mask bits per bin (FilterArgs::bits) of a thread's sixteen outputs: P = the medians, H = the block's own samples
@@ -69,6 +72,20 @@ __global__ __launch_bounds__(256, ZEN_BIG_MINB) void median_big_kernel(FilterArg
 	constexpr int NSORT = 256 + G::NB - 1;
 	__shared__ __attribute__((aligned(16))) int raw[NRAW * RSTR];
 	__shared__ __attribute__((aligned(16))) int srt[NSORT * RSTR];
+	// Round 6: every adjacent pair of sorted blocks merged ONCE (entry s = blocks s, s + 1 as one sorted list of 32): the first
+	// level of every thread's merge tree -- BIG/2 merges of 32 per thread, of which all but one are a neighbour's -- becomes one
+	// merge per thread and BIG/2 loads (36 words per entry: consecutive threads' 16-byte reads fall into different banks).
+	// Eight-block trees only: 171 / 187 taps -3.5..4 % (80.4 KB of LDS: still two workgroups per CU); 255 / 257 taps 3.4-3.7 ->
+	// 1.35-1.79 ms per 6 460 x 16 384 although the image (82.3 KB) leaves one workgroup per CU -- the shorter tree needs 72-190
+	// bytes of scratch per lane instead of 1.1 KB; four-block trees (129 taps) lose 4 % (one merge saved, a barrier and an
+	// LDS round trip added).
+	constexpr int S2STR = 36;
+#ifdef ZEN_BIG_NO_SHARE32 // (A/B: the kernel of rounds 2-5)
+	constexpr bool SHARE32 = false;
+#else
+	constexpr bool SHARE32 = G::BIG >= 8 && sizeof(int) * (size_t)(NRAW * RSTR + NSORT * RSTR + (NSORT - 1) * S2STR) <= ZEN_BIG_SHARE32_MAX_LDS;
+#endif
+	__shared__ __attribute__((aligned(16))) int srt2[SHARE32 ? (NSORT - 1) * S2STR : 4];
 
 	const int tid = threadIdx.x;
 	const int cols = a.cols;
@@ -104,6 +121,16 @@ __global__ __launch_bounds__(256, ZEN_BIG_MINB) void median_big_kernel(FilterArg
 		znet::lds_store<16>(&srt[s * RSTR], v);
 	}
 	__syncthreads();
+	if constexpr (SHARE32) {
+		for (int s = tid; s < NSORT - 1; s += 256) {
+			int v[32];
+			znet::lds_load<16>(&srt[s * RSTR], v);
+			znet::lds_load<16>(&srt[(s + 1) * RSTR], v + 16);
+			znet::oe_merge<32, 0>(v);
+			znet::lds_store<32>(&srt2[s * S2STR], v);
+		}
+		__syncthreads();
+	}
 	// ---- 16 outputs per thread
 	const bool wanted = (col0 >> 4) + tid < nblk_main;
 	int out[16];
@@ -117,8 +144,22 @@ __global__ __launch_bounds__(256, ZEN_BIG_MINB) void median_big_kernel(FilterArg
 			__device__ __forceinline__ void sorted(int i, int* v) const { znet::lds_load<16>(srt_t + i * RSTR, v); }
 			__device__ __forceinline__ void rawl(int j, int* v) const { znet::lds_load<16>(raw_t + j * RSTR, v); }
 			__device__ __forceinline__ void rawr(int j, int* v) const { znet::lds_load<16>(raw_t + (G::a + G::b + 2 + j) * RSTR, v); }
-		} ld{&srt[tid * RSTR], &raw[tid * RSTR]};
-		zbig::medians_big<W>(ld, out);
+		};
+		struct Loader32 : Loader {
+			const int* srt2_t; // sorted pair (t-a, t-a+1)
+			__device__ __forceinline__ void sorted32(int i, int* v) const { znet::lds_load<32>(srt2_t + i * S2STR, v); }
+		};
+		if constexpr (SHARE32) {
+			Loader32 ld;
+			ld.srt_t = &srt[tid * RSTR];
+			ld.raw_t = &raw[tid * RSTR];
+			ld.srt2_t = &srt2[tid * S2STR];
+			zbig::medians_big<W>(ld, out);
+		}
+		else {
+			Loader ld{&srt[tid * RSTR], &raw[tid * RSTR]};
+			zbig::medians_big<W>(ld, out);
+		}
 	}
 	if constexpr (BITS) {
 		if (wanted) {
