@@ -1,5 +1,14 @@
-import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+#!/usr/bin/env python3
+"""zen_hip_hpr_process_host (the headline block, pinned host memory in and out) at several piece lengths of its three-stream
+pipeline (option "host_block_hops"; 0 = the default, ~8 MiB of input per piece): wall clock per 25 840-hop block and the
+link measured with the same buffers.  On the GPU box: python tools/ab_block_host.py"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import zen_amd, bench
 zen_amd.init(0)
 M = 25840

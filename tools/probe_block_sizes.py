@@ -1,5 +1,13 @@
-import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+#!/usr/bin/env python3
+"""What a block call of zen_hip_hpr_process costs as a function of its length (hop 1024, P only, resident input): microseconds
+per call, hops/s, and the engine's own per-kernel times.  On the GPU box: python tools/probe_block_sizes.py"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import zen_amd
 zen_amd.init(0)
 hop = 1024
