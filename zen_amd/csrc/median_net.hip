@@ -95,9 +95,18 @@ __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowM
 	const int herm = a.hermitian;
 	const int o0 = col0 + tid * T; // this thread's first output column
 	const bool wanted = !herm || o0 <= (cols >> 1) || o0 + T > cols - mid;
-	// Keys: the raw bits, which order non-negative samples (magnitudes) as they are.  Without the caller's promise (NONNEG)
-	// every wave ORs the sign bits of what it stages; only a workgroup that saw one re-keys its windows (and maps its results
-	// back): a row of magnitudes costs what it costs with the promise.
+	// Keys: with the caller's promise (NONNEG: magnitudes) the raw bits, which order non-negative samples as they are.
+	// Without the promise every sample is keyed as it is staged and every result mapped back (6 VALU instructions per element:
+	// 0.687 of the HBM roof where the promise reads 0.712, 13 taps on 1024-bin rows).  -DZEN_MN_DETECT_SIGN (A/B, round 6)
+	// instead stages raw bits, ORs the sign bits per wave and re-keys only workgroups that saw one: 0.673 on magnitudes -- the
+	// flag's read and branch between the two barriers of a 330-instruction workgroup cost more than the keys -- and 0.574
+	// against 0.640 on signed data (a window is re-keyed per thread, not per sample).  Not the default.
+#ifdef ZEN_MN_DETECT_SIGN
+	constexpr bool DETECT = !NONNEG;
+#else
+	constexpr bool DETECT = false;
+#endif
+	constexpr bool RAWKEYS = NONNEG || DETECT; // the image holds raw bits
 	__shared__ int wneg[4];
 	int sgn = 0;
 	if (vec_ok) { // cols % 4 == 0 and 16-byte aligned rows: a vector is wholly inside or wholly outside
@@ -109,7 +118,7 @@ __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowM
 			// one cache line -- instead of the next segment's first 4 KB, which they used to fetch and throw away: rows of
 			// several segments moved up to twice their bytes through the L1)
 			const int vi = tid + 256 * i < SPANV ? tid + 256 * i : SPANV - 1;
-			k[i] = row_vec_keys<true>(srow, c_lo + 4 * vi, cols, herm);
+			k[i] = row_vec_keys<RAWKEYS>(srow, c_lo + 4 * vi, cols, herm);
 			sgn |= k[i].x | k[i].y | k[i].z | k[i].w;
 		}
 #pragma unroll
@@ -124,12 +133,12 @@ __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowM
 			int c = c_lo + g;
 			c = c < 0 ? 0 : (c > cols - 1 ? cols - 1 : c);
 			ZH_CHK(srow + c, 1);
-			const int b = __float_as_int(srow[c]);
+			const int b = to_key<RAWKEYS>(srow[c]);
 			sgn |= b;
 			tile[IM::addr(g)] = b;
 		}
 	}
-	if constexpr (!NONNEG) {
+	if constexpr (DETECT) {
 		const bool any = __ballot(sgn < 0) != 0ull;
 		if ((tid & 63) == 0)
 			wneg[tid >> 6] = any ? 1 : 0;
@@ -140,7 +149,7 @@ __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowM
 	                  // out in line, the two branches a workgroup of magnitudes TOOK around them cost 4.5 % of the launch
 	                  // (0.674 against 0.704 of 8 TB/s, 13 taps on 1024-bin rows; variant builds, same box)
 	auto read_neg = [&]() {
-		if constexpr (!NONNEG)
+		if constexpr (DETECT)
 			neg = __builtin_amdgcn_readfirstlane(wneg[0] | wneg[1] | wneg[2] | wneg[3]) != 0;
 	};
 	auto rekey = [](int b) { return b ^ ((b >> 31) & 0x7fffffff); }; // raw bits <-> ordering key (an involution: znet::f2key)
@@ -247,10 +256,10 @@ __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowM
 				const int4 k = *reinterpret_cast<const int4*>(&tile[IM::addr(g)]);
 				float* dq = reinterpret_cast<float*>(__builtin_assume_aligned(drow + c, 16)); // streaming store
 				ZH_CHK(dq, 4);
-				__builtin_nontemporal_store(__int_as_float(k.x), dq);
-				__builtin_nontemporal_store(__int_as_float(k.y), dq + 1);
-				__builtin_nontemporal_store(__int_as_float(k.z), dq + 2);
-				__builtin_nontemporal_store(__int_as_float(k.w), dq + 3);
+				__builtin_nontemporal_store(from_key<RAWKEYS>(k.x), dq);
+				__builtin_nontemporal_store(from_key<RAWKEYS>(k.y), dq + 1);
+				__builtin_nontemporal_store(from_key<RAWKEYS>(k.z), dq + 2);
+				__builtin_nontemporal_store(from_key<RAWKEYS>(k.w), dq + 3);
 			}
 		}
 	}
@@ -259,7 +268,7 @@ __global__ __launch_bounds__(256) void median_net_freq_kernel(FilterArgs a, RowM
 			const int c = col0 + g;
 			if (c < cols) {
 				ZH_CHK(drow + c, 1);
-				drow[c] = __int_as_float(tile[IM::addr(g)]);
+				drow[c] = from_key<RAWKEYS>(tile[IM::addr(g)]);
 			}
 		}
 	}
