@@ -214,6 +214,16 @@ def test_median_networks_on_the_host(tmp_path):
     assert r.returncode == 0 and "passed" in r.stdout, r.stdout[-2000:]
 
 
+def test_block_merge_selection_on_the_host(tmp_path):
+    """zen_amd/csrc/median_big.h compiled as plain C++ (tests/cpp/test_median_big_host.cpp): zbig::medians_big<W> for every long
+    mask the kernels instantiate (65 .. 257 taps), through a loader of sorted 16-blocks and through one that also hands out
+    the sorted PAIRS of blocks neighbouring threads share (round 6, median_big.hip), against a brute-force median."""
+    exe = str(tmp_path / "test_median_big_host")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cpp", "test_median_big_host.cpp"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "0 failures" in r.stdout and "W = 257" in r.stdout, r.stdout[-2000:]
+
+
 def test_real_input_transform_on_the_host(tmp_path, oracle):
     """zen_amd/csrc/rfft_dev.h compiled for the CPU (tests/cpp/test_rfft_host.cpp; the image's host clang++, scalar
     butterflies): the Hermitian half of the radix-2 DAG on real frames, the N/32 threads of a frame run one after the other,
