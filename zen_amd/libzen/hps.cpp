@@ -1,6 +1,7 @@
 // hps.cpp -- HPR<GPU>, HPRRealtime<GPU>, HPRIOffline<GPU> over the C-ABI engine.
 // Mirrors the control flow of the reference's libzen/hps.cu:21-427; the per-hop arithmetic
 // (hps.cu:429-652) runs inside libzen_hip.so.
+#include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <cstdlib>
@@ -403,7 +404,7 @@ namespace hps {
 
 		struct AppendCtx {
 			std::vector<float>* v[2];
-			bool out_of_order = false;
+			std::atomic<bool> out_of_order{false}; // (set from either output's thread)
 		};
 		// zen_hip_hpri_sink_fn: the range is appended to its vector (capacity reserved: no allocation, nothing to throw)
 		extern "C" void append_range(void* user, int output, std::size_t begin, const float* samples, std::size_t count)
@@ -411,7 +412,7 @@ namespace hps {
 			AppendCtx* c = static_cast<AppendCtx*>(user);
 			std::vector<float>& v = *c->v[output];
 			if (begin != v.size() || v.capacity() - v.size() < count) {
-				c->out_of_order = true;
+				c->out_of_order.store(true, std::memory_order_relaxed);
 				return;
 			}
 			v.insert(v.end(), samples, samples + count);
@@ -462,7 +463,9 @@ namespace hps {
 			catch (const std::system_error&) {
 			}
 			int rc;
-			AppendCtx ctx{{&harmonic_out, &percussive_out}};
+			AppendCtx ctx;
+			ctx.v[0] = &harmonic_out;
+			ctx.v[1] = &percussive_out;
 			{
 				Populator ph, pp;
 				ph.start(harmonic_out.data(), n * sizeof(float));
@@ -476,7 +479,7 @@ namespace hps {
 			if (wr.err)
 				std::rethrow_exception(wr.err);
 			throw_or_die(rc, "HPRIOffline::process");
-			if (ctx.out_of_order || harmonic_out.size() != n || percussive_out.size() != n)
+			if (ctx.out_of_order.load() || harmonic_out.size() != n || percussive_out.size() != n)
 				throw ZgException("HPRIOffline::process: the ranges of the clip did not arrive in order (internal)");
 		}
 		else {
